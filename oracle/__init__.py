@@ -1,0 +1,166 @@
+"""CPU oracle bindings — TEST INFRASTRUCTURE ONLY.
+
+ctypes views of oracle/libfastecc_oracle.so (our plain-C restatement, fastecc_oracle.c) and, when it
+has been built, oracle/_ref/libfastecc_ref*.so (the unmodified reference behind ref_shim.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the
+product package (fastecc_amd) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = 0xFFF00001
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_sz = ctypes.c_size_t
+_u32 = ctypes.c_uint32
+
+
+def build(force=False):
+    """Compile the restatement (and the reference shim when /root/reference is present)."""
+    so = os.path.join(HERE, "libfastecc_oracle.so")
+    src = os.path.join(HERE, "fastecc_oracle.c")
+    have_ref = os.path.exists("/root/reference/ntt.cpp")
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    ref_missing = have_ref and not os.path.exists(os.path.join(HERE, "_ref", "libfastecc_ref.so"))
+    if force or stale or ref_missing:
+        subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+class Oracle:
+    """Plain-C restatement (fastecc_oracle.c)."""
+
+    def __init__(self):
+        self.lib = lib = ctypes.CDLL(build())
+        for name in ("add", "sub", "mul", "mul_wide", "pow"):
+            f = getattr(lib, "orc_gf_" + name)
+            f.argtypes, f.restype = [_u32, _u32], _u32
+        for name in ("root", "inv"):
+            f = getattr(lib, "orc_gf_" + name)
+            f.argtypes, f.restype = [_u32], _u32
+        for name in ("slow_ntt", "ntt", "ntt_fast"):
+            f = getattr(lib, "orc_" + name)
+            f.argtypes, f.restype = [_u32p, _sz, _sz, ctypes.c_int], None
+        lib.orc_scale_blocks.argtypes, lib.orc_scale_blocks.restype = [_u32p, _sz, _sz, _u32, _u32], None
+        for name in ("encode", "encode_fast"):
+            f = getattr(lib, "orc_" + name)
+            f.argtypes, f.restype = [_u32p, _sz, _sz], None
+        lib.orc_encode_by_definition.argtypes = [_u32p, _u32p, _sz, _sz]
+        lib.orc_encode_by_definition.restype = None
+        lib.orc_hash.argtypes, lib.orc_hash.restype = [_u32p, _sz], _u32
+        lib.orc_fill_linear.argtypes, lib.orc_fill_linear.restype = [_u32p, _sz], None
+        lib.orc_fill_splitmix.argtypes, lib.orc_fill_splitmix.restype = [_u32p, _sz, ctypes.c_uint64], None
+        lib.orc_num_threads.restype = ctypes.c_int
+
+    # field
+    def gf_add(self, x, y): return self.lib.orc_gf_add(x, y)
+    def gf_sub(self, x, y): return self.lib.orc_gf_sub(x, y)
+    def gf_mul(self, x, y): return self.lib.orc_gf_mul(x, y)
+    def gf_mul_wide(self, x, y): return self.lib.orc_gf_mul_wide(x, y)
+    def gf_pow(self, x, n): return self.lib.orc_gf_pow(x, n)
+    def gf_root(self, n): return self.lib.orc_gf_root(n)
+    def gf_inv(self, x): return self.lib.orc_gf_inv(x)
+
+    # transforms on a [N, size] uint32 array; all return a new array
+    def _run(self, fn, data, *extra):
+        a = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        N, size = a.shape
+        fn(a, N, size, *extra)
+        return a
+
+    def slow_ntt(self, data, inverse=False): return self._run(self.lib.orc_slow_ntt, data, int(inverse))
+    def ntt(self, data, inverse=False): return self._run(self.lib.orc_ntt, data, int(inverse))
+    def ntt_fast(self, data, inverse=False): return self._run(self.lib.orc_ntt_fast, data, int(inverse))
+    def scale_blocks(self, data, scale, base): return self._run(self.lib.orc_scale_blocks, data, scale, base)
+    def encode(self, data): return self._run(self.lib.orc_encode, data)
+    def encode_fast(self, data): return self._run(self.lib.orc_encode_fast, data)
+
+    def encode_fast_inplace(self, a):
+        """In-place variant for large buffers (no copy)."""
+        N, size = a.shape
+        self.lib.orc_encode_fast(a, N, size)
+        return a
+
+    def encode_by_definition(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint32)
+        out = np.empty_like(a)
+        self.lib.orc_encode_by_definition(a, out, a.shape[0], a.shape[1])
+        return out
+
+    def hash(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint32).reshape(-1)
+        return int(self.lib.orc_hash(a, a.size))
+
+    def fill_linear(self, N, size):
+        a = np.empty((N, size), dtype=np.uint32)
+        self.lib.orc_fill_linear(a.reshape(-1), a.size)
+        return a
+
+    def fill_splitmix(self, N, size, seed=0x1234):
+        a = np.empty((N, size), dtype=np.uint32)
+        self.lib.orc_fill_splitmix(a.reshape(-1), a.size, seed)
+        return a
+
+    def num_threads(self): return int(self.lib.orc_num_threads())
+
+
+class Reference:
+    """The unmodified reference behind oracle/ref_shim.cpp (only if oracle/_ref/ was built)."""
+
+    @staticmethod
+    def path(avx2=False):
+        return os.path.join(HERE, "_ref", "libfastecc_ref_avx2.so" if avx2 else "libfastecc_ref.so")
+
+    @classmethod
+    def available(cls, avx2=False):
+        return os.path.exists(cls.path(avx2))
+
+    def __init__(self, avx2=False):
+        self.lib = lib = ctypes.CDLL(self.path(avx2))
+        for name in ("add", "sub", "mul", "pow"):
+            f = getattr(lib, "ref_gf_" + name)
+            f.argtypes, f.restype = [_u32, _u32], _u32
+        for name in ("root", "inv"):
+            f = getattr(lib, "ref_gf_" + name)
+            f.argtypes, f.restype = [_u32], _u32
+        lib.ref_ntt.argtypes, lib.ref_ntt.restype = [_u32p, _sz, _sz, ctypes.c_int, ctypes.c_int], None
+        lib.ref_encode.argtypes, lib.ref_encode.restype = [_u32p, _sz, _sz], None
+        lib.ref_hash.argtypes, lib.ref_hash.restype = [_u32p, _sz, _sz], _u32
+        lib.ref_simd_level.restype = ctypes.c_int
+
+    def gf_add(self, x, y): return self.lib.ref_gf_add(x, y)
+    def gf_sub(self, x, y): return self.lib.ref_gf_sub(x, y)
+    def gf_mul(self, x, y): return self.lib.ref_gf_mul(x, y)
+    def gf_pow(self, x, n): return self.lib.ref_gf_pow(x, n)
+    def gf_root(self, n): return self.lib.ref_gf_root(n)
+    def gf_inv(self, x): return self.lib.ref_gf_inv(x)
+
+    MFA, REC, SLOW = 0, 1, 2
+
+    def ntt(self, data, inverse=False, which=0):
+        a = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        self.lib.ref_ntt(a, a.shape[0], a.shape[1], int(inverse), which)
+        return a
+
+    def encode(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        self.lib.ref_encode(a, a.shape[0], a.shape[1])
+        return a
+
+    def encode_inplace(self, a):
+        self.lib.ref_encode(a, a.shape[0], a.shape[1])
+        return a
+
+    def hash(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        return int(self.lib.ref_hash(a, a.shape[0], a.shape[1]))
+
+    def simd_level(self): return int(self.lib.ref_simd_level())
