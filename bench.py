@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — encode GB/s at (n,k) = (2^20, 2^19), 4 KB blocks (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one fastecc_encode of one stripe (k = 2^19 data blocks of 4 KB -> 2^19 parity blocks), inputs
+already resident in HBM, called through the C ABI (include/fastecc.h) exactly as a C++ host would.
+Multi-GPU: one process per GPU, every rank encodes its own independent stripe (the path has no exchange
+step: word columns and stripes are independent — DESIGN.md §multi-GPU), so scaling is "weak" and there is
+no collective inside the timed region; ranks only meet at the barriers that bracket it.
+
+Throughput convention = the reference's (RS.cpp:38): bytes = data + parity = 2*k*block_bytes per encode,
+reported in GB/s (1e9).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_WAIT_POLICY", "active")  # CPU baseline: avoid passive-wait barrier stalls
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+P = 0xFFF00001
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2k", type=int, default=19, help="k = 2^log2k data blocks (headline: 19)")
+    ap.add_argument("--block-bytes", type=int, default=4096)
+    ap.add_argument("--plan", type=int, default=0, help="kernel plan (0 = library default); see DESIGN.md")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the parity (reported separately)")
+    return ap.parse_args()
+
+
+def random_stripe(n_words, device, seed):
+    """Uniform words in [0,p) as the int32 bit patterns of uint32, generated on the device in chunks."""
+    out = torch.empty(n_words, dtype=torch.int32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    chunk = 1 << 26
+    for i in range(0, n_words, chunk):
+        m = min(chunk, n_words - i)
+        r = torch.randint(0, P, (m,), dtype=torch.int64, device=device, generator=g)
+        out[i:i + m] = r.to(torch.int32)  # keeps the low 32 bits
+    return out
+
+
+def cpu_baseline(log2k, block_bytes):
+    """FastECC's own CPU path on this host's cores: the unmodified reference (oracle/_ref, AVX2+OpenMP
+    build) when it was prebuilt, else our plain-C port.  One untimed warm-up, then best of 2."""
+    from oracle import Oracle, Reference
+    N, S = 1 << log2k, block_bytes // 4
+    orc = Oracle()
+    x = orc.fill_splitmix(N, S, 0x1234)
+    if Reference.available(avx2=True):
+        ref, kind = Reference(avx2=True), "reference"
+        run = lambda buf: ref.encode_inplace(buf)  # noqa: E731
+        what = "FastECC RS.cpp:41-63 call sequence on MFA_NTT, g++ -O3 -fopenmp -mavx2 -DSIMD=AVX2"
+    else:
+        kind = "port"
+        run = lambda buf: orc.encode_fast_inplace(buf)  # noqa: E731
+        what = "oracle/fastecc_oracle.c (plain C + OpenMP)"
+    best = None
+    for it in range(3):
+        buf = x.copy()
+        t0 = time.perf_counter()
+        run(buf)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    cores = orc.num_threads()
+    return {"value": round(2.0 * N * S * 4 / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": kind,
+            "sample": "one full encode of k=2^%d blocks x %d B (%s), best of 2 after a warm-up, %.2f s each, %d OpenMP threads"
+                      % (log2k, block_bytes, what, best, cores)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch for `kernel` from a committed rocprofv3 --pmc summary, if there is one."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from fastecc_amd import _build
+    if not os.path.exists(_build.LIB_PATH):
+        _build.build_library()
+    import fastecc_amd
+
+    k = 1 << args.log2k
+    n = 2 * k
+    S = args.block_bytes // 4
+    data = random_stripe(k * S, device, seed=0x1234 + rank)
+    parity = torch.empty_like(data)
+    enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local)
+    if args.plan:
+        enc.set_plan(args.plan)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc.encode(data, parity, stream=stream)
+    barrier()
+    enc.profile(True)      # HIP events around every kernel, on the stream the kernels run on
+    enc.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode(data, parity, stream=stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = enc.profile_read()
+    enc.profile(False)
+
+    gather_ms = None
+    if args.gather and world > 1:
+        outs = [torch.empty_like(parity) for _ in range(world)]
+        dist.all_gather(outs, parity)
+        barrier()
+        t1 = time.perf_counter()
+        dist.all_gather(outs, parity)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        del outs
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        bytes_per_encode = 2.0 * k * args.block_bytes  # data + parity, RS.cpp:38
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * bytes_per_encode / (ms_per_step * 1e-3) / 1e9
+        # dominant kernel by total time; every pass reads the stripe once and writes it once
+        dom = max(kernels.items(), key=lambda kv: kv[1][0]) if kernels else None
+        roof = None
+        if dom:
+            name, (ms_total, launches) = dom
+            avg_ms = ms_total / launches
+            achieved = bytes_per_encode / (avg_ms * 1e-3) / 1e9
+            kernel_ms_per_step = sum(v[0] for v in kernels.values()) / args.steps
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
+                    "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": bytes_per_encode,
+                    "encode": {"kernels_ms_per_step": round(kernel_ms_per_step, 4),
+                               "achieved": round(bytes_per_encode / (kernel_ms_per_step * 1e-3) / 1e9, 1),
+                               "frac": round(bytes_per_encode / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                    "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
+                    "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(args.cpu_log2k or args.log2k, args.block_bytes)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                cpu = {"error": repr(e)}
+        line = {
+            "metric": "encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes),
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "RS encode (n,k)=(2^%d,2^%d), %d B blocks, GF(0xFFF00001), one %.0f MiB stripe per GPU, HBM-resident, out of place"
+                                   % (args.log2k + 1, args.log2k, args.block_bytes, k * args.block_bytes / 2**20),
+                       "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
+            "data_only_GBps": round(value / 2, 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if gather_ms is not None:
+            line["rccl_all_gather_parity_ms"] = round(gather_ms, 3)
+        print(json.dumps(line), flush=True)
+    enc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

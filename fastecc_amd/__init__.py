@@ -1,0 +1,179 @@
+"""fastecc_amd — MI355X-native NTT Reed-Solomon encode path (FastECC-compatible).
+
+Host-side Python harness over the C ABI of ``fastecc_amd/lib/libfastecc_hip.so`` (include/fastecc.h).
+The product is the shared library; this module only binds it with ctypes so that tests and bench.py can
+call exactly the entry points a C++ host (fastecc_amd/host/rs_main.cpp, or FastECC's RS.cpp patched as
+in INTEGRATION.md) calls.  torch is used by callers for device memory and streams only — no torch type
+appears in any signature here, just integer addresses.
+
+There is no CPU compute path in this package: if the HIP library is missing or no GPU is present the
+calls raise.
+"""
+import ctypes
+import os
+
+from . import _build
+
+P = 0xFFF00001  # RS.cpp:86
+FIELD_GF_FFF00001 = 0
+MEM_HOST, MEM_DEVICE = 0, 1
+
+OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
+
+_LIB = None
+
+
+class FastEccError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__("%s: %s (%d)" % (what, lib().fastecc_strerror(code).decode(), code))
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load libfastecc_hip.so (never falls back to anything else)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(fastecc_amd has no CPU fallback)" % path)
+    L = ctypes.CDLL(path)
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    L.fastecc_strerror.argtypes, L.fastecc_strerror.restype = [i32], ctypes.c_char_p
+    L.fastecc_version.argtypes, L.fastecc_version.restype = [], i32
+    L.fastecc_create.argtypes, L.fastecc_create.restype = [ctypes.POINTER(vp), u64, u64, u64, i32, i32], i32
+    L.fastecc_destroy.argtypes, L.fastecc_destroy.restype = [vp], None
+    L.fastecc_encode.argtypes, L.fastecc_encode.restype = [vp, vp, vp, i32, vp], i32
+    L.fastecc_encode_blocks.argtypes, L.fastecc_encode_blocks.restype = [vp, ctypes.POINTER(vp)], i32
+    L.fastecc_ntt.argtypes, L.fastecc_ntt.restype = [vp, vp, i32, i32, vp], i32
+    L.fastecc_scale_blocks.argtypes, L.fastecc_scale_blocks.restype = [vp, vp, u32, u32, i32, vp], i32
+    L.fastecc_gf_binary.argtypes, L.fastecc_gf_binary.restype = [vp, i32, vp, vp, vp, u64, vp], i32
+    for name in ("mul", "pow"):
+        f = getattr(L, "fastecc_gf_" + name)
+        f.argtypes, f.restype = [u32, u32], u32
+    for name in ("root", "inv"):
+        f = getattr(L, "fastecc_gf_" + name)
+        f.argtypes, f.restype = [u32], u32
+    L.fastecc_profile_enable.argtypes, L.fastecc_profile_enable.restype = [vp, i32], i32
+    L.fastecc_profile_reset.argtypes, L.fastecc_profile_reset.restype = [vp], i32
+    L.fastecc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(u64), i32]
+    L.fastecc_profile_read.restype = i32
+    L.fastecc_plan_string.argtypes, L.fastecc_plan_string.restype = [vp], ctypes.c_char_p
+    L.fastecc_set_plan.argtypes, L.fastecc_set_plan.restype = [vp, i32], i32
+    _LIB = L
+    return L
+
+
+def _check(code, what):
+    if code < 0:
+        raise FastEccError(code, what)
+    return code
+
+
+def _addr(x):
+    """Integer address of a torch tensor / numpy array / int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    raise TypeError("need an address, torch tensor or numpy array")
+
+
+class Encoder:
+    """(n,k) = (2N,N) Reed-Solomon encoder over GF(0xFFF00001): the RS.cpp:22-68 operation.
+
+    ``data``/``parity`` arguments are device tensors (or raw addresses) of k*block_bytes bytes laid out
+    block-major, exactly the ``T** data`` stripe of RS.cpp:28-33 stored back to back.
+    """
+
+    def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001):
+        self._h = ctypes.c_void_p()
+        self.n, self.k, self.block_bytes, self.device = n, k, block_bytes, device
+        _check(lib().fastecc_create(ctypes.byref(self._h), n, k, block_bytes, field, device), "fastecc_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fastecc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def words_per_block(self):
+        return self.block_bytes // 4
+
+    def encode(self, data, parity=None, stream=0, mem=MEM_DEVICE):
+        """parity <- encode(data); parity=None encodes in place (the reference's behaviour)."""
+        if parity is None:
+            parity = data
+        _check(lib().fastecc_encode(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_encode")
+        return parity
+
+    def encode_host(self, data_np, parity_np=None):
+        return self.encode(data_np, parity_np, mem=MEM_HOST)
+
+    def encode_blocks(self, block_addresses):
+        arr = (ctypes.c_void_p * len(block_addresses))(*block_addresses)
+        _check(lib().fastecc_encode_blocks(self._h, arr), "fastecc_encode_blocks")
+
+    def ntt(self, data, inverse=False, stream=0, mem=MEM_DEVICE):
+        _check(lib().fastecc_ntt(self._h, _addr(data), int(inverse), mem, stream or None), "fastecc_ntt")
+        return data
+
+    def scale_blocks(self, data, scale, base, stream=0, mem=MEM_DEVICE):
+        _check(lib().fastecc_scale_blocks(self._h, _addr(data), scale, base, mem, stream or None),
+               "fastecc_scale_blocks")
+        return data
+
+    def gf_binary(self, op, x, y, out, count, stream=0):
+        code = {"add": 0, "sub": 1, "mul": 2, "mul_mont": 3}[op] if isinstance(op, str) else op
+        _check(lib().fastecc_gf_binary(self._h, code, _addr(x), _addr(y), _addr(out), count, stream or None),
+               "fastecc_gf_binary")
+        return out
+
+    # ---- introspection used by bench.py ----
+    def set_plan(self, plan):
+        _check(lib().fastecc_set_plan(self._h, plan), "fastecc_set_plan")
+
+    def plan(self):
+        return lib().fastecc_plan_string(self._h).decode()
+
+    def profile(self, on=True):
+        _check(lib().fastecc_profile_enable(self._h, int(on)), "fastecc_profile_enable")
+
+    def profile_reset(self):
+        _check(lib().fastecc_profile_reset(self._h), "fastecc_profile_reset")
+
+    def profile_read(self, cap=64):
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_double * cap)()
+        cnt = (ctypes.c_uint64 * cap)()
+        n = _check(lib().fastecc_profile_read(self._h, names, ms, cnt, cap), "fastecc_profile_read")
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(n)}
+
+
+def gf_mul(x, y): return lib().fastecc_gf_mul(x, y)
+def gf_pow(x, e): return lib().fastecc_gf_pow(x, e)
+def gf_root(order): return lib().fastecc_gf_root(order)
+def gf_inv(x): return lib().fastecc_gf_inv(x)

@@ -1,0 +1,92 @@
+"""Build recipe for the gfx950 shared library and the C++ host driver (explicit hipcc, in-tree outputs)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfastecc_hip.so")
+RS_PATH = os.path.join(LIB_DIR, "rs_hip")
+MICROBENCH_PATH = os.path.join(LIB_DIR, "microbench")
+
+HIP_SOURCES = ["kernels.hip", "api.hip"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _deps():
+    out = [os.path.join(ROOT, "include", "fastecc.h")]
+    for d in (CSRC, os.path.join(PKG, "host")):
+        for f in os.listdir(d):
+            out.append(os.path.join(d, f))
+    return out
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> fastecc_amd/lib/libfastecc_hip.so"""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if not (force or _newer(LIB_PATH, _deps())):
+        return LIB_PATH
+    objs = []
+    for src in HIP_SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def build_host(force=False, verbose=False):
+    """The rs-compatible C++ host driver (fastecc_amd/host/rs_main.cpp) linked against the C ABI."""
+    src = os.path.join(PKG, "host", "rs_main.cpp")
+    if not os.path.exists(src):
+        return None
+    if not (force or _newer(RS_PATH, [src, LIB_PATH])):
+        return RS_PATH
+    cmd = [hipcc(), "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", RS_PATH,
+           "-L", LIB_DIR, "-lfastecc_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return RS_PATH
+
+
+def build_microbench(force=False, verbose=False):
+    src = os.path.join(ROOT, "tools", "microbench.hip")
+    if not os.path.exists(src):
+        return None
+    if not (force or _newer(MICROBENCH_PATH, [src, os.path.join(CSRC, "gf.hpp")])):
+        return MICROBENCH_PATH
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", MICROBENCH_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return MICROBENCH_PATH
+
+
+def build_all(force=False, verbose=False):
+    build_library(force, verbose)
+    build_host(force, verbose)
+    build_microbench(force, verbose)
+    return LIB_PATH

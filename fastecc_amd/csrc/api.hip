@@ -1,0 +1,535 @@
+// api.hip — the C ABI of libfastecc_hip.so (include/fastecc.h): context, twiddle tables, pass plan.
+//
+// Host side of the encode path.  It replaces the body of EncodeReedSolomon (RS.cpp:22-68) and the
+// drivers MFA_NTT / Rec_NTT (ntt.cpp:349-447): where the reference picks an R x C (x L) split so a
+// sub-transform fits the CPU's L2 (ntt.cpp:385-394), the plan here picks how many radix-2 levels each
+// GPU pass keeps in registers.  No CPU compute fallback exists: every entry point that moves data runs
+// HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fastecc.h"
+#include "gf.hpp"
+#include "kernels.hpp"
+
+using namespace fastecc;
+
+namespace {
+
+struct Pass {
+    int mode;  // MODE_DIF / MODE_DIT / MODE_MID
+    int logr;  // levels kept in registers
+    int s;     // log2 of the smallest stride
+};
+
+struct ProfileRec {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct fastecc_ctx {
+    int device = 0;
+    uint64_t N = 0;   // k
+    int n = 0;        // log2 k
+    uint64_t S = 0;   // words per block
+    size_t stripe_bytes = 0;
+
+    // device tables (Montgomery form, see gf.hpp)
+    uint32_t* tw_fwd = nullptr;  // w_N^e,  e < max(N/2,1)
+    uint32_t* tw_inv = nullptr;  // w_N^-e
+    uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
+    uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
+    uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
+    void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
+    size_t pinned_bytes = 0;
+
+    int rmax = 4;  // levels per register pass
+    int vec = 4;   // words per lane
+    std::vector<Pass> encode_plan, ntt_plan;
+    std::string plan_text;
+
+    bool profiling = false;
+    std::vector<ProfileRec> prof;
+    size_t prof_used = 0;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t e_ = (expr);                    \
+        if (e_ != hipSuccess) {                    \
+            (void)hipGetLastError();               \
+            return e_ == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE; \
+        }                                          \
+    } while (0)
+
+int ilog2_exact(uint64_t v)
+{
+    int l = 0;
+    while ((1ull << l) < v) l++;
+    return ((1ull << l) == v) ? l : -1;
+}
+
+uint32_t bitrev_host(uint32_t v, int bits)
+{
+    uint32_t r = 0;
+    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (bits - 1 - b);
+    return r;
+}
+
+// Split `bits` levels into ceil(bits/rmax) passes of near-equal size, largest first.
+std::vector<int> split_levels(int bits, int rmax)
+{
+    std::vector<int> r;
+    if (bits <= 0) return r;
+    const int q = (bits + rmax - 1) / rmax;
+    for (int i = 0; i < q; i++) r.push_back(bits / q + (i < bits % q ? 1 : 0));
+    return r;
+}
+
+void build_plans(fastecc_ctx* c)
+{
+    const int n = c->n;
+    c->encode_plan.clear();
+    c->ntt_plan.clear();
+    // encode: DIF over the high levels, MID over the low r_mid levels, DIT back up (kernels.hip header)
+    const int r_mid = std::min(n, c->rmax);
+    const std::vector<int> outer = split_levels(n - r_mid, c->rmax);
+    int s = n;
+    for (int r : outer) {
+        s -= r;
+        c->encode_plan.push_back({MODE_DIF, r, s});
+    }
+    c->encode_plan.push_back({MODE_MID, r_mid, 0});
+    s = r_mid;
+    for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
+        c->encode_plan.push_back({MODE_DIT, *it, s});
+        s += *it;
+    }
+    // stand-alone transform: DIF over all levels, then the block bit-reversal
+    s = n;
+    for (int r : split_levels(n, c->rmax)) {
+        s -= r;
+        c->ntt_plan.push_back({MODE_DIF, r, s});
+    }
+    char buf[64];
+    c->plan_text.clear();
+    for (const Pass& p : c->encode_plan) {
+        snprintf(buf, sizeof buf, "%s%s%d@%d", c->plan_text.empty() ? "" : ",",
+                 p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
+        c->plan_text += buf;
+    }
+    snprintf(buf, sizeof buf, " v%d", c->vec);
+    c->plan_text += buf;
+}
+
+// widest lane vector that the block size and the pointers allow
+int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
+{
+    int v = c->vec;
+    const uintptr_t bits = (uintptr_t)a | (uintptr_t)b;
+    while (v > 1 && ((c->S % v) != 0 || (bits % (4u * v)) != 0)) v >>= 1;
+    return v;
+}
+
+const char* pass_name(const Pass& p, int vec, char* buf, size_t cap)
+{
+    snprintf(buf, cap, "%s%dv%d", p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, vec);
+    return buf;
+}
+
+struct ProfScope {
+    fastecc_ctx* c;
+    hipStream_t st;
+    ProfileRec* rec = nullptr;
+    ProfScope(fastecc_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_)
+    {
+        if (!c->profiling) return;
+        if (c->prof_used == c->prof.size()) {
+            ProfileRec r;
+            if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+            c->prof.push_back(r);
+        }
+        rec = &c->prof[c->prof_used++];
+        rec->name = name;
+        (void)hipEventRecord(rec->start, st);
+    }
+    ~ProfScope()
+    {
+        if (rec) (void)hipEventRecord(rec->stop, st);
+    }
+};
+
+int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in, uint32_t* out, const uint32_t* tw_dif,
+               const uint32_t* tw_dit, hipStream_t st)
+{
+    const int vec = pick_vec(c, in, out);
+    const uint32_t* src = in;
+    char name[32];
+    for (const Pass& p : plan) {
+        PassArgs a{};
+        a.in = src;
+        a.out = out;
+        a.tw_dif = tw_dif;
+        a.tw_dit = tw_dit;
+        a.dscale = c->dscale;
+        a.S = (uint32_t)c->S;
+        a.n = c->n;
+        a.s = p.s;
+        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
+        HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
+        src = out;  // after the first pass everything is in place on `out`
+    }
+    return FASTECC_OK;
+}
+
+int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
+    return run_passes(c, c->encode_plan, data, parity, c->tw_inv, c->tw_fwd, st);
+}
+
+int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
+{
+    const uint32_t* tw = inverse ? c->tw_inv : c->tw_fwd;
+    int rc = run_passes(c, c->ntt_plan, data, data, tw, tw, st);
+    if (rc != FASTECC_OK) return rc;
+    if (c->n >= 2) {
+        ProfScope ps(c, st, "bitrev_rows");
+        HIP_TRY(launch_bitrev_rows(data, (uint32_t)c->S, c->n, pick_vec(c, data, data), st));
+    }
+    return FASTECC_OK;
+}
+
+int ensure_dbuf(fastecc_ctx* c)
+{
+    if (c->dbuf) return FASTECC_OK;
+    HIP_TRY(hipMalloc((void**)&c->dbuf, c->stripe_bytes));
+    return FASTECC_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* fastecc_strerror(int code)
+{
+    switch (code) {
+        case FASTECC_OK: return "ok";
+        case FASTECC_E_INVAL: return "invalid argument";
+        case FASTECC_E_NOMEM: return "out of memory";
+        case FASTECC_E_DEVICE: return "HIP device or runtime error";
+        case FASTECC_E_UNSUPPORTED: return "unsupported field or size";
+        default: return "unknown error";
+    }
+}
+
+int fastecc_version(void) { return FASTECC_VERSION; }
+
+uint32_t fastecc_gf_mul(uint32_t x, uint32_t y) { return gf::h_mul(x % gf::P, y % gf::P); }
+uint32_t fastecc_gf_pow(uint32_t x, uint32_t e) { return gf::h_pow(x % gf::P, e); }
+uint32_t fastecc_gf_root(uint32_t order) { return (order == 0 || ((gf::P - 1u) % order) != 0) ? 0u : gf::h_root(order); }
+uint32_t fastecc_gf_inv(uint32_t x) { return gf::h_inv(x % gf::P); }
+
+int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device)
+{
+    if (!out) return FASTECC_E_INVAL;
+    *out = nullptr;
+    if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
+    if (k < 2 || n != 2 * k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
+    const int lg = ilog2_exact(k);
+    if (lg < 0) return FASTECC_E_INVAL;
+    if (lg > 19) return FASTECC_E_UNSUPPORTED;  // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51)
+    if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return FASTECC_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) return FASTECC_E_INVAL;
+
+    fastecc_ctx* c = new (std::nothrow) fastecc_ctx();
+    if (!c) return FASTECC_E_NOMEM;
+    c->device = device;
+    c->N = k;
+    c->n = lg;
+    c->S = block_bytes / 4;
+    c->stripe_bytes = (size_t)k * block_bytes;
+    build_plans(c);
+
+    DeviceGuard dg(device);
+    if (!dg.ok) {
+        delete c;
+        return FASTECC_E_DEVICE;
+    }
+
+    // ---- twiddle tables (replaces ntt.cpp:397-402 and the GF_Pow calls of RS.cpp:54 / ntt.cpp:422) ----
+    const uint64_t N = k;
+    const uint64_t half = std::max<uint64_t>(N / 2, 1);
+    std::vector<uint32_t> fwd(half), inv(half), dsc(N);
+    const uint32_t wN = gf::h_root((uint32_t)N), wNi = gf::h_inv(wN);
+    uint32_t a = 1, b = 1;
+    for (uint64_t e = 0; e < half; e++) {
+        fwd[e] = gf::h_to_mont(a);
+        inv[e] = gf::h_to_mont(b);
+        a = gf::h_mul(a, wN);
+        b = gf::h_mul(b, wNi);
+    }
+    const uint32_t w2N = gf::h_root((uint32_t)(2 * N)), invN = gf::h_inv((uint32_t)N);
+    uint32_t d = invN;  // w_2N^i / N
+    for (uint64_t i = 0; i < N; i++) {
+        dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);
+        d = gf::h_mul(d, w2N);
+    }
+    int rc = FASTECC_OK;
+    auto upload = [&](uint32_t** dst, const std::vector<uint32_t>& src) {
+        if (rc != FASTECC_OK) return;
+        hipError_t e = hipMalloc((void**)dst, src.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc = e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+        }
+    };
+    upload(&c->tw_fwd, fwd);
+    upload(&c->tw_inv, inv);
+    upload(&c->dscale, dsc);
+    if (rc == FASTECC_OK && hipMalloc((void**)&c->factor, N * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        rc = FASTECC_E_NOMEM;
+    }
+    if (rc != FASTECC_OK) {
+        fastecc_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return FASTECC_OK;
+}
+
+void fastecc_destroy(fastecc_ctx* c)
+{
+    if (!c) return;
+    DeviceGuard dg(c->device);
+    for (ProfileRec& r : c->prof) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    if (c->tw_fwd) (void)hipFree(c->tw_fwd);
+    if (c->tw_inv) (void)hipFree(c->tw_inv);
+    if (c->dscale) (void)hipFree(c->dscale);
+    if (c->factor) (void)hipFree(c->factor);
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+}
+
+int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind, void* stream)
+{
+    if (!c || !data || !parity) return FASTECC_E_INVAL;
+    if (((uintptr_t)data | (uintptr_t)parity) & 3u) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
+    if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
+    int rc = ensure_dbuf(c);
+    if (rc != FASTECC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+    rc = encode_device(c, c->dbuf, c->dbuf, st);
+    if (rc != FASTECC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
+
+int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
+{
+    if (!c || !blocks) return FASTECC_E_INVAL;
+    for (uint64_t i = 0; i < c->N; i++)
+        if (!blocks[i] || ((uintptr_t)blocks[i] & 3u)) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    int rc = ensure_dbuf(c);
+    if (rc != FASTECC_OK) return rc;
+    const size_t bb = (size_t)c->S * 4;
+    // bounce through a pinned buffer in chunks of whole blocks (<= 64 MiB)
+    const size_t per_chunk = std::max<size_t>(1, std::min<size_t>(c->N, (64u << 20) / bb));
+    if (c->pinned_bytes < per_chunk * bb) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->pinned, per_chunk * bb, hipHostMallocDefault));
+        c->pinned_bytes = per_chunk * bb;
+    }
+    char* bounce = (char*)c->pinned;
+    for (uint64_t i0 = 0; i0 < c->N; i0 += per_chunk) {
+        const size_t cnt = std::min<uint64_t>(per_chunk, c->N - i0);
+        for (size_t i = 0; i < cnt; i++) memcpy(bounce + i * bb, blocks[i0 + i], bb);
+        HIP_TRY(hipMemcpy((char*)c->dbuf + i0 * bb, bounce, cnt * bb, hipMemcpyHostToDevice));
+    }
+    rc = encode_device(c, c->dbuf, c->dbuf, nullptr);
+    if (rc != FASTECC_OK) return rc;
+    for (uint64_t i0 = 0; i0 < c->N; i0 += per_chunk) {
+        const size_t cnt = std::min<uint64_t>(per_chunk, c->N - i0);
+        HIP_TRY(hipMemcpy(bounce, (char*)c->dbuf + i0 * bb, cnt * bb, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) memcpy(blocks[i0 + i], bounce + i * bb, bb);
+    }
+    return FASTECC_OK;
+}
+
+int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* stream)
+{
+    if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    if (mem_kind == FASTECC_MEM_DEVICE) return ntt_device(c, (uint32_t*)data, inverse != 0, st);
+    if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
+    int rc = ensure_dbuf(c);
+    if (rc != FASTECC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+    rc = ntt_device(c, c->dbuf, inverse != 0, st);
+    if (rc != FASTECC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
+
+int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t base, int mem_kind, void* stream)
+{
+    if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint32_t> f(c->N);
+    uint32_t cur = scale;
+    for (uint64_t i = 0; i < c->N; i++) {
+        f[i] = gf::h_to_mont(cur);
+        cur = gf::h_mul(cur, base);
+    }
+    // the factor table is consumed by a kernel on `st`; a synchronous copy keeps the host vector's lifetime simple
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(c->factor, f.data(), c->N * 4, hipMemcpyHostToDevice));
+    uint32_t* dev = (uint32_t*)data;
+    if (mem_kind == FASTECC_MEM_HOST) {
+        int rc = ensure_dbuf(c);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        dev = c->dbuf;
+    } else if (mem_kind != FASTECC_MEM_DEVICE) {
+        return FASTECC_E_INVAL;
+    }
+    {
+        ProfScope ps(c, st, "scale_rows");
+        HIP_TRY(launch_scale_rows(dev, c->factor, (uint32_t)c->S, c->N, pick_vec(c, dev, dev), st));
+    }
+    if (mem_kind == FASTECC_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return FASTECC_OK;
+}
+
+int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, void* stream)
+{
+    if (!c || !x || !y || !out || op < 0 || op > 3) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    ProfScope ps(c, (hipStream_t)stream, "gf_binary");
+    HIP_TRY(launch_gf_binary(op, x, y, out, count, (hipStream_t)stream));
+    return FASTECC_OK;
+}
+
+int fastecc_profile_enable(fastecc_ctx* c, int on)
+{
+    if (!c) return FASTECC_E_INVAL;
+    c->profiling = on != 0;
+    return FASTECC_OK;
+}
+
+int fastecc_profile_reset(fastecc_ctx* c)
+{
+    if (!c) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    (void)hipDeviceSynchronize();
+    c->prof_used = 0;
+    return FASTECC_OK;
+}
+
+int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, int cap)
+{
+    if (!c || !names || !ms || !launches || cap <= 0) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    // names returned point into the context's records (valid until the next reset/launch)
+    std::map<std::string, int> slot;
+    int used = 0;
+    for (size_t i = 0; i < c->prof_used; i++) {
+        ProfileRec& r = c->prof[i];
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        auto it = slot.find(r.name);
+        int idx;
+        if (it == slot.end()) {
+            if (used == cap) continue;
+            idx = used++;
+            slot[r.name] = idx;
+            names[idx] = r.name.c_str();
+            ms[idx] = 0.0;
+            launches[idx] = 0;
+        } else {
+            idx = it->second;
+        }
+        ms[idx] += t;
+        launches[idx] += 1;
+    }
+    return used;
+}
+
+const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str() : ""; }
+
+int fastecc_set_plan(fastecc_ctx* c, int plan)
+{
+    if (!c) return FASTECC_E_INVAL;
+    int rmax = 4, vec = 4;
+    if (plan != 0) {
+        rmax = plan / 10;
+        vec = plan % 10;
+    }
+    if (rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
+    c->rmax = rmax;
+    c->vec = vec;
+    build_plans(c);
+    return FASTECC_OK;
+}
+
+}  // extern "C"

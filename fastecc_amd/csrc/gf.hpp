@@ -1,0 +1,83 @@
+// gf.hpp — GF(p), p = 0xFFF00001 = 2^32 - 2^20 + 1, for gfx950 device code and the host table builder.
+//
+// Semantics follow the reference (GF(p).cpp:37-48 add/sub, 110-127 mul, 254-297 pow/root/inv): every
+// function returns the canonical representative in [0,p).  The algorithms are our own:
+//
+//   * Twiddle multiplies use a Montgomery step with R = 2^32.  A constant w is stored as
+//     w~ = w * 2^32 mod p, and mont(x, w~) = x * w~ / 2^32 = x * w (mod p): the DATA never leaves the
+//     ordinary representation, so results are bit-identical to the reference's Barrett form.
+//     Because p = 1 - 2^20 (mod 2^32), p^-1 = 1 + 2^20 (mod 2^32), so the Montgomery quotient digit
+//     is one shift-add (v_lshl_add_u32) instead of a multiply; the reduction is
+//         t = hi(x*w~) - hi(m*p),  m = lo(x*w~) * (1 + 2^20),   t in (-p, p)  ->  +p if negative.
+//     (The low words of x*w~ and m*p are equal by construction, so there is no borrow between words.)
+//   * p > 2^31, so no lazy (unreduced) intermediates fit in 32 bits: add/sub normalise every time,
+//     exactly like GF(p).cpp:37-48.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GF_HD __host__ __device__ __forceinline__
+#define GF_D __device__ __forceinline__
+#else
+#define GF_HD inline
+#endif
+
+namespace gf {
+
+constexpr uint32_t P = 0xFFF00001u;
+constexpr uint32_t GENERATOR = 19u;         // GF(p).cpp:272
+constexpr uint32_t MONT_ONE = 0x000FFFFFu;  // 2^32 mod p = 2^20 - 1
+
+// ---- host-side exact arithmetic (table generation; not performance relevant) ----
+inline uint32_t h_mul(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * y) % P); }
+inline uint32_t h_pow(uint32_t x, uint64_t e)
+{
+    uint32_t r = 1;
+    for (; e; e >>= 1) {
+        if (e & 1) r = h_mul(r, x);
+        x = h_mul(x, x);
+    }
+    return r;
+}
+inline uint32_t h_root(uint32_t order) { return h_pow(GENERATOR, (P - 1u) / order); }  // GF(p).cpp:268-276
+inline uint32_t h_inv(uint32_t x) { return h_pow(x, P - 2u); }                         // GF(p).cpp:293-297
+inline uint32_t h_to_mont(uint32_t w) { return (uint32_t)((((uint64_t)w) << 32) % P); }
+
+#if defined(__HIPCC__)
+// ---- device arithmetic ----
+GF_D uint32_t sub(uint32_t x, uint32_t y)
+{
+    uint32_t d = x - y;
+    return (x < y) ? d + P : d;
+}
+
+GF_D uint32_t add(uint32_t x, uint32_t y)
+{
+    return sub(x, P - y);  // y == 0 -> x - p wraps, +p restores x
+}
+
+// x * w mod p for a constant held in Montgomery form (wm = w * 2^32 mod p).  x may be any uint32.
+GF_D uint32_t mul_mont(uint32_t x, uint32_t wm)
+{
+    const uint64_t t = (uint64_t)x * wm;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    const uint32_t m = lo + (lo << 20);  // lo * p^-1 mod 2^32
+    const uint32_t q = __umulhi(m, P);
+    const uint32_t r = hi - q;
+    return (hi < q) ? r + P : r;
+}
+
+// General product of two canonical values, Barrett form with the 32-bit reciprocal 0x001000FF
+// (same estimate as GF(p).cpp:110-127; used by the element-wise test kernel and to lift values into
+// Montgomery form on the device).
+GF_D uint32_t mul(uint32_t x, uint32_t y)
+{
+    uint64_t t = (uint64_t)x * y;
+    const uint64_t q = (t + (t >> 32) * 0x001000FFull) >> 32;
+    t -= q * P;
+    return (uint32_t)(t >= P ? t - P : t);
+}
+#endif
+
+}  // namespace gf

@@ -1,0 +1,319 @@
+// kernels.hip — gfx950 kernels of the NTT Reed-Solomon encode path.
+//
+// Data: a stripe is X[N][S] uint32, block-major (RS.cpp:28-33).  The transform runs down the block
+// index; the S word columns are independent (ntt.cpp:348-350).  Mapping used by every kernel here:
+//
+//      lane  <->  V adjacent words of one block          (coalesced: a wave reads 64*V*4 contiguous bytes)
+//      wave  <->  one column chunk of R = 2^r blocks     (the butterfly operands live in VGPRs)
+//      twiddles are the same for all 64 lanes            (fetched with scalar loads into SGPRs)
+//
+// A "pass" executes r consecutive radix-2 levels entirely in registers: the wave loads its R block
+// segments, runs r butterfly levels, stores them back.  Three flavours:
+//
+//   DIF  decimation in frequency, strides 2^(s+r-1) .. 2^s  : (a,b) -> (a+b, (a-b)*w)       natural -> bit-reversed
+//   DIT  decimation in time,      strides 2^s .. 2^(s+r-1)  : (a,b) -> (a+b*w, a-b*w)       bit-reversed -> natural
+//   MID  s = 0: DIF levels, multiply block p by D[bitrev(p)] (D_i = w_2N^i/N, RS.cpp:51-59), DIT levels
+//
+// The reference's radix-2 butterfly is ntt.cpp:16-22 / 259-281; its bit-reversal (ntt.cpp:292-309) and
+// pointer transposes (ntt.cpp:322-341) become index arithmetic: encode = DIF(inverse roots) over all
+// levels, D, DIT(forward roots) over all levels, and no permutation pass exists at all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf.hpp"
+#include "kernels.hpp"
+
+namespace fastecc {
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = uint32_t; };
+template <> struct VecT<2> { using type = uint2; };
+template <> struct VecT<4> { using type = uint4; };
+
+template <int V> __device__ __forceinline__ void load_vec(uint32_t (&dst)[V], const uint32_t* p)
+{
+    if constexpr (V == 1) {
+        dst[0] = *p;
+    } else if constexpr (V == 2) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        dst[0] = t.x; dst[1] = t.y;
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    }
+}
+
+template <int V> __device__ __forceinline__ void store_vec(uint32_t* p, const uint32_t (&src)[V])
+{
+    if constexpr (V == 1) {
+        *p = src[0];
+    } else if constexpr (V == 2) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(src[0], src[1]);
+    } else {
+        *reinterpret_cast<uint4*>(p) = make_uint4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits)
+{
+    return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+// r DIF levels on x[R][V].  Level t pairs (j, j + 2^t); the twiddle exponent (in units of w_N) of the
+// butterfly at block p is (p mod h) * N/(2h), h = 2^(s+t), p mod h = (j mod 2^t)*2^s + lo.
+template <int LOGR, int V, bool LO_ZERO>
+__device__ __forceinline__ void dif_levels(uint32_t (&x)[1 << LOGR][V], const uint32_t* __restrict__ tw, uint32_t lo, int s,
+                                           int n)
+{
+    constexpr int R = 1 << LOGR;
+#pragma unroll
+    for (int t = LOGR - 1; t >= 0; --t) {
+        const int half = 1 << t;
+#pragma unroll
+        for (int m = 0; m < half; ++m) {
+            const bool unit = LO_ZERO && m == 0;  // exponent 0: w = 1 (ntt.cpp:259-267 special-cases it too)
+            uint32_t w = 0;
+            if (!unit) w = tw[(((uint32_t)m << s) + lo) << (n - 1 - s - t)];
+#pragma unroll
+            for (int j0 = 0; j0 < R; j0 += 2 * half) {
+                const int ja = j0 + m, jb = ja + half;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const uint32_t a = x[ja][v], b = x[jb][v];
+                    x[ja][v] = gf::add(a, b);
+                    const uint32_t d = gf::sub(a, b);
+                    x[jb][v] = unit ? d : gf::mul_mont(d, w);
+                }
+            }
+        }
+    }
+}
+
+template <int LOGR, int V, bool LO_ZERO>
+__device__ __forceinline__ void dit_levels(uint32_t (&x)[1 << LOGR][V], const uint32_t* __restrict__ tw, uint32_t lo, int s,
+                                           int n)
+{
+    constexpr int R = 1 << LOGR;
+#pragma unroll
+    for (int t = 0; t < LOGR; ++t) {
+        const int half = 1 << t;
+#pragma unroll
+        for (int m = 0; m < half; ++m) {
+            const bool unit = LO_ZERO && m == 0;
+            uint32_t w = 0;
+            if (!unit) w = tw[(((uint32_t)m << s) + lo) << (n - 1 - s - t)];
+#pragma unroll
+            for (int j0 = 0; j0 < R; j0 += 2 * half) {
+                const int ja = j0 + m, jb = ja + half;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const uint32_t a = x[ja][v];
+                    const uint32_t b = unit ? x[jb][v] : gf::mul_mont(x[jb][v], w);
+                    x[ja][v] = gf::add(a, b);
+                    x[jb][v] = gf::sub(a, b);
+                }
+            }
+        }
+    }
+}
+
+// One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
+template <int LOGR, int V, int MODE>
+__global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
+{
+    constexpr int R = 1 << LOGR;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= a.items) return;  // wave-uniform
+    const uint32_t cc = (uint32_t)(item % a.col_chunks);
+    const uint32_t g = (uint32_t)(item / a.col_chunks);
+    const uint32_t col = (cc * 64u + lane) * V;
+    const bool live = col < a.S;  // S % V == 0 is guaranteed by the launcher
+
+    const int s = MODE == MODE_MID ? 0 : a.s;
+    const uint32_t lo = g & ((1u << s) - 1u);
+    const uint32_t hi = g >> s;
+    const uint32_t base = (hi << (s + LOGR)) + lo;  // first block of this group
+
+    uint32_t x[R][V];
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t* row = a.in + (size_t)(base + ((uint32_t)j << s)) * a.S;
+            load_vec<V>(x[j], row + col);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int v = 0; v < V; ++v) x[j][v] = 0;
+    }
+
+    if constexpr (MODE == MODE_DIF) {
+        if (a.s == 0) dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0, a.n);
+        else          dif_levels<LOGR, V, false>(x, a.tw_dif, lo, s, a.n);
+    } else if constexpr (MODE == MODE_DIT) {
+        if (a.s == 0) dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0, a.n);
+        else          dit_levels<LOGR, V, false>(x, a.tw_dit, lo, s, a.n);
+    } else {
+        dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0, a.n);
+        // position p = hi*R + j holds coefficient bitrev_n(p); a.dscale is stored in position order
+        const uint32_t* __restrict__ d = a.dscale + (size_t)hi * R;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t f = d[j];
+#pragma unroll
+            for (int v = 0; v < V; ++v) x[j][v] = gf::mul_mont(x[j][v], f);
+        }
+        dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0, a.n);
+    }
+
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            uint32_t* row = a.out + (size_t)(base + ((uint32_t)j << s)) * a.S;
+            store_vec<V>(row + col, x[j]);
+        }
+    }
+}
+
+// Swap block j with block bitrev(j) (the data movement the reference avoids by permuting pointers,
+// ntt.cpp:292-309; only the stand-alone fastecc_ntt needs it).
+template <int V>
+__global__ __launch_bounds__(256) void bitrev_rows_kernel(uint32_t* data, uint32_t S, int n, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t j = (uint32_t)(item / col_chunks);
+    const uint32_t rj = bitrev(j, n);
+    if (rj <= j) return;
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t* pa = data + (size_t)j * S + col;
+    uint32_t* pb = data + (size_t)rj * S + col;
+    uint32_t va[V], vb[V];
+    load_vec<V>(va, pa);
+    load_vec<V>(vb, pb);
+    store_vec<V>(pa, vb);
+    store_vec<V>(pb, va);
+}
+
+// block i *= factor[i] (Montgomery-form factors) — RS.cpp:52-59 / ntt.cpp:421-431 as a stand-alone kernel.
+template <int V>
+__global__ __launch_bounds__(256) void scale_rows_kernel(uint32_t* data, const uint32_t* __restrict__ factor, uint32_t S,
+                                                         uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t i = (uint32_t)(item / col_chunks);
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    const uint32_t f = factor[i];
+    uint32_t* p = data + (size_t)i * S + col;
+    uint32_t x[V];
+    load_vec<V>(x, p);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
+    store_vec<V>(p, x);
+}
+
+__global__ __launch_bounds__(256) void gf_binary_kernel(int op, const uint32_t* __restrict__ x, const uint32_t* __restrict__ y,
+                                                        uint32_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = x[i], b = y[i];
+        uint32_t r;
+        if (op == 0) r = gf::add(a, b);
+        else if (op == 1) r = gf::sub(a, b);
+        else if (op == 2) r = gf::mul(a, b);
+        else r = gf::mul_mont(a, gf::mul(b, gf::MONT_ONE));  // op 3: the Montgomery path, b lifted on the fly
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+
+template <int LOGR, int V>
+static hipError_t launch_pass_rv(int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (mode) {
+        case MODE_DIF: hipLaunchKernelGGL((ntt_pass_kernel<LOGR, V, MODE_DIF>), grid, dim3(256), 0, st, a); break;
+        case MODE_DIT: hipLaunchKernelGGL((ntt_pass_kernel<LOGR, V, MODE_DIT>), grid, dim3(256), 0, st, a); break;
+        default:       hipLaunchKernelGGL((ntt_pass_kernel<LOGR, V, MODE_MID>), grid, dim3(256), 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+template <int V>
+static hipError_t launch_pass_v(int logr, int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (logr) {
+        case 1: return launch_pass_rv<1, V>(mode, a, grid, st);
+        case 2: return launch_pass_rv<2, V>(mode, a, grid, st);
+        case 3: return launch_pass_rv<3, V>(mode, a, grid, st);
+        case 4: return launch_pass_rv<4, V>(mode, a, grid, st);
+        case 5: return launch_pass_rv<5, V>(mode, a, grid, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st)
+{
+    a.col_chunks = (a.S + 64u * vec - 1u) / (64u * vec);
+    a.items = (uint64_t)a.col_chunks << (a.n - logr);
+    const uint64_t blocks = (a.items + 3u) / 4u;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    switch (vec) {
+        case 1: return launch_pass_v<1>(logr, mode, a, grid, st);
+        case 2: return launch_pass_v<2>(logr, mode, a, grid, st);
+        case 4: return launch_pass_v<4>(logr, mode, a, grid, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st)
+{
+    const uint32_t col_chunks = (S + 64u * vec - 1u) / (64u * vec);
+    const uint64_t items = (uint64_t)col_chunks << n;
+    const dim3 grid((unsigned)((items + 3u) / 4u));
+    switch (vec) {
+        case 1: hipLaunchKernelGGL((bitrev_rows_kernel<1>), grid, dim3(256), 0, st, data, S, n, col_chunks, items); break;
+        case 2: hipLaunchKernelGGL((bitrev_rows_kernel<2>), grid, dim3(256), 0, st, data, S, n, col_chunks, items); break;
+        default: hipLaunchKernelGGL((bitrev_rows_kernel<4>), grid, dim3(256), 0, st, data, S, n, col_chunks, items); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st)
+{
+    const uint32_t col_chunks = (S + 64u * vec - 1u) / (64u * vec);
+    const uint64_t items = (uint64_t)col_chunks * rows;
+    const dim3 grid((unsigned)((items + 3u) / 4u));
+    switch (vec) {
+        case 1: hipLaunchKernelGGL((scale_rows_kernel<1>), grid, dim3(256), 0, st, data, factor, S, col_chunks, items); break;
+        case 2: hipLaunchKernelGGL((scale_rows_kernel<2>), grid, dim3(256), 0, st, data, factor, S, col_chunks, items); break;
+        default: hipLaunchKernelGGL((scale_rows_kernel<4>), grid, dim3(256), 0, st, data, factor, S, col_chunks, items); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, hipStream_t st)
+{
+    uint64_t blocks = (count + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(gf_binary_kernel, dim3((unsigned)blocks), dim3(256), 0, st, op, x, y, out, count);
+    return hipGetLastError();
+}
+
+}  // namespace fastecc

@@ -1,0 +1,29 @@
+// kernels.hpp — launcher interface between the C-ABI host code (api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fastecc {
+
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2 };
+
+// Arguments of one register pass (kernels.hip: ntt_pass_kernel).
+struct PassArgs {
+    const uint32_t* in;      // stripe X[N][S] read by this pass
+    uint32_t* out;           // stripe written (may equal `in`)
+    const uint32_t* tw_dif;  // Montgomery-form roots for DIF levels: tw[e] = w^e * 2^32 mod p, e < N/2
+    const uint32_t* tw_dit;  // same for DIT levels
+    const uint32_t* dscale;  // MID only: D[bitrev_n(pos)] in Montgomery form, indexed by position
+    uint32_t S;              // words per block
+    int n;                   // log2 N
+    int s;                   // log2 of the smallest stride of this pass
+    uint32_t col_chunks;     // filled by the launcher
+    uint64_t items;          // filled by the launcher
+};
+
+hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
+hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
+hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);
+hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, hipStream_t st);
+
+}  // namespace fastecc

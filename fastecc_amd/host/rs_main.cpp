@@ -1,0 +1,105 @@
+// rs_main.cpp — `rs`-compatible host driver over the C ABI (include/fastecc.h).
+//
+// Keeps the command line of the reference benchmark (RS.cpp:71-87, RS.md:4):
+//     rs_hip [.][log2(N) [block_bytes]]          defaults: N = 2^19, 2052-byte blocks, "." = quiet
+// fills the stripe with the reference's i % p pattern (RS.cpp:28-29), encodes it on the GPU through
+// fastecc_encode, and reports time / MiB/s in the reference's convention (data + parity bytes per
+// second, RS.cpp:38, wall_clock_timer.h:91).  Unlike the reference it also prints the parity checksum
+// (main.cpp:202-212 formula) so a run can be compared with SURVEY.md Appendix B.
+//
+// The host stays C++ and knows nothing about HIP kernels: everything goes through the C ABI.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fastecc.h"
+
+static uint32_t rolling_hash(const uint32_t* w, size_t count)
+{
+    uint32_t h = 314159253u;
+    for (size_t i = 0; i < count; i++) h = (h + w[i]) * 123456791u + (h >> 17);
+    return h;
+}
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv)
+{
+    bool verbose = true;
+    int logn = 19;
+    size_t block_bytes = 2052;
+    int arg = 1;
+    if (argc > arg && argv[arg][0] == '.') {
+        verbose = false;
+        if (argv[arg][1] == 0) arg++;
+        else argv[arg]++;
+    }
+    if (argc > arg) logn = atoi(argv[arg++]);
+    if (argc > arg) block_bytes = (size_t)atoll(argv[arg++]);
+    const uint64_t N = 1ull << logn;
+    const size_t words = block_bytes / 4;  // RS.cpp:86 truncates the same way
+    const size_t total = N * words;
+
+    fastecc_ctx* ctx = nullptr;
+    int rc = fastecc_create(&ctx, 2 * N, N, words * 4, FASTECC_FIELD_GF_FFF00001, 0);
+    if (rc != FASTECC_OK) {
+        fprintf(stderr, "fastecc_create: %s\n", fastecc_strerror(rc));
+        return 1;
+    }
+
+    std::vector<uint32_t> host(total);
+    for (size_t i = 0; i < total; i++) host[i] = (uint32_t)(i % 0xFFF00001ull);
+    if (verbose) printf("Allocated %.0lf MiB\n", total * 4 / 1048576.0);
+
+    void* dev = nullptr;
+    if (hipMalloc(&dev, total * 4) != hipSuccess) {
+        fprintf(stderr, "Can't alloc %.0lf MiB of device memory!\n", total * 4 / 1048576.0);
+        return 1;
+    }
+    const double t_h2d0 = now_ms();
+    hipMemcpy(dev, host.data(), total * 4, hipMemcpyHostToDevice);
+    const double t_h2d1 = now_ms();
+
+    // warm-up on a scratch copy is not possible in place; time the first real call like the reference does
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, nullptr);
+    rc = fastecc_encode(ctx, dev, dev, FASTECC_MEM_DEVICE, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    if (rc != FASTECC_OK) {
+        fprintf(stderr, "fastecc_encode: %s\n", fastecc_strerror(rc));
+        return 1;
+    }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+
+    const double t_d2h0 = now_ms();
+    hipMemcpy(host.data(), dev, total * 4, hipMemcpyDeviceToHost);
+    const double t_d2h1 = now_ms();
+
+    const double bytes = 2.0 * N * words * 4;
+    printf("Reed-Solomon encoding (2^%.0lf source blocks => 2^%.0lf ECC blocks, %.0lf bytes each): %.3lf ms = %.0lf MiB/s"
+           "  [MI355X, HBM-resident; plan %s]\n",
+           std::log2((double)N), std::log2((double)N), words * 4.0, ms, bytes / ms * 1000 / (1 << 20),
+           fastecc_plan_string(ctx));
+    if (verbose) {
+        const double e2e = (t_h2d1 - t_h2d0) + ms + (t_d2h1 - t_d2h0);
+        printf("  with PCIe copies: %.0lf ms = %.0lf MiB/s (h2d %.0lf ms, d2h %.0lf ms)\n", e2e, bytes / e2e * 1000 / (1 << 20),
+               t_h2d1 - t_h2d0, t_d2h1 - t_d2h0);
+        printf("  parity checksum: %u\n", rolling_hash(host.data(), total));
+    }
+    hipFree(dev);
+    fastecc_destroy(ctx);
+    return 0;
+}

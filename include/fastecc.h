@@ -1,0 +1,130 @@
+/*
+ * fastecc.h — C ABI of libfastecc_hip.so: the MI355X (gfx950) NTT Reed-Solomon encode path.
+ *
+ * This is the drop-in boundary for FastECC's encode hot path.  The reference has no ABI: the path is
+ * C++ templates #included into RS.cpp.  Each entry point below names the reference code it replaces
+ * (file:line in Bulat-Ziganshin/FastECC); INTEGRATION.md shows the host-side binding.
+ *
+ * Conventions
+ *   - Field: GF(p), p = 0xFFF00001 (RS.cpp:86).  Words are native little-endian uint32, every input
+ *     word must be < p (README.md:160-162); every output word is the canonical value in [0,p).
+ *   - Code: (n,k) = (2N,N), N = 2^m, 1 <= m <= 19 (RS.cpp:36,82; GF.md:20).  A "block" is
+ *     block_bytes/4 consecutive words; a stripe is N blocks back to back (block-major), exactly the
+ *     layout RS.cpp:28-33 builds.  parity block j = f(w_2N^(2j+1)) where f interpolates the data
+ *     blocks at the powers of w_N = 19^((p-1)/N)   (RS.cpp:40-63).
+ *   - All functions return FASTECC_OK (0) or a negative FASTECC_E_* code; no exceptions cross the
+ *     ABI and nothing is printed.  The reference returns void and has no error path (RS.cpp:26 prints
+ *     and returns on allocation failure); preconditions it leaves implicit are checked here.
+ *   - A context is bound to one HIP device and one (n,k,block_bytes).  Use one context per host
+ *     thread; distinct contexts are independent.
+ *   - There is NO CPU fallback: without a usable HIP device fastecc_create fails with
+ *     FASTECC_E_DEVICE.
+ */
+#ifndef FASTECC_H
+#define FASTECC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTECC_VERSION 100 /* 0.1.0 */
+
+enum {
+    FASTECC_OK = 0,
+    FASTECC_E_INVAL = -1,       /* bad argument (n != 2k, k not a power of two, block_bytes % 4, null pointer, ...) */
+    FASTECC_E_NOMEM = -2,       /* host or device allocation failed */
+    FASTECC_E_DEVICE = -3,      /* no HIP device / HIP runtime error */
+    FASTECC_E_UNSUPPORTED = -4  /* field or size outside what GF(0xFFF00001) admits (k > 2^19) */
+};
+
+enum { FASTECC_FIELD_GF_FFF00001 = 0 };               /* the only field RS.cpp instantiates (RS.cpp:86) */
+enum { FASTECC_MEM_HOST = 0, FASTECC_MEM_DEVICE = 1 }; /* where `data`/`parity` pointers live */
+
+typedef struct fastecc_ctx fastecc_ctx;
+
+/* Human-readable text for an error code. */
+const char *fastecc_strerror(int code);
+int fastecc_version(void);
+
+/*
+ * Create an encoder for (n,k) with `block_bytes`-byte blocks on HIP device `device`.
+ * Replaces the set-up part of EncodeReedSolomon<T,P>(N,SIZE) (RS.cpp:22-37) plus the per-call root
+ * tables MFA_NTT rebuilds (ntt.cpp:397-402) and the per-block GF_Pow of RS.cpp:51-54: all twiddle
+ * tables are built once here and live in HBM.
+ * Requires n == 2k, k = 2^m with 1 <= m <= 19, block_bytes > 0 and a multiple of 4.
+ */
+int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);
+void fastecc_destroy(fastecc_ctx *ctx);
+
+/*
+ * encode(n,k,block_bytes, data -> parity).  Replaces the timed lambda RS.cpp:39-67:
+ *     MFA_NTT(data,N,SIZE,true); block_i *= root(2N)^i / N; MFA_NTT(data,N,SIZE,false);
+ * data   : k blocks, block-major, k*block_bytes bytes (read only unless parity == data)
+ * parity : k blocks, same layout; parity == data gives the reference's in-place behaviour.
+ * mem_kind FASTECC_MEM_DEVICE: both pointers are device memory on the context's device; the work is
+ *          enqueued on `stream` (a hipStream_t, NULL = default stream) and the call does not
+ *          synchronise.  FASTECC_MEM_HOST: pointers are host memory; the call stages through HBM and
+ *          returns when `parity` is complete.
+ */
+int fastecc_encode(fastecc_ctx *ctx, const void *data, void *parity, int mem_kind, void *stream);
+
+/*
+ * The reference's own calling form: an array of k HOST block pointers, transformed in place
+ * (T** data of RS.cpp:31-33 / ntt.cpp:348-350).  On return blocks[j] holds parity block j (the
+ * pointer array itself is left untouched, which is also what two MFA_NTT calls leave behind,
+ * SURVEY.md §8 a1).
+ */
+int fastecc_encode_blocks(fastecc_ctx *ctx, void *const *blocks);
+
+/*
+ * Length-k number-theoretic transform of the stripe, natural order in and out, unscaled, forward
+ * root w_k (inverse != 0: w_k^-1).  Replaces MFA_NTT<T,P>(data,N,SIZE,InvNTT) (ntt.cpp:382-447) and
+ * Rec_NTT (ntt.cpp:349-378) followed by reading the blocks through the permuted pointer array.
+ * In place on `data` (k*block_bytes bytes).
+ */
+int fastecc_ntt(fastecc_ctx *ctx, void *data, int inverse, int mem_kind, void *stream);
+
+/*
+ * block i *= scale * base^i for i in [0,k): the per-block twiddle multiply of RS.cpp:51-59
+ * (scale = 1/N, base = root(2N)) and, with other arguments, the MFA twiddle of ntt.cpp:421-431.
+ * In place on device or host memory as for fastecc_encode.
+ */
+int fastecc_scale_blocks(fastecc_ctx *ctx, void *data, uint32_t scale, uint32_t base, int mem_kind, void *stream);
+
+/*
+ * Element-wise field kernels over `count` words of DEVICE memory (parity tests of the device
+ * GF_Mul/GF_Add/GF_Sub against GF(p).cpp:37-48,110-127).  op: 0 = add, 1 = sub, 2 = mul.
+ */
+int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, uint64_t count,
+                      void *stream);
+
+/* Host-side field helpers (GF(p).cpp:254-297), used to build tables and by bindings. */
+uint32_t fastecc_gf_mul(uint32_t x, uint32_t y);
+uint32_t fastecc_gf_pow(uint32_t x, uint32_t e);
+uint32_t fastecc_gf_root(uint32_t order); /* 19^((p-1)/order); order must divide 2^20 */
+uint32_t fastecc_gf_inv(uint32_t x);
+
+/*
+ * Introspection for the benchmark: time the last `fastecc_encode` enqueued on DEVICE memory spent in
+ * kernels, measured with HIP events on the stream it ran on.  Enable before the encode calls.
+ *   fastecc_profile_enable(ctx, 1)  -> every kernel launch is bracketed by hipEvents
+ *   fastecc_profile_read(ctx, names, ms, launches, cap) -> per-kernel accumulated ms and launch counts
+ *                                      since the last reset (synchronises the stream); returns the
+ *                                      number of distinct kernels written (<= cap)
+ */
+int fastecc_profile_enable(fastecc_ctx *ctx, int on);
+int fastecc_profile_read(fastecc_ctx *ctx, const char **names, double *ms, uint64_t *launches, int cap);
+int fastecc_profile_reset(fastecc_ctx *ctx);
+
+/* Plan description, e.g. "dif5,dif5,...|mid...|dit..." — for logs and DESIGN.md tables. */
+const char *fastecc_plan_string(fastecc_ctx *ctx);
+/* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md. */
+int fastecc_set_plan(fastecc_ctx *ctx, int plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTECC_H */

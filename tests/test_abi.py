@@ -1,0 +1,80 @@
+"""CPU tests of the drop-in boundary: the shared library loads, exports every symbol include/fastecc.h
+declares, validates arguments before touching the device, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fastecc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fastecc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for must in ("fastecc_create", "fastecc_destroy", "fastecc_encode", "fastecc_encode_blocks", "fastecc_ntt",
+                 "fastecc_scale_blocks", "fastecc_gf_binary", "fastecc_strerror"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in declared_symbols():
+        assert hasattr(hip_lib, name), "libfastecc_hip.so does not export " + name
+
+
+def test_host_field_helpers(hip_lib, oracle):
+    import fastecc_amd as fe
+    P = fe.P
+    for x, y in [(0, 5), (1, P - 1), (P - 1, P - 1), (123456789, 987654321)]:
+        assert fe.gf_mul(x, y) == oracle.gf_mul(x, y)
+    for order in (2, 4, 1 << 10, 1 << 20):
+        assert fe.gf_root(order) == oracle.gf_root(order)
+    assert fe.gf_root(1 << 21) == 0  # 2^21 does not divide p-1 = 2^20*4095 (GF.md:20)
+    assert fe.gf_inv(1 << 19) == oracle.gf_inv(1 << 19)
+    assert fe.gf_pow(19, 12345) == oracle.gf_pow(19, 12345)
+
+
+def test_argument_validation_needs_no_device(hip_lib):
+    import fastecc_amd as fe
+    h = ctypes.c_void_p()
+    create = hip_lib.fastecc_create
+    # n != 2k, k not a power of two, k < 2, block_bytes % 4, zero block, unknown field, k > 2^19
+    assert create(ctypes.byref(h), 100, 64, 4096, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 96, 48, 4096, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 2, 1, 4096, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 256, 128, 4098, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 256, 128, 0, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 256, 128, 4096, 7, 0) == fe.E_UNSUPPORTED
+    assert create(ctypes.byref(h), 1 << 21, 1 << 20, 4096, 0, 0) == fe.E_UNSUPPORTED
+    assert create(None, 256, 128, 4096, 0, 0) == fe.E_INVAL
+    assert not h.value
+    assert hip_lib.fastecc_encode(None, None, None, 1, None) == fe.E_INVAL
+    assert hip_lib.fastecc_strerror(fe.E_DEVICE).decode().startswith("HIP")
+    assert hip_lib.fastecc_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu(hip_lib):
+    """On a box without a GPU the product must refuse to run rather than compute on the CPU."""
+    import torch
+    import fastecc_amd as fe
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.Encoder(256, 128, 4096)
+    assert ei.value.code == fe.E_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/ (task rule)."""
+    pkg = os.path.join(ROOT, "fastecc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "fastecc_oracle" not in text and "libfastecc_ref" not in text, f

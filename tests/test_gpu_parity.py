@@ -1,0 +1,309 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI of libfastecc_hip.so and is compared
+bit-for-bit with the CPU oracle, the committed golden fixtures, or a size-independent property.
+
+Bar: bit-exact (integer arithmetic mod p = 0xFFF00001); no tolerance anywhere."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFF00001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to("cuda:0")
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def rand_stripe(rng, N, S):
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    # edge values: 0, 1, p-1 and the wrap-around neighbourhood of 2^32 mod p
+    flat = x.reshape(-1)
+    edge = [0, 1, P - 1, P - 2, 0x000FFFFF, 0x00100000, 0xFFEFFFFF]
+    flat[: min(len(edge), flat.size)] = edge[: flat.size]
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# field kernels (GF(p).cpp:37-48, 110-127)
+# ------------------------------------------------------------------------------------------------
+def test_gf_kernels_match_oracle(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    edge = np.array([0, 1, 2, P - 1, P - 2, 0x000FFFFF, 0x00100000, 0x00100001, 0xFFEFFFFF, 0xFFF00000], dtype=np.uint32)
+    x = np.concatenate([np.repeat(edge, edge.size), rng.integers(0, P, 200_000).astype(np.uint32)])
+    y = np.concatenate([np.tile(edge, edge.size), rng.integers(0, P, 200_000).astype(np.uint32)])
+    dx, dy = to_dev(torch, x), to_dev(torch, y)
+    out = torch.empty_like(dx)
+    X, Y = x.astype(object), y.astype(object)
+    want = {"add": (X + Y) % P, "sub": (X - Y) % P, "mul": (X * Y) % P, "mul_mont": (X * Y) % P}
+    with fe.Encoder(4, 2, 4) as enc:
+        for op in ("add", "sub", "mul", "mul_mont"):
+            enc.gf_binary(op, dx, dy, out, x.size)
+            torch.cuda.synchronize()
+            got = to_host(out)
+            assert np.array_equal(got.astype(object), want[op]), op
+    # and the same through the oracle's C routines on a sample (pins oracle == bigint == GPU)
+    for i in range(0, 300):
+        assert oracle.gf_mul(int(x[i]), int(y[i])) == int(want["mul"][i])
+
+
+# ------------------------------------------------------------------------------------------------
+# per-block twiddle multiply (RS.cpp:51-59, ntt.cpp:421-431)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,S", [(2, 1), (8, 3), (64, 513), (256, 1024)])
+def test_scale_blocks(torch_cuda, fe, oracle, N, S):
+    torch = torch_cuda
+    x = rand_stripe(np.random.default_rng(N * 7 + S), N, S)
+    scale, base = oracle.gf_inv(N), oracle.gf_root(2 * N)
+    d = to_dev(torch, x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.scale_blocks(d, scale, base)
+        torch.cuda.synchronize()
+    assert np.array_equal(to_host(d), oracle.scale_blocks(x, scale, base))
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone transform (MFA_NTT / Rec_NTT semantics, natural order in and out)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log2n,S", [(1, 1), (2, 4), (3, 3), (5, 513), (6, 64), (9, 7), (10, 1024), (13, 6)])
+def test_ntt_matches_oracle(torch_cuda, fe, oracle, log2n, S):
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(100 + log2n), N, S)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        for inverse in (False, True):
+            d = to_dev(torch, x)
+            enc.ntt(d, inverse)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(d), oracle.ntt_fast(x, inverse)), (log2n, S, inverse)
+        # round trip: inverse(forward(x)) * 1/N == x  (main.cpp:286-299)
+        d = to_dev(torch, x)
+        enc.ntt(d, False)
+        enc.ntt(d, True)
+        enc.scale_blocks(d, oracle.gf_inv(N), 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(d), x)
+
+
+def test_ntt_golden_vectors(torch_cuda, fe, golden_vectors):
+    torch = torch_cuda
+    for key in sorted(k[:-3] for k in golden_vectors if k.endswith("_in")):
+        x = golden_vectors[key + "_in"]
+        N, S = x.shape
+        with fe.Encoder(2 * N, N, 4 * S) as enc:
+            for inverse, suffix in ((False, "_fwd"), (True, "_inv")):
+                d = to_dev(torch, x)
+                enc.ntt(d, inverse)
+                torch.cuda.synchronize()
+                assert np.array_equal(to_host(d), golden_vectors[key + suffix]), (key, suffix)
+
+
+# ------------------------------------------------------------------------------------------------
+# encode (RS.cpp:39-67)
+# ------------------------------------------------------------------------------------------------
+def test_encode_golden_vectors(torch_cuda, fe, golden_vectors):
+    torch = torch_cuda
+    for key in sorted(k[:-3] for k in golden_vectors if k.endswith("_in")):
+        x = golden_vectors[key + "_in"]
+        N, S = x.shape
+        d = to_dev(torch, x)
+        out = torch.empty_like(d)
+        with fe.Encoder(2 * N, N, 4 * S) as enc:
+            enc.encode(d, out)
+            torch.cuda.synchronize()
+        assert np.array_equal(to_host(out), golden_vectors[key + "_parity"]), key
+        assert np.array_equal(to_host(d), x), "out-of-place encode must not touch its input"
+
+
+@pytest.mark.parametrize("log2n", list(range(1, 15)))
+@pytest.mark.parametrize("S", [1, 6, 513, 1024])
+def test_encode_matches_oracle(torch_cuda, fe, oracle, log2n, S):
+    torch = torch_cuda
+    N = 1 << log2n
+    if N * S > (1 << 22):
+        pytest.skip("kept for the golden-hash test")
+    x = rand_stripe(np.random.default_rng(1000 * log2n + S), N, S)
+    d = to_dev(torch, x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(d)  # in place, like the reference
+        torch.cuda.synchronize()
+    assert np.array_equal(to_host(d), oracle.encode_fast(x))
+
+
+@pytest.mark.parametrize("plan", [11, 14, 21, 22, 24, 31, 32, 34, 41, 42, 44, 51, 52, 54])
+def test_every_plan_is_bit_exact(torch_cuda, fe, oracle, plan):
+    """plan = levels-per-pass * 10 + words-per-lane; all must give identical parity."""
+    torch = torch_cuda
+    for log2n, S in [(4, 4), (9, 12), (11, 64)]:
+        N = 1 << log2n
+        x = rand_stripe(np.random.default_rng(plan * 31 + log2n), N, S)
+        want = oracle.encode_fast(x)
+        d = to_dev(torch, x)
+        with fe.Encoder(2 * N, N, 4 * S) as enc:
+            enc.set_plan(plan)
+            enc.encode(d)
+            torch.cuda.synchronize()
+        assert np.array_equal(to_host(d), want), (plan, log2n, enc.plan())
+
+
+def test_encode_golden_hashes(torch_cuda, fe, oracle, golden_hashes):
+    """BASELINE configs 1 and 2 ((256,128) and (2^16,2^15), 4 KB blocks) + ragged sizes, against values
+    recorded from the unmodified reference (tests/golden/make_golden.py)."""
+    torch = torch_cuda
+    for c in golden_hashes["cases"]:
+        N, S = 1 << c["log2N"], c["block_bytes"] // 4
+        x = oracle.fill_linear(N, S) if c["input"] == "linear" else oracle.fill_splitmix(N, S, golden_hashes["splitmix_seed"])
+        assert oracle.hash(x) == c["hash_input"]
+        d = to_dev(torch, x)
+        with fe.Encoder(2 * N, N, 4 * S) as enc:
+            enc.encode(d)
+            torch.cuda.synchronize()
+        par = to_host(d)
+        assert oracle.hash(par) == c["hash_parity"], c
+        assert par[0, :4].tolist() == c["parity_0_0_4"]
+        assert int(par[1, 0]) == c["parity_1_0"] and int(par[-1, -1]) == c["parity_last_last"]
+
+
+def test_host_memory_and_block_pointer_forms(torch_cuda, fe, oracle):
+    N, S = 256, 513
+    x = rand_stripe(np.random.default_rng(77), N, S)
+    want = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        # FASTECC_MEM_HOST: plain host buffers in, parity out
+        out = np.empty_like(x)
+        enc.encode_host(x, out)
+        assert np.array_equal(out, want)
+        # the reference's T** form: k separately allocated blocks, in place (RS.cpp:31-33)
+        blocks = [np.ascontiguousarray(x[i]).copy() for i in range(N)]
+        enc.encode_blocks([b.ctypes.data for b in blocks])
+        assert np.array_equal(np.stack(blocks), want)
+        # host-memory transform
+        y = x.copy()
+        enc.ntt(y, inverse=True, mem=fe.MEM_HOST)
+        assert np.array_equal(y, oracle.ntt_fast(x, True))
+
+
+def test_error_codes_on_device(torch_cuda, fe):
+    torch = torch_cuda
+    with fe.Encoder(16, 8, 16) as enc:
+        d = torch.zeros(8 * 4, dtype=torch.int32, device="cuda:0")
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.encode(0, d)
+        assert ei.value.code == fe.E_INVAL
+        with pytest.raises(fe.FastEccError):
+            enc.encode(d.data_ptr() + 2, d)  # misaligned
+        with pytest.raises(fe.FastEccError):
+            enc.scale_blocks(d, P, 1)  # scale not a field element
+        with pytest.raises(fe.FastEccError):
+            enc.set_plan(99)
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.Encoder(16, 8, 16, device=4096)
+    assert ei.value.code == fe.E_INVAL
+
+
+def test_streams_are_respected(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    N, S = 1024, 256
+    x = rand_stripe(np.random.default_rng(5), N, S)
+    want = oracle.encode_fast(x)
+    st = torch.cuda.Stream()
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        with torch.cuda.stream(st):
+            d = to_dev(torch, x)
+            out = torch.empty_like(d)
+            enc.encode(d, out, stream=st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(to_host(out), want)
+
+
+# ------------------------------------------------------------------------------------------------
+# headline size (2^20, 2^19), 4 KB blocks: golden hash + size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def headline(torch_cuda, fe):
+    N, S = 1 << 19, 1024
+    enc = fe.Encoder(2 * N, N, 4 * S)
+    yield enc, N, S
+    enc.close()
+
+
+def test_headline_golden_hash_splitmix(torch_cuda, headline, oracle, golden_hashes):
+    torch = torch_cuda
+    enc, N, S = headline
+    c = [g for g in golden_hashes["survey_appendix_b"] if g["input"] == "splitmix"][0]
+    x = oracle.fill_splitmix(N, S, golden_hashes["splitmix_seed"])
+    assert oracle.hash(x) == c["hash_input"]
+    d = to_dev(torch, x)
+    del x
+    enc.encode(d)
+    torch.cuda.synchronize()
+    par = to_host(d)
+    assert par[0, :4].tolist() == c["parity_0_0_4"]
+    assert int(par[1, 0]) == c["parity_1_0"] and int(par[-1, -1]) == c["parity_last_last"]
+    assert oracle.hash(par) == c["hash_parity"]
+
+
+def test_headline_golden_hash_linear(torch_cuda, headline, oracle, golden_hashes):
+    torch = torch_cuda
+    enc, N, S = headline
+    c = [g for g in golden_hashes["survey_appendix_b"] if g["input"] == "linear"][0]
+    # i % p on the device (RS.cpp:28-29); 2^29 < p so it is just iota
+    d = torch.arange(N * S, dtype=torch.int32, device="cuda:0")
+    enc.encode(d)
+    torch.cuda.synchronize()
+    par = to_host(d).reshape(N, S)
+    assert par[0, :4].tolist() == c["parity_0_0_4"]
+    assert int(par[1, 0]) == c["parity_1_0"] and int(par[-1, -1]) == c["parity_last_last"]
+    assert oracle.hash(par) == c["hash_parity"]
+
+
+def test_headline_properties(torch_cuda, headline, oracle):
+    """Linearity, constant-polynomial fixed point and a column-slab cross-check against the oracle."""
+    torch = torch_cuda
+    enc, N, S = headline
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(2026)
+    a = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g)
+    b = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g)
+    ab = ((a + b) % P).to(torch.int32)       # wraps into int32 bit patterns of uint32 values
+    a32 = (a % (1 << 32)).to(torch.int32)
+    b32 = (b % (1 << 32)).to(torch.int32)
+    # int64 -> int32 conversion keeps the low 32 bits
+    del a, b
+    # keep 8 columns of the inputs for the oracle cross-check before encoding in place
+    cols = slice(500, 508)
+    a_cols = to_host(a32.view(N, S)[:, cols].contiguous())
+    enc.encode(a32)
+    enc.encode(b32)
+    enc.encode(ab)
+    s = torch.empty_like(ab)
+    enc.gf_binary("add", a32, b32, s, N * S)
+    torch.cuda.synchronize()
+    assert torch.equal(s, ab), "encode(a+b) != encode(a)+encode(b)"
+    # columns are independent transforms: the oracle on an 8-column slab must reproduce those columns
+    want = oracle.encode_fast(a_cols)
+    assert np.array_equal(to_host(a32.view(N, S)[:, cols].contiguous()), want)
+    # constant stripe -> parity equals data
+    c = torch.full((N * S,), 123456789, dtype=torch.int32, device="cuda:0")
+    enc.encode(c)
+    torch.cuda.synchronize()
+    assert bool((c == 123456789).all())

@@ -1,0 +1,119 @@
+"""CPU tests: the oracle restatement against golden vectors, the published KAT and (when prebuilt) the
+unmodified reference.  These pin the checker that the -m gpu parity tests rely on."""
+import numpy as np
+import pytest
+
+P = 0xFFF00001
+
+
+def test_field_ops_against_bigint(oracle):
+    rng = np.random.default_rng(1)
+    xs = [0, 1, 2, P - 1, P - 2, 0x000FFFFF, 0x00100000, 0xFFEFFFFF] + rng.integers(0, P, 200).tolist()
+    ys = [0, 1, P - 1, 19, 0xFDB9DED3] + rng.integers(0, P, 40).tolist()
+    for x in xs:
+        for y in ys:
+            assert oracle.gf_add(x, y) == (x + y) % P
+            assert oracle.gf_sub(x, y) == (x - y) % P
+            assert oracle.gf_mul(x, y) == (x * y) % P
+            assert oracle.gf_mul_wide(x, y) == (x * y) % P
+
+
+def test_constants_survey_appendix_c(oracle):
+    # SURVEY.md Appendix C (computed from GF_Root / GF_Inv of the reference)
+    assert oracle.gf_root(2) == P - 1
+    assert oracle.gf_root(4) == 4256816851
+    assert oracle.gf_root(1 << 7) == 955468005
+    assert oracle.gf_root(1 << 19) == 1390037254
+    assert oracle.gf_root(1 << 20) == 3156611342
+    assert oracle.gf_inv(1 << 19) == 4293910531
+    assert oracle.gf_pow(19, P - 1) == 1
+    assert oracle.gf_mul(oracle.gf_root(1 << 20), oracle.gf_root(1 << 20)) == oracle.gf_root(1 << 19)
+
+
+def test_field_ops_against_reference(oracle, reference):
+    rng = np.random.default_rng(2)
+    for x, y in rng.integers(0, P, (500, 2)).tolist() + [[0, 0], [P - 1, P - 1], [P - 1, 1], [0, P - 1]]:
+        assert oracle.gf_add(x, y) == reference.gf_add(x, y)
+        assert oracle.gf_sub(x, y) == reference.gf_sub(x, y)
+        assert oracle.gf_mul(x, y) == reference.gf_mul(x, y)
+    for order in [2, 4, 256, 1 << 15, 1 << 20]:
+        assert oracle.gf_root(order) == reference.gf_root(order)
+
+
+def test_published_kat_forward_ntt(oracle, golden_hashes):
+    # Benchmarks.md:491,499,507: `ntt {q,o,n} 20 32`
+    kat = golden_hashes["published_kat"]["ntt_fwd_2^20x32B_linear"]
+    x = oracle.fill_linear(1 << 20, 8)
+    assert oracle.hash(x) == kat["hash_input"]
+    assert oracle.hash(oracle.ntt_fast(x)) == kat["hash_output"]
+
+
+def test_three_ntt_formulations_agree(oracle):
+    rng = np.random.default_rng(3)
+    for N, S in [(2, 3), (8, 5), (64, 4), (256, 2)]:
+        x = rng.integers(0, P, (N, S)).astype(np.uint32)
+        for inv in (False, True):
+            a = oracle.slow_ntt(x, inv)
+            assert np.array_equal(a, oracle.ntt(x, inv))
+            assert np.array_equal(a, oracle.ntt_fast(x, inv))
+        # inverse(forward(x)) / N == x   (main.cpp:286-299)
+        back = oracle.scale_blocks(oracle.ntt(oracle.ntt(x), True), oracle.gf_inv(N), 1)
+        assert np.array_equal(back, x)
+
+
+def test_encode_matches_mathematical_contract(oracle):
+    # parity[j] = f(w_2N^(2j+1)), f interpolating the data at powers of w_N
+    rng = np.random.default_rng(4)
+    for N, S in [(2, 2), (4, 4), (16, 3), (32, 1)]:
+        x = rng.integers(0, P, (N, S)).astype(np.uint32)
+        assert np.array_equal(oracle.encode(x), oracle.encode_by_definition(x))
+        assert np.array_equal(oracle.encode_fast(x), oracle.encode_by_definition(x))
+
+
+def test_golden_hash_cases(oracle, golden_hashes):
+    for c in golden_hashes["cases"]:
+        if c["log2N"] > 15:
+            continue
+        N, S = 1 << c["log2N"], c["block_bytes"] // 4
+        x = oracle.fill_linear(N, S) if c["input"] == "linear" else oracle.fill_splitmix(N, S, golden_hashes["splitmix_seed"])
+        assert oracle.hash(x) == c["hash_input"]
+        par = oracle.encode_fast(x)
+        assert oracle.hash(par) == c["hash_parity"], c
+        assert par[0, :4].tolist() == c["parity_0_0_4"]
+        assert int(par[1, 0]) == c["parity_1_0"] and int(par[-1, -1]) == c["parity_last_last"]
+        if "hash_ntt_fwd" in c:
+            assert oracle.hash(oracle.ntt_fast(x, False)) == c["hash_ntt_fwd"]
+            assert oracle.hash(oracle.ntt_fast(x, True)) == c["hash_ntt_inv"]
+
+
+def test_golden_vectors(oracle, golden_vectors):
+    keys = sorted(k[:-3] for k in golden_vectors if k.endswith("_in"))
+    assert keys
+    for k in keys:
+        x = golden_vectors[k + "_in"]
+        assert np.array_equal(oracle.encode(x), golden_vectors[k + "_parity"]), k
+        assert np.array_equal(oracle.ntt(x, False), golden_vectors[k + "_fwd"]), k
+        assert np.array_equal(oracle.ntt(x, True), golden_vectors[k + "_inv"]), k
+
+
+def test_oracle_against_reference_encode(oracle, reference):
+    rng = np.random.default_rng(5)
+    for N, S in [(2, 1), (4, 7), (128, 1024), (1024, 513), (4096, 33)]:
+        x = rng.integers(0, P, (N, S)).astype(np.uint32)
+        assert np.array_equal(oracle.encode_fast(x), reference.encode(x)), (N, S)
+        assert reference.hash(x) == oracle.hash(x)
+
+
+def test_linearity_and_edge_inputs(oracle):
+    rng = np.random.default_rng(6)
+    N, S = 64, 6
+    a = rng.integers(0, P, (N, S)).astype(np.uint32)
+    b = rng.integers(0, P, (N, S)).astype(np.uint32)
+    ab = ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    ea, eb, eab = oracle.encode(a), oracle.encode(b), oracle.encode(ab)
+    assert np.array_equal(((ea.astype(np.uint64) + eb) % P).astype(np.uint32), eab)
+    z = np.zeros((N, S), dtype=np.uint32)
+    assert not oracle.encode(z).any()
+    # a constant stripe is the constant polynomial: parity == data
+    c = np.full((N, S), P - 1, dtype=np.uint32)
+    assert np.array_equal(oracle.encode(c), c)
