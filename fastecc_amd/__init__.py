@@ -26,7 +26,9 @@ _LIB = None
 class FastEccError(RuntimeError):
     def __init__(self, code, what):
         self.code = code
-        super().__init__("%s: %s (%d)" % (what, lib().fastecc_strerror(code).decode(), code))
+        detail = lib().fastecc_last_error_detail().decode()
+        super().__init__("%s: %s (%d)%s" % (what, lib().fastecc_strerror(code).decode(), code,
+                                             " [" + detail + "]" if detail else ""))
 
 
 def lib_path():
@@ -47,6 +49,7 @@ def lib():
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     L.fastecc_strerror.argtypes, L.fastecc_strerror.restype = [i32], ctypes.c_char_p
     L.fastecc_version.argtypes, L.fastecc_version.restype = [], i32
+    L.fastecc_last_error_detail.argtypes, L.fastecc_last_error_detail.restype = [], ctypes.c_char_p
     L.fastecc_create.argtypes, L.fastecc_create.restype = [ctypes.POINTER(vp), u64, u64, u64, i32, i32], i32
     L.fastecc_destroy.argtypes, L.fastecc_destroy.restype = [vp], None
     L.fastecc_encode.argtypes, L.fastecc_encode.restype = [vp, vp, vp, i32, vp], i32

@@ -24,9 +24,11 @@ using namespace fastecc;
 namespace {
 
 struct Pass {
-    int mode;  // MODE_DIF / MODE_DIT / MODE_MID
-    int logr;  // levels kept in registers
-    int s;     // log2 of the smallest stride
+    int mode;   // MODE_DIF / MODE_DIT / MODE_MID
+    int logr;   // levels covered by the pass (register pass: held in VGPRs; tile pass: log2 of the tile rows)
+    int s;      // log2 of the smallest stride
+    bool tile;  // LDS-tiled kernel (tile_kernels.hip) instead of a register pass (kernels.hip)
+    bool pair;  // tile only: 32-word rows with the cross-lane top level
 };
 
 struct ProfileRec {
@@ -52,8 +54,10 @@ struct fastecc_ctx {
     void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
     size_t pinned_bytes = 0;
 
-    int rmax = 4;  // levels per register pass
-    int vec = 4;   // words per lane
+    int rmax = 5;            // levels per register pass
+    int vec = 1;             // words per lane in register passes
+    int tile_mid = 9;        // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
+    bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
     std::vector<Pass> encode_plan, ntt_plan;
     std::string plan_text;
 
@@ -64,13 +68,19 @@ struct fastecc_ctx {
 
 namespace {
 
-#define HIP_TRY(expr)                              \
-    do {                                           \
-        hipError_t e_ = (expr);                    \
-        if (e_ != hipSuccess) {                    \
-            (void)hipGetLastError();               \
-            return e_ == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE; \
-        }                                          \
+thread_local char g_detail[256] = "";
+
+int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_detail, sizeof g_detail, "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
 
 int ilog2_exact(uint64_t v)
@@ -97,35 +107,67 @@ std::vector<int> split_levels(int bits, int rmax)
     return r;
 }
 
+// How a run of `bits` consecutive levels is executed: an LDS tile when one exists for that size,
+// register passes otherwise.
+void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
+{
+    if (c->tile_mid > 0 && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true});
+    else if (c->tile_mid > 0 && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false});
+    else if (mode == MODE_DIT) {
+        int ss = s;
+        const std::vector<int> parts = split_levels(bits, c->rmax);
+        for (auto it = parts.rbegin(); it != parts.rend(); ++it) {
+            plan.push_back({mode, *it, ss, false, false});
+            ss += *it;
+        }
+    } else {
+        int ss = s + bits;
+        for (int r : split_levels(bits, c->rmax)) {
+            ss -= r;
+            plan.push_back({mode, r, ss, false, false});
+        }
+    }
+}
+
 void build_plans(fastecc_ctx* c)
 {
     const int n = c->n;
     c->encode_plan.clear();
     c->ntt_plan.clear();
-    // encode: DIF over the high levels, MID over the low r_mid levels, DIT back up (kernels.hip header)
-    const int r_mid = std::min(n, c->rmax);
-    const std::vector<int> outer = split_levels(n - r_mid, c->rmax);
+    // encode: DIF over the high levels, MID over the low levels, DIT back up (kernels.hip header)
+    int mid = std::min(n, c->rmax);
+    bool mid_tile = false, mid_pair = false;
+    if (c->tile_mid > 0) {
+        const int want = std::min(n, c->tile_mid);
+        if (tile_supported(want, !c->tile_mid_wide)) {
+            mid = want, mid_tile = true, mid_pair = !c->tile_mid_wide;
+        } else if (tile_supported(want, c->tile_mid_wide)) {
+            mid = want, mid_tile = true, mid_pair = c->tile_mid_wide;
+        }
+    }
+    const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
+    const std::vector<int> outer = split_levels(n - mid, max_chunk);
     int s = n;
     for (int r : outer) {
         s -= r;
-        c->encode_plan.push_back({MODE_DIF, r, s});
+        push_chunk(c->encode_plan, MODE_DIF, r, s, c);
     }
-    c->encode_plan.push_back({MODE_MID, r_mid, 0});
-    s = r_mid;
+    c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair});
+    s = mid;
     for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
-        c->encode_plan.push_back({MODE_DIT, *it, s});
+        push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
         s += *it;
     }
     // stand-alone transform: DIF over all levels, then the block bit-reversal
     s = n;
-    for (int r : split_levels(n, c->rmax)) {
+    for (int r : split_levels(n, max_chunk)) {
         s -= r;
-        c->ntt_plan.push_back({MODE_DIF, r, s});
+        push_chunk(c->ntt_plan, MODE_DIF, r, s, c);
     }
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
-        snprintf(buf, sizeof buf, "%s%s%d@%d", c->plan_text.empty() ? "" : ",",
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
@@ -144,7 +186,9 @@ int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
 
 const char* pass_name(const Pass& p, int vec, char* buf, size_t cap)
 {
-    snprintf(buf, cap, "%s%dv%d", p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, vec);
+    const char* m = p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid";
+    if (p.tile) snprintf(buf, cap, "tile_%s%d_w%d", m, p.logr, p.pair ? 32 : 64);
+    else snprintf(buf, cap, "%s%dv%d", m, p.logr, vec);
     return buf;
 }
 
@@ -177,17 +221,30 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     const uint32_t* src = in;
     char name[32];
     for (const Pass& p : plan) {
-        PassArgs a{};
-        a.in = src;
-        a.out = out;
-        a.tw_dif = tw_dif;
-        a.tw_dit = tw_dit;
-        a.dscale = c->dscale;
-        a.S = (uint32_t)c->S;
-        a.n = c->n;
-        a.s = p.s;
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
-        HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
+        if (p.tile) {
+            TileArgs a{};
+            a.in = src;
+            a.out = out;
+            a.tw_dif = tw_dif;
+            a.tw_dit = tw_dit;
+            a.dscale = c->dscale;
+            a.S = (uint32_t)c->S;
+            a.n = c->n;
+            a.s = p.s;
+            HIP_TRY(launch_tile(p.logr, p.pair, p.mode, a, st));
+        } else {
+            PassArgs a{};
+            a.in = src;
+            a.out = out;
+            a.tw_dif = tw_dif;
+            a.tw_dit = tw_dit;
+            a.dscale = c->dscale;
+            a.S = (uint32_t)c->S;
+            a.n = c->n;
+            a.s = p.s;
+            HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
+        }
         src = out;  // after the first pass everything is in place on `out`
     }
     return FASTECC_OK;
@@ -250,6 +307,8 @@ const char* fastecc_strerror(int code)
 
 int fastecc_version(void) { return FASTECC_VERSION; }
 
+const char* fastecc_last_error_detail(void) { return g_detail; }
+
 uint32_t fastecc_gf_mul(uint32_t x, uint32_t y) { return gf::h_mul(x % gf::P, y % gf::P); }
 uint32_t fastecc_gf_pow(uint32_t x, uint32_t e) { return gf::h_pow(x % gf::P, e); }
 uint32_t fastecc_gf_root(uint32_t order) { return (order == 0 || ((gf::P - 1u) % order) != 0) ? 0u : gf::h_root(order); }
@@ -267,9 +326,9 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
 
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        (void)hipGetLastError();
-        return FASTECC_E_DEVICE;
+    {
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount");
     }
     if (device < 0 || device >= ndev) return FASTECC_E_INVAL;
 
@@ -285,7 +344,7 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     DeviceGuard dg(device);
     if (!dg.ok) {
         delete c;
-        return FASTECC_E_DEVICE;
+        return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
     }
 
     // ---- twiddle tables (replaces ntt.cpp:397-402 and the GF_Pow calls of RS.cpp:54 / ntt.cpp:422) ----
@@ -310,18 +369,19 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     auto upload = [&](uint32_t** dst, const std::vector<uint32_t>& src) {
         if (rc != FASTECC_OK) return;
         hipError_t e = hipMalloc((void**)dst, src.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            (void)hipGetLastError();
-            rc = e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+            rc = hip_fail(e, "hipMalloc(table)");
+            return;
         }
+        e = hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(table)");
     };
     upload(&c->tw_fwd, fwd);
     upload(&c->tw_inv, inv);
     upload(&c->dscale, dsc);
-    if (rc == FASTECC_OK && hipMalloc((void**)&c->factor, N * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        rc = FASTECC_E_NOMEM;
+    if (rc == FASTECC_OK) {
+        const hipError_t e = hipMalloc((void**)&c->factor, N * 4);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(factor)");
     }
     if (rc != FASTECC_OK) {
         fastecc_destroy(c);
@@ -520,14 +580,25 @@ const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str(
 int fastecc_set_plan(fastecc_ctx* c, int plan)
 {
     if (!c) return FASTECC_E_INVAL;
-    int rmax = 4, vec = 4;
-    if (plan != 0) {
+    // 0            default
+    // rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
+    // 1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows
+    int rmax = 5, vec = 1, tile_mid = 9;
+    bool wide = false;
+    if (plan >= 1000) {
+        tile_mid = (plan - 1000) / 10;
+        wide = ((plan - 1000) % 10) & 1;
+        if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
+    } else if (plan != 0) {
         rmax = plan / 10;
         vec = plan % 10;
+        tile_mid = 0;
     }
     if (rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
     c->rmax = rmax;
     c->vec = vec;
+    c->tile_mid = tile_mid;
+    c->tile_mid_wide = wide;
     build_plans(c);
     return FASTECC_OK;
 }

@@ -48,24 +48,37 @@ inline uint32_t h_to_mont(uint32_t w) { return (uint32_t)((((uint64_t)w) << 32) 
 // ---- device arithmetic ----
 GF_D uint32_t sub(uint32_t x, uint32_t y)
 {
-    uint32_t d = x - y;
-    return (x < y) ? d + P : d;
+    uint32_t d;
+    const bool borrow = __builtin_usub_overflow(x, y, &d);  // v_sub_co_u32
+    return borrow ? d + P : d;
 }
 
+// s = x + y; u = s - p (mod 2^32) = s + (2^20 - 1).  Take u when x + y overflowed 32 bits or s >= p; the
+// second condition is exactly "s + (2^20-1) carries".  Three VALU ops + one scalar OR of the carry masks
+// (measured 5 % faster than x - (p - y), tools/microbench.hip).
 GF_D uint32_t add(uint32_t x, uint32_t y)
 {
-    return sub(x, P - y);  // y == 0 -> x - p wraps, +p restores x
+    uint32_t s, u;
+    const bool c1 = __builtin_uadd_overflow(x, y, &s);
+    const bool c2 = __builtin_uadd_overflow(s, MONT_ONE, &u);
+    return (c1 | c2) ? u : s;
 }
 
 // x * w mod p for a constant held in Montgomery form (wm = w * 2^32 mod p).  x may be any uint32.
+//   t = x * wm                     (v_mad_u64_u32)            t <= (2^32-1)(p-1)
+//   m = lo(t) * (1 + 2^20)         (v_lshl_add_u32)           m * p == lo(t)  (mod 2^32)
+//   u = t + m * (2^20 - 1)         (v_mad_u64_u32)            = t - m*p + m*2^32, lo(u) == 0, no overflow:
+//                                                              u <= (2^32-1)(p-1+2^20-1) = (2^32-1)^2
+//   r = hi(u) - m  in (-p, p)      (v_sub_co_u32, +p if it borrowed)
 GF_D uint32_t mul_mont(uint32_t x, uint32_t wm)
 {
     const uint64_t t = (uint64_t)x * wm;
-    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-    const uint32_t m = lo + (lo << 20);  // lo * p^-1 mod 2^32
-    const uint32_t q = __umulhi(m, P);
-    const uint32_t r = hi - q;
-    return (hi < q) ? r + P : r;
+    const uint32_t lo = (uint32_t)t;
+    const uint32_t m = lo + (lo << 20);
+    const uint64_t u = t + (uint64_t)m * MONT_ONE;
+    uint32_t r;
+    const bool borrow = __builtin_usub_overflow((uint32_t)(u >> 32), m, &r);
+    return borrow ? r + P : r;
 }
 
 // General product of two canonical values, Barrett form with the 32-bit reciprocal 0x001000FF

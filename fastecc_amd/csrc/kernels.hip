@@ -22,100 +22,9 @@
 
 #include "gf.hpp"
 #include "kernels.hpp"
+#include "ntt_device.hpp"
 
 namespace fastecc {
-
-template <int V> struct VecT;
-template <> struct VecT<1> { using type = uint32_t; };
-template <> struct VecT<2> { using type = uint2; };
-template <> struct VecT<4> { using type = uint4; };
-
-template <int V> __device__ __forceinline__ void load_vec(uint32_t (&dst)[V], const uint32_t* p)
-{
-    if constexpr (V == 1) {
-        dst[0] = *p;
-    } else if constexpr (V == 2) {
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
-        dst[0] = t.x; dst[1] = t.y;
-    } else {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
-        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-    }
-}
-
-template <int V> __device__ __forceinline__ void store_vec(uint32_t* p, const uint32_t (&src)[V])
-{
-    if constexpr (V == 1) {
-        *p = src[0];
-    } else if constexpr (V == 2) {
-        *reinterpret_cast<uint2*>(p) = make_uint2(src[0], src[1]);
-    } else {
-        *reinterpret_cast<uint4*>(p) = make_uint4(src[0], src[1], src[2], src[3]);
-    }
-}
-
-__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits)
-{
-    return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
-}
-
-// r DIF levels on x[R][V].  Level t pairs (j, j + 2^t); the twiddle exponent (in units of w_N) of the
-// butterfly at block p is (p mod h) * N/(2h), h = 2^(s+t), p mod h = (j mod 2^t)*2^s + lo.
-template <int LOGR, int V, bool LO_ZERO>
-__device__ __forceinline__ void dif_levels(uint32_t (&x)[1 << LOGR][V], const uint32_t* __restrict__ tw, uint32_t lo, int s,
-                                           int n)
-{
-    constexpr int R = 1 << LOGR;
-#pragma unroll
-    for (int t = LOGR - 1; t >= 0; --t) {
-        const int half = 1 << t;
-#pragma unroll
-        for (int m = 0; m < half; ++m) {
-            const bool unit = LO_ZERO && m == 0;  // exponent 0: w = 1 (ntt.cpp:259-267 special-cases it too)
-            uint32_t w = 0;
-            if (!unit) w = tw[(((uint32_t)m << s) + lo) << (n - 1 - s - t)];
-#pragma unroll
-            for (int j0 = 0; j0 < R; j0 += 2 * half) {
-                const int ja = j0 + m, jb = ja + half;
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const uint32_t a = x[ja][v], b = x[jb][v];
-                    x[ja][v] = gf::add(a, b);
-                    const uint32_t d = gf::sub(a, b);
-                    x[jb][v] = unit ? d : gf::mul_mont(d, w);
-                }
-            }
-        }
-    }
-}
-
-template <int LOGR, int V, bool LO_ZERO>
-__device__ __forceinline__ void dit_levels(uint32_t (&x)[1 << LOGR][V], const uint32_t* __restrict__ tw, uint32_t lo, int s,
-                                           int n)
-{
-    constexpr int R = 1 << LOGR;
-#pragma unroll
-    for (int t = 0; t < LOGR; ++t) {
-        const int half = 1 << t;
-#pragma unroll
-        for (int m = 0; m < half; ++m) {
-            const bool unit = LO_ZERO && m == 0;
-            uint32_t w = 0;
-            if (!unit) w = tw[(((uint32_t)m << s) + lo) << (n - 1 - s - t)];
-#pragma unroll
-            for (int j0 = 0; j0 < R; j0 += 2 * half) {
-                const int ja = j0 + m, jb = ja + half;
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const uint32_t a = x[ja][v];
-                    const uint32_t b = unit ? x[jb][v] : gf::mul_mont(x[jb][v], w);
-                    x[ja][v] = gf::add(a, b);
-                    x[jb][v] = gf::sub(a, b);
-                }
-            }
-        }
-    }
-}
 
 // One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
 template <int LOGR, int V, int MODE>

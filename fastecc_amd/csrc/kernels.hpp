@@ -21,7 +21,22 @@ struct PassArgs {
     uint64_t items;          // filled by the launcher
 };
 
+// Arguments of one LDS-tiled pass (tile_kernels.hip: ntt_tile_kernel); fields as in PassArgs.
+struct TileArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    const uint32_t* tw_dif;
+    const uint32_t* tw_dit;
+    const uint32_t* dscale;
+    uint32_t S;
+    int n;
+    int s;
+    uint32_t col_chunks;  // filled by the launcher
+};
+
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
+bool tile_supported(int logt, bool pair);
+hipError_t launch_tile(int logt, bool pair, int mode, const TileArgs& a, hipStream_t st);
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);
 hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, hipStream_t st);

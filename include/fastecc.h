@@ -47,6 +47,8 @@ typedef struct fastecc_ctx fastecc_ctx;
 
 /* Human-readable text for an error code. */
 const char *fastecc_strerror(int code);
+/* Which HIP call failed behind the last FASTECC_E_DEVICE / _NOMEM on this thread ("" if none). */
+const char *fastecc_last_error_detail(void);
 int fastecc_version(void);
 
 /*

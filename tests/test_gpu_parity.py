@@ -149,11 +149,13 @@ def test_encode_matches_oracle(torch_cuda, fe, oracle, log2n, S):
     assert np.array_equal(to_host(d), oracle.encode_fast(x))
 
 
-@pytest.mark.parametrize("plan", [11, 14, 21, 22, 24, 31, 32, 34, 41, 42, 44, 51, 52, 54])
+@pytest.mark.parametrize("plan", [11, 14, 21, 22, 24, 31, 32, 34, 41, 42, 44, 51, 52, 54,
+                                  1060, 1061, 1070, 1071, 1080, 1081, 1090, 1091, 1100])
 def test_every_plan_is_bit_exact(torch_cuda, fe, oracle, plan):
-    """plan = levels-per-pass * 10 + words-per-lane; all must give identical parity."""
+    """Register plans (levels-per-pass * 10 + words-per-lane) and LDS-tiled plans (1000 + 10*mid_levels
+    + wide flag, fastecc_set_plan): all must give identical parity."""
     torch = torch_cuda
-    for log2n, S in [(4, 4), (9, 12), (11, 64)]:
+    for log2n, S in [(4, 4), (6, 3), (7, 70), (9, 12), (10, 33), (11, 64), (13, 40), (15, 16), (17, 5)]:
         N = 1 << log2n
         x = rand_stripe(np.random.default_rng(plan * 31 + log2n), N, S)
         want = oracle.encode_fast(x)

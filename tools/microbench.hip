@@ -260,6 +260,7 @@ static void run_copy(const uint32_t* in, uint32_t* out, uint32_t S, int n, int s
     constexpr int ROWS = K * (64 / LPR);
     constexpr int W = LPR * V;
     const uint32_t col_chunks = S / W;
+    if (((uint64_t)ROWS << s) > (1ull << n)) return;  // group would not fit in the matrix
     const uint64_t items = ((uint64_t)col_chunks << n) / ROWS;
     const unsigned blocks = (unsigned)((items + 3) / 4);
     hipStream_t st = nullptr;
@@ -331,7 +332,10 @@ int main(int argc, char** argv)
         for (int s : {0, 9, 10}) {
             run_copy<4, 8, 8>(a, a, S, n, s);    // 128 B segments, 64 rows per wave
             run_copy<4, 4, 8>(a, a, S, n, s);    // 64 B segments, 128 rows per wave
-            run_copy<1, 32, 32>(a, a, S, n, s);  // 128 B segments, dword lanes
+            run_copy<1, 32, 32>(a, a, S, n, s);  // 128 B segments, dword lanes, 64 rows per wave
+            run_copy<1, 32, 16>(a, a, S, n, s);  // 128 B segments, dword lanes, 32 rows per wave
+            run_copy<1, 16, 16>(a, a, S, n, s);  // 64 B segments, dword lanes, 64 rows per wave
+            run_copy<1, 64, 32>(a, a, S, n, s);  // 256 B segments, dword lanes, 32 rows per wave
             run_copy<2, 32, 16>(a, a, S, n, s);  // 256 B segments, dwordx2 lanes, 2 rows per instr
             run_copy<4, 16, 8>(a, a, S, n, s);   // 256 B segments, dwordx4 lanes, 4 rows per instr
         }

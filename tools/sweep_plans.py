@@ -15,7 +15,7 @@ import fastecc_amd  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2k", type=int, default=19)
 ap.add_argument("--block-bytes", type=int, default=4096)
-ap.add_argument("--plans", default="31,32,34,41,42,44,51,52,54")
+ap.add_argument("--plans", default="51,1090,1091,1100,1080,1081")
 ap.add_argument("--steps", type=int, default=5)
 args = ap.parse_args()
 
