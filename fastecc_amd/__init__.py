@@ -45,6 +45,15 @@ def lib():
         raise FileNotFoundError(
             "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(fastecc_amd has no CPU fallback)" % path)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64/libhsa-runtime64, and a
+    # process that initialises two HSA runtimes loses the GPU in the second one ("no ROCm-capable
+    # device").  Callers of this harness use torch for device memory, so let torch's runtime load first;
+    # libfastecc_hip.so's DT_NEEDED libamdhip64.so.* then binds to the copy already in the process.  A
+    # C++ host (fastecc_amd/host/rs_main.cpp) links the system runtime directly and has no such issue.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(path)
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     L.fastecc_strerror.argtypes, L.fastecc_strerror.restype = [i32], ctypes.c_char_p
