@@ -46,8 +46,11 @@ struct fastecc_ctx {
     size_t stripe_bytes = 0;
 
     // device tables (Montgomery form, see gf.hpp)
-    uint32_t* tw_fwd = nullptr;  // w_N^e,  e < max(N/2,1)
-    uint32_t* tw_inv = nullptr;  // w_N^-e
+    // level-packed twiddle tables (ntt_device.hpp), N words each, rebuilt whenever the plan changes:
+    uint32_t* tw_enc_dif = nullptr;  // inverse roots, ordered for the encode plan's DIF/MID passes
+    uint32_t* tw_enc_dit = nullptr;  // forward roots, same ordering (the DIT passes mirror the DIF ones)
+    uint32_t* tw_ntt_fwd = nullptr;  // forward roots, ordered for the stand-alone transform's passes
+    uint32_t* tw_ntt_inv = nullptr;  // inverse roots, same ordering
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
@@ -253,12 +256,12 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
-    return run_passes(c, c->encode_plan, data, parity, c->tw_inv, c->tw_fwd, st);
+    return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
 }
 
 int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
 {
-    const uint32_t* tw = inverse ? c->tw_inv : c->tw_fwd;
+    const uint32_t* tw = inverse ? c->tw_ntt_inv : c->tw_ntt_fwd;
     int rc = run_passes(c, c->ntt_plan, data, data, tw, tw, st);
     if (rc != FASTECC_OK) return rc;
     if (c->n >= 2) {
@@ -266,6 +269,62 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
         HIP_TRY(launch_bitrev_rows(data, (uint32_t)c->S, c->n, pick_vec(c, data, data), st));
     }
     return FASTECC_OK;
+}
+
+// For every level l: the stride 2^sl of the register run that executes it (see ntt_device.hpp).
+std::vector<int> level_strides(const std::vector<Pass>& plan, int n)
+{
+    std::vector<int> sl(n, 0);
+    for (const Pass& p : plan) {
+        if (p.mode == MODE_DIT) continue;  // DIT passes mirror the DIF ones level for level
+        if (!p.tile) {
+            for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
+        } else {
+            const int l2 = p.logr - 5 - (p.pair ? 1 : 0);  // TileCfg::L2 with LOGR = 5
+            for (int l = p.s; l < p.s + l2; l++) sl[l] = p.s;
+            for (int l = p.s + l2; l < p.s + p.logr; l++) sl[l] = p.s + l2;
+        }
+    }
+    return sl;
+}
+
+// Level-packed table: entry 2^l + ((i mod 2^sl) << (l - sl)) + (i >> sl) = (root of order 2^(l+1))^i, i < 2^l,
+// in Montgomery form.  Replaces the roots[] array of ntt.cpp:397-402 and the running root_i *= root of
+// ntt.cpp:270-281: every twiddle of every level is tabulated once per context.
+std::vector<uint32_t> build_level_table(int n, uint32_t root_of_order_N, const std::vector<int>& sl)
+{
+    std::vector<uint32_t> tab(std::max<size_t>((size_t)1 << n, 2), 0);
+    for (int l = 0; l < n; l++) {
+        const uint32_t h = 1u << l;
+        const uint32_t root = gf::h_pow(root_of_order_N, (uint64_t)1 << (n - 1 - l));
+        const int t = l - sl[l];
+        const uint32_t lowmask = (1u << sl[l]) - 1u;
+        uint32_t w = 1;
+        for (uint32_t i = 0; i < h; i++) {
+            tab[h + (((i & lowmask) << t) | (i >> sl[l]))] = gf::h_to_mont(w);
+            w = gf::h_mul(w, root);
+        }
+    }
+    return tab;
+}
+
+int upload_table(uint32_t** dst, const std::vector<uint32_t>& src)
+{
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, src.size() * 4));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    return FASTECC_OK;
+}
+
+// (Re)build the four twiddle tables for the current plans.  The device must be idle w.r.t. this context.
+int upload_twiddles(fastecc_ctx* c)
+{
+    const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
+    const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
+    int rc = upload_table(&c->tw_enc_dif, build_level_table(c->n, wNi, enc));  // interpolate: inverse roots (RS.cpp:41)
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc));  // evaluate (RS.cpp:63)
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
+    return rc;
 }
 
 int ensure_dbuf(fastecc_ctx* c)
@@ -347,38 +406,17 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
         return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
     }
 
-    // ---- twiddle tables (replaces ntt.cpp:397-402 and the GF_Pow calls of RS.cpp:54 / ntt.cpp:422) ----
+    // ---- tables: per-level twiddles for the plan, and the per-block factors w_2N^i / N of RS.cpp:51-54 ----
     const uint64_t N = k;
-    const uint64_t half = std::max<uint64_t>(N / 2, 1);
-    std::vector<uint32_t> fwd(half), inv(half), dsc(N);
-    const uint32_t wN = gf::h_root((uint32_t)N), wNi = gf::h_inv(wN);
-    uint32_t a = 1, b = 1;
-    for (uint64_t e = 0; e < half; e++) {
-        fwd[e] = gf::h_to_mont(a);
-        inv[e] = gf::h_to_mont(b);
-        a = gf::h_mul(a, wN);
-        b = gf::h_mul(b, wNi);
-    }
+    std::vector<uint32_t> dsc(N);
     const uint32_t w2N = gf::h_root((uint32_t)(2 * N)), invN = gf::h_inv((uint32_t)N);
-    uint32_t d = invN;  // w_2N^i / N
+    uint32_t d = invN;
     for (uint64_t i = 0; i < N; i++) {
-        dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);
+        dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);  // stored by position: position p holds coefficient bitrev(p)
         d = gf::h_mul(d, w2N);
     }
-    int rc = FASTECC_OK;
-    auto upload = [&](uint32_t** dst, const std::vector<uint32_t>& src) {
-        if (rc != FASTECC_OK) return;
-        hipError_t e = hipMalloc((void**)dst, src.size() * 4);
-        if (e != hipSuccess) {
-            rc = hip_fail(e, "hipMalloc(table)");
-            return;
-        }
-        e = hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(table)");
-    };
-    upload(&c->tw_fwd, fwd);
-    upload(&c->tw_inv, inv);
-    upload(&c->dscale, dsc);
+    int rc = upload_twiddles(c);
+    if (rc == FASTECC_OK) rc = upload_table(&c->dscale, dsc);
     if (rc == FASTECC_OK) {
         const hipError_t e = hipMalloc((void**)&c->factor, N * 4);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(factor)");
@@ -399,8 +437,10 @@ void fastecc_destroy(fastecc_ctx* c)
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    if (c->tw_fwd) (void)hipFree(c->tw_fwd);
-    if (c->tw_inv) (void)hipFree(c->tw_inv);
+    if (c->tw_enc_dif) (void)hipFree(c->tw_enc_dif);
+    if (c->tw_enc_dit) (void)hipFree(c->tw_enc_dit);
+    if (c->tw_ntt_fwd) (void)hipFree(c->tw_ntt_fwd);
+    if (c->tw_ntt_inv) (void)hipFree(c->tw_ntt_inv);
     if (c->dscale) (void)hipFree(c->dscale);
     if (c->factor) (void)hipFree(c->factor);
     if (c->dbuf) (void)hipFree(c->dbuf);
@@ -600,7 +640,10 @@ int fastecc_set_plan(fastecc_ctx* c, int plan)
     c->tile_mid = tile_mid;
     c->tile_mid_wide = wide;
     build_plans(c);
-    return FASTECC_OK;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+    HIP_TRY(hipDeviceSynchronize());  // kernels still reading the old tables
+    return upload_twiddles(c);
 }
 
 }  // extern "C"

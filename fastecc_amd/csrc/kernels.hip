@@ -60,13 +60,13 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     }
 
     if constexpr (MODE == MODE_DIF) {
-        if (a.s == 0) dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0, a.n);
-        else          dif_levels<LOGR, V, false>(x, a.tw_dif, lo, s, a.n);
+        if (a.s == 0) dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0);
+        else          dif_levels<LOGR, V, false>(x, a.tw_dif, lo, s);
     } else if constexpr (MODE == MODE_DIT) {
-        if (a.s == 0) dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0, a.n);
-        else          dit_levels<LOGR, V, false>(x, a.tw_dit, lo, s, a.n);
+        if (a.s == 0) dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0);
+        else          dit_levels<LOGR, V, false>(x, a.tw_dit, lo, s);
     } else {
-        dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0, a.n);
+        dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0);
         // position p = hi*R + j holds coefficient bitrev_n(p); a.dscale is stored in position order
         const uint32_t* __restrict__ d = a.dscale + (size_t)hi * R;
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
 #pragma unroll
             for (int v = 0; v < V; ++v) x[j][v] = gf::mul_mont(x[j][v], f);
         }
-        dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0, a.n);
+        dit_levels<LOGR, V, true>(x, a.tw_dit, 0u, 0);
     }
 
     if (live) {

@@ -45,45 +45,65 @@ struct TileCfg {
     static_assert(THREADS <= 1024, "workgroup size");
 };
 
-// Top level of a PAIR tile, decimation in frequency: (a, b) -> (a + b, (a - b) * w).
+// Top level of a PAIR tile (level sl + LOGR as seen from layout A: partner distance "2^LOGR registers" is
+// the other half-wave).  Its 2^LOGR twiddles, one per register, are contiguous in the level table; they
+// are fetched 16 at a time to bound SGPR pressure.  The low half-wave needs w[ja], the high one w[jb]:
+// selected with (wa ^ ((wa ^ wb) & upper_mask)) — one scalar xor, two vector ops — because writing it as a
+// ?: on SGPR array elements makes the compiler build a 32-way compare/select chain.
 template <int LOGR>
-__device__ __forceinline__ void pair_level_dif(uint32_t (&x)[1 << LOGR][1], const uint32_t* __restrict__ tw, uint32_t g, int G,
-                                               uint32_t lo, int s, int shift, bool upper)
+__device__ __forceinline__ uint32_t pair_twiddle(uint32_t wa, uint32_t wb, uint32_t upper_mask)
 {
-    constexpr int R = 1 << LOGR;
+    return wa ^ ((wa ^ wb) & upper_mask);
+}
+
+// Decimation in frequency: (a, b) -> (a + b, (a - b) * w).
+template <int LOGR>
+__device__ __forceinline__ void pair_level_dif(uint32_t (&x)[1 << LOGR][1], const uint32_t* __restrict__ twl, uint32_t off, int sl,
+                                               uint32_t upper_mask)
+{
+    constexpr int R = 1 << LOGR, CH = R < 16 ? R : 16;
+    const uint32_t* __restrict__ p = twl + (1u << (sl + LOGR)) + (off << LOGR);
 #pragma unroll
-    for (int ja = 0; ja < R; ja += 2) {
-        const int jb = ja + 1;
-        const uint32_t wa = tw[((((uint32_t)ja * G + g) << s) + lo) << shift];
-        const uint32_t wb = tw[((((uint32_t)jb * G + g) << s) + lo) << shift];
-        const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
-        const uint32_t a = r[0], b = r[1];
-        const uint32_t w = upper ? wb : wa;
-        const uint32_t sum = gf::add(a, b);
-        const uint32_t dif = gf::mul_mont(gf::sub(a, b), w);
-        const auto o = __builtin_amdgcn_permlane32_swap(sum, dif, false, false);
-        x[ja][0] = o[0];
-        x[jb][0] = o[1];
+    for (int c0 = 0; c0 < R; c0 += CH) {
+        uint32_t w[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) w[i] = p[c0 + i];
+#pragma unroll
+        for (int i = 0; i < CH; i += 2) {
+            const int ja = c0 + i, jb = ja + 1;
+            const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
+            const uint32_t a = r[0], b = r[1];
+            const uint32_t sum = gf::add(a, b);
+            const uint32_t dif = gf::mul_mont(gf::sub(a, b), pair_twiddle<LOGR>(w[i], w[i + 1], upper_mask));
+            const auto o = __builtin_amdgcn_permlane32_swap(sum, dif, false, false);
+            x[ja][0] = o[0];
+            x[jb][0] = o[1];
+        }
     }
 }
 
-// Top level of a PAIR tile, decimation in time: (a, b) -> (a + b*w, a - b*w).
+// Decimation in time: (a, b) -> (a + b*w, a - b*w).
 template <int LOGR>
-__device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], const uint32_t* __restrict__ tw, uint32_t g, int G,
-                                               uint32_t lo, int s, int shift, bool upper)
+__device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], const uint32_t* __restrict__ twl, uint32_t off, int sl,
+                                               uint32_t upper_mask)
 {
-    constexpr int R = 1 << LOGR;
+    constexpr int R = 1 << LOGR, CH = R < 16 ? R : 16;
+    const uint32_t* __restrict__ p = twl + (1u << (sl + LOGR)) + (off << LOGR);
 #pragma unroll
-    for (int ja = 0; ja < R; ja += 2) {
-        const int jb = ja + 1;
-        const uint32_t wa = tw[((((uint32_t)ja * G + g) << s) + lo) << shift];
-        const uint32_t wb = tw[((((uint32_t)jb * G + g) << s) + lo) << shift];
-        const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
-        const uint32_t a = r[0];
-        const uint32_t b = gf::mul_mont(r[1], upper ? wb : wa);
-        const auto o = __builtin_amdgcn_permlane32_swap(gf::add(a, b), gf::sub(a, b), false, false);
-        x[ja][0] = o[0];
-        x[jb][0] = o[1];
+    for (int c0 = 0; c0 < R; c0 += CH) {
+        uint32_t w[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) w[i] = p[c0 + i];
+#pragma unroll
+        for (int i = 0; i < CH; i += 2) {
+            const int ja = c0 + i, jb = ja + 1;
+            const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
+            const uint32_t a = r[0];
+            const uint32_t b = gf::mul_mont(r[1], pair_twiddle<LOGR>(w[i], w[i + 1], upper_mask));
+            const auto o = __builtin_amdgcn_permlane32_swap(gf::add(a, b), gf::sub(a, b), false, false);
+            x[ja][0] = o[0];
+            x[jb][0] = o[1];
+        }
     }
 }
 
@@ -98,7 +118,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS)) void ntt_tile
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = PAIR ? (lane & 31u) : lane;
     const uint32_t half = PAIR ? (lane >> 5) : 0u;
-    const bool upper = half != 0;
+    const uint32_t upper_mask = 0u - half;  // all ones in the high half-wave of a PAIR tile
 
     const uint32_t cc = blockIdx.x % a.col_chunks;
     const uint32_t grp = blockIdx.x / a.col_chunks;
@@ -109,76 +129,102 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS)) void ntt_tile
     const uint32_t col = cc * W + c;
     const bool live = col < a.S;
 
-    // block held in register j (layout A) / k (layout B)
-    const uint32_t qa0 = half * (T / 2) + g;                 // + j*G
-    const uint32_t qb0 = (PAIR ? 2u * g + half : g) * R;     // + k
+    // Block held in register j (layout A) / k (layout B), split into a wave-uniform part (SGPRs) and the
+    // half-wave part of a PAIR tile, which is folded ONCE into per-lane base pointers / LDS offsets so that
+    // every global and LDS address below is "lane base + uniform offset".
+    const uint32_t qa_u = g;                                 // + j*G          (+ half*T/2 per lane)
+    const uint32_t qb_u = (PAIR ? 2u * g : g) * R;           // + k            (+ half*R   per lane)
+    const uint32_t qa_l = half * (T / 2), qb_l = half * R;
+    const size_t lane_a = ((size_t)qa_l << s) * a.S + col, lane_b = ((size_t)qb_l << s) * a.S + col;
+    const uint32_t* in_a = a.in + lane_a;
+    const uint32_t* in_b = a.in + lane_b;
+    uint32_t* out_a = a.out + lane_a;
+    uint32_t* out_b = a.out + lane_b;
+    uint32_t* lds_a = lds + qa_l * W + c;
+    uint32_t* lds_b = lds + qb_l * W + c;
+    const size_t row_elems = (size_t)a.S << s;               // distance between consecutive tile blocks
+    const size_t tile_origin = (size_t)base_row * a.S;
     // layout A as seen by dif_levels/dit_levels: stride 2^(s+L2), offset (g << s) + lo below it
     const int sl = s + L2;
     const uint32_t off = (g << s) + lo;
-    const int pair_shift = a.n - s - LOGT;  // exponent scale of the pair level (half-size 2^(s+LOGT-1))
 
     uint32_t x[R][1];
 
-    auto load_rows = [&](uint32_t q0, uint32_t qstep) {
+    auto load_rows = [&](const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const size_t row = base_row + ((size_t)(q0 + j * qstep) << s);
-            x[j][0] = live ? a.in[row * a.S + col] : 0u;
+            for (int j = 0; j < R; ++j) x[j][0] = lane_base[tile_origin + (size_t)(q0 + j * qstep) * row_elems];
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j][0] = 0u;
         }
     };
-    auto store_rows = [&](uint32_t q0, uint32_t qstep) {
+    auto store_rows = [&](uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
         if (!live) return;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const size_t row = base_row + ((size_t)(q0 + j * qstep) << s);
-            a.out[row * a.S + col] = x[j][0];
-        }
+        for (int j = 0; j < R; ++j) lane_base[tile_origin + (size_t)(q0 + j * qstep) * row_elems] = x[j][0];
     };
-    auto lds_write = [&](uint32_t q0, uint32_t qstep) {
+    auto lds_write = [&](uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) lds[(q0 + j * qstep) * W + c] = x[j][0];
+        for (int j = 0; j < R; ++j) lane_base[(q0 + j * qstep) * W] = x[j][0];
     };
-    auto lds_read = [&](uint32_t q0, uint32_t qstep) {
+    auto lds_read = [&](const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) x[j][0] = lds[(q0 + j * qstep) * W + c];
+        for (int j = 0; j < R; ++j) x[j][0] = lane_base[(q0 + j * qstep) * W];
     };
 
     if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
-        load_rows(qa0, G);
-        if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, g, G, lo, s, pair_shift, upper);
-        dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl, a.n);
-        lds_write(qa0, G);
+        load_rows(in_a, qa_u, G);
+        if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
+        dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
+        lds_write(lds_a, qa_u, G);
         __syncthreads();
-        lds_read(qb0, 1);
+        lds_read(lds_b, qb_u, 1);
         if constexpr (MODE == MODE_DIF) {
-            if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0, a.n);
-            else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, lo, s, a.n);
-            store_rows(qb0, 1);
+            if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+            else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, lo, s);
+            store_rows(out_b, qb_u, 1);
         } else {
-            dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0, a.n);
-            // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order
-            const uint32_t* __restrict__ d = a.dscale + ((size_t)hi << LOGT) + qb0;
+            dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+            // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so the
+            // R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different blocks:
+            // both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
+            const uint32_t* __restrict__ d = a.dscale + ((size_t)hi << LOGT) + qb_u;
+            constexpr int CH = 8;
 #pragma unroll
-            for (int k = 0; k < R; ++k) x[k][0] = gf::mul_mont(x[k][0], d[k]);
-            dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0, a.n);
+            for (int k0 = 0; k0 < R; k0 += CH) {
+                uint32_t dl[CH], dh[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) dl[i] = d[k0 + i];
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) dh[i] = d[R + k0 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const uint32_t f = PAIR ? pair_twiddle<LOGR>(dl[i], dh[i], upper_mask) : dl[i];
+                    x[k0 + i][0] = gf::mul_mont(x[k0 + i][0], f);
+                }
+            }
+            dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
             __syncthreads();  // every lane has finished reading the first exchange
-            lds_write(qb0, 1);
+            lds_write(lds_b, qb_u, 1);
             __syncthreads();
-            lds_read(qa0, G);
-            dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl, a.n);
-            if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, g, G, lo, s, pair_shift, upper);
-            store_rows(qa0, G);
+            lds_read(lds_a, qa_u, G);
+            dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
+            if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+            store_rows(out_a, qa_u, G);
         }
     } else {
-        load_rows(qb0, 1);
-        if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0, a.n);
-        else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, lo, s, a.n);
-        lds_write(qb0, 1);
+        load_rows(in_b, qb_u, 1);
+        if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
+        else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, lo, s);
+        lds_write(lds_b, qb_u, 1);
         __syncthreads();
-        lds_read(qa0, G);
-        dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl, a.n);
-        if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, g, G, lo, s, pair_shift, upper);
-        store_rows(qa0, G);
+        lds_read(lds_a, qa_u, G);
+        dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
+        if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+        store_rows(out_a, qa_u, G);
     }
 }
 
