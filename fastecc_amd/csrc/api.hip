@@ -61,6 +61,9 @@ struct fastecc_ctx {
     int vec = 1;             // words per lane in register passes
     int tile_mid = 9;        // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
+    bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
+    bool prefetch = true;    // ... that request the next tile before computing the current one
+    int cus = 256;           // compute units of the device (sizes the persistent grids)
     std::vector<Pass> encode_plan, ntt_plan;
     std::string plan_text;
 
@@ -112,10 +115,17 @@ std::vector<int> split_levels(int bits, int rmax)
 
 // How a run of `bits` consecutive levels is executed: an LDS tile when one exists for that size,
 // register passes otherwise.
+// A tile pass addresses its tile with 32-bit offsets from a per-tile buffer descriptor (tile_kernels.hip).
+bool tile_fits(const fastecc_ctx* c, int logt, int s)
+{
+    return (((uint64_t)c->S * 4) << (logt + s)) <= (1ull << 31);
+}
+
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
 {
-    if (c->tile_mid > 0 && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true});
-    else if (c->tile_mid > 0 && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false});
+    const bool fits = tile_fits(c, bits, s);
+    if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true});
+    else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false});
     else if (mode == MODE_DIT) {
         int ss = s;
         const std::vector<int> parts = split_levels(bits, c->rmax);
@@ -142,7 +152,9 @@ void build_plans(fastecc_ctx* c)
     bool mid_tile = false, mid_pair = false;
     if (c->tile_mid > 0) {
         const int want = std::min(n, c->tile_mid);
-        if (tile_supported(want, !c->tile_mid_wide)) {
+        if (!tile_fits(c, want, 0)) {
+            // blocks too large for 32-bit tile offsets: register passes handle the low levels
+        } else if (tile_supported(want, !c->tile_mid_wide)) {
             mid = want, mid_tile = true, mid_pair = !c->tile_mid_wide;
         } else if (tile_supported(want, c->tile_mid_wide)) {
             mid = want, mid_tile = true, mid_pair = c->tile_mid_wide;
@@ -223,6 +235,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     const int vec = pick_vec(c, in, out);
     const uint32_t* src = in;
     char name[32];
+    tile_config(c->persistent ? c->cus : 0, c->prefetch);
     for (const Pass& p : plan) {
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
         if (p.tile) {
@@ -398,6 +411,11 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     c->n = lg;
     c->S = block_bytes / 4;
     c->stripe_bytes = (size_t)k * block_bytes;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+        else (void)hipGetLastError();
+    }
     build_plans(c);
 
     DeviceGuard dg(device);
@@ -622,12 +640,19 @@ int fastecc_set_plan(fastecc_ctx* c, int plan)
     if (!c) return FASTECC_E_INVAL;
     // 0            default
     // rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
-    // 1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows
+    // 1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
+    //              f&2: no next-tile prefetch; f&4: one workgroup per tile instead of persistent workgroups
     int rmax = 5, vec = 1, tile_mid = 9;
     bool wide = false;
+    c->persistent = true;
+    c->prefetch = true;
     if (plan >= 1000) {
         tile_mid = (plan - 1000) / 10;
-        wide = ((plan - 1000) % 10) & 1;
+        const int f = (plan - 1000) % 10;
+        wide = f & 1;
+        c->prefetch = !(f & 2);
+        c->persistent = !(f & 4);
+        if (f > 7) return FASTECC_E_INVAL;
         if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
     } else if (plan != 0) {
         rmax = plan / 10;

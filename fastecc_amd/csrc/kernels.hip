@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     } else {
         dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0);
         // position p = hi*R + j holds coefficient bitrev_n(p); a.dscale is stored in position order
-        const uint32_t* __restrict__ d = a.dscale + (size_t)hi * R;
+        const_u32_ptr d = as_constant(a.dscale) + (size_t)hi * R;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const uint32_t f = d[j];

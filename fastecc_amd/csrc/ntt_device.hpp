@@ -49,10 +49,19 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits)
 // and arrive with one or two wide scalar loads (s_load_dwordx2..x16) instead of 2^t separate ones.
 // Values are in Montgomery form (gf.hpp).  LO_ZERO (sl == 0, off == 0) lets exponent-0 butterflies skip
 // the multiply at compile time, as the reference does for the first butterfly of a group (ntt.cpp:259-267).
+// Tables (twiddles, per-block factors) are immutable while a kernel runs.  Reading them through the
+// CONSTANT address space tells the compiler so: a wave-uniform address then always becomes a scalar load
+// (s_load_dword*), even inside a persistent loop whose stores could otherwise be assumed to clobber it.
+using const_u32_ptr = const uint32_t __attribute__((address_space(4)))*;
+__device__ __forceinline__ const_u32_ptr as_constant(const uint32_t* p)
+{
+    return (const_u32_ptr)(reinterpret_cast<uintptr_t>(p));
+}
+
 template <int T>
 __device__ __forceinline__ void load_level(uint32_t (&w)[1 << T], const uint32_t* __restrict__ twl, uint32_t off, int sl)
 {
-    const uint32_t* __restrict__ p = twl + (1u << (sl + T)) + (off << T);
+    const_u32_ptr p = as_constant(twl) + (1u << (sl + T)) + (off << T);
 #pragma unroll
     for (int m = 0; m < (1 << T); ++m) w[m] = p[m];
 }

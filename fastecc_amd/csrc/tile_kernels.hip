@@ -62,7 +62,7 @@ __device__ __forceinline__ void pair_level_dif(uint32_t (&x)[1 << LOGR][1], cons
                                                uint32_t upper_mask)
 {
     constexpr int R = 1 << LOGR, CH = R < 16 ? R : 16;
-    const uint32_t* __restrict__ p = twl + (1u << (sl + LOGR)) + (off << LOGR);
+    const_u32_ptr p = as_constant(twl) + (1u << (sl + LOGR)) + (off << LOGR);
 #pragma unroll
     for (int c0 = 0; c0 < R; c0 += CH) {
         uint32_t w[CH];
@@ -88,7 +88,7 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
                                                uint32_t upper_mask)
 {
     constexpr int R = 1 << LOGR, CH = R < 16 ? R : 16;
-    const uint32_t* __restrict__ p = twl + (1u << (sl + LOGR)) + (off << LOGR);
+    const_u32_ptr p = as_constant(twl) + (1u << (sl + LOGR)) + (off << LOGR);
 #pragma unroll
     for (int c0 = 0; c0 < R; c0 += CH) {
         uint32_t w[CH];
@@ -107,10 +107,45 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
     }
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE>
-__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS)) void ntt_tile_kernel(const TileArgs a)
+// Per-tile addressing.  Global memory is reached through raw buffer descriptors (one per tile, built from
+// wave-uniform values only) so that each access is ONE instruction:
+//     buffer_load_dword  v, v_lane_off, s[desc], s_block_off offen
+// v_lane_off  = 32-bit byte offset of the lane inside the tile (column + half-tile of a PAIR tile); it
+//               does not depend on the tile, and is set past num_records for lanes whose column does not
+//               exist (col >= S): the hardware bounds check then returns 0 / drops the store, so ragged
+//               block sizes need no branches;
+// s_block_off = 32-bit byte offset of the tile block, wave-uniform (SGPR).
+// The host only selects a tile pass when a tile spans <= 2^31 bytes (tile_fits, api.hip), so live lane
+// offsets stay below num_records = 2^32-1 and "offset | dead_mask" = 2^32-1 is always out of range.
+// Workgroup barrier for the LDS exchanges.  __syncthreads() also fences global memory (s_waitcnt
+// vmcnt(0)), which would drain the next tile's prefetch and the previous tile's stores at every exchange;
+// the exchange only needs this wave's LDS traffic to have completed.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct TileView {
+    uint32_t lo, hi;          // tile group: stripe block of tile block q is (hi << (s+LOGT)) + lo + (q << s)
+    uint32_t dead_mask;       // all ones in lanes whose column does not exist
+    __amdgpu_buffer_rsrc_t in, out;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
+{
+    // the pointer is wave-uniform; passing its halves through readfirstlane makes that provable to the
+    // compiler, which otherwise wraps every buffer op in a waterfall loop (cdna_hip_programming.md T20)
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0xFFFFFFFFu, 0x00020000);
+}
+
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
+__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_tile_kernel(const TileArgs a)
 {
     using C = TileCfg<LOGT, LOGR, PAIR>;
+    using View = TileView;
     constexpr int R = C::R, G = C::G, W = C::W, L2 = C::L2, T = C::T;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
@@ -119,123 +154,172 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS)) void ntt_tile
     const uint32_t c = PAIR ? (lane & 31u) : lane;
     const uint32_t half = PAIR ? (lane >> 5) : 0u;
     const uint32_t upper_mask = 0u - half;  // all ones in the high half-wave of a PAIR tile
-
-    const uint32_t cc = blockIdx.x % a.col_chunks;
-    const uint32_t grp = blockIdx.x / a.col_chunks;
     const int s = MODE == MODE_MID ? 0 : a.s;
-    const uint32_t lo = grp & ((1u << s) - 1u);
-    const uint32_t hi = grp >> s;
-    const uint32_t base_row = (hi << (s + LOGT)) + lo;  // tile block q is stripe block base_row + (q << s)
-    const uint32_t col = cc * W + c;
-    const bool live = col < a.S;
 
     // Block held in register j (layout A) / k (layout B), split into a wave-uniform part (SGPRs) and the
-    // half-wave part of a PAIR tile, which is folded ONCE into per-lane base pointers / LDS offsets so that
-    // every global and LDS address below is "lane base + uniform offset".
-    const uint32_t qa_u = g;                                 // + j*G          (+ half*T/2 per lane)
-    const uint32_t qb_u = (PAIR ? 2u * g : g) * R;           // + k            (+ half*R   per lane)
+    // half-wave part of a PAIR tile, which is folded once into per-lane offsets.
+    const uint32_t qa_u = g;                        // + j*G   (+ half*T/2 per lane)
+    const uint32_t qb_u = (PAIR ? 2u * g : g) * R;  // + k     (+ half*R   per lane)
     const uint32_t qa_l = half * (T / 2), qb_l = half * R;
-    const size_t lane_a = ((size_t)qa_l << s) * a.S + col, lane_b = ((size_t)qb_l << s) * a.S + col;
-    const uint32_t* in_a = a.in + lane_a;
-    const uint32_t* in_b = a.in + lane_b;
-    uint32_t* out_a = a.out + lane_a;
-    uint32_t* out_b = a.out + lane_b;
     uint32_t* lds_a = lds + qa_l * W + c;
     uint32_t* lds_b = lds + qb_l * W + c;
-    const size_t row_elems = (size_t)a.S << s;               // distance between consecutive tile blocks
-    const size_t tile_origin = (size_t)base_row * a.S;
-    // layout A as seen by dif_levels/dit_levels: stride 2^(s+L2), offset (g << s) + lo below it
-    const int sl = s + L2;
-    const uint32_t off = (g << s) + lo;
+    const uint32_t lane_a = (((qa_l << s) * a.S) + c) * 4u;
+    const uint32_t lane_b = (((qb_l << s) * a.S) + c) * 4u;
+    const uint32_t row_bytes = (a.S * 4u) << s;     // distance between consecutive tile blocks
+    const int sl = s + L2;                          // layout A as seen by dif_levels/dit_levels
 
+    auto view_of = [&](uint32_t tile) {
+        View v;
+        // `tile` is wave-uniform by construction; readfirstlane makes it provably so, which keeps every
+        // twiddle fetch below a SCALAR load.  (A vector load there would sit behind the prefetch in the
+        // in-order vmcnt queue and force it to drain.)
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const uint32_t cc = tile % a.col_chunks, grp = tile / a.col_chunks;
+        v.lo = grp & ((1u << s) - 1u);
+        v.hi = grp >> s;
+        v.dead_mask = (cc * W + c < a.S) ? 0u : 0xFFFFFFFFu;
+        const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.S + cc * W;
+        v.in = make_desc(a.in + origin);
+        v.out = make_desc(a.out + origin);
+        return v;
+    };
+    auto load_rows = [&](uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+        const uint32_t voff = lane_off | v.dead_mask;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r[j][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, (q0 + j * qstep) * row_bytes, 0);
+    };
+    auto store_rows = [&](const uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+        const uint32_t voff = lane_off | v.dead_mask;
+#pragma unroll
+        for (int j = 0; j < R; ++j) __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, (q0 + j * qstep) * row_bytes, 0);
+    };
+    auto lds_write = [&](const uint32_t (&r)[R][1], uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) lane_base[(q0 + j * qstep) * W] = r[j][0];
+    };
+    auto lds_read = [&](uint32_t (&r)[R][1], const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) r[j][0] = lane_base[(q0 + j * qstep) * W];
+    };
+    constexpr bool LOAD_A = MODE != MODE_DIT;  // DIF and MID start in layout A, DIT in layout B
+    auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
+        if constexpr (LOAD_A) load_rows(r, v, lane_a, qa_u, G);
+        else                  load_rows(r, v, lane_b, qb_u, 1);
+    };
+
+    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With PREFETCH the next tile's
+    // blocks are requested before the current tile is computed, so HBM latency and the store drain of the
+    // previous tile hide behind the butterflies even with a single resident workgroup per CU.
+    uint32_t tile = blockIdx.x;
+    if (tile >= a.tiles) return;
+    View v = view_of(tile);
     uint32_t x[R][1];
+    load_tile(x, v);
+    if constexpr (PREFETCH) {
+        // Consume the first tile's loads before the loop.  Otherwise the compiler's wait-count pass merges
+        // "x still in flight" (this path) into the loop header and conservatively drains the NEXT tile's
+        // prefetch at the first use of x in every iteration.
+#pragma unroll
+        for (int j = 0; j < R; ++j) asm volatile("" : "+v"(x[j][0]));
+    }
 
-    auto load_rows = [&](const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) x[j][0] = lane_base[tile_origin + (size_t)(q0 + j * qstep) * row_elems];
-        } else {
-#pragma unroll
-            for (int j = 0; j < R; ++j) x[j][0] = 0u;
-        }
-    };
-    auto store_rows = [&](uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
-        if (!live) return;
-#pragma unroll
-        for (int j = 0; j < R; ++j) lane_base[tile_origin + (size_t)(q0 + j * qstep) * row_elems] = x[j][0];
-    };
-    auto lds_write = [&](uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) lane_base[(q0 + j * qstep) * W] = x[j][0];
-    };
-    auto lds_read = [&](const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) x[j][0] = lane_base[(q0 + j * qstep) * W];
-    };
-
-    if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
-        load_rows(in_a, qa_u, G);
-        if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
-        dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
-        lds_write(lds_a, qa_u, G);
-        __syncthreads();
-        lds_read(lds_b, qb_u, 1);
-        if constexpr (MODE == MODE_DIF) {
-            if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
-            else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, lo, s);
-            store_rows(out_b, qb_u, 1);
-        } else {
-            dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
-            // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so the
-            // R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different blocks:
-            // both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
-            const uint32_t* __restrict__ d = a.dscale + ((size_t)hi << LOGT) + qb_u;
-            constexpr int CH = 8;
-#pragma unroll
-            for (int k0 = 0; k0 < R; k0 += CH) {
-                uint32_t dl[CH], dh[CH];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) dl[i] = d[k0 + i];
-                if constexpr (PAIR) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) dh[i] = d[R + k0 + i];
-                }
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const uint32_t f = PAIR ? pair_twiddle<LOGR>(dl[i], dh[i], upper_mask) : dl[i];
-                    x[k0 + i][0] = gf::mul_mont(x[k0 + i][0], f);
-                }
+    for (;;) {
+        const uint32_t next = tile + gridDim.x;
+        const bool has_next = next < a.tiles;  // uniform
+        View vn = v;
+        uint32_t y[PREFETCH ? R : 1][1];
+        if constexpr (PREFETCH) {
+            if (has_next) {
+                vn = view_of(next);
+                load_tile(y, vn);
             }
-            dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
-            __syncthreads();  // every lane has finished reading the first exchange
-            lds_write(lds_b, qb_u, 1);
-            __syncthreads();
-            lds_read(lds_a, qa_u, G);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
+        }
+
+        const uint32_t off = (g << s) + v.lo;
+        if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
+            if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
+            dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
+            lds_write(x, lds_a, qa_u, G);
+            lds_barrier();
+            lds_read(x, lds_b, qb_u, 1);
+            if constexpr (MODE == MODE_DIF) {
+                if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
+                store_rows(x, v, lane_b, qb_u, 1);
+            } else {
+                dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so
+                // the R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different
+                // blocks: both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
+                const_u32_ptr d = as_constant(a.dscale) + ((size_t)v.hi << LOGT) + qb_u;
+                constexpr int CH = 8;
+#pragma unroll
+                for (int k0 = 0; k0 < R; k0 += CH) {
+                    uint32_t dl[CH], dh[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) dl[i] = d[k0 + i];
+                    if constexpr (PAIR) {
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) dh[i] = d[R + k0 + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const uint32_t f = PAIR ? pair_twiddle<LOGR>(dl[i], dh[i], upper_mask) : dl[i];
+                        x[k0 + i][0] = gf::mul_mont(x[k0 + i][0], f);
+                    }
+                }
+                dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
+                lds_barrier();  // every lane has finished reading the first exchange
+                lds_write(x, lds_b, qb_u, 1);
+                lds_barrier();
+                lds_read(x, lds_a, qa_u, G);
+                dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
+                if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+                store_rows(x, v, lane_a, qa_u, G);
+            }
+        } else {
+            if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
+            else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
+            lds_write(x, lds_b, qb_u, 1);
+            lds_barrier();
+            lds_read(x, lds_a, qa_u, G);
             dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
             if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
-            store_rows(out_a, qa_u, G);
+            store_rows(x, v, lane_a, qa_u, G);
         }
-    } else {
-        load_rows(in_b, qb_u, 1);
-        if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
-        else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, lo, s);
-        lds_write(lds_b, qb_u, 1);
-        __syncthreads();
-        lds_read(lds_a, qa_u, G);
-        dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
-        if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
-        store_rows(out_a, qa_u, G);
+
+        if (!has_next) break;
+        tile = next;
+        if constexpr (PREFETCH) {
+            v = vn;
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j][0] = y[j][0];
+        } else {
+            v = view_of(tile);
+            load_tile(x, v);
+        }
+        lds_barrier();  // the LDS tile is rewritten by the next iteration
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE>
+static int g_persistent_cus = 0;  // 0 = one workgroup per tile; else CU count used to size persistent grids
+static bool g_prefetch = true;
+
+void tile_config(int persistent_cus, bool prefetch)
+{
+    g_persistent_cus = persistent_cus;
+    g_prefetch = prefetch;
+}
+
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH>;
     static bool configured = false;  // per instantiation; the attribute is idempotent
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -244,8 +328,17 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     }
     TileArgs b = a;
     b.col_chunks = (a.S + C::W - 1) / C::W;
-    const uint64_t blocks = ((uint64_t)1 << (a.n - LOGT)) * b.col_chunks;
-    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t tiles = ((uint64_t)1 << (a.n - LOGT)) * b.col_chunks;
+    if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    b.tiles = (uint32_t)tiles;
+    uint64_t blocks = tiles;
+    if (g_persistent_cus > 0) {
+        // resident workgroups per CU: LDS (160 KiB) and 16 waves (4 per SIMD at <= 128 VGPRs)
+        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / C::G;
+        const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : (by_waves < 1 ? 1 : by_waves);
+        const uint64_t cap = (uint64_t)g_persistent_cus * per_cu;
+        if (blocks > cap) blocks = cap;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, b);
     return hipGetLastError();
 }
@@ -253,10 +346,11 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 template <int LOGT, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
+    const bool pf = g_prefetch && g_persistent_cus > 0;
     switch (mode) {
-        case MODE_DIF: return launch_one<LOGT, 5, PAIR, MODE_DIF>(a, st);
-        case MODE_DIT: return launch_one<LOGT, 5, PAIR, MODE_DIT>(a, st);
-        default:       return launch_one<LOGT, 5, PAIR, MODE_MID>(a, st);
+        case MODE_DIF: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIF, false>(a, st);
+        case MODE_DIT: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIT, false>(a, st);
+        default:       return launch_one<LOGT, 5, PAIR, MODE_MID, false>(a, st);
     }
 }
 
