@@ -59,10 +59,10 @@ struct fastecc_ctx {
 
     int rmax = 5;            // levels per register pass
     int vec = 1;             // words per lane in register passes
-    int tile_mid = 9;        // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
+    int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
-    bool prefetch = true;    // ... that request the next tile before computing the current one
+    bool prefetch = false;   // ... that request the next tile before computing the current one
     int cus = 256;           // compute units of the device (sizes the persistent grids)
     std::vector<Pass> encode_plan, ntt_plan;
     std::string plan_text;
@@ -641,16 +641,16 @@ int fastecc_set_plan(fastecc_ctx* c, int plan)
     // 0            default
     // rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
     // 1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
-    //              f&2: no next-tile prefetch; f&4: one workgroup per tile instead of persistent workgroups
-    int rmax = 5, vec = 1, tile_mid = 9;
+    //              f&2: next-tile prefetch in persistent DIF/DIT tiles; f&4: never use persistent workgroups
+    int rmax = 5, vec = 1, tile_mid = 10;
     bool wide = false;
     c->persistent = true;
-    c->prefetch = true;
+    c->prefetch = false;
     if (plan >= 1000) {
         tile_mid = (plan - 1000) / 10;
         const int f = (plan - 1000) % 10;
         wide = f & 1;
-        c->prefetch = !(f & 2);
+        c->prefetch = (f & 2) != 0;
         c->persistent = !(f & 4);
         if (f > 7) return FASTECC_E_INVAL;
         if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_t
 // launcher
 // ------------------------------------------------------------------------------------------------
 static int g_persistent_cus = 0;  // 0 = one workgroup per tile; else CU count used to size persistent grids
-static bool g_prefetch = true;
+static bool g_prefetch = false;
 
 void tile_config(int persistent_cus, bool prefetch)
 {
@@ -332,7 +332,10 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     b.tiles = (uint32_t)tiles;
     uint64_t blocks = tiles;
-    if (g_persistent_cus > 0) {
+    // Persistent workgroups pay off when only ONE workgroup fits a CU (128 KiB tiles): the grid is sized to
+    // the machine and each workgroup walks its tiles.  Smaller tiles leave room for two or more resident
+    // workgroups, and the hardware dispatcher interleaving them measured faster (sweep table).
+    if (g_persistent_cus > 0 && C::LDS_BYTES > 80 * 1024) {
         // resident workgroups per CU: LDS (160 KiB) and 16 waves (4 per SIMD at <= 128 VGPRs)
         const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / C::G;
         const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : (by_waves < 1 ? 1 : by_waves);
@@ -346,7 +349,7 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 template <int LOGT, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
-    const bool pf = g_prefetch && g_persistent_cus > 0;
+    const bool pf = g_prefetch && g_persistent_cus > 0 && TileCfg<LOGT, 5, PAIR>::LDS_BYTES > 80 * 1024;
     switch (mode) {
         case MODE_DIF: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIF, false>(a, st);
         case MODE_DIT: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIT, false>(a, st);
