@@ -66,26 +66,26 @@ int main(int argc, char** argv)
         return 1;
     }
     const double t_h2d0 = now_ms();
-    hipMemcpy(dev, host.data(), total * 4, hipMemcpyHostToDevice);
+    if (hipMemcpy(dev, host.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
     const double t_h2d1 = now_ms();
 
     // warm-up on a scratch copy is not possible in place; time the first real call like the reference does
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, nullptr);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
     rc = fastecc_encode(ctx, dev, dev, FASTECC_MEM_DEVICE, nullptr);
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
     if (rc != FASTECC_OK) {
         fprintf(stderr, "fastecc_encode: %s\n", fastecc_strerror(rc));
         return 1;
     }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
 
     const double t_d2h0 = now_ms();
-    hipMemcpy(host.data(), dev, total * 4, hipMemcpyDeviceToHost);
+    if (hipMemcpy(host.data(), dev, total * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     const double t_d2h1 = now_ms();
 
     const double bytes = 2.0 * N * words * 4;
@@ -99,7 +99,7 @@ int main(int argc, char** argv)
                t_h2d1 - t_h2d0, t_d2h1 - t_d2h0);
         printf("  parity checksum: %u\n", rolling_hash(host.data(), total));
     }
-    hipFree(dev);
+    (void)hipFree(dev);
     fastecc_destroy(ctx);
     return 0;
 }

@@ -140,6 +140,37 @@ __device__ __forceinline__ uint32_t mont_d(uint32_t x, uint32_t wm)
 // E: Barrett as in the reference (general operands)
 __device__ __forceinline__ uint32_t mul_e(uint32_t x, uint32_t w) { return gf::mul(x, w); }
 
+// F: like D but the second multiply is a plain high multiply: r = hi(t) - hi(m*p)
+__device__ __forceinline__ uint32_t mont_f(uint32_t x, uint32_t wm)
+{
+    const uint64_t t = (uint64_t)x * wm;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    const uint32_t m = lo + (lo << 20);
+    const uint32_t q = __umulhi(m, P);
+    uint32_t r;
+    const bool borrow = __builtin_usub_overflow(hi, q, &r);
+    return borrow ? r + P : r;
+}
+
+// G: returns p - (x*w) (or 0 when the product is 0): the negated product, same cost as F
+__device__ __forceinline__ uint32_t mont_neg(uint32_t x, uint32_t wm)
+{
+    const uint64_t t = (uint64_t)x * wm;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    const uint32_t m = lo + (lo << 20);
+    const uint32_t q = __umulhi(m, P);
+    uint32_t r;
+    const bool borrow = __builtin_usub_overflow(q, hi, &r);
+    return borrow ? r + P : r;
+}
+
+__device__ __forceinline__ uint32_t sub1(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    const bool borrow = __builtin_usub_overflow(a, b, &d);
+    return borrow ? d + P : d;
+}
+
 __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b)
 {
     // carry-based: s = a+b; u = s - p (mod 2^32); take u when a+b overflowed or s >= p
@@ -170,13 +201,24 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
             if constexpr (VAR == 3) t = v::mont_d(b[i], w);
             if constexpr (VAR == 4) t = v::mul_e(b[i], w);
             if constexpr (VAR == 5) t = v::mont_b(b[i], w);
+            if constexpr (VAR == 6) t = v::mont_f(b[i], w);
+            if constexpr (VAR == 7) t = v::mont_f(b[i], w);
+            if constexpr (VAR == 8) t = v::mont_neg(b[i], w);
+            if constexpr (VAR == 9) t = v::mont_d(b[i], w);
             const uint32_t x = a[i];
-            if constexpr (VAR == 5) {
+            if constexpr (VAR == 5 || VAR == 6) {
                 a[i] = v::add2(x, t);
+                b[i] = v::sub1(x, t);
+            } else if constexpr (VAR == 7 || VAR == 9) {
+                a[i] = v::sub1(x, gf::P - t);  // add as subtract of the negation
+                b[i] = v::sub1(x, t);
+            } else if constexpr (VAR == 8) {
+                a[i] = v::sub1(x, t);          // t holds p - b*w: x + b*w
+                b[i] = v::sub1(x, gf::P - t);  // x - b*w   (t == 0 -> p - 0 = p -> x - p wraps -> +p -> x)
             } else {
                 a[i] = gf::add(x, t);
+                b[i] = gf::sub(x, t);
             }
-            b[i] = gf::sub(x, t);
         }
         w = w * 3u + 1u;  // keep the twiddle scalar but changing (SALU)
         w = w >= gf::P ? w - gf::P : w;
@@ -188,7 +230,9 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
 }
 
 static const char* BFLY_NAME[] = {"mont:mad64+mulhi (gf.hpp)", "mont:mullo+mulhi+mulhi,usub_overflow", "mont:mad64+shift-form hi(m*p)",
-                                  "mont:2x mad64", "barrett (reference form)", "mont B + carry-form add"};
+                                  "mont:2x mad64", "barrett (reference form)", "mont B + carry-form add",
+                                  "mont F(mad64+mulhi) + carry-form add", "mont F + add-as-sub(p-t)", "mont NEG + sub-only",
+                                  "mont D(2x mad64) + add-as-sub(p-t)"};
 
 template <int VAR>
 static void run_bfly(uint32_t* d_out, int blocks, std::vector<uint32_t>* first)
@@ -308,6 +352,10 @@ int main(int argc, char** argv)
         run_bfly<3>(d_out, blocks, &first);
         run_bfly<4>(d_out, blocks, &first);
         run_bfly<5>(d_out, blocks, &first);
+        run_bfly<6>(d_out, blocks, &first);
+        run_bfly<7>(d_out, blocks, &first);
+        run_bfly<8>(d_out, blocks, &first);
+        run_bfly<9>(d_out, blocks, &first);
     }
     if (do_copy) {
         const int n = 19;
