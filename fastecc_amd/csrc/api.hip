@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -236,6 +237,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     const uint32_t* src = in;
     char name[32];
     tile_config(c->persistent ? c->cus : 0, c->prefetch);
+
     for (const Pass& p : plan) {
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
         if (p.tile) {

@@ -237,16 +237,21 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_t
         }
 
         const uint32_t off = (g << s) + v.lo;
+        const bool compute = !(a.debug & 1u), stores = !(a.debug & 2u);  // uniform; always true outside experiments
         if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
-            if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
-            dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
+            if (compute) {
+                if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
+                dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
+            }
             lds_write(x, lds_a, qa_u, G);
             lds_barrier();
             lds_read(x, lds_b, qb_u, 1);
             if constexpr (MODE == MODE_DIF) {
-                if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
-                else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
-                store_rows(x, v, lane_b, qb_u, 1);
+                if (compute) {
+                    if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                    else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
+                }
+                if (stores) store_rows(x, v, lane_b, qb_u, 1);
             } else {
                 dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
                 // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so
@@ -306,6 +311,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_t
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
+static uint32_t g_debug = 0;  // ablation switches (profiles/r01/ablation_dif_tiles.md); never set by the product
+void tile_debug(uint32_t flags) { g_debug = flags; }
 static int g_persistent_cus = 0;  // 0 = one workgroup per tile; else CU count used to size persistent grids
 static bool g_prefetch = false;
 
@@ -320,17 +327,21 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR>;
     auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH>;
-    static bool configured = false;  // per instantiation; the attribute is idempotent
-    if (!configured) {
+    // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
-        configured = true;
+        if (dev >= 0 && dev < 64) configured[dev] = true;
     }
     TileArgs b = a;
     b.col_chunks = (a.S + C::W - 1) / C::W;
     const uint64_t tiles = ((uint64_t)1 << (a.n - LOGT)) * b.col_chunks;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     b.tiles = (uint32_t)tiles;
+    b.debug = g_debug;
     uint64_t blocks = tiles;
     // Persistent workgroups pay off when only ONE workgroup fits a CU (128 KiB tiles): the grid is sized to
     // the machine and each workgroup walks its tiles.  Smaller tiles leave room for two or more resident
