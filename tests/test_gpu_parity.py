@@ -309,3 +309,45 @@ def test_headline_properties(torch_cuda, headline, oracle):
     enc.encode(c)
     torch.cuda.synchronize()
     assert bool((c == 123456789).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# shapes that exercise the tile kernels' bounds-checked lanes and the large-block fallback
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log2n,S", [(16, 33), (18, 7), (19, 5), (19, 40)])
+def test_large_n_with_ragged_blocks(torch_cuda, fe, oracle, log2n, S):
+    """Full-depth plans (dif9/mid10/dit9 at 2^19) with block sizes that are not a multiple of the 32-word
+    tile rows: lanes past the block end are masked by the buffer bounds check."""
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n * 100 + S), N, S)
+    d = to_dev(torch, x)
+    guard = torch.full((1024,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")  # allocated right after d
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(d)
+        torch.cuda.synchronize()
+    assert np.array_equal(to_host(d), oracle.encode_fast(x))
+    assert bool((guard == 0x5A5A5A5A).all())
+
+
+def test_blocks_too_large_for_tile_offsets_fall_back(torch_cuda, fe, oracle):
+    """32 MiB blocks: a 64-block tile would span > 2^31 bytes, so the plan must use register passes
+    (64-bit addressing).  Checked against an explicit register plan and, on column slabs, the oracle."""
+    torch = torch_cuda
+    N, S = 64, (1 << 23) + 4
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(7)
+    d = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    ref_cols = [slice(0, 8), slice(S - 8, S), slice(S // 2, S // 2 + 8)]
+    inputs = [to_host(d.view(N, S)[:, c].contiguous()) for c in ref_cols]
+    out_default = torch.empty_like(d)
+    out_reg = torch.empty_like(d)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        assert "T32" not in enc.plan() and "T64" not in enc.plan(), enc.plan()
+        enc.encode(d, out_default)
+        enc.set_plan(34)
+        enc.encode(d, out_reg)
+        torch.cuda.synchronize()
+    assert torch.equal(out_default, out_reg)
+    for c, xin in zip(ref_cols, inputs):
+        assert np.array_equal(to_host(out_default.view(N, S)[:, c].contiguous()), oracle.encode_fast(xin))
