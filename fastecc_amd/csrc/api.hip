@@ -236,7 +236,6 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     const int vec = pick_vec(c, in, out);
     const uint32_t* src = in;
     char name[32];
-    tile_config(c->persistent ? c->cus : 0, c->prefetch);
 
     for (const Pass& p : plan) {
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
@@ -250,6 +249,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.S = (uint32_t)c->S;
             a.n = c->n;
             a.s = p.s;
+            a.persistent_cus = c->persistent ? c->cus : 0;
+            a.prefetch = c->prefetch;
             HIP_TRY(launch_tile(p.logr, p.pair, p.mode, a, st));
         } else {
             PassArgs a{};
@@ -637,23 +638,21 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 
 const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str() : ""; }
 
-int fastecc_set_plan(fastecc_ctx* c, int plan)
+// Plan ids:
+//   0            default
+//   rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
+//   1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
+//                f&2: next-tile prefetch in persistent DIF/DIT tiles; f&4: never use persistent workgroups
+static int apply_plan(fastecc_ctx* c, int plan)
 {
-    if (!c) return FASTECC_E_INVAL;
-    // 0            default
-    // rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
-    // 1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
-    //              f&2: next-tile prefetch in persistent DIF/DIT tiles; f&4: never use persistent workgroups
     int rmax = 5, vec = 1, tile_mid = 10;
-    bool wide = false;
-    c->persistent = true;
-    c->prefetch = false;
+    bool wide = false, prefetch = false, persistent = true;
     if (plan >= 1000) {
         tile_mid = (plan - 1000) / 10;
         const int f = (plan - 1000) % 10;
         wide = f & 1;
-        c->prefetch = (f & 2) != 0;
-        c->persistent = !(f & 4);
+        prefetch = (f & 2) != 0;
+        persistent = !(f & 4);
         if (f > 7) return FASTECC_E_INVAL;
         if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
     } else if (plan != 0) {
@@ -661,16 +660,64 @@ int fastecc_set_plan(fastecc_ctx* c, int plan)
         vec = plan % 10;
         tile_mid = 0;
     }
-    if (rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
+    if (plan < 0 || rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
     c->rmax = rmax;
     c->vec = vec;
     c->tile_mid = tile_mid;
     c->tile_mid_wide = wide;
+    c->prefetch = prefetch;
+    c->persistent = persistent;
     build_plans(c);
+    return FASTECC_OK;
+}
+
+int fastecc_set_plan(fastecc_ctx* c, int plan)
+{
+    if (!c) return FASTECC_E_INVAL;
+    const int rc = apply_plan(c, plan);
+    if (rc != FASTECC_OK) return rc;
     DeviceGuard dg(c->device);
     if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
     HIP_TRY(hipDeviceSynchronize());  // kernels still reading the old tables
     return upload_twiddles(c);
+}
+
+// ---- host-only introspection: no device is touched, so the planning logic is testable anywhere ----
+static int host_plan(fastecc_ctx* c, uint64_t k, uint64_t block_bytes, int plan)
+{
+    const int lg = ilog2_exact(k);
+    if (k < 2 || lg < 0 || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
+    if (lg > 19) return FASTECC_E_UNSUPPORTED;
+    c->N = k;
+    c->n = lg;
+    c->S = block_bytes / 4;
+    return apply_plan(c, plan);
+}
+
+int fastecc_plan_describe(uint64_t k, uint64_t block_bytes, int plan, char* buf, size_t cap)
+{
+    if (!buf || cap == 0) return FASTECC_E_INVAL;
+    fastecc_ctx c;
+    const int rc = host_plan(&c, k, block_bytes, plan);
+    if (rc != FASTECC_OK) return rc;
+    snprintf(buf, cap, "%s", c.plan_text.c_str());
+    return FASTECC_OK;
+}
+
+int fastecc_plan_twiddles(uint64_t k, uint64_t block_bytes, int plan, int which, uint32_t* out, int32_t* level_stride)
+{
+    if (!out || which < 0 || which > 3) return FASTECC_E_INVAL;
+    fastecc_ctx c;
+    const int rc = host_plan(&c, k, block_bytes, plan);
+    if (rc != FASTECC_OK) return rc;
+    const uint32_t wN = gf::h_root((uint32_t)k), wNi = gf::h_inv(wN);
+    const std::vector<int> sl = level_strides(which < 2 ? c.encode_plan : c.ntt_plan, c.n);
+    const bool inverse_roots = (which == 0 || which == 3);
+    const std::vector<uint32_t> tab = build_level_table(c.n, inverse_roots ? wNi : wN, sl);
+    memcpy(out, tab.data(), (size_t)k * 4);
+    if (level_stride)
+        for (int l = 0; l < c.n; l++) level_stride[l] = sl[l];
+    return FASTECC_OK;
 }
 
 }  // extern "C"

@@ -33,13 +33,11 @@ struct TileArgs {
     int s;
     uint32_t col_chunks;  // filled by the launcher
     uint32_t tiles;       // filled by the launcher: tiles in this pass (persistent workgroups loop over them)
-    uint32_t debug;       // experiments only (FASTECC_TILE_DEBUG env): 1 = skip the butterflies, 2 = skip the stores
+    uint32_t debug;       // ablation switches (profiles/r01/ablation_dif_tiles.md); always 0 in the product
+    int persistent_cus;   // > 0: 128-KiB tiles run as persistent workgroups sized for that many CUs
+    bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
 };
 
-// persistent_cus > 0: tile kernels run as persistent workgroups sized for that many CUs (0: one
-// workgroup per tile); prefetch: DIF/DIT tile kernels request the next tile before computing this one.
-void tile_config(int persistent_cus, bool prefetch);
-void tile_debug(uint32_t flags);
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
 bool tile_supported(int logt, bool pair);
 hipError_t launch_tile(int logt, bool pair, int mode, const TileArgs& a, hipStream_t st);

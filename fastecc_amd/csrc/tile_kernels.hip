@@ -311,17 +311,6 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_t
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-static uint32_t g_debug = 0;  // ablation switches (profiles/r01/ablation_dif_tiles.md); never set by the product
-void tile_debug(uint32_t flags) { g_debug = flags; }
-static int g_persistent_cus = 0;  // 0 = one workgroup per tile; else CU count used to size persistent grids
-static bool g_prefetch = false;
-
-void tile_config(int persistent_cus, bool prefetch)
-{
-    g_persistent_cus = persistent_cus;
-    g_prefetch = prefetch;
-}
-
 template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
@@ -341,16 +330,15 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     const uint64_t tiles = ((uint64_t)1 << (a.n - LOGT)) * b.col_chunks;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     b.tiles = (uint32_t)tiles;
-    b.debug = g_debug;
     uint64_t blocks = tiles;
     // Persistent workgroups pay off when only ONE workgroup fits a CU (128 KiB tiles): the grid is sized to
     // the machine and each workgroup walks its tiles.  Smaller tiles leave room for two or more resident
     // workgroups, and the hardware dispatcher interleaving them measured faster (sweep table).
-    if (g_persistent_cus > 0 && C::LDS_BYTES > 80 * 1024) {
+    if (a.persistent_cus > 0 && C::LDS_BYTES > 80 * 1024) {
         // resident workgroups per CU: LDS (160 KiB) and 16 waves (4 per SIMD at <= 128 VGPRs)
         const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / C::G;
         const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : (by_waves < 1 ? 1 : by_waves);
-        const uint64_t cap = (uint64_t)g_persistent_cus * per_cu;
+        const uint64_t cap = (uint64_t)a.persistent_cus * per_cu;
         if (blocks > cap) blocks = cap;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, b);
@@ -360,7 +348,7 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 template <int LOGT, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
-    const bool pf = g_prefetch && g_persistent_cus > 0 && TileCfg<LOGT, 5, PAIR>::LDS_BYTES > 80 * 1024;
+    const bool pf = a.prefetch && a.persistent_cus > 0 && TileCfg<LOGT, 5, PAIR>::LDS_BYTES > 80 * 1024;
     switch (mode) {
         case MODE_DIF: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIF, false>(a, st);
         case MODE_DIT: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIT, false>(a, st);

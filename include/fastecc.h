@@ -123,8 +123,19 @@ int fastecc_profile_reset(fastecc_ctx *ctx);
 
 /* Plan description, e.g. "dif5,dif5,...|mid...|dit..." — for logs and DESIGN.md tables. */
 const char *fastecc_plan_string(fastecc_ctx *ctx);
-/* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md. */
+/* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md §8. */
 int fastecc_set_plan(fastecc_ctx *ctx, int plan);
+
+/*
+ * Host-only introspection (no HIP device is touched): the pass plan that (k, block_bytes, plan) selects,
+ * and the level-packed twiddle table that goes with it — what replaces the roots[] array of
+ * ntt.cpp:397-402.  which: 0 = encode/interpolate (inverse roots), 1 = encode/evaluate (forward roots),
+ * 2 = fastecc_ntt forward, 3 = fastecc_ntt inverse.  `out` receives k words (Montgomery form, w*2^32 mod p;
+ * level l at [2^l, 2^(l+1))); level_stride (optional, log2(k) ints) the log2 stride of the register run
+ * that executes each level.
+ */
+int fastecc_plan_describe(uint64_t k, uint64_t block_bytes, int plan, char *buf, size_t cap);
+int fastecc_plan_twiddles(uint64_t k, uint64_t block_bytes, int plan, int which, uint32_t *out, int32_t *level_stride);
 
 #ifdef __cplusplus
 }
