@@ -351,3 +351,43 @@ def test_blocks_too_large_for_tile_offsets_fall_back(torch_cuda, fe, oracle):
     assert torch.equal(out_default, out_reg)
     for c, xin in zip(ref_cols, inputs):
         assert np.array_equal(to_host(out_default.view(N, S)[:, c].contiguous()), oracle.encode_fast(xin))
+
+
+# ------------------------------------------------------------------------------------------------
+# directly against the unmodified reference (prebuilt oracle/_ref travels to the GPU box)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log2n,S,avx2", [(7, 1024, False), (12, 513, True), (15, 1024, True), (16, 256, False)])
+def test_encode_equals_unmodified_reference(torch_cuda, fe, log2n, S, avx2):
+    """HIP encode vs FastECC's own code (RS.cpp:41-63 call sequence on MFA_NTT, scalar and AVX2 builds)."""
+    from oracle import Reference
+    if not Reference.available(avx2):
+        pytest.skip("oracle/_ref not prebuilt")
+    torch = torch_cuda
+    ref = Reference(avx2)
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n + S), N, S)
+    d = to_dev(torch, x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(d)
+        torch.cuda.synchronize()
+    assert np.array_equal(to_host(d), ref.encode(x))
+
+
+@pytest.mark.parametrize("log2n,S", [(8, 1024), (13, 64)])
+def test_ntt_equals_unmodified_reference(torch_cuda, fe, log2n, S):
+    """fastecc_ntt vs MFA_NTT and Rec_NTT of the reference, read back in logical block order."""
+    from oracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref not prebuilt")
+    torch = torch_cuda
+    ref = Reference()
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n), N, S)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        for inverse in (False, True):
+            d = to_dev(torch, x)
+            enc.ntt(d, inverse)
+            torch.cuda.synchronize()
+            got = to_host(d)
+            assert np.array_equal(got, ref.ntt(x, inverse, Reference.MFA))
+            assert np.array_equal(got, ref.ntt(x, inverse, Reference.REC))
