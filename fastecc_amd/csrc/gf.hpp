@@ -65,19 +65,21 @@ GF_D uint32_t add(uint32_t x, uint32_t y)
 }
 
 // x * w mod p for a constant held in Montgomery form (wm = w * 2^32 mod p).  x may be any uint32.
-//   t = x * wm                     (v_mad_u64_u32)            t <= (2^32-1)(p-1)
+//   t = x * wm                     (v_mad_u64_u32: both halves in one instruction)   t <= (2^32-1)(p-1)
 //   m = lo(t) * (1 + 2^20)         (v_lshl_add_u32)           m * p == lo(t)  (mod 2^32)
-//   u = t + m * (2^20 - 1)         (v_mad_u64_u32)            = t - m*p + m*2^32, lo(u) == 0, no overflow:
-//                                                              u <= (2^32-1)(p-1+2^20-1) = (2^32-1)^2
-//   r = hi(u) - m  in (-p, p)      (v_sub_co_u32, +p if it borrowed)
+//   q = hi(m * p)                  (v_mul_hi_u32)             lo(m*p) == lo(t), so t - m*p = (hi(t) - q) * 2^32 exactly
+//   r = hi(t) - q  in (-p, p)      (v_sub_co_u32, +p if it borrowed)
+// Equivalent forms measured on MI355X (tools/microbench.hip "bfly", profiles/r01/microbench_bfly_variants.jsonl):
+// a second v_mad_u64_u32 folding the reduction (u = t + m*(2^20-1), r = hi(u) - m), mul_lo+mul_hi+mul_hi, a
+// shift-only hi(m*p), and a two-word twiddle without the 64-bit product are all within 0-5 % of this one.
 GF_D uint32_t mul_mont(uint32_t x, uint32_t wm)
 {
     const uint64_t t = (uint64_t)x * wm;
-    const uint32_t lo = (uint32_t)t;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     const uint32_t m = lo + (lo << 20);
-    const uint64_t u = t + (uint64_t)m * MONT_ONE;
+    const uint32_t q = __umulhi(m, P);
     uint32_t r;
-    const bool borrow = __builtin_usub_overflow((uint32_t)(u >> 32), m, &r);
+    const bool borrow = __builtin_usub_overflow(hi, q, &r);
     return borrow ? r + P : r;
 }
 

@@ -164,6 +164,17 @@ __device__ __forceinline__ uint32_t mont_neg(uint32_t x, uint32_t wm)
     return borrow ? r + P : r;
 }
 
+// H: two-word twiddle (wm, wq = wm * p^-1 mod 2^32): no 64-bit product, three 32-bit multiplies
+__device__ __forceinline__ uint32_t mont_h(uint32_t x, uint32_t wm, uint32_t wq)
+{
+    const uint32_t hi = __umulhi(x, wm);
+    const uint32_t m = x * wq;
+    const uint32_t q = __umulhi(m, P);
+    uint32_t r;
+    const bool borrow = __builtin_usub_overflow(hi, q, &r);
+    return borrow ? r + P : r;
+}
+
 __device__ __forceinline__ uint32_t sub1(uint32_t a, uint32_t b)
 {
     uint32_t d;
@@ -205,8 +216,9 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
             if constexpr (VAR == 7) t = v::mont_f(b[i], w);
             if constexpr (VAR == 8) t = v::mont_neg(b[i], w);
             if constexpr (VAR == 9) t = v::mont_d(b[i], w);
+            if constexpr (VAR == 10) t = v::mont_h(b[i], w, w * 0x00100001u);
             const uint32_t x = a[i];
-            if constexpr (VAR == 5 || VAR == 6) {
+            if constexpr (VAR == 5 || VAR == 6 || VAR == 10) {
                 a[i] = v::add2(x, t);
                 b[i] = v::sub1(x, t);
             } else if constexpr (VAR == 7 || VAR == 9) {
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
 static const char* BFLY_NAME[] = {"mont:mad64+mulhi (gf.hpp)", "mont:mullo+mulhi+mulhi,usub_overflow", "mont:mad64+shift-form hi(m*p)",
                                   "mont:2x mad64", "barrett (reference form)", "mont B + carry-form add",
                                   "mont F(mad64+mulhi) + carry-form add", "mont F + add-as-sub(p-t)", "mont NEG + sub-only",
-                                  "mont D(2x mad64) + add-as-sub(p-t)"};
+                                  "mont D(2x mad64) + add-as-sub(p-t)", "mont H(two-word twiddle, 3 mul32) + carry-form add"};
 
 template <int VAR>
 static void run_bfly(uint32_t* d_out, int blocks, std::vector<uint32_t>* first)
@@ -356,6 +368,8 @@ int main(int argc, char** argv)
         run_bfly<7>(d_out, blocks, &first);
         run_bfly<8>(d_out, blocks, &first);
         run_bfly<9>(d_out, blocks, &first);
+        run_bfly<10>(d_out, blocks, &first);
+        run_bfly<6>(d_out, blocks, &first);
     }
     if (do_copy) {
         const int n = 19;
