@@ -32,7 +32,8 @@ class FastEccError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # FASTECC_HIP_LIB lets experiments A/B another build of the same library (e.g. different hipcc flags)
+    return os.environ.get("FASTECC_HIP_LIB") or _build.LIB_PATH
 
 
 def lib():
