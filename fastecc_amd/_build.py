@@ -73,15 +73,18 @@ def build_host(force=False, verbose=False):
 
 
 def build_microbench(force=False, verbose=False):
-    src = os.path.join(ROOT, "tools", "microbench.hip")
-    if not os.path.exists(src):
-        return None
-    if not (force or _newer(MICROBENCH_PATH, [src, os.path.join(CSRC, "gf.hpp")])):
-        return MICROBENCH_PATH
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", MICROBENCH_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
+    for name in ("microbench", "microbench_valu2"):
+        src = os.path.join(ROOT, "tools", name + ".hip")
+        out = os.path.join(LIB_DIR, name)
+        if not os.path.exists(src):
+            continue
+        if not (force or _newer(out, [src, os.path.join(CSRC, "gf.hpp")])):
+            continue
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return MICROBENCH_PATH
 
 

@@ -30,6 +30,7 @@ struct Pass {
     int s;      // log2 of the smallest stride
     bool tile;  // LDS-tiled kernel (tile_kernels.hip) instead of a register pass (kernels.hip)
     bool pair;  // tile only: 32-word rows with the cross-lane top level
+    int rlog;   // tile only: log2 of the words a lane keeps in registers (5, or 4 for the slim outer tiles)
 };
 
 struct ProfileRec {
@@ -62,6 +63,7 @@ struct fastecc_ctx {
     int vec = 1;             // words per lane in register passes
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
+    bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
     bool prefetch = false;   // ... that request the next tile before computing the current one
     int cus = 256;           // compute units of the device (sizes the persistent grids)
@@ -125,20 +127,21 @@ bool tile_fits(const fastecc_ctx* c, int logt, int s)
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
 {
     const bool fits = tile_fits(c, bits, s);
-    if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true});
-    else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false});
+    if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
+    else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
+    else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
     else if (mode == MODE_DIT) {
         int ss = s;
         const std::vector<int> parts = split_levels(bits, c->rmax);
         for (auto it = parts.rbegin(); it != parts.rend(); ++it) {
-            plan.push_back({mode, *it, ss, false, false});
+            plan.push_back({mode, *it, ss, false, false, 0});
             ss += *it;
         }
     } else {
         int ss = s + bits;
         for (int r : split_levels(bits, c->rmax)) {
             ss -= r;
-            plan.push_back({mode, r, ss, false, false});
+            plan.push_back({mode, r, ss, false, false, 0});
         }
     }
 }
@@ -168,7 +171,7 @@ void build_plans(fastecc_ctx* c)
         s -= r;
         push_chunk(c->encode_plan, MODE_DIF, r, s, c);
     }
-    c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair});
+    c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair, 5});
     s = mid;
     for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
         push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
@@ -183,7 +186,7 @@ void build_plans(fastecc_ctx* c)
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
-        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.pair ? "T32:" : "T64:") : "",
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
@@ -203,7 +206,7 @@ int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
 const char* pass_name(const Pass& p, int vec, char* buf, size_t cap)
 {
     const char* m = p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid";
-    if (p.tile) snprintf(buf, cap, "tile_%s%d_w%d", m, p.logr, p.pair ? 32 : 64);
+    if (p.tile) snprintf(buf, cap, "tile_%s%d_w%d%s", m, p.logr, p.pair ? 32 : 64, p.rlog == 4 ? "_r16" : "");
     else snprintf(buf, cap, "%s%dv%d", m, p.logr, vec);
     return buf;
 }
@@ -251,7 +254,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.s = p.s;
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
-            HIP_TRY(launch_tile(p.logr, p.pair, p.mode, a, st));
+            HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
             PassArgs a{};
             a.in = src;
@@ -296,7 +299,7 @@ std::vector<int> level_strides(const std::vector<Pass>& plan, int n)
         if (!p.tile) {
             for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
         } else {
-            const int l2 = p.logr - 5 - (p.pair ? 1 : 0);  // TileCfg::L2 with LOGR = 5
+            const int l2 = p.logr - p.rlog - (p.pair ? 1 : 0);  // TileCfg::L2
             for (int l = p.s; l < p.s + l2; l++) sl[l] = p.s;
             for (int l = p.s + l2; l < p.s + p.logr; l++) sl[l] = p.s + l2;
         }
@@ -646,10 +649,12 @@ const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str(
 static int apply_plan(fastecc_ctx* c, int plan)
 {
     int rmax = 5, vec = 1, tile_mid = 10;
-    bool wide = false, prefetch = false, persistent = true;
+    bool wide = false, prefetch = false, persistent = true, slim = true;  // plan 0 == 2100
     if (plan >= 1000) {
-        tile_mid = (plan - 1000) / 10;
-        const int f = (plan - 1000) % 10;
+        slim = plan >= 2000;  // 2000+10*a+f: as 1000+10*a+f with 16-word-per-lane outer tiles (8/9 levels)
+        if (plan >= 3000) return FASTECC_E_INVAL;
+        tile_mid = (plan % 1000) / 10;
+        const int f = (plan % 1000) % 10;
         wide = f & 1;
         prefetch = (f & 2) != 0;
         persistent = !(f & 4);
@@ -667,6 +672,7 @@ static int apply_plan(fastecc_ctx* c, int plan)
     c->tile_mid_wide = wide;
     c->prefetch = prefetch;
     c->persistent = persistent;
+    c->slim_outer = slim;
     build_plans(c);
     return FASTECC_OK;
 }

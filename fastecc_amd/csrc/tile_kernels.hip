@@ -142,7 +142,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
 }
 
 template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
-__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), 4) void ntt_tile_kernel(const TileArgs a)
+__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
     using C = TileCfg<LOGT, LOGR, PAIR>;
     using View = TileView;
@@ -336,7 +336,7 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     // workgroups, and the hardware dispatcher interleaving them measured faster (sweep table).
     if (a.persistent_cus > 0 && C::LDS_BYTES > 80 * 1024) {
         // resident workgroups per CU: LDS (160 KiB) and 16 waves (4 per SIMD at <= 128 VGPRs)
-        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = 16 / C::G;
+        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = (LOGR <= 4 ? 32 : 16) / C::G;
         const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : (by_waves < 1 ? 1 : by_waves);
         const uint64_t cap = (uint64_t)a.persistent_cus * per_cu;
         if (blocks > cap) blocks = cap;
@@ -345,38 +345,48 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int LOGT, bool PAIR>
+template <int LOGT, int LOGR, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
-    const bool pf = a.prefetch && a.persistent_cus > 0 && TileCfg<LOGT, 5, PAIR>::LDS_BYTES > 80 * 1024;
+    const bool pf = a.prefetch && a.persistent_cus > 0 && TileCfg<LOGT, LOGR, PAIR>::LDS_BYTES > 80 * 1024;
     switch (mode) {
-        case MODE_DIF: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIF, false>(a, st);
-        case MODE_DIT: return pf ? launch_one<LOGT, 5, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, 5, PAIR, MODE_DIT, false>(a, st);
-        default:       return launch_one<LOGT, 5, PAIR, MODE_MID, false>(a, st);
+        case MODE_DIF: return pf ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, false>(a, st);
+        case MODE_DIT: return pf ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, false>(a, st);
+        default:
+            if constexpr (LOGR == 5) return launch_one<LOGT, LOGR, PAIR, MODE_MID, false>(a, st);
+            else return hipErrorInvalidValue;
     }
 }
 
-bool tile_supported(int logt, bool pair)
+// Tile shapes that are instantiated.  logr = registers per lane (log2): 5 everywhere; 4 additionally for the
+// 8- and 9-level pair tiles of the outer passes (16 words per lane, <= 64 VGPRs, twice the waves per CU).
+bool tile_supported(int logt, bool pair, int logr)
 {
-    return pair ? (logt >= 7 && logt <= 10) : (logt >= 6 && logt <= 9);
+    if (logr == 5) return pair ? (logt >= 7 && logt <= 10) : (logt >= 6 && logt <= 9);
+    if (logr == 4) return pair && (logt == 8 || logt == 9);
+    return false;
 }
 
-hipError_t launch_tile(int logt, bool pair, int mode, const TileArgs& a, hipStream_t st)
+hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st)
 {
-    if (!tile_supported(logt, pair) || a.n < logt) return hipErrorInvalidValue;
+    if (!tile_supported(logt, pair, logr) || a.n < logt) return hipErrorInvalidValue;
+    if (logr == 4) {
+        if (mode == MODE_MID) return hipErrorInvalidValue;
+        return logt == 8 ? launch_mode<8, 4, true>(mode, a, st) : launch_mode<9, 4, true>(mode, a, st);
+    }
     if (pair) {
         switch (logt) {
-            case 7: return launch_mode<7, true>(mode, a, st);
-            case 8: return launch_mode<8, true>(mode, a, st);
-            case 9: return launch_mode<9, true>(mode, a, st);
-            default: return launch_mode<10, true>(mode, a, st);
+            case 7: return launch_mode<7, 5, true>(mode, a, st);
+            case 8: return launch_mode<8, 5, true>(mode, a, st);
+            case 9: return launch_mode<9, 5, true>(mode, a, st);
+            default: return launch_mode<10, 5, true>(mode, a, st);
         }
     }
     switch (logt) {
-        case 6: return launch_mode<6, false>(mode, a, st);
-        case 7: return launch_mode<7, false>(mode, a, st);
-        case 8: return launch_mode<8, false>(mode, a, st);
-        default: return launch_mode<9, false>(mode, a, st);
+        case 6: return launch_mode<6, 5, false>(mode, a, st);
+        case 7: return launch_mode<7, 5, false>(mode, a, st);
+        case 8: return launch_mode<8, 5, false>(mode, a, st);
+        default: return launch_mode<9, 5, false>(mode, a, st);
     }
 }
 

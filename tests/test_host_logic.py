@@ -42,11 +42,13 @@ def parse(text):
 def test_headline_plan_is_three_trips(hip_lib):
     rc, text = describe(hip_lib, 1 << 19, 4096)
     assert rc == 0
+    assert parse(text) == [("S32", "dif", 9, 10), ("T32", "mid", 10, 0), ("S32", "dit", 9, 10)], text
+    rc, text = describe(hip_lib, 1 << 19, 4096, 1100)
     assert parse(text) == [("T32", "dif", 9, 10), ("T32", "mid", 10, 0), ("T32", "dit", 9, 10)], text
 
 
 @pytest.mark.parametrize("log2k", range(1, 20))
-@pytest.mark.parametrize("plan", [0, 31, 54, 1060, 1081, 1090, 1100])
+@pytest.mark.parametrize("plan", [0, 31, 54, 1060, 1081, 1090, 1100, 2080, 2100])
 def test_every_plan_covers_every_level_once(hip_lib, log2k, plan):
     rc, text = describe(hip_lib, 1 << log2k, 4096, plan)
     assert rc == 0, (log2k, plan)
@@ -66,7 +68,7 @@ def test_every_plan_covers_every_level_once(hip_lib, log2k, plan):
 
 def test_blocks_too_large_for_tiles_use_register_passes(hip_lib):
     rc, text = describe(hip_lib, 64, (1 << 25) + 16)
-    assert rc == 0 and "T32" not in text and "T64" not in text
+    assert rc == 0 and "T32" not in text and "T64" not in text and "S32" not in text
     rc, text = describe(hip_lib, 1 << 19, 65536)  # 64 KB blocks (BASELINE config 5's block size)
     assert rc == 0 and "T32:mid10@0" in text and "T32:dif" not in text, text
 
@@ -79,7 +81,7 @@ def test_plan_argument_validation(hip_lib):
     assert describe(hip_lib, 256, 4096, 1118)[0] == -1
 
 
-@pytest.mark.parametrize("log2k,plan", [(3, 0), (7, 0), (10, 0), (13, 0), (13, 51), (16, 1090), (19, 0)])
+@pytest.mark.parametrize("log2k,plan", [(3, 0), (7, 0), (10, 0), (13, 0), (13, 51), (16, 1090), (18, 0), (19, 0), (19, 1100)])
 def test_level_tables_hold_the_reference_roots(hip_lib, oracle, log2k, plan):
     """Entry 2^l + ((i mod 2^sl) << (l-sl)) + (i >> sl) must be (root of order 2^(l+1))^i * 2^32 mod p, with
     the root the reference uses (GF_Root = 19^((p-1)/N), inverse for the interpolation half)."""
