@@ -67,6 +67,7 @@ def lib():
     L.fastecc_ntt.argtypes, L.fastecc_ntt.restype = [vp, vp, i32, i32, vp], i32
     L.fastecc_scale_blocks.argtypes, L.fastecc_scale_blocks.restype = [vp, vp, u32, u32, i32, vp], i32
     L.fastecc_gf_binary.argtypes, L.fastecc_gf_binary.restype = [vp, i32, vp, vp, vp, u64, vp], i32
+    L.fastecc_check_range.argtypes, L.fastecc_check_range.restype = [vp, vp, i32, vp, ctypes.POINTER(u64)], i32
     for name in ("mul", "pow"):
         f = getattr(L, "fastecc_gf_" + name)
         f.argtypes, f.restype = [u32, u32], u32
@@ -164,6 +165,12 @@ class Encoder:
         _check(lib().fastecc_gf_binary(self._h, code, _addr(x), _addr(y), _addr(out), count, stream or None),
                "fastecc_gf_binary")
         return out
+
+    def check_range(self, data, stream=0, mem=MEM_DEVICE):
+        """Number of words >= p in the stripe (0 = encodable); README.md:160-162 of the reference."""
+        bad = ctypes.c_uint64()
+        _check(lib().fastecc_check_range(self._h, _addr(data), mem, stream or None, ctypes.byref(bad)), "fastecc_check_range")
+        return int(bad.value)
 
     # ---- introspection used by bench.py ----
     def set_plan(self, plan):

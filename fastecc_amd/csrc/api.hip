@@ -590,6 +590,45 @@ int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t*
     return FASTECC_OK;
 }
 
+int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* stream, uint64_t* bad_words)
+{
+    if (!c || !data || !bad_words || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t* dev = (const uint32_t*)data;
+    if (mem_kind == FASTECC_MEM_HOST) {
+        int rc = ensure_dbuf(c);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        dev = c->dbuf;
+    } else if (mem_kind != FASTECC_MEM_DEVICE) {
+        return FASTECC_E_INVAL;
+    }
+    // c->factor (N >= 2 words of scratch) holds the 64-bit counter
+    unsigned long long* counter = reinterpret_cast<unsigned long long*>(c->factor);
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    uint64_t words = c->N * c->S, head = 0;
+    // the vector loop wants a 16-byte aligned start: count the few leading words on the host copy of them
+    unsigned long long result = 0;
+    while (((uintptr_t)(dev + head) & 15u) && head < words) head++;
+    if (head) {
+        uint32_t first[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(first, dev, head * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < head; i++) result += first[i] >= gf::P;
+    }
+    {
+        ProfScope ps(c, st, "count_out_of_range");
+        HIP_TRY(launch_count_out_of_range(dev + head, words - head, counter, st));
+    }
+    unsigned long long on_device = 0;
+    HIP_TRY(hipMemcpyAsync(&on_device, counter, sizeof on_device, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *bad_words = result + on_device;
+    return FASTECC_OK;
+}
+
 int fastecc_profile_enable(fastecc_ctx* c, int on)
 {
     if (!c) return FASTECC_E_INVAL;

@@ -147,6 +147,22 @@ __global__ __launch_bounds__(256) void gf_binary_kernel(int op, const uint32_t* 
     }
 }
 
+// Count words that are not field elements (>= p).  The encode requires every input word < p
+// (README.md:160-162 of the reference; GF_Add/GF_Sub are only defined on [0,p), GF(p).cpp:37-48).
+__global__ __launch_bounds__(256) void count_out_of_range_kernel(const uint4* __restrict__ x4, const uint32_t* __restrict__ tail,
+                                                                  uint64_t n4, uint32_t ntail, unsigned long long* __restrict__ bad)
+{
+    unsigned int local = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = x4[i];
+        local += (v.x >= gf::P) + (v.y >= gf::P) + (v.z >= gf::P) + (v.w >= gf::P);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ntail) local += tail[threadIdx.x] >= gf::P;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63u) == 0 && local) atomicAdd(bad, (unsigned long long)local);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -213,6 +229,19 @@ hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S,
         case 2: hipLaunchKernelGGL((scale_rows_kernel<2>), grid, dim3(256), 0, st, data, factor, S, col_chunks, items); break;
         default: hipLaunchKernelGGL((scale_rows_kernel<4>), grid, dim3(256), 0, st, data, factor, S, col_chunks, items); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_count_out_of_range(const uint32_t* x, uint64_t count, unsigned long long* bad, hipStream_t st)
+{
+    // x is 4-byte aligned; peel words up to a 16-byte boundary on the host side of the call (api.hip)
+    const uint64_t n4 = count / 4;
+    const uint32_t ntail = (uint32_t)(count % 4);
+    uint64_t blocks = (n4 + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(count_out_of_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(x), x + n4 * 4, n4, ntail,
+                       bad);
     return hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ bool tile_supported(int logt, bool pair, int logr = 5);
 hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st);
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);
+hipError_t launch_count_out_of_range(const uint32_t* x, uint64_t count, unsigned long long* bad, hipStream_t st);
 hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, hipStream_t st);
 
 }  // namespace fastecc

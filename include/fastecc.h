@@ -103,6 +103,13 @@ int fastecc_scale_blocks(fastecc_ctx *ctx, void *data, uint32_t scale, uint32_t 
 int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_t *y, uint32_t *out, uint64_t count,
                       void *stream);
 
+/*
+ * Count the words of a stripe that are not field elements (>= p).  The reference documents "all words < p"
+ * as a precondition (README.md:160-162) and never checks it; a host can call this before encoding
+ * untrusted data.  Synchronises `stream`.  *bad_words == 0 means the stripe is encodable.
+ */
+int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *stream, uint64_t *bad_words);
+
 /* Host-side field helpers (GF(p).cpp:254-297), used to build tables and by bindings. */
 uint32_t fastecc_gf_mul(uint32_t x, uint32_t y);
 uint32_t fastecc_gf_pow(uint32_t x, uint32_t e);

@@ -391,3 +391,23 @@ def test_ntt_equals_unmodified_reference(torch_cuda, fe, log2n, S):
             got = to_host(d)
             assert np.array_equal(got, ref.ntt(x, inverse, Reference.MFA))
             assert np.array_equal(got, ref.ntt(x, inverse, Reference.REC))
+
+
+def test_check_range_counts_non_field_words(torch_cuda, fe):
+    """Inputs must be < p (README.md:160-162); fastecc_check_range finds the ones that are not."""
+    torch = torch_cuda
+    N, S = 64, 1021  # odd width: exercises the unaligned head / tail paths
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        assert enc.check_range(to_dev(torch, x)) == 0
+        bad_pos = rng.choice(N * S, size=37, replace=False)
+        y = x.reshape(-1).copy()
+        y[bad_pos] = rng.integers(P, 1 << 32, size=37, dtype=np.uint64).astype(np.uint32)
+        y[0], y[-1] = 0xFFFFFFFF, P  # first and last word
+        want = int((y.astype(np.uint64) >= P).sum())
+        assert enc.check_range(to_dev(torch, y)) == want
+        assert enc.check_range(y.reshape(N, S), mem=fe.MEM_HOST) == want
+        # a view starting 4 bytes into an allocation (not 16-byte aligned)
+        z = to_dev(torch, np.concatenate([[0], y]).astype(np.uint32))
+        assert enc.check_range(z.data_ptr() + 4) == want
