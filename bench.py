@@ -14,7 +14,6 @@ Throughput convention = the reference's (RS.cpp:38): bytes = data + parity = 2*k
 reported in GB/s (1e9).  Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -31,6 +30,9 @@ import torch  # noqa: E402
 
 P = 0xFFF00001
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+# Secondary (informational) bound: the path is integer-VALU bound once fused.  Chip-wide rate of
+# the radix-2 GF(p) butterfly measured in isolation (tools/microbench.hip, profiles/r01/microbench_bfly_variants.jsonl).
+VALU_PEAK_GBFLY = 3700.0
 
 
 def parse():
@@ -197,6 +199,11 @@ def main():
                     "encode": {"kernels_ms_per_step": round(kernel_ms_per_step, 4),
                                "achieved": round(bytes_per_encode / (kernel_ms_per_step * 1e-3) / 1e9, 1),
                                "frac": round(bytes_per_encode / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                    "valu": {"what": "radix-2 GF(p) butterflies per second over the whole encode (2*log2(k)*k/2 per word column, "
+                                     "plus k/2 butterfly-equivalents for the per-block factor multiply)",
+                             "achieved_Gbfly_per_s": round((2 * args.log2k + 1) * (k / 2) * S / (kernel_ms_per_step * 1e-3) / 1e9, 1),
+                             "microbench_peak_Gbfly_per_s": VALU_PEAK_GBFLY,
+                             "frac": round((2 * args.log2k + 1) * (k / 2) * S / (kernel_ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GBFLY, 4)},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
         cpu = None
