@@ -185,13 +185,27 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
     };
     auto load_rows = [&](uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
         const uint32_t voff = lane_off | v.dead_mask;
+        // running block offset kept in ONE SGPR: the empty asm stops the compiler from materialising all R
+        // offsets up front (they would sit in SGPRs for the whole kernel and spill to VGPR lanes)
+        uint32_t soff = q0 * row_bytes;
+        const uint32_t step = qstep * row_bytes;
 #pragma unroll
-        for (int j = 0; j < R; ++j) r[j][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, (q0 + j * qstep) * row_bytes, 0);
+        for (int j = 0; j < R; ++j) {
+            r[j][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff, 0);
+            soff += step;
+            asm volatile("" : "+s"(soff));
+        }
     };
     auto store_rows = [&](const uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
         const uint32_t voff = lane_off | v.dead_mask;
+        uint32_t soff = q0 * row_bytes;
+        const uint32_t step = qstep * row_bytes;
 #pragma unroll
-        for (int j = 0; j < R; ++j) __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, (q0 + j * qstep) * row_bytes, 0);
+        for (int j = 0; j < R; ++j) {
+            __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, soff, 0);
+            soff += step;
+            asm volatile("" : "+s"(soff));
+        }
     };
     auto lds_write = [&](const uint32_t (&r)[R][1], uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
 #pragma unroll
