@@ -63,6 +63,7 @@ struct fastecc_ctx {
     int vec = 1;             // words per lane in register passes
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
+    bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
     bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
     bool prefetch = false;   // ... that request the next tile before computing the current one
@@ -254,6 +255,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.s = p.s;
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
+            a.split2 = c->split2;
             HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
             PassArgs a{};
@@ -689,9 +691,11 @@ static int apply_plan(fastecc_ctx* c, int plan)
 {
     int rmax = 5, vec = 1, tile_mid = 10;
     bool wide = false, prefetch = false, persistent = true, slim = true;  // plan 0 == 2100
+    bool split2 = true;  // plan 0 == 3100
     if (plan >= 1000) {
         slim = plan >= 2000;  // 2000+10*a+f: as 1000+10*a+f with 16-word-per-lane outer tiles (8/9 levels)
-        if (plan >= 3000) return FASTECC_E_INVAL;
+        split2 = plan >= 3000;  // 3000+10*a+f: as 2000+... with the two-round (64 KiB) exchange in 1024-block tiles
+        if (plan >= 4000) return FASTECC_E_INVAL;
         tile_mid = (plan % 1000) / 10;
         const int f = (plan % 1000) % 10;
         wide = f & 1;
@@ -712,6 +716,7 @@ static int apply_plan(fastecc_ctx* c, int plan)
     c->prefetch = prefetch;
     c->persistent = persistent;
     c->slim_outer = slim;
+    c->split2 = split2;
     build_plans(c);
     return FASTECC_OK;
 }

@@ -36,6 +36,7 @@ struct TileArgs {
     uint32_t debug;       // ablation switches (profiles/r01/ablation_dif_tiles.md); always 0 in the product
     int persistent_cus;   // > 0: 128-KiB tiles run as persistent workgroups sized for that many CUs
     bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
+    bool split2;          // 1024-block pair tiles exchange 16 columns at a time (64 KiB LDS, 2 workgroups per CU)
 };
 
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);

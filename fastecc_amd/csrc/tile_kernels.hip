@@ -32,7 +32,7 @@
 
 namespace fastecc {
 
-template <int LOGT, int LOGR, bool PAIR>
+template <int LOGT, int LOGR, bool PAIR, int SPLIT = 1>
 struct TileCfg {
     static constexpr int T = 1 << LOGT;
     static constexpr int R = 1 << LOGR;
@@ -40,7 +40,11 @@ struct TileCfg {
     static constexpr int G = 1 << L2;                        // waves per workgroup
     static constexpr int W = PAIR ? 32 : 64;                 // words per tile row
     static constexpr int THREADS = G * 64;
-    static constexpr int LDS_BYTES = T * W * 4;
+    // An exchange only ever moves data between registers of the SAME column, so it can be done SPLIT
+    // column groups at a time through an LDS buffer SPLIT times smaller (lanes of the other groups idle
+    // during a round).  SPLIT = 2 brings the 1024-block pair tile down to 64 KiB: two workgroups per CU.
+    static constexpr int WS = W / SPLIT;                     // words per LDS row
+    static constexpr int LDS_BYTES = T * WS * 4;
     static_assert(L2 >= 1 && L2 <= LOGR, "tile shape");
     static_assert(THREADS <= 1024, "workgroup size");
 };
@@ -141,10 +145,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0xFFFFFFFFu, 0x00020000);
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
-__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1>
+__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
-    using C = TileCfg<LOGT, LOGR, PAIR>;
+    using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
     using View = TileView;
     constexpr int R = C::R, G = C::G, W = C::W, L2 = C::L2, T = C::T;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -161,8 +165,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
     const uint32_t qa_u = g;                        // + j*G   (+ half*T/2 per lane)
     const uint32_t qb_u = (PAIR ? 2u * g : g) * R;  // + k     (+ half*R   per lane)
     const uint32_t qa_l = half * (T / 2), qb_l = half * R;
-    uint32_t* lds_a = lds + qa_l * W + c;
-    uint32_t* lds_b = lds + qb_l * W + c;
+    constexpr int WS = C::WS;
+    const uint32_t my_round = c / WS;  // the exchange round this lane's column takes part in (always 0 when SPLIT == 1)
+    uint32_t* lds_a = lds + qa_l * WS + (c % WS);
+    uint32_t* lds_b = lds + qb_l * WS + (c % WS);
     const uint32_t lane_a = (((qa_l << s) * a.S) + c) * 4u;
     const uint32_t lane_b = (((qb_l << s) * a.S) + c) * 4u;
     const uint32_t row_bytes = (a.S * 4u) << s;     // distance between consecutive tile blocks
@@ -207,13 +213,24 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
             asm volatile("" : "+s"(soff));
         }
     };
-    auto lds_write = [&](const uint32_t (&r)[R][1], uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
+    // Change the set of blocks a lane holds: write the registers in one layout, read them back in the other.
+    // The caller guarantees that nobody still reads the LDS buffer when this starts.
+    auto exchange = [&](uint32_t (&r)[R][1], uint32_t* wbase, uint32_t wq0, uint32_t wstep, const uint32_t* rbase, uint32_t rq0,
+                        uint32_t rstep) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) lane_base[(q0 + j * qstep) * W] = r[j][0];
-    };
-    auto lds_read = [&](uint32_t (&r)[R][1], const uint32_t* lane_base, uint32_t q0, uint32_t qstep) {
+        for (int round = 0; round < SPLIT; ++round) {
+            const bool mine = SPLIT == 1 || my_round == (uint32_t)round;
+            if (mine) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) r[j][0] = lane_base[(q0 + j * qstep) * W];
+                for (int j = 0; j < R; ++j) wbase[(wq0 + j * wstep) * WS] = r[j][0];
+            }
+            lds_barrier();
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) r[j][0] = rbase[(rq0 + j * rstep) * WS];
+            }
+            if (round + 1 < SPLIT) lds_barrier();  // the buffer is reused by the next column group
+        }
     };
     constexpr bool LOAD_A = MODE != MODE_DIT;  // DIF and MID start in layout A, DIT in layout B
     auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
@@ -257,9 +274,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
                 if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
                 dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
             }
-            lds_write(x, lds_a, qa_u, G);
-            lds_barrier();
-            lds_read(x, lds_b, qb_u, 1);
+            exchange(x, lds_a, qa_u, G, lds_b, qb_u, 1);
             if constexpr (MODE == MODE_DIF) {
                 if (compute) {
                     if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
@@ -290,9 +305,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
                 }
                 dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
                 lds_barrier();  // every lane has finished reading the first exchange
-                lds_write(x, lds_b, qb_u, 1);
-                lds_barrier();
-                lds_read(x, lds_a, qa_u, G);
+                exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
                 dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
                 if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
                 store_rows(x, v, lane_a, qa_u, G);
@@ -300,9 +313,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
         } else {
             if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
             else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
-            lds_write(x, lds_b, qb_u, 1);
-            lds_barrier();
-            lds_read(x, lds_a, qa_u, G);
+            exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
             dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
             if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
             store_rows(x, v, lane_a, qa_u, G);
@@ -325,11 +336,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ? 
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH>
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
-    using C = TileCfg<LOGT, LOGR, PAIR>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH>;
+    using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT>;
     // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
     static bool configured[64] = {};
     int dev = 0;
@@ -350,7 +361,7 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     // workgroups, and the hardware dispatcher interleaving them measured faster (sweep table).
     if (a.persistent_cus > 0 && C::LDS_BYTES > 80 * 1024) {
         // resident workgroups per CU: LDS (160 KiB) and 16 waves (4 per SIMD at <= 128 VGPRs)
-        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = (LOGR <= 4 ? 32 : 16) / C::G;
+        const int by_lds = (160 * 1024) / C::LDS_BYTES, by_waves = (LOGR <= 4 || SPLIT > 1 ? 32 : 16) / C::G;
         const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : (by_waves < 1 ? 1 : by_waves);
         const uint64_t cap = (uint64_t)a.persistent_cus * per_cu;
         if (blocks > cap) blocks = cap;
@@ -362,6 +373,15 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 template <int LOGT, int LOGR, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
+    if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
+        if (a.split2) {  // 1024-block tiles through a 64 KiB buffer: two workgroups per CU, never persistent
+            switch (mode) {
+                case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2>(a, st);
+                case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2>(a, st);
+                default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, false, 2>(a, st);
+            }
+        }
+    }
     const bool pf = a.prefetch && a.persistent_cus > 0 && TileCfg<LOGT, LOGR, PAIR>::LDS_BYTES > 80 * 1024;
     switch (mode) {
         case MODE_DIF: return pf ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, false>(a, st);
