@@ -79,6 +79,10 @@ def lib():
     L.fastecc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(u64), i32]
     L.fastecc_profile_read.restype = i32
+    L.fastecc_profile_read_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(u64), ctypes.POINTER(u64), i32]
+    L.fastecc_profile_read_bytes.restype = i32
+    L.fastecc_set_option.argtypes, L.fastecc_set_option.restype = [vp, ctypes.c_char_p, i32], i32
     L.fastecc_plan_string.argtypes, L.fastecc_plan_string.restype = [vp], ctypes.c_char_p
     L.fastecc_set_plan.argtypes, L.fastecc_set_plan.restype = [vp, i32], i32
     _LIB = L
@@ -185,12 +189,17 @@ class Encoder:
     def profile_reset(self):
         _check(lib().fastecc_profile_reset(self._h), "fastecc_profile_reset")
 
+    def set_option(self, name, value):
+        _check(lib().fastecc_set_option(self._h, name.encode(), int(value)), "fastecc_set_option")
+
     def profile_read(self, cap=64):
+        """{kernel: (total ms, launches, total algorithmic bytes)} since the last reset."""
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_double * cap)()
         cnt = (ctypes.c_uint64 * cap)()
-        n = _check(lib().fastecc_profile_read(self._h, names, ms, cnt, cap), "fastecc_profile_read")
-        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(n)}
+        nbytes = (ctypes.c_uint64 * cap)()
+        n = _check(lib().fastecc_profile_read_bytes(self._h, names, ms, cnt, nbytes, cap), "fastecc_profile_read_bytes")
+        return {names[i].decode(): (ms[i], int(cnt[i]), int(nbytes[i])) for i in range(n)}
 
 
 def gf_mul(x, y): return lib().fastecc_gf_mul(x, y)

@@ -36,6 +36,7 @@ struct Pass {
 struct ProfileRec {
     std::string name;
     hipEvent_t start, stop;
+    uint64_t bytes;  // algorithmic bytes of the launch (stripe or slab read once + written once)
 };
 
 }  // namespace
@@ -64,6 +65,12 @@ struct fastecc_ctx {
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
     bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
+    int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
+                             // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
+    static constexpr int MAX_SLABS = 8;
+    hipStream_t slab_stream[MAX_SLABS] = {};
+    hipEvent_t slab_fork = nullptr, slab_first_done[MAX_SLABS] = {}, slab_done[MAX_SLABS] = {};
+    bool slab_ready = false;
     bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
     bool prefetch = false;   // ... that request the next tile before computing the current one
@@ -216,7 +223,7 @@ struct ProfScope {
     fastecc_ctx* c;
     hipStream_t st;
     ProfileRec* rec = nullptr;
-    ProfScope(fastecc_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_)
+    ProfScope(fastecc_ctx* c_, hipStream_t st_, const char* name, uint64_t bytes = 0) : c(c_), st(st_)
     {
         if (!c->profiling) return;
         if (c->prof_used == c->prof.size()) {
@@ -226,23 +233,32 @@ struct ProfScope {
         }
         rec = &c->prof[c->prof_used++];
         rec->name = name;
+        rec->bytes = bytes;
         (void)hipEventRecord(rec->start, st);
     }
-    ~ProfScope()
+    void finish()
     {
         if (rec) (void)hipEventRecord(rec->stop, st);
+        rec = nullptr;
     }
+    ~ProfScope() { finish(); }
 };
 
+// Runs the passes of `plan` on columns [col0, col0 + width) of every block (the whole block by default).
+// first_done (optional) is recorded on `st` right after the first pass.
 int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in, uint32_t* out, const uint32_t* tw_dif,
-               const uint32_t* tw_dit, hipStream_t st)
+               const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr)
 {
+    if (width == 0) width = (uint32_t)c->S;
+    in += col0;
+    out += col0;
     const int vec = pick_vec(c, in, out);
     const uint32_t* src = in;
     char name[32];
+    bool first = true;
 
     for (const Pass& p : plan) {
-        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name));
+        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), 2ull * c->N * width * 4ull);
         if (p.tile) {
             TileArgs a{};
             a.in = src;
@@ -250,7 +266,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.tw_dif = tw_dif;
             a.tw_dit = tw_dit;
             a.dscale = c->dscale;
-            a.S = (uint32_t)c->S;
+            a.S = width;
+            a.ld = (uint32_t)c->S;
             a.n = c->n;
             a.s = p.s;
             a.persistent_cus = c->persistent ? c->cus : 0;
@@ -270,14 +287,60 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
         src = out;  // after the first pass everything is in place on `out`
+        if (first && first_done) {
+            ps.finish();
+            HIP_TRY(hipEventRecord(first_done, st));
+        }
+        first = false;
     }
     return FASTECC_OK;
+}
+
+int ensure_slab_streams(fastecc_ctx* c)
+{
+    if (c->slab_ready) return FASTECC_OK;
+    HIP_TRY(hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
+    for (int h = 0; h < fastecc_ctx::MAX_SLABS; h++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->slab_stream[h], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->slab_first_done[h], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->slab_done[h], hipEventDisableTiming));
+    }
+    c->slab_ready = true;
+    return FASTECC_OK;
+}
+
+bool plan_is_all_tiles(const std::vector<Pass>& plan)
+{
+    for (const Pass& p : plan)
+        if (!p.tile) return false;
+    return !plan.empty();
 }
 
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
-    return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
+    const int H = c->slabs;
+    const bool slabbed = H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
+                         (c->S % (32u * H)) == 0;
+    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
+
+    // Column slabs are independent transforms.  Slab h runs on its own stream and starts when slab h-1 has
+    // finished its first pass, so that at any time the GPU holds one slab in each kind of pass: the
+    // VALU-bound MID tiles and the HBM-bound outer tiles then share the CUs (both are 64 KiB / 16 waves).
+    int rc = ensure_slab_streams(c);
+    if (rc != FASTECC_OK) return rc;
+    const uint32_t width = (uint32_t)(c->S / H);
+    HIP_TRY(hipEventRecord(c->slab_fork, st));
+    for (int h = 0; h < H; h++) {
+        hipStream_t sh = c->slab_stream[h];
+        HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
+        if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));
+        rc = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width, c->slab_first_done[h]);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipEventRecord(c->slab_done[h], sh));
+        HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
+    }
+    return FASTECC_OK;
 }
 
 int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
@@ -463,6 +526,15 @@ void fastecc_destroy(fastecc_ctx* c)
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
+    if (c->slab_ready) {
+        for (int h = 0; h < fastecc_ctx::MAX_SLABS; h++) {
+            if (c->slab_stream[h]) (void)hipStreamSynchronize(c->slab_stream[h]);
+            if (c->slab_first_done[h]) (void)hipEventDestroy(c->slab_first_done[h]);
+            if (c->slab_done[h]) (void)hipEventDestroy(c->slab_done[h]);
+            if (c->slab_stream[h]) (void)hipStreamDestroy(c->slab_stream[h]);
+        }
+        if (c->slab_fork) (void)hipEventDestroy(c->slab_fork);
+    }
     if (c->tw_enc_dif) (void)hipFree(c->tw_enc_dif);
     if (c->tw_enc_dit) (void)hipFree(c->tw_enc_dit);
     if (c->tw_ntt_fwd) (void)hipFree(c->tw_ntt_fwd);
@@ -647,7 +719,25 @@ int fastecc_profile_reset(fastecc_ctx* c)
     return FASTECC_OK;
 }
 
+int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, uint64_t* bytes, int cap);
+
 int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, int cap)
+{
+    return fastecc_profile_read_bytes(c, names, ms, launches, nullptr, cap);
+}
+
+int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return FASTECC_E_INVAL;
+    if (!strcmp(name, "slabs")) {
+        if (value < 1 || value > fastecc_ctx::MAX_SLABS) return FASTECC_E_INVAL;
+        c->slabs = value;
+        return FASTECC_OK;
+    }
+    return FASTECC_E_INVAL;
+}
+
+int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, uint64_t* bytes, int cap)
 {
     if (!c || !names || !ms || !launches || cap <= 0) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
@@ -671,11 +761,13 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
             names[idx] = r.name.c_str();
             ms[idx] = 0.0;
             launches[idx] = 0;
+            if (bytes) bytes[idx] = 0;
         } else {
             idx = it->second;
         }
         ms[idx] += t;
         launches[idx] += 1;
+        if (bytes) bytes[idx] += r.bytes;
     }
     return used;
 }

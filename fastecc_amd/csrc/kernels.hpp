@@ -28,7 +28,8 @@ struct TileArgs {
     const uint32_t* tw_dif;
     const uint32_t* tw_dit;
     const uint32_t* dscale;
-    uint32_t S;
+    uint32_t S;           // words per block covered by this launch (a column slab may be narrower than a block)
+    uint32_t ld;          // words between consecutive blocks in memory (the full block size)
     int n;
     int s;
     uint32_t col_chunks;  // filled by the launcher

@@ -169,9 +169,9 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     const uint32_t my_round = c / WS;  // the exchange round this lane's column takes part in (always 0 when SPLIT == 1)
     uint32_t* lds_a = lds + qa_l * WS + (c % WS);
     uint32_t* lds_b = lds + qb_l * WS + (c % WS);
-    const uint32_t lane_a = (((qa_l << s) * a.S) + c) * 4u;
-    const uint32_t lane_b = (((qb_l << s) * a.S) + c) * 4u;
-    const uint32_t row_bytes = (a.S * 4u) << s;     // distance between consecutive tile blocks
+    const uint32_t lane_a = (((qa_l << s) * a.ld) + c) * 4u;
+    const uint32_t lane_b = (((qb_l << s) * a.ld) + c) * 4u;
+    const uint32_t row_bytes = (a.ld * 4u) << s;    // distance between consecutive tile blocks
     const int sl = s + L2;                          // layout A as seen by dif_levels/dit_levels
 
     auto view_of = [&](uint32_t tile) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         v.lo = grp & ((1u << s) - 1u);
         v.hi = grp >> s;
         v.dead_mask = (cc * W + c < a.S) ? 0u : 0xFFFFFFFFu;
-        const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.S + cc * W;
+        const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.ld + cc * W;
         v.in = make_desc(a.in + origin);
         v.out = make_desc(a.out + origin);
         return v;

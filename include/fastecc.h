@@ -126,10 +126,21 @@ uint32_t fastecc_gf_inv(uint32_t x);
  */
 int fastecc_profile_enable(fastecc_ctx *ctx, int on);
 int fastecc_profile_read(fastecc_ctx *ctx, const char **names, double *ms, uint64_t *launches, int cap);
+/* As above, plus the accumulated ALGORITHMIC bytes of those launches (each launch reads its part of the stripe
+ * once and writes it once): bytes[i] / launches[i] is the per-launch figure the roofline uses. */
+int fastecc_profile_read_bytes(fastecc_ctx *ctx, const char **names, double *ms, uint64_t *launches, uint64_t *bytes, int cap);
 int fastecc_profile_reset(fastecc_ctx *ctx);
 
 /* Plan description, e.g. "dif5,dif5,...|mid...|dit..." — for logs and DESIGN.md tables. */
 const char *fastecc_plan_string(fastecc_ctx *ctx);
+/*
+ * Tuning options.  "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
+ * behind the previous, so that different kinds of passes overlap on the GPU.  The call still
+ * behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream`
+ * waits for it.
+ */
+int fastecc_set_option(fastecc_ctx *ctx, const char *name, int value);
+
 /* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md §8. */
 int fastecc_set_plan(fastecc_ctx *ctx, int plan);
 

@@ -17,6 +17,7 @@ ap.add_argument("--log2k", type=int, default=19)
 ap.add_argument("--block-bytes", type=int, default=4096)
 ap.add_argument("--plans", default="51,1090,1091,1100,1080,1081")
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--slabs", default="1")
 args = ap.parse_args()
 
 k, S = 1 << args.log2k, args.block_bytes // 4
@@ -26,8 +27,9 @@ parity = torch.empty_like(data)
 enc = fastecc_amd.Encoder(2 * k, k, args.block_bytes)
 st = torch.cuda.current_stream().cuda_stream
 bytes_per = 2.0 * k * args.block_bytes
-for plan in [int(p) for p in args.plans.split(",")]:
+for plan, slabs in [(int(p), int(h)) for p in args.plans.split(",") for h in args.slabs.split(",")]:
     enc.set_plan(plan)
+    enc.set_option("slabs", slabs)
     enc.encode(data, parity, stream=st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -41,6 +43,6 @@ for plan in [int(p) for p in args.plans.split(",")]:
         enc.encode(data, parity, stream=st)
     kern = enc.profile_read()
     enc.profile(False)
-    print(json.dumps({"plan": plan, "text": enc.plan(), "ms_per_encode": round(ms, 4), "GBps": round(bytes_per / ms / 1e6, 1),
+    print(json.dumps({"plan": plan, "slabs": slabs, "text": enc.plan(), "ms_per_encode": round(ms, 4), "GBps": round(bytes_per / ms / 1e6, 1),
                       "kernels_avg_ms": {n: round(v[0] / v[1], 4) for n, v in sorted(kern.items())},
                       "launches": {n: v[1] // args.steps for n, v in sorted(kern.items())}}), flush=True)
