@@ -17,11 +17,18 @@
 // (no redundant work) and all remaining levels again see wave-uniform twiddles.  This is what makes a
 // 1024-block tile fit: 1024 x 32 words = 128 KiB of the CU's 160 KiB LDS, in 128-byte row segments.
 //
+// Occupancy variants (chosen by the host plan):
+//   SPLIT = 2   an exchange never mixes columns, so it can run 16 columns at a time through a 64 KiB buffer:
+//               the 1024-block MID tile then needs 55 VGPRs / 64 KiB and two workgroups (32 waves) share a CU
+//               (measured 2.01 -> 1.66 ms for the same arithmetic);
+//   LOGR = 4    "slim" 8/9-level tiles keep 16 words per lane (<= 64 VGPRs, 1024 threads): 32 waves per CU in
+//               the HBM-bound outer passes.
+//
 //   DIF  load A -> [pair level] -> LOGR levels -> A=>B -> L2 levels -> store B
 //   DIT  load B -> L2 levels -> B=>A -> LOGR levels -> [pair level] -> store A
 //   MID  DIF half, multiply block p by D[bitrev(p)] (RS.cpp:51-59), DIT half: 2*LOGT levels per HBM trip
 //
-// With N = 2^19 the encode is 3 launches: DIF over levels 18..9, MID over 8..0 twice, DIT over 9..18
+// With N = 2^19 the encode is 3 launches: DIF over levels 18..10, MID over 9..0 twice, DIT over 10..18
 // (the reference needs 2 x (3 sweeps + twiddle sweep), ntt.cpp:412-446).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
