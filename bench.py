@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the parity (reported separately)")
     ap.add_argument("--slabs", type=int, default=0, help="column slabs on internal streams (0 = library default)")
+    ap.add_argument("--option", action="append", default=[], help="library tuning option name=value (fastecc_set_option)")
     return ap.parse_args()
 
 
@@ -134,6 +135,9 @@ def main():
         enc.set_plan(args.plan)
     if args.slabs:
         enc.set_option("slabs", args.slabs)
+    for kv in args.option:
+        name, value = kv.split("=")
+        enc.set_option(name, int(value))
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

@@ -65,6 +65,7 @@ struct fastecc_ctx {
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
     bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
+    int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
     static constexpr int MAX_SLABS = 8;
@@ -273,6 +274,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
             a.split2 = c->split2;
+            a.xcd_swizzle = c->xcd_swizzle;
             HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
             PassArgs a{};
@@ -729,6 +731,11 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
+    if (!strcmp(name, "xcd_swizzle")) {
+        if (value < 0 || value > 2) return FASTECC_E_INVAL;
+        c->xcd_swizzle = value;
+        return FASTECC_OK;
+    }
     if (!strcmp(name, "slabs")) {
         if (value < 1 || value > fastecc_ctx::MAX_SLABS) return FASTECC_E_INVAL;
         c->slabs = value;

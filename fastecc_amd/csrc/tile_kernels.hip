@@ -187,7 +187,19 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         // twiddle fetch below a SCALAR load.  (A vector load there would sit behind the prefetch in the
         // in-order vmcnt queue and force it to drain.)
         tile = __builtin_amdgcn_readfirstlane(tile);
-        const uint32_t cc = tile % a.col_chunks, grp = tile / a.col_chunks;
+        uint32_t cc = tile % a.col_chunks;
+        uint32_t grp = tile / a.col_chunks;
+        // XCD-aware order (speed only): workgroup b runs on XCD b % 8.
+        //   1: each XCD takes a CONTIGUOUS run of column chunks of a block group instead of every 8th one — its
+        //      requests to a 4 KiB block fall into one 512-byte stretch and arrive close together;
+        //   2: each XCD takes whole block groups (all column chunks, consecutive in its own dispatch order).
+        if (a.xcd_swizzle == 1 && (a.col_chunks & 7u) == 0) {
+            cc = (cc & 7u) * (a.col_chunks >> 3) + (cc >> 3);
+        } else if (a.xcd_swizzle == 2 && ((a.tiles / a.col_chunks) & 7u) == 0) {
+            const uint32_t x = tile & 7u, i = tile >> 3;
+            cc = i % a.col_chunks;
+            grp = (i / a.col_chunks) * 8u + x;
+        }
         v.lo = grp & ((1u << s) - 1u);
         v.hi = grp >> s;
         v.dead_mask = (cc * W + c < a.S) ? 0u : 0xFFFFFFFFu;
