@@ -65,6 +65,7 @@ struct fastecc_ctx {
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
     bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
+    int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
@@ -275,6 +276,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.prefetch = c->prefetch;
             a.split2 = c->split2;
             a.xcd_swizzle = c->xcd_swizzle;
+            a.cache_policy = p.mode == MODE_MID ? (c->cache_policy >> 2) & 3 : c->cache_policy & 3;
             HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
             PassArgs a{};
@@ -731,6 +733,11 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
+    if (!strcmp(name, "cache_policy")) {
+        if (value < 0 || value > 15) return FASTECC_E_INVAL;
+        c->cache_policy = value;
+        return FASTECC_OK;
+    }
     if (!strcmp(name, "xcd_swizzle")) {
         if (value < 0 || value > 2) return FASTECC_E_INVAL;
         c->xcd_swizzle = value;

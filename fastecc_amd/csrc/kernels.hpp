@@ -38,6 +38,7 @@ struct TileArgs {
     int persistent_cus;   // > 0: 128-KiB tiles run as persistent workgroups sized for that many CUs
     bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
     bool split2;          // 1024-block pair tiles exchange 16 columns at a time (64 KiB LDS, 2 workgroups per CU)
+    int cache_policy;     // bit 0: non-temporal stripe loads, bit 1: non-temporal stripe stores
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
 };
 

@@ -134,7 +134,10 @@ int fastecc_profile_reset(fastecc_ctx *ctx);
 /* Plan description, e.g. "dif5,dif5,...|mid...|dit..." — for logs and DESIGN.md tables. */
 const char *fastecc_plan_string(fastecc_ctx *ctx);
 /*
- * Tuning options.  "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
+ * Tuning options (all bit-exact; defaults are the measured best on MI355X).
+ *   "cache_policy" 0..15: bit 0/1 non-temporal stripe loads/stores in the outer passes, bit 2/3 in MID (default 15);
+ *   "xcd_swizzle"  0..2 : tile order per XCD (default 1);
+ *   "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
  * behind the previous, so that different kinds of passes overlap on the GPU.  The call still
  * behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream`
  * waits for it.
