@@ -131,7 +131,8 @@ std::vector<int> split_levels(int bits, int rmax)
 // A tile pass addresses its tile with 32-bit offsets from a per-tile buffer descriptor (tile_kernels.hip).
 bool tile_fits(const fastecc_ctx* c, int logt, int s)
 {
-    return (((uint64_t)c->S * 4) << (logt + s)) <= (1ull << 31);
+    // block offsets (SGPR) and lane offsets (VGPR) are 32-bit and their sum must stay below num_records = 2^32-1
+    return (((uint64_t)c->S * 4) << (logt + s)) <= 0xFFFF0000ull;
 }
 
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
@@ -276,7 +277,11 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.prefetch = c->prefetch;
             a.split2 = c->split2;
             a.xcd_swizzle = c->xcd_swizzle;
-            a.cache_policy = p.mode == MODE_MID ? (c->cache_policy >> 2) & 3 : c->cache_policy & 3;
+            // Non-temporal streaming only pays when block rows are cache-line aligned: with e.g. 2052- or 4100-byte
+            // blocks every 128-byte row segment straddles two lines that the neighbouring workgroup needs too,
+            // and keeping them cacheable is worth 1.2-1.4x (profiles/r01/ablation_dif_tiles.md).
+            const bool rows_aligned = ((c->S * 4) % 128) == 0;
+            a.cache_policy = !rows_aligned ? 0 : p.mode == MODE_MID ? (c->cache_policy >> 2) & 3 : c->cache_policy & 3;
             HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
             PassArgs a{};

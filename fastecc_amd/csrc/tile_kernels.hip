@@ -126,8 +126,8 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
 //               exist (col >= S): the hardware bounds check then returns 0 / drops the store, so ragged
 //               block sizes need no branches;
 // s_block_off = 32-bit byte offset of the tile block, wave-uniform (SGPR).
-// The host only selects a tile pass when a tile spans <= 2^31 bytes (tile_fits, api.hip), so live lane
-// offsets stay below num_records = 2^32-1 and "offset | dead_mask" = 2^32-1 is always out of range.
+// The host only selects a tile pass when a tile spans < 2^32 - 2^16 bytes (tile_fits, api.hip), so live lane
+// offset + block offset stay below num_records = 2^32-1 and "offset | dead_mask" = 2^32-1 is always out of range.
 // Workgroup barrier for the LDS exchanges.  __syncthreads() also fences global memory (s_waitcnt
 // vmcnt(0)), which would drain the next tile's prefetch and the previous tile's stores at every exchange;
 // the exchange only needs this wave's LDS traffic to have completed.

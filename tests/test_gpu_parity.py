@@ -330,20 +330,20 @@ def test_large_n_with_ragged_blocks(torch_cuda, fe, oracle, log2n, S):
     assert bool((guard == 0x5A5A5A5A).all())
 
 
-def test_blocks_too_large_for_tile_offsets_fall_back(torch_cuda, fe, oracle):
-    """32 MiB blocks: a 64-block tile would span > 2^31 bytes, so the plan must use register passes
-    (64-bit addressing).  Checked against an explicit register plan and, on column slabs, the oracle."""
-    torch = torch_cuda
-    N, S = 64, (1 << 23) + 4
+def _big_block_case(torch, fe, oracle, N, S, expect_tiles):
     g = torch.Generator(device="cuda:0")
     g.manual_seed(7)
-    d = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    d = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
+    for i in range(0, N * S, 1 << 26):
+        m = min(1 << 26, N * S - i)
+        d[i:i + m] = torch.randint(0, P, (m,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
     ref_cols = [slice(0, 8), slice(S - 8, S), slice(S // 2, S // 2 + 8)]
     inputs = [to_host(d.view(N, S)[:, c].contiguous()) for c in ref_cols]
     out_default = torch.empty_like(d)
     out_reg = torch.empty_like(d)
     with fe.Encoder(2 * N, N, 4 * S) as enc:
-        assert not any(t in enc.plan() for t in ("T32", "T64", "S32")), enc.plan()
+        has_tiles = any(t in enc.plan() for t in ("T32", "T64", "S32"))
+        assert has_tiles == expect_tiles, enc.plan()
         enc.encode(d, out_default)
         enc.set_plan(34)
         enc.encode(d, out_reg)
@@ -351,6 +351,18 @@ def test_blocks_too_large_for_tile_offsets_fall_back(torch_cuda, fe, oracle):
     assert torch.equal(out_default, out_reg)
     for c, xin in zip(ref_cols, inputs):
         assert np.array_equal(to_host(out_default.view(N, S)[:, c].contiguous()), oracle.encode_fast(xin))
+
+
+def test_tile_offsets_between_2g_and_4g(torch_cuda, fe, oracle):
+    """32 MiB blocks, 64-block tile: the tile spans 2^31 + 1 KiB bytes, so scalar block offsets exceed 2^31 while
+    staying below the 2^32-1 bound of the buffer descriptor.  Checked against register passes and the oracle."""
+    _big_block_case(torch_cuda, fe, oracle, 64, (1 << 23) + 4, expect_tiles=True)
+
+
+def test_blocks_too_large_for_tile_offsets_fall_back(torch_cuda, fe, oracle):
+    """64 MiB blocks: a 64-block tile would span > 2^32 bytes, so the plan must use register passes
+    (64-bit addressing)."""
+    _big_block_case(torch_cuda, fe, oracle, 64, (1 << 24) + 4, expect_tiles=False)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -67,8 +67,12 @@ def test_every_plan_covers_every_level_once(hip_lib, log2k, plan):
 
 
 def test_blocks_too_large_for_tiles_use_register_passes(hip_lib):
-    rc, text = describe(hip_lib, 64, (1 << 25) + 16)
+    rc, text = describe(hip_lib, 64, (1 << 26) + 16)   # a 64-block tile would span > 2^32 bytes
     assert rc == 0 and "T32" not in text and "T64" not in text and "S32" not in text
+    rc, text = describe(hip_lib, 64, (1 << 25) + 16)   # 2^31 < span < 2^32: still addressable with 32-bit offsets
+    assert rc == 0 and "T64:mid6@0" in text
+    rc, text = describe(hip_lib, 1 << 19, 4100)  # 4096 data bytes + the packing word (GF.md:72-104): still 3 tile trips
+    assert rc == 0 and parse(text) == [("S32", "dif", 9, 10), ("T32", "mid", 10, 0), ("S32", "dit", 9, 10)], text
     rc, text = describe(hip_lib, 1 << 19, 65536)  # 64 KB blocks (BASELINE config 5's block size)
     assert rc == 0 and "T32:mid10@0" in text and "T32:dif" not in text, text
 

@@ -18,6 +18,7 @@ ap.add_argument("--block-bytes", type=int, default=4096)
 ap.add_argument("--plans", default="51,1090,1091,1100,1080,1081")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--slabs", default="1")
+ap.add_argument("--option", action="append", default=[])
 args = ap.parse_args()
 
 k, S = 1 << args.log2k, args.block_bytes // 4
@@ -30,6 +31,8 @@ bytes_per = 2.0 * k * args.block_bytes
 for plan, slabs in [(int(p), int(h)) for p in args.plans.split(",") for h in args.slabs.split(",")]:
     enc.set_plan(plan)
     enc.set_option("slabs", slabs)
+    for kv in args.option:
+        enc.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     enc.encode(data, parity, stream=st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
