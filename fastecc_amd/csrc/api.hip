@@ -46,6 +46,7 @@ struct fastecc_ctx {
     uint64_t N = 0;   // k
     int n = 0;        // log2 k
     uint64_t S = 0;   // words per block
+    uint64_t ld = 0;  // words between consecutive blocks in DEVICE stripes (row pitch, >= S; S unless "row_pitch_words" is set)
     size_t stripe_bytes = 0;
 
     // device tables (Montgomery form, see gf.hpp)
@@ -132,7 +133,7 @@ std::vector<int> split_levels(int bits, int rmax)
 bool tile_fits(const fastecc_ctx* c, int logt, int s)
 {
     // block offsets (SGPR) and lane offsets (VGPR) are 32-bit and their sum must stay below num_records = 2^32-1
-    return (((uint64_t)c->S * 4) << (logt + s)) <= 0xFFFF0000ull;
+    return (((uint64_t)c->ld * 4) << (logt + s)) <= 0xFFFF0000ull;
 }
 
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
@@ -210,7 +211,7 @@ int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
 {
     int v = c->vec;
     const uintptr_t bits = (uintptr_t)a | (uintptr_t)b;
-    while (v > 1 && ((c->S % v) != 0 || (bits % (4u * v)) != 0)) v >>= 1;
+    while (v > 1 && ((c->S % v) != 0 || (c->ld % v) != 0 || (bits % (4u * v)) != 0)) v >>= 1;
     return v;
 }
 
@@ -270,7 +271,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.tw_dit = tw_dit;
             a.dscale = c->dscale;
             a.S = width;
-            a.ld = (uint32_t)c->S;
+            a.ld = (uint32_t)c->ld;
             a.n = c->n;
             a.s = p.s;
             a.persistent_cus = c->persistent ? c->cus : 0;
@@ -280,7 +281,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             // Non-temporal streaming only pays when block rows are cache-line aligned: with e.g. 2052- or 4100-byte
             // blocks every 128-byte row segment straddles two lines that the neighbouring workgroup needs too,
             // and keeping them cacheable is worth 1.2-1.4x (profiles/r01/ablation_dif_tiles.md).
-            const bool rows_aligned = ((c->S * 4) % 128) == 0;
+            const bool rows_aligned = ((c->ld * 4) % 128) == 0;
             a.cache_policy = !rows_aligned ? 0 : p.mode == MODE_MID ? (c->cache_policy >> 2) & 3 : c->cache_policy & 3;
             HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
         } else {
@@ -291,6 +292,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.tw_dit = tw_dit;
             a.dscale = c->dscale;
             a.S = (uint32_t)c->S;
+            a.ld = (uint32_t)c->ld;
             a.n = c->n;
             a.s = p.s;
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
@@ -490,6 +492,7 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     c->N = k;
     c->n = lg;
     c->S = block_bytes / 4;
+    c->ld = c->S;
     c->stripe_bytes = (size_t)k * block_bytes;
     {
         int cus = 0;
@@ -564,6 +567,7 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     hipStream_t st = (hipStream_t)stream;
     if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     int rc = ensure_dbuf(c);
     if (rc != FASTECC_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
@@ -612,6 +616,7 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* stream)
 {
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // a row pitch applies to fastecc_encode on device stripes only
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -631,6 +636,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
 {
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
     if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -738,6 +744,19 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
+    if (!strcmp(name, "row_pitch_words")) {
+        // DEVICE stripes passed to fastecc_encode are then [k][pitch] words with the first block_bytes/4 of each
+        // row valid: a host that owns its HBM layout can pad e.g. 4100-byte blocks to 4224 bytes so that every
+        // 128-byte row segment is cache-line aligned.  0 restores the contiguous layout.
+        const uint64_t pitch = value == 0 ? c->S : (uint64_t)value;
+        if (value < 0 || pitch < c->S) return FASTECC_E_INVAL;
+        c->ld = pitch;
+        build_plans(c);  // tile eligibility depends on the pitch
+        DeviceGuard dg(c->device);
+        if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+        HIP_TRY(hipDeviceSynchronize());
+        return upload_twiddles(c);
+    }
     if (!strcmp(name, "cache_policy")) {
         if (value < 0 || value > 15) return FASTECC_E_INVAL;
         c->cache_policy = value;
@@ -852,6 +871,7 @@ static int host_plan(fastecc_ctx* c, uint64_t k, uint64_t block_bytes, int plan)
     c->N = k;
     c->n = lg;
     c->S = block_bytes / 4;
+    c->ld = c->S;
     return apply_plan(c, plan);
 }
 

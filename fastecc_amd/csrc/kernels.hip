@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const uint32_t* row = a.in + (size_t)(base + ((uint32_t)j << s)) * a.S;
+            const uint32_t* row = a.in + (size_t)(base + ((uint32_t)j << s)) * a.ld;
             load_vec<V>(x[j], row + col);
         }
     } else {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            uint32_t* row = a.out + (size_t)(base + ((uint32_t)j << s)) * a.S;
+            uint32_t* row = a.out + (size_t)(base + ((uint32_t)j << s)) * a.ld;
             store_vec<V>(row + col, x[j]);
         }
     }

@@ -15,6 +15,7 @@ struct PassArgs {
     const uint32_t* tw_dit;  // same for DIT levels
     const uint32_t* dscale;  // MID only: D[bitrev_n(pos)] in Montgomery form, indexed by position
     uint32_t S;              // words per block
+    uint32_t ld;             // words between consecutive blocks in memory (>= S; the row pitch)
     int n;                   // log2 N
     int s;                   // log2 of the smallest stride of this pass
     uint32_t col_chunks;     // filled by the launcher

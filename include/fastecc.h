@@ -137,6 +137,10 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  * Tuning options (all bit-exact; defaults are the measured best on MI355X).
  *   "cache_policy" 0..15: bit 0/1 non-temporal stripe loads/stores in the outer passes, bit 2/3 in MID (default 15);
  *   "xcd_swizzle"  0..2 : tile order per XCD (default 1);
+ *   "row_pitch_words" = L >= block_bytes/4 (0 = contiguous): DEVICE stripes given to fastecc_encode are [k][L]
+ *                  words, the first block_bytes/4 of each row valid, the rest untouched.  Lets a host that owns its
+ *                  HBM layout pad odd block sizes (2052, 4100 bytes) to a multiple of 128 bytes: +50 % throughput.
+ *                  Other entry points return FASTECC_E_UNSUPPORTED while a pitch is set;
  *   "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
  * behind the previous, so that different kinds of passes overlap on the GPU.  The call still
  * behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream`

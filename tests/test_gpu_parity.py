@@ -444,3 +444,34 @@ def test_column_slab_pipeline_is_bit_exact(torch_cuda, fe, oracle, slabs):
             st.synchronize()
         assert np.array_equal(to_host(out), want), (slabs, log2n, S)
         assert np.array_equal(to_host(d), want), (slabs, log2n, S)
+
+
+@pytest.mark.parametrize("log2n,S,pitch", [(10, 513, 544), (16, 1025, 1056), (12, 7, 32), (9, 64, 65)])
+def test_row_pitch(torch_cuda, fe, oracle, log2n, S, pitch):
+    """fastecc_set_option("row_pitch_words", L): stripes are [k][L] words, only the first S of a row are data."""
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n + pitch), N, S)
+    want = oracle.encode_fast(x)
+    padded = np.full((N, pitch), 0xDEADBEEF, dtype=np.uint32)
+    padded[:, :S] = x
+    d = to_dev(torch, padded)
+    out = torch.full_like(d, 0x0BADF00D)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.set_option("row_pitch_words", pitch)
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        got = to_host(out).reshape(N, pitch)
+        assert np.array_equal(got[:, :S], want)
+        assert (got[:, S:] == 0x0BADF00D).all(), "padding words of the output must not be written"
+        enc.encode(d)  # in place
+        torch.cuda.synchronize()
+        got = to_host(d).reshape(N, pitch)
+        assert np.array_equal(got[:, :S], want) and (got[:, S:] == 0xDEADBEEF).all()
+        with pytest.raises(fe.FastEccError):
+            enc.ntt(d)
+        enc.set_option("row_pitch_words", 0)
+        c = to_dev(torch, x)
+        enc.encode(c)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(c), want)

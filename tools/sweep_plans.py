@@ -19,11 +19,13 @@ ap.add_argument("--plans", default="51,1090,1091,1100,1080,1081")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--slabs", default="1")
 ap.add_argument("--option", action="append", default=[])
+ap.add_argument("--pitch", type=int, default=0, help="row pitch in words (0 = contiguous)")
 args = ap.parse_args()
 
 k, S = 1 << args.log2k, args.block_bytes // 4
 dev = torch.device("cuda", 0)
-data = torch.randint(0, 0xFFF00001, (k * S,), dtype=torch.int64, device=dev).to(torch.int32)
+L = args.pitch or S
+data = torch.randint(0, 0xFFF00001, (k * L,), dtype=torch.int64, device=dev).to(torch.int32)
 parity = torch.empty_like(data)
 enc = fastecc_amd.Encoder(2 * k, k, args.block_bytes)
 st = torch.cuda.current_stream().cuda_stream
@@ -31,6 +33,8 @@ bytes_per = 2.0 * k * args.block_bytes
 for plan, slabs in [(int(p), int(h)) for p in args.plans.split(",") for h in args.slabs.split(",")]:
     enc.set_plan(plan)
     enc.set_option("slabs", slabs)
+    if args.pitch:
+        enc.set_option("row_pitch_words", args.pitch)
     for kv in args.option:
         enc.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     enc.encode(data, parity, stream=st)
