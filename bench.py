@@ -19,7 +19,10 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_WAIT_POLICY", "active")  # CPU baseline: avoid passive-wait barrier stalls
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # CPU baseline (single-process runs only): avoid passive-wait barrier stalls in the reference's OpenMP regions
+    # (SURVEY.md §6).  Multi-rank runs must not have hundreds of spinning OpenMP workers per rank on the host.
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
