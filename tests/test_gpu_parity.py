@@ -2,7 +2,6 @@
 bit-for-bit with the CPU oracle, the committed golden fixtures, or a size-independent property.
 
 Bar: bit-exact (integer arithmetic mod p = 0xFFF00001); no tolerance anywhere."""
-import ctypes
 
 import numpy as np
 import pytest

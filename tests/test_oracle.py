@@ -1,7 +1,6 @@
 """CPU tests: the oracle restatement against golden vectors, the published KAT and (when prebuilt) the
 unmodified reference.  These pin the checker that the -m gpu parity tests rely on."""
 import numpy as np
-import pytest
 
 P = 0xFFF00001
 
