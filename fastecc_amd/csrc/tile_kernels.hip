@@ -14,7 +14,10 @@
 // q + T/2 — butterfly partners at the top level.  That level is done across lanes with
 // v_permlane32_swap: swapping registers (ja, jb) gives the low half-wave both operands of pair ja and
 // the high half-wave both operands of pair jb, so every lane does one full butterfly per two registers
-// (no redundant work) and all remaining levels again see wave-uniform twiddles.  This is what makes a
+// (no redundant work) and all remaining levels again see wave-uniform twiddles.  Only ONE swap per pair is
+// needed: on the DIF side the blocks are LOADED in that "paired" order (register 2i: block (2i+half)*G+g,
+// register 2i+1: the same + T/2) and swapped into layout A after the butterfly; on the DIT side they are
+// swapped out of layout A before it and STORED from the paired order.  This is what makes a
 // 1024-block tile fit: 1024 x 32 words = 128 KiB of the CU's 160 KiB LDS, in 128-byte row segments.
 //
 // Occupancy variants (chosen by the host plan):
@@ -81,11 +84,12 @@ __device__ __forceinline__ void pair_level_dif(uint32_t (&x)[1 << LOGR][1], cons
         for (int i = 0; i < CH; ++i) w[i] = p[c0 + i];
 #pragma unroll
         for (int i = 0; i < CH; i += 2) {
+            // x arrives in the PAIRED order (see the kernel): this lane already holds both operands of one pair
             const int ja = c0 + i, jb = ja + 1;
-            const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
-            const uint32_t a = r[0], b = r[1];
+            const uint32_t a = x[ja][0], b = x[jb][0];
             const uint32_t sum = gf::add(a, b);
             const uint32_t dif = gf::mul_mont(gf::sub(a, b), pair_twiddle<LOGR>(w[i], w[i + 1], upper_mask));
+            // one swap turns (sum, dif) of pair ja [low lanes] / pair jb [high lanes] into layout A
             const auto o = __builtin_amdgcn_permlane32_swap(sum, dif, false, false);
             x[ja][0] = o[0];
             x[jb][0] = o[1];
@@ -107,13 +111,14 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
         for (int i = 0; i < CH; ++i) w[i] = p[c0 + i];
 #pragma unroll
         for (int i = 0; i < CH; i += 2) {
+            // one swap gives this lane both operands of one pair; the results stay in the PAIRED order and are
+            // stored from there (see the kernel)
             const int ja = c0 + i, jb = ja + 1;
             const auto r = __builtin_amdgcn_permlane32_swap(x[ja][0], x[jb][0], false, false);
             const uint32_t a = r[0];
             const uint32_t b = gf::mul_mont(r[1], pair_twiddle<LOGR>(w[i], w[i + 1], upper_mask));
-            const auto o = __builtin_amdgcn_permlane32_swap(gf::add(a, b), gf::sub(a, b), false, false);
-            x[ja][0] = o[0];
-            x[jb][0] = o[1];
+            x[ja][0] = gf::add(a, b);
+            x[jb][0] = gf::sub(a, b);
         }
     }
 }
@@ -178,6 +183,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     uint32_t* lds_b = lds + qb_l * WS + (c % WS);
     const uint32_t lane_a = (((qa_l << s) * a.ld) + c) * 4u;
     const uint32_t lane_b = (((qb_l << s) * a.ld) + c) * 4u;
+    const uint32_t lane_p = ((((half * G) << s) * a.ld) + c) * 4u;  // paired order: high half-wave is G blocks further
     const uint32_t row_bytes = (a.ld * 4u) << s;    // distance between consecutive tile blocks
     const int sl = s + L2;                          // layout A as seen by dif_levels/dit_levels
 
@@ -238,6 +244,36 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         if (a.cache_policy & 2) { FASTECC_STORE_LOOP(2) } else { FASTECC_STORE_LOOP(0) }
 #undef FASTECC_STORE_LOOP
     };
+    // Paired order of a PAIR tile: register 2i <-> block g + 2i*G (+ G in the high half-wave), register 2i+1 <-> that
+    // block + T/2.  Two running scalar offsets.
+    auto load_paired = [&](uint32_t (&r)[R][1], const View& v) {
+        const uint32_t voff = lane_p | v.dead_mask;
+        uint32_t soff = g * row_bytes;
+        const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+#define FASTECC_LOAD_LOOP(AUX)                                                                 \
+    _Pragma("unroll") for (int j = 0; j < R; j += 2) {                                          \
+        r[j][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff, AUX);                  \
+        r[j + 1][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff + far, AUX);        \
+        soff += step;                                                                           \
+        asm volatile("" : "+s"(soff));                                                          \
+    }
+        if (a.cache_policy & 1) { FASTECC_LOAD_LOOP(2) } else { FASTECC_LOAD_LOOP(0) }
+#undef FASTECC_LOAD_LOOP
+    };
+    auto store_paired = [&](const uint32_t (&r)[R][1], const View& v) {
+        const uint32_t voff = lane_p | v.dead_mask;
+        uint32_t soff = g * row_bytes;
+        const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+#define FASTECC_STORE_LOOP(AUX)                                                                \
+    _Pragma("unroll") for (int j = 0; j < R; j += 2) {                                          \
+        __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, soff, AUX);                 \
+        __builtin_amdgcn_raw_buffer_store_b32(r[j + 1][0], v.out, voff, soff + far, AUX);       \
+        soff += step;                                                                           \
+        asm volatile("" : "+s"(soff));                                                          \
+    }
+        if (a.cache_policy & 2) { FASTECC_STORE_LOOP(2) } else { FASTECC_STORE_LOOP(0) }
+#undef FASTECC_STORE_LOOP
+    };
     // Change the set of blocks a lane holds: write the registers in one layout, read them back in the other.
     // The caller guarantees that nobody still reads the LDS buffer when this starts.
     auto exchange = [&](uint32_t (&r)[R][1], uint32_t* wbase, uint32_t wq0, uint32_t wstep, const uint32_t* rbase, uint32_t rq0,
@@ -259,8 +295,9 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     };
     constexpr bool LOAD_A = MODE != MODE_DIT;  // DIF and MID start in layout A, DIT in layout B
     auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
-        if constexpr (LOAD_A) load_rows(r, v, lane_a, qa_u, G);
-        else                  load_rows(r, v, lane_b, qb_u, 1);
+        if constexpr (LOAD_A && PAIR) load_paired(r, v);
+        else if constexpr (LOAD_A)    load_rows(r, v, lane_a, qa_u, G);
+        else                          load_rows(r, v, lane_b, qb_u, 1);
     };
 
     // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With PREFETCH the next tile's
@@ -332,16 +369,24 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 lds_barrier();  // every lane has finished reading the first exchange
                 exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
                 dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
-                if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
-                store_rows(x, v, lane_a, qa_u, G);
+                if constexpr (PAIR) {
+                    pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+                    store_paired(x, v);
+                } else {
+                    store_rows(x, v, lane_a, qa_u, G);
+                }
             }
         } else {
             if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
             else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
             exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
             dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
-            if constexpr (PAIR) pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
-            store_rows(x, v, lane_a, qa_u, G);
+            if constexpr (PAIR) {
+                pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+                store_paired(x, v);
+            } else {
+                store_rows(x, v, lane_a, qa_u, G);
+            }
         }
 
         if (!has_next) break;
