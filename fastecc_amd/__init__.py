@@ -15,7 +15,9 @@ import os
 from . import _build
 
 P = 0xFFF00001  # RS.cpp:86
+P61 = (1 << 61) - 1
 FIELD_GF_FFF00001 = 0
+FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
 MEM_HOST, MEM_DEVICE = 0, 1
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -74,6 +76,11 @@ def lib():
     for name in ("root", "inv"):
         f = getattr(L, "fastecc_gf_" + name)
         f.argtypes, f.restype = [u32], u32
+    pair = ctypes.POINTER(u64)
+    L.fastecc_gf61_mul.argtypes, L.fastecc_gf61_mul.restype = [pair, pair, pair], i32
+    L.fastecc_gf61_pow.argtypes, L.fastecc_gf61_pow.restype = [pair, u64, pair], i32
+    L.fastecc_gf61_inv.argtypes, L.fastecc_gf61_inv.restype = [pair, pair], i32
+    L.fastecc_gf61_root.argtypes, L.fastecc_gf61_root.restype = [u64, pair], i32
     L.fastecc_profile_enable.argtypes, L.fastecc_profile_enable.restype = [vp, i32], i32
     L.fastecc_profile_reset.argtypes, L.fastecc_profile_reset.restype = [vp], i32
     L.fastecc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
@@ -117,7 +124,7 @@ class Encoder:
 
     def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001):
         self._h = ctypes.c_void_p()
-        self.n, self.k, self.block_bytes, self.device = n, k, block_bytes, device
+        self.n, self.k, self.block_bytes, self.device, self.field = n, k, block_bytes, device, field
         _check(lib().fastecc_create(ctypes.byref(self._h), n, k, block_bytes, field, device), "fastecc_create")
 
     def close(self):
@@ -206,3 +213,32 @@ def gf_mul(x, y): return lib().fastecc_gf_mul(x, y)
 def gf_pow(x, e): return lib().fastecc_gf_pow(x, e)
 def gf_root(order): return lib().fastecc_gf_root(order)
 def gf_inv(x): return lib().fastecc_gf_inv(x)
+
+
+# GF((2^61-1)^2) scalars, (re, im) tuples
+def _pair(z):
+    return (ctypes.c_uint64 * 2)(int(z[0]), int(z[1]))
+
+
+def gf61_mul(x, y):
+    out = _pair((0, 0))
+    _check(lib().fastecc_gf61_mul(_pair(x), _pair(y), out), "fastecc_gf61_mul")
+    return (int(out[0]), int(out[1]))
+
+
+def gf61_pow(x, e):
+    out = _pair((0, 0))
+    _check(lib().fastecc_gf61_pow(_pair(x), e, out), "fastecc_gf61_pow")
+    return (int(out[0]), int(out[1]))
+
+
+def gf61_inv(x):
+    out = _pair((0, 0))
+    _check(lib().fastecc_gf61_inv(_pair(x), out), "fastecc_gf61_inv")
+    return (int(out[0]), int(out[1]))
+
+
+def gf61_root(order):
+    out = _pair((0, 0))
+    _check(lib().fastecc_gf61_root(order, out), "fastecc_gf61_root")
+    return (int(out[0]), int(out[1]))

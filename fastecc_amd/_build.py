@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libfastecc_hip.so")
 RS_PATH = os.path.join(LIB_DIR, "rs_hip")
 MICROBENCH_PATH = os.path.join(LIB_DIR, "microbench")
 
-HIP_SOURCES = ["kernels.hip", "tile_kernels.hip", "api.hip"]
+HIP_SOURCES = ["kernels.hip", "tile_kernels.hip", "gf61_kernels.hip", "api.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -43,13 +43,16 @@ def build_library(force=False, verbose=False):
     if not (force or _newer(LIB_PATH, _deps())):
         return LIB_PATH
     objs = []
+    headers = [os.path.join(ROOT, "include", "fastecc.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     for src in HIP_SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not (force or _newer(obj, headers + [os.path.join(CSRC, src)])):
+            continue  # this translation unit is up to date
         cmd = [hipcc()] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-        objs.append(obj)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -18,6 +18,8 @@
 
 #include "../../include/fastecc.h"
 #include "gf.hpp"
+#include "gf61.hpp"
+#include "gf61_path.hpp"
 #include "kernels.hpp"
 
 using namespace fastecc;
@@ -43,6 +45,8 @@ struct ProfileRec {
 
 struct fastecc_ctx {
     int device = 0;
+    int field = FASTECC_FIELD_GF_FFF00001;
+    p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
     int n = 0;        // log2 k
     uint64_t S = 0;   // words per block
@@ -327,8 +331,33 @@ bool plan_is_all_tiles(const std::vector<Pass>& plan)
     return !plan.empty();
 }
 
+// fastecc_profile_* for the launches of gf61_kernels.hip: one ProfScope per launch (launches of a context are serial)
+struct P61Hooks {
+    fastecc_ctx* c;
+    ProfScope* open = nullptr;
+    p61::LaunchHooks h;
+    explicit P61Hooks(fastecc_ctx* c_) : c(c_)
+    {
+        h.user = this;
+        h.begin = [](void* u, hipStream_t st, const char* name, uint64_t bytes) {
+            P61Hooks* self = (P61Hooks*)u;
+            self->open = new (std::nothrow) ProfScope(self->c, st, name, bytes);
+        };
+        h.end = [](void* u, hipStream_t) {
+            P61Hooks* self = (P61Hooks*)u;
+            delete self->open;
+            self->open = nullptr;
+        };
+    }
+    ~P61Hooks() { delete open; }
+};
+
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
+    if (c->p61) {
+        P61Hooks hk(c);
+        return p61::encode(c->p61, (const uint64_t*)data, (uint64_t*)parity, st, c->profiling ? &hk.h : nullptr);
+    }
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
     const int H = c->slabs;
     const bool slabbed = H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
@@ -356,6 +385,10 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
 
 int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
 {
+    if (c->p61) {
+        P61Hooks hk(c);
+        return p61::ntt(c->p61, (uint64_t*)data, inverse, st, c->profiling ? &hk.h : nullptr);
+    }
     const uint32_t* tw = inverse ? c->tw_ntt_inv : c->tw_ntt_fwd;
     int rc = run_passes(c, c->ntt_plan, data, data, tw, tw, st);
     if (rc != FASTECC_OK) return rc;
@@ -468,15 +501,52 @@ uint32_t fastecc_gf_pow(uint32_t x, uint32_t e) { return gf::h_pow(x % gf::P, e)
 uint32_t fastecc_gf_root(uint32_t order) { return (order == 0 || ((gf::P - 1u) % order) != 0) ? 0u : gf::h_root(order); }
 uint32_t fastecc_gf_inv(uint32_t x) { return gf::h_inv(x % gf::P); }
 
+// GF((2^61-1)^2) scalars: z[0] = re, z[1] = im; inputs are reduced mod p first
+static gf61::Elem elem_of(const uint64_t z[2]) { return gf61::Elem{z[0] % gf61::P, z[1] % gf61::P}; }
+int fastecc_gf61_mul(const uint64_t x[2], const uint64_t y[2], uint64_t out[2])
+{
+    if (!x || !y || !out) return FASTECC_E_INVAL;
+    const gf61::Elem r = gf61::h_mul(elem_of(x), elem_of(y));
+    out[0] = r.re;
+    out[1] = r.im;
+    return FASTECC_OK;
+}
+int fastecc_gf61_pow(const uint64_t x[2], uint64_t e, uint64_t out[2])
+{
+    if (!x || !out) return FASTECC_E_INVAL;
+    const gf61::Elem r = gf61::h_pow(elem_of(x), e);
+    out[0] = r.re;
+    out[1] = r.im;
+    return FASTECC_OK;
+}
+int fastecc_gf61_inv(const uint64_t x[2], uint64_t out[2])
+{
+    if (!x || !out) return FASTECC_E_INVAL;
+    const gf61::Elem r = gf61::h_inv(elem_of(x));
+    out[0] = r.re;
+    out[1] = r.im;
+    return FASTECC_OK;
+}
+int fastecc_gf61_root(uint64_t order, uint64_t out[2])
+{
+    if (!out) return FASTECC_E_INVAL;
+    const gf61::Elem r = gf61::h_root(order);
+    out[0] = r.re;
+    out[1] = r.im;
+    return (r.re | r.im) ? FASTECC_OK : FASTECC_E_INVAL;
+}
+
 int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device)
 {
     if (!out) return FASTECC_E_INVAL;
     *out = nullptr;
-    if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
-    if (k < 2 || n != 2 * k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
+    const bool f61 = field == FASTECC_FIELD_GF_P61_SQUARED;
+    if (field != FASTECC_FIELD_GF_FFF00001 && !f61) return FASTECC_E_UNSUPPORTED;
+    if (k < 2 || n != 2 * k || block_bytes == 0 || (block_bytes % (f61 ? 16 : 4)) != 0) return FASTECC_E_INVAL;
     const int lg = ilog2_exact(k);
     if (lg < 0) return FASTECC_E_INVAL;
-    if (lg > 19) return FASTECC_E_UNSUPPORTED;  // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51)
+    // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51); in GF(p61^2) 2N | 2^62, the bound is table memory
+    if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
 
     int ndev = 0;
@@ -489,6 +559,7 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     fastecc_ctx* c = new (std::nothrow) fastecc_ctx();
     if (!c) return FASTECC_E_NOMEM;
     c->device = device;
+    c->field = field;
     c->N = k;
     c->n = lg;
     c->S = block_bytes / 4;
@@ -499,12 +570,26 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
         else (void)hipGetLastError();
     }
-    build_plans(c);
+    if (!f61) build_plans(c);
 
     DeviceGuard dg(device);
     if (!dg.ok) {
         delete c;
         return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+    }
+    if (f61) {
+        int rc = p61::create(&c->p61, lg, block_bytes / 16, g_detail, sizeof g_detail);
+        if (rc == FASTECC_OK) {
+            const hipError_t e = hipMalloc((void**)&c->factor, 8);  // counter of fastecc_check_range
+            if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(counter)");
+        }
+        if (rc != FASTECC_OK) {
+            fastecc_destroy(c);
+            return rc;
+        }
+        c->plan_text = p61::plan_string(c->p61);
+        *out = c;
+        return FASTECC_OK;
     }
 
     // ---- tables: per-level twiddles for the plan, and the per-block factors w_2N^i / N of RS.cpp:51-54 ----
@@ -547,6 +632,7 @@ void fastecc_destroy(fastecc_ctx* c)
         }
         if (c->slab_fork) (void)hipEventDestroy(c->slab_fork);
     }
+    p61::destroy(c->p61);
     if (c->tw_enc_dif) (void)hipFree(c->tw_enc_dif);
     if (c->tw_enc_dit) (void)hipFree(c->tw_enc_dit);
     if (c->tw_ntt_fwd) (void)hipFree(c->tw_ntt_fwd);
@@ -561,7 +647,7 @@ void fastecc_destroy(fastecc_ctx* c)
 int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind, void* stream)
 {
     if (!c || !data || !parity) return FASTECC_E_INVAL;
-    if (((uintptr_t)data | (uintptr_t)parity) & 3u) return FASTECC_E_INVAL;
+    if (((uintptr_t)data | (uintptr_t)parity) & (c->p61 ? 15u : 3u)) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -615,7 +701,7 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 
 int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* stream)
 {
-    if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    if (!c || !data || ((uintptr_t)data & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // a row pitch applies to fastecc_encode on device stripes only
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
@@ -636,6 +722,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
 {
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
     if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
+    if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit scalars: GF(0xFFF00001) only
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
@@ -672,6 +759,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
 int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, void* stream)
 {
     if (!c || !x || !y || !out || op < 0 || op > 3) return FASTECC_E_INVAL;
+    if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit words: GF(0xFFF00001) only
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     ProfScope ps(c, (hipStream_t)stream, "gf_binary");
@@ -697,6 +785,18 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
     // c->factor (N >= 2 words of scratch) holds the 64-bit counter
     unsigned long long* counter = reinterpret_cast<unsigned long long*>(c->factor);
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    if (c->p61) {
+        if ((uintptr_t)data & 7u) return FASTECC_E_INVAL;
+        ProfScope ps(c, st, "p61_count_out_of_range");
+        const int rc = p61::count_out_of_range(c->p61, (const uint64_t*)dev, counter, st);
+        if (rc != FASTECC_OK) return rc;
+        ps.finish();
+        unsigned long long found = 0;
+        HIP_TRY(hipMemcpyAsync(&found, counter, sizeof found, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *bad_words = found;
+        return FASTECC_OK;
+    }
     uint64_t words = c->N * c->S, head = 0;
     // the vector loop wants a 16-byte aligned start: count the few leading words on the host copy of them
     unsigned long long result = 0;
@@ -744,6 +844,7 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
+    if (c->p61) return FASTECC_E_UNSUPPORTED;  // the options below tune the GF(0xFFF00001) tile kernels
     if (!strcmp(name, "row_pitch_words")) {
         // DEVICE stripes passed to fastecc_encode are then [k][pitch] words with the first block_bytes/4 of each
         // row valid: a host that owns its HBM layout can pad e.g. 4100-byte blocks to 4224 bytes so that every
@@ -854,6 +955,16 @@ static int apply_plan(fastecc_ctx* c, int plan)
 int fastecc_set_plan(fastecc_ctx* c, int plan)
 {
     if (!c) return FASTECC_E_INVAL;
+    if (c->p61) {
+        // plan ids of this field: 0 = default, 1..5 = radix-2 levels per register pass
+        DeviceGuard dg(c->device);
+        if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+        HIP_TRY(hipDeviceSynchronize());
+        if (plan < 0 || plan > 5) return FASTECC_E_INVAL;
+        const int rc = p61::set_levels_per_pass(c->p61, plan == 0 ? p61::DEFAULT_LEVELS : plan, g_detail, sizeof g_detail);
+        c->plan_text = p61::plan_string(c->p61);
+        return rc;
+    }
     const int rc = apply_plan(c, plan);
     if (rc != FASTECC_OK) return rc;
     DeviceGuard dg(c->device);

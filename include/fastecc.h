@@ -40,7 +40,24 @@ enum {
     FASTECC_E_UNSUPPORTED = -4  /* field or size outside what GF(0xFFF00001) admits (k > 2^19) */
 };
 
-enum { FASTECC_FIELD_GF_FFF00001 = 0 };               /* the only field RS.cpp instantiates (RS.cpp:86) */
+enum {
+    FASTECC_FIELD_GF_FFF00001 = 0,   /* the only field RS.cpp instantiates (RS.cpp:86) */
+    /*
+     * GF(p^2), p = 2^61 - 1: the "64-bit field" of the 64 KB-block configuration.  The reference has NO code for
+     * it (README.md:178 and GF.md:30-31 only name the idea; GF(2^61-1) itself has no roots of unity of order
+     * > 2), so the conventions are defined HERE and nothing upstream pins them:
+     *   - an element is (re, im) = two consecutive little-endian uint64 words, i^2 = -1, both words < p;
+     *     a block of block_bytes bytes holds block_bytes / 16 elements (block_bytes % 16 == 0);
+     *   - roots of unity: w_(2^62) = (4 + i)^(2^60 - 1)  (4 + i is the first non-square a + i), the root of
+     *     order 2^t is w_(2^62)^(2^(62-t)); so w_4 = i and w_8 = 2^30 (1 + i);
+     *   - the encoder is the same composition as RS.cpp:40-63 over this field: parity block j is the value at
+     *     w_2N^(2j+1) of the polynomial of degree < N whose value at w_N^i is data block i.
+     * Supported by create/destroy/encode/encode_blocks/ntt/check_range/profile/plan_string and
+     * fastecc_set_plan (plan = radix-2 levels per pass, 1..5; 0 = default); the 32-bit-word entry points
+     * (scale_blocks, gf_binary, set_option) return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
+     */
+    FASTECC_FIELD_GF_P61_SQUARED = 1
+};
 enum { FASTECC_MEM_HOST = 0, FASTECC_MEM_DEVICE = 1 }; /* where `data`/`parity` pointers live */
 
 typedef struct fastecc_ctx fastecc_ctx;
@@ -115,6 +132,12 @@ uint32_t fastecc_gf_mul(uint32_t x, uint32_t y);
 uint32_t fastecc_gf_pow(uint32_t x, uint32_t e);
 uint32_t fastecc_gf_root(uint32_t order); /* 19^((p-1)/order); order must divide 2^20 */
 uint32_t fastecc_gf_inv(uint32_t x);
+/* The same for FASTECC_FIELD_GF_P61_SQUARED: z[0] = re, z[1] = im (inputs are reduced mod p); out may alias.
+ * fastecc_gf61_root returns FASTECC_E_INVAL unless order is a power of two <= 2^62. */
+int fastecc_gf61_mul(const uint64_t x[2], const uint64_t y[2], uint64_t out[2]);
+int fastecc_gf61_pow(const uint64_t x[2], uint64_t e, uint64_t out[2]);
+int fastecc_gf61_inv(const uint64_t x[2], uint64_t out[2]);
+int fastecc_gf61_root(uint64_t order, uint64_t out[2]);
 
 /*
  * Introspection for the benchmark: time the last `fastecc_encode` enqueued on DEVICE memory spent in

@@ -23,9 +23,9 @@ _u32 = ctypes.c_uint32
 def build(force=False):
     """Compile the restatement (and the reference shim when /root/reference is present)."""
     so = os.path.join(HERE, "libfastecc_oracle.so")
-    src = os.path.join(HERE, "fastecc_oracle.c")
+    srcs = [os.path.join(HERE, f) for f in ("fastecc_oracle.c", "fastecc_oracle_p61.c")]
     have_ref = os.path.exists("/root/reference/ntt.cpp")
-    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
     ref_missing = have_ref and not os.path.exists(os.path.join(HERE, "_ref", "libfastecc_ref.so"))
     if force or stale or ref_missing:
         subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), check=True,
@@ -108,6 +108,80 @@ class Oracle:
         return a
 
     def num_threads(self): return int(self.lib.orc_num_threads())
+
+
+P61 = (1 << 61) - 1
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u64 = ctypes.c_uint64
+_pair = ctypes.c_uint64 * 2
+
+
+class OracleP61:
+    """Plain-C restatement of the encode composition over GF((2^61-1)^2) (fastecc_oracle_p61.c).
+
+    PARITY UNPINNED: the reference has no implementation of this field (see fastecc_oracle_p61.h).
+    Stripes are [N, 2*elems] uint64 arrays: element c of a block is (re, im) = words (2c, 2c+1).
+    """
+
+    def __init__(self):
+        self.lib = lib = ctypes.CDLL(build())
+        for name in ("add", "sub", "mul"):
+            f = getattr(lib, "orc61_" + name)
+            f.argtypes, f.restype = [_u64, _u64], _u64
+        lib.orc61c_mul.argtypes, lib.orc61c_mul.restype = [_pair, _pair, _pair], None
+        lib.orc61c_pow.argtypes, lib.orc61c_pow.restype = [_pair, _u64, _pair], None
+        lib.orc61c_inv.argtypes, lib.orc61c_inv.restype = [_pair, _pair], None
+        lib.orc61c_root.argtypes, lib.orc61c_root.restype = [_u64, _pair], None
+        for name in ("slow_ntt", "ntt"):
+            f = getattr(lib, "orc61_" + name)
+            f.argtypes, f.restype = [_u64p, _sz, _sz, ctypes.c_int], None
+        lib.orc61_scale_blocks.argtypes, lib.orc61_scale_blocks.restype = [_u64p, _sz, _sz, _pair, _pair], None
+        lib.orc61_encode.argtypes, lib.orc61_encode.restype = [_u64p, _sz, _sz], None
+        lib.orc61_encode_by_definition.argtypes, lib.orc61_encode_by_definition.restype = [_u64p, _u64p, _sz, _sz], None
+        lib.orc61_fill_splitmix.argtypes, lib.orc61_fill_splitmix.restype = [_u64p, _sz, _u64], None
+
+    def cmul(self, x, y):
+        out = _pair()
+        self.lib.orc61c_mul(_pair(*x), _pair(*y), out)
+        return (int(out[0]), int(out[1]))
+
+    def cpow(self, x, e):
+        out = _pair()
+        self.lib.orc61c_pow(_pair(*x), e, out)
+        return (int(out[0]), int(out[1]))
+
+    def cinv(self, x):
+        out = _pair()
+        self.lib.orc61c_inv(_pair(*x), out)
+        return (int(out[0]), int(out[1]))
+
+    def root(self, order):
+        out = _pair()
+        self.lib.orc61c_root(order, out)
+        return (int(out[0]), int(out[1]))
+
+    def _run(self, fn, data, *extra):
+        a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        fn(a, a.shape[0], a.shape[1] // 2, *extra)
+        return a
+
+    def slow_ntt(self, data, inverse=False): return self._run(self.lib.orc61_slow_ntt, data, int(inverse))
+    def ntt(self, data, inverse=False): return self._run(self.lib.orc61_ntt, data, int(inverse))
+    def encode(self, data): return self._run(self.lib.orc61_encode, data)
+
+    def scale_blocks(self, data, scale, base):
+        return self._run(self.lib.orc61_scale_blocks, data, _pair(*scale), _pair(*base))
+
+    def encode_by_definition(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.empty_like(a)
+        self.lib.orc61_encode_by_definition(a, out, a.shape[0], a.shape[1] // 2)
+        return out
+
+    def fill_splitmix(self, N, elems, seed=0x1234):
+        a = np.empty((N, 2 * elems), dtype=np.uint64)
+        self.lib.orc61_fill_splitmix(a.reshape(-1), a.size, seed)
+        return a
 
 
 class Reference:

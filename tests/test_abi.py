@@ -78,3 +78,23 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "fastecc_oracle" not in text and "libfastecc_ref" not in text, f
+
+
+def test_p61_field_host_helpers_and_validation(hip_lib):
+    """FASTECC_FIELD_GF_P61_SQUARED: scalar helpers against the oracle, argument checks before any device use."""
+    import fastecc_amd as fe
+    import oracle as orc
+    o = orc.OracleP61()
+    for t in (1, 2, 3, 10, 20, 62):
+        assert fe.gf61_root(1 << t) == o.root(1 << t)
+    with pytest.raises(fe.FastEccError):
+        fe.gf61_root(24)
+    x, y = (123456789012345678, 2305843009213693950), (2305843009213693951 + 5, 77)  # y.re is reduced mod p first
+    assert fe.gf61_mul(x, y) == o.cmul(x, (5, 77))
+    assert fe.gf61_pow(x, (1 << 61) + 12345) == o.cpow(x, (1 << 61) + 12345)
+    assert fe.gf61_mul(fe.gf61_inv(x), x) == (1, 0)
+    h = ctypes.c_void_p()
+    create = hip_lib.fastecc_create
+    assert create(ctypes.byref(h), 256, 128, 4100, fe.FIELD_GF_P61_SQUARED, 0) == fe.E_INVAL      # block_bytes % 16
+    assert create(ctypes.byref(h), 1 << 26, 1 << 25, 64, fe.FIELD_GF_P61_SQUARED, 0) == fe.E_UNSUPPORTED
+    assert not h.value

@@ -1,0 +1,203 @@
+"""GPU parity tests (-m gpu) for FASTECC_FIELD_GF_P61_SQUARED, the 64-bit-field configuration
+(BASELINE.json configs[4]: 64 KB blocks over GF((2^61-1)^2)).
+
+PARITY UNPINNED upstream: the reference has no code for this field.  The checker is our oracle
+(oracle/fastecc_oracle_p61.c), itself checked against the independent big-integer vectors of
+tests/golden/golden_p61.json; every comparison here is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P61 = (1 << 61) - 1
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+@pytest.fixture(scope="module")
+def orc61():
+    import oracle
+    return oracle.OracleP61()
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def rand_stripe(rng, N, elems):
+    x = rng.integers(0, P61, size=(N, 2 * elems), dtype=np.uint64)
+    flat = x.reshape(-1)
+    edge = [0, 1, P61 - 1, P61 - 2, 1 << 31, (1 << 31) - 1, 1 << 60, (1 << 60) + (1 << 30), (1 << 32) - 1]
+    flat[: min(len(edge), flat.size)] = edge[: flat.size]
+    return x
+
+
+def encoder(fe, N, elems):
+    return fe.Encoder(2 * N, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED)
+
+
+def test_golden_vectors(torch_cuda, fe):
+    doc = json.load(open(os.path.join(HERE, "golden", "golden_p61.json")))
+    for case in doc["cases"]:
+        N, elems = case["N"], case["elems"]
+        x = np.array([int(w) for w in case["data"]], dtype=np.uint64).reshape(N, 2 * elems)
+        want = np.array([int(w) for w in case["parity"]], dtype=np.uint64).reshape(N, 2 * elems)
+        with encoder(fe, N, elems) as enc:
+            d = to_dev(torch_cuda, x)
+            out = torch_cuda.empty_like(d)
+            enc.encode(d, out)
+            assert (to_host(out) == want).all(), (N, elems)
+            assert (to_host(d) == x).all()  # out of place leaves the data alone
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 4, 5, 6, 7, 9, 10, 12])
+@pytest.mark.parametrize("elems", [1, 3, 64, 100])
+def test_encode_matches_oracle(torch_cuda, fe, orc61, logn, elems):
+    N = 1 << logn
+    if N * elems > (1 << 17):
+        pytest.skip("oracle time")
+    x = rand_stripe(np.random.default_rng(1000 * logn + elems), N, elems)
+    want = orc61.encode(x)
+    with encoder(fe, N, elems) as enc:
+        d = to_dev(torch_cuda, x)
+        enc.encode(d)  # in place, the reference's behaviour
+        got = to_host(d)
+    assert (got < P61).all(), "parity words must be canonical"
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("plan", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("logn", [3, 8, 11])
+def test_every_plan(torch_cuda, fe, orc61, plan, logn):
+    N, elems = 1 << logn, 37
+    x = rand_stripe(np.random.default_rng(plan * 100 + logn), N, elems)
+    want = orc61.encode(x)
+    with encoder(fe, N, elems) as enc:
+        enc.set_plan(plan)
+        d = to_dev(torch_cuda, x)
+        out = torch_cuda.empty_like(d)
+        enc.encode(d, out)
+        assert (to_host(out) == want).all(), enc.plan()
+
+
+@pytest.mark.parametrize("logn", [1, 4, 6, 9])
+def test_ntt_matches_oracle_and_inverts(torch_cuda, fe, orc61, logn):
+    N, elems = 1 << logn, 5
+    x = rand_stripe(np.random.default_rng(logn), N, elems)
+    with encoder(fe, N, elems) as enc:
+        for inverse in (False, True):
+            d = to_dev(torch_cuda, x)
+            enc.ntt(d, inverse=inverse)
+            assert (to_host(d) == orc61.ntt(x, inverse)).all(), (logn, inverse)
+        # inverse(forward(x)) = N * x  (both transforms are unscaled, ntt.cpp:451-483)
+        d = to_dev(torch_cuda, x)
+        enc.ntt(d)
+        enc.ntt(d, inverse=True)
+        got = to_host(d).astype(object)
+        assert (got == (x.astype(object) * N) % P61).all()
+
+
+def test_host_stripe_and_block_pointers(torch_cuda, fe, orc61):
+    N, elems = 64, 9
+    x = rand_stripe(np.random.default_rng(5), N, elems)
+    want = orc61.encode(x)
+    with encoder(fe, N, elems) as enc:
+        out = np.empty_like(x)
+        enc.encode_host(x, out)
+        assert (out == want).all()
+        blocks = [np.ascontiguousarray(x[i]).copy() for i in range(N)]
+        enc.encode_blocks([b.ctypes.data for b in blocks])
+        assert (np.stack(blocks) == want).all()
+
+
+def test_check_range(torch_cuda, fe):
+    N, elems = 32, 16
+    x = rand_stripe(np.random.default_rng(6), N, elems)
+    with encoder(fe, N, elems) as enc:
+        d = to_dev(torch_cuda, x)
+        assert enc.check_range(d) == 0
+        x[3, 5] = P61
+        x[31, 31] = (1 << 64) - 1
+        assert enc.check_range(to_dev(torch_cuda, x)) == 2
+
+
+def test_unsupported_entry_points(torch_cuda, fe):
+    with encoder(fe, 4, 4) as enc:
+        d = torch_cuda.zeros(4 * 8, dtype=torch_cuda.int64, device="cuda:0")
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.scale_blocks(d, 1, 1)
+        assert ei.value.code == fe.E_UNSUPPORTED
+        with pytest.raises(fe.FastEccError):
+            enc.set_option("slabs", 2)
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.Encoder(8, 4, 24, field=fe.FIELD_GF_P61_SQUARED)  # block_bytes % 16
+    assert ei.value.code == fe.E_INVAL
+
+
+def sample_columns_check(torch, orc61, data_dev, parity_dev, N, elems, cols):
+    """Columns are independent transforms: the oracle re-encodes a few of them exactly."""
+    d = data_dev.view(N, 2 * elems)
+    p = parity_dev.view(N, 2 * elems)
+    for c in cols:
+        x = d[:, 2 * c:2 * c + 2].contiguous().cpu().numpy().view(np.uint64)
+        got = p[:, 2 * c:2 * c + 2].contiguous().cpu().numpy().view(np.uint64)
+        assert (got == orc61.encode(x)).all(), c
+
+
+def test_linearity_and_sampled_columns_2_16(torch_cuda, fe, orc61):
+    torch = torch_cuda
+    N, elems = 1 << 16, 128
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    a = torch.randint(0, P61, (N * 2 * elems,), dtype=torch.int64, device="cuda:0", generator=g)
+    b = torch.randint(0, P61, (N * 2 * elems,), dtype=torch.int64, device="cuda:0", generator=g)
+    s = a + b
+    s = torch.where(s >= P61, s - P61, s)
+    with encoder(fe, N, elems) as enc:
+        ea, eb, es = torch.empty_like(a), torch.empty_like(b), torch.empty_like(s)
+        enc.encode(a, ea)
+        enc.encode(b, eb)
+        enc.encode(s, es)
+        t = ea + eb
+        t = torch.where(t >= P61, t - P61, t)
+        assert bool((t == es).all())
+        sample_columns_check(torch, orc61, a, ea, N, elems, [0, 63, 64, 127])
+
+
+def test_headline_size_sampled_columns(torch_cuda, fe, orc61):
+    """(n,k) = (2^20, 2^19), 64 KB blocks: 32 GiB of data, encoded in place; four columns re-encoded by the oracle."""
+    torch = torch_cuda
+    N, elems = 1 << 19, 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70 * (1 << 30):
+        pytest.skip("needs 64 GiB of HBM")
+    g = torch.Generator(device="cuda:0").manual_seed(19)
+    data = torch.randint(0, P61, (N * 2 * elems,), dtype=torch.int64, device="cuda:0", generator=g)
+    cols = [0, 1, 2047, 4095]
+    keep = {c: data.view(N, 2 * elems)[:, 2 * c:2 * c + 2].contiguous().cpu().numpy().view(np.uint64) for c in cols}
+    with encoder(fe, N, elems) as enc:
+        assert enc.check_range(data) == 0
+        enc.encode(data)
+        torch.cuda.synchronize()
+    par = data.view(N, 2 * elems)
+    for c in cols:
+        got = par[:, 2 * c:2 * c + 2].contiguous().cpu().numpy().view(np.uint64)
+        assert (got == orc61.encode(keep[c])).all(), c

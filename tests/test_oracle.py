@@ -1,5 +1,7 @@
 """CPU tests: the oracle restatement against golden vectors, the published KAT and (when prebuilt) the
 unmodified reference.  These pin the checker that the -m gpu parity tests rely on."""
+import os
+
 import numpy as np
 
 P = 0xFFF00001
@@ -116,3 +118,40 @@ def test_linearity_and_edge_inputs(oracle):
     # a constant stripe is the constant polynomial: parity == data
     c = np.full((N, S), P - 1, dtype=np.uint32)
     assert np.array_equal(oracle.encode(c), c)
+
+
+# ------------------------------------------------------------------------------------------------
+# GF((2^61-1)^2) oracle (parity unpinned upstream): pinned to independent big-integer vectors
+# ------------------------------------------------------------------------------------------------
+def test_p61_oracle_against_independent_golden():
+    import json
+    import oracle as orc
+    o = orc.OracleP61()
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_p61.json")))
+    assert o.root(1 << 62) == tuple(int(v) for v in doc["w_2^62"])
+    for t, v in doc["roots"].items():
+        assert o.root(1 << int(t)) == tuple(int(x) for x in v)
+    assert o.root(4) == (0, 1) and o.root(8) == (1 << 30, 1 << 30)  # w_4 = i, w_8 = 2^30 (1 + i)
+    assert o.root(3) == (0, 0) and o.root(1 << 63) == (0, 0)
+    for case in doc["cases"]:
+        N = case["N"]
+        x = np.array([int(w) for w in case["data"]], dtype=np.uint64).reshape(N, -1)
+        want = np.array([int(w) for w in case["parity"]], dtype=np.uint64).reshape(N, -1)
+        assert (o.encode(x) == want).all()
+        assert (o.encode_by_definition(x) == want).all()
+
+
+def test_p61_oracle_fast_transform_is_the_definition():
+    import oracle as orc
+    o = orc.OracleP61()
+    x = o.fill_splitmix(64, 3, 42)
+    for inverse in (False, True):
+        assert (o.ntt(x, inverse) == o.slow_ntt(x, inverse)).all()
+    # codeword property: data (even points) and parity (odd points) interleaved are the values of one polynomial
+    # of degree < N on the 2N-th roots of unity, so the inverse 2N-transform has a zero upper half
+    N = 64
+    par = o.encode(x)
+    word = np.empty((2 * N, x.shape[1]), dtype=np.uint64)
+    word[0::2], word[1::2] = x, par
+    coef = o.ntt(word, inverse=True)
+    assert (coef[N:] == 0).all() and (coef[:N] != 0).any()
