@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 P = 0xFFF00001
+P61 = (1 << 61) - 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 # Secondary (informational) bound: the path is integer-VALU bound once fused.  Chip-wide rate of
 # the radix-2 GF(p) butterfly measured in isolation (tools/microbench.hip, profiles/r01/microbench_bfly_variants.jsonl).
@@ -43,7 +44,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2k", type=int, default=19, help="k = 2^log2k data blocks (headline: 19)")
-    ap.add_argument("--block-bytes", type=int, default=4096)
+    ap.add_argument("--block-bytes", type=int, default=0, help="default 4096 (65536 with --field p61)")
+    ap.add_argument("--field", choices=["fff00001", "p61"], default="fff00001",
+                    help="p61 = GF((2^61-1)^2), the 64 KB-block configuration of BASELINE.json configs[4] (not the headline metric)")
     ap.add_argument("--plan", type=int, default=0, help="kernel plan (0 = library default); see DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
@@ -64,6 +67,34 @@ def random_stripe(n_words, device, seed):
         r = torch.randint(0, P, (m,), dtype=torch.int64, device=device, generator=g)
         out[i:i + m] = r.to(torch.int32)  # keeps the low 32 bits
     return out
+
+
+def random_stripe_p61(n_words, device, seed):
+    """Uniform uint64 words in [0, 2^61-1) (int64 bit patterns), generated on the device in chunks."""
+    out = torch.empty(n_words, dtype=torch.int64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    chunk = 1 << 26
+    for i in range(0, n_words, chunk):
+        m = min(chunk, n_words - i)
+        out[i:i + m] = torch.randint(0, P61, (m,), dtype=torch.int64, device=device, generator=g)
+    return out
+
+
+def cpu_baseline_p61(log2k, block_bytes):
+    """No reference code exists for this field: the baseline is our plain-C oracle on a bounded sample
+    (same k, 1 KiB slices of the blocks: columns are independent, so the rate per byte is the same)."""
+    from oracle import Oracle, OracleP61
+    N, elems = 1 << log2k, min(block_bytes // 16, 64)
+    orc = OracleP61()
+    x = orc.fill_splitmix(N, elems, 0x1234)
+    t0 = time.perf_counter()
+    orc.lib.orc61_encode(x, N, elems)
+    dt = time.perf_counter() - t0
+    cores = Oracle().num_threads()
+    return {"value": round(2.0 * N * elems * 16 / dt / 1e9, 4), "unit": "GB/s", "cores": min(cores, elems), "kind": "port",
+            "sample": "one encode of k=2^%d blocks x %d B (a %d-element column slice of the %d B blocks) by oracle/fastecc_oracle_p61.c "
+                      "(plain C, 128-bit %% arithmetic, OpenMP over columns), %.2f s" % (log2k, elems * 16, elems, block_bytes, dt)}
 
 
 def cpu_baseline(log2k, block_bytes):
@@ -129,10 +160,17 @@ def main():
 
     k = 1 << args.log2k
     n = 2 * k
+    p61 = args.field == "p61"
+    if not args.block_bytes:
+        args.block_bytes = 65536 if p61 else 4096
     S = args.block_bytes // 4
-    data = random_stripe(k * S, device, seed=0x1234 + rank)
+    if p61:
+        data = random_stripe_p61(k * (args.block_bytes // 8), device, seed=0x1234 + rank)
+    else:
+        data = random_stripe(k * S, device, seed=0x1234 + rank)
     parity = torch.empty_like(data)
-    enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local)
+    enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local,
+                              field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001)
     if args.plan:
         enc.set_plan(args.plan)
     if args.slabs:
@@ -164,7 +202,7 @@ def main():
     # Optional second mode (reported separately, never part of `value`): ONE stripe split into column slabs,
     # each rank encodes its slab, RCCL all_gather over xGMI re-assembles the parity on every rank.
     sharded = None
-    if args.gather and world > 1 and S % world == 0:
+    if args.gather and world > 1 and S % world == 0 and not p61:
         from fastecc_amd import sharding
         senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local)
         stripe2d = data.view(k, S)
@@ -204,32 +242,34 @@ def main():
             per_launch = nbytes / launches
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             kernel_ms_per_step = sum(v[0] for v in kernels.values()) / args.steps  # summed durations (kernels may overlap)
-            bfly = (2 * args.log2k + 1) * (k / 2) * S / (ms_per_step * 1e-3) / 1e9
+            per_block = args.block_bytes // 16 if p61 else S  # field elements per block
+            bfly = (2 * args.log2k + 1) * (k / 2) * per_block / (ms_per_step * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
                     "encode": {"ms_per_step": round(ms_per_step, 4), "sum_of_kernel_ms_per_step": round(kernel_ms_per_step, 4),
                                "achieved": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-                    "valu": {"what": "radix-2 GF(p) butterflies per second over the whole encode (2*log2(k)*k/2 per word column, "
+                    "valu": {"what": "radix-2 butterflies per second over the whole encode (2*log2(k)*k/2 per element column, "
                                      "plus k/2 butterfly-equivalents for the per-block factor multiply)",
-                             "achieved_Gbfly_per_s": round(bfly, 1), "microbench_peak_Gbfly_per_s": VALU_PEAK_GBFLY,
-                             "frac": round(bfly / VALU_PEAK_GBFLY, 4)},
+                             "achieved_Gbfly_per_s": round(bfly, 1), "microbench_peak_Gbfly_per_s": None if p61 else VALU_PEAK_GBFLY,
+                             "frac": None if p61 else round(bfly / VALU_PEAK_GBFLY, 4)},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                cpu = cpu_baseline(args.cpu_log2k or args.log2k, args.block_bytes)
+                cpu = (cpu_baseline_p61 if p61 else cpu_baseline)(args.cpu_log2k or args.log2k, args.block_bytes)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cpu = {"error": repr(e)}
         line = {
             "metric": "encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "RS encode (n,k)=(2^%d,2^%d), %d B blocks, GF(0xFFF00001), one %.0f MiB stripe per GPU, HBM-resident, out of place"
-                                   % (args.log2k + 1, args.log2k, args.block_bytes, k * args.block_bytes / 2**20),
+            "dtype": "u64" if p61 else "u32", "data": "synthetic",
+            "config": {"workload": "RS encode (n,k)=(2^%d,2^%d), %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
+                                   % (args.log2k + 1, args.log2k, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
+                                      k * args.block_bytes / 2**20),
                        "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
             "data_only_GBps": round(value / 2, 2),
             "roofline": roof, "cpu_baseline": cpu,

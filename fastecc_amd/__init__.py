@@ -76,6 +76,8 @@ def lib():
     for name in ("root", "inv"):
         f = getattr(L, "fastecc_gf_" + name)
         f.argtypes, f.restype = [u32], u32
+    L.fastecc_pack_blocks.argtypes, L.fastecc_pack_blocks.restype = [vp, vp, vp, i32, vp], i32
+    L.fastecc_unpack_blocks.argtypes, L.fastecc_unpack_blocks.restype = [vp, vp, vp, i32, vp, ctypes.POINTER(u64)], i32
     pair = ctypes.POINTER(u64)
     L.fastecc_gf61_mul.argtypes, L.fastecc_gf61_mul.restype = [pair, pair, pair], i32
     L.fastecc_gf61_pow.argtypes, L.fastecc_gf61_pow.restype = [pair, u64, pair], i32
@@ -182,6 +184,18 @@ class Encoder:
         bad = ctypes.c_uint64()
         _check(lib().fastecc_check_range(self._h, _addr(data), mem, stream or None, ctypes.byref(bad)), "fastecc_check_range")
         return int(bad.value)
+
+    def pack_blocks(self, raw, packed, stream=0, mem=MEM_DEVICE):
+        """GF.md:72-104: k blocks of block_bytes - 4 arbitrary bytes -> k encodable blocks of block_bytes."""
+        _check(lib().fastecc_pack_blocks(self._h, _addr(raw), _addr(packed), mem, stream or None), "fastecc_pack_blocks")
+        return packed
+
+    def unpack_blocks(self, packed, raw, stream=0, mem=MEM_DEVICE, count_bad=True):
+        """Inverse of pack_blocks; returns the number of blocks that are not packer output (None if not counted)."""
+        bad = ctypes.c_uint64()
+        _check(lib().fastecc_unpack_blocks(self._h, _addr(packed), _addr(raw), mem, stream or None,
+                                           ctypes.byref(bad) if count_bad else None), "fastecc_unpack_blocks")
+        return int(bad.value) if count_bad else None
 
     # ---- introspection used by bench.py ----
     def set_plan(self, plan):

@@ -62,6 +62,7 @@ struct fastecc_ctx {
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
+    uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
     void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
     size_t pinned_bytes = 0;
 
@@ -640,6 +641,7 @@ void fastecc_destroy(fastecc_ctx* c)
     if (c->dscale) (void)hipFree(c->dscale);
     if (c->factor) (void)hipFree(c->factor);
     if (c->dbuf) (void)hipFree(c->dbuf);
+    if (c->rawbuf) (void)hipFree(c->rawbuf);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
@@ -815,6 +817,85 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
     HIP_TRY(hipMemcpyAsync(&on_device, counter, sizeof on_device, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *bad_words = result + on_device;
+    return FASTECC_OK;
+}
+
+// GF.md:72-104: W = S - 1 raw words per block <-> S packed words (pack_kernels.hip)
+static int pack_args_ok(const fastecc_ctx* c, const void* a, const void* b)
+{
+    if (!c || !a || !b || (((uintptr_t)a | (uintptr_t)b) & 3u)) return FASTECC_E_INVAL;
+    if (c->p61) return FASTECC_E_UNSUPPORTED;                       // the recoding is specific to p = 0xFFF00001
+    if (c->S < 2 || c->S > 1025 || c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
+    return FASTECC_OK;
+}
+
+static int ensure_rawbuf(fastecc_ctx* c)
+{
+    if (c->rawbuf) return FASTECC_OK;
+    HIP_TRY(hipMalloc((void**)&c->rawbuf, c->N * (c->S - 1) * 4));
+    return FASTECC_OK;
+}
+
+int fastecc_pack_blocks(fastecc_ctx* c, const void* raw, void* packed, int mem_kind, void* stream)
+{
+    int rc = pack_args_ok(c, raw, packed);
+    if (rc != FASTECC_OK) return rc;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t words = (uint32_t)c->S - 1;
+    const uint64_t alg_bytes = c->N * (2ull * words + 1) * 4;
+    if (mem_kind == FASTECC_MEM_DEVICE) {
+        ProfScope ps(c, st, "pack_blocks", alg_bytes);
+        HIP_TRY(launch_pack_blocks((const uint32_t*)raw, (uint32_t*)packed, words, c->N, st));
+        return FASTECC_OK;
+    }
+    if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
+    rc = ensure_dbuf(c);
+    if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
+    if (rc != FASTECC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->rawbuf, raw, c->N * words * 4, hipMemcpyHostToDevice, st));
+    {
+        ProfScope ps(c, st, "pack_blocks", alg_bytes);
+        HIP_TRY(launch_pack_blocks(c->rawbuf, c->dbuf, words, c->N, st));
+    }
+    HIP_TRY(hipMemcpyAsync(packed, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
+
+int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem_kind, void* stream, uint64_t* bad_blocks)
+{
+    int rc = pack_args_ok(c, packed, raw);
+    if (rc != FASTECC_OK) return rc;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t words = (uint32_t)c->S - 1;
+    const uint64_t alg_bytes = c->N * (2ull * words + 1) * 4;
+    const uint32_t* src = (const uint32_t*)packed;
+    uint32_t* dst = (uint32_t*)raw;
+    if (mem_kind == FASTECC_MEM_HOST) {
+        rc = ensure_dbuf(c);
+        if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->dbuf, packed, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        src = c->dbuf;
+        dst = c->rawbuf;
+    } else if (mem_kind != FASTECC_MEM_DEVICE) {
+        return FASTECC_E_INVAL;
+    }
+    unsigned long long* counter = bad_blocks ? reinterpret_cast<unsigned long long*>(c->factor) : nullptr;  // N >= 2 words of scratch
+    if (counter) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    {
+        ProfScope ps(c, st, "unpack_blocks", alg_bytes);
+        HIP_TRY(launch_unpack_blocks(src, dst, words, c->N, counter, st));
+    }
+    unsigned long long found = 0;
+    if (counter) HIP_TRY(hipMemcpyAsync(&found, counter, sizeof found, hipMemcpyDeviceToHost, st));
+    if (mem_kind == FASTECC_MEM_HOST) HIP_TRY(hipMemcpyAsync(raw, c->rawbuf, c->N * words * 4, hipMemcpyDeviceToHost, st));
+    if (counter || mem_kind == FASTECC_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (bad_blocks) *bad_blocks = found;
     return FASTECC_OK;
 }
 

@@ -127,6 +127,26 @@ int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_
  */
 int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *stream, uint64_t *bad_words);
 
+/*
+ * Data packing (GF.md:72-104 "Efficient data packing", README.md:160-163): RS.cpp only encodes words < p, so
+ * arbitrary bytes are first recoded with one extra word per block — 4096-byte sectors become the 4100-byte
+ * blocks the encoder then works on.  The reference describes this in prose and has NO code for it; the exact
+ * format is therefore defined here (nothing upstream pins it):
+ *   a word is (digit << 20) | low20, digit = its top 12 bits.  Only words with digit 0xFFF can be >= p.
+ *   raw block   : W = block_bytes/4 - 1 arbitrary uint32 words (1 <= W <= 1024)
+ *   packed block: W + 1 words, all < 0xFFF00000 < p.  Word j keeps low20 of raw word j; the digit string is
+ *     flag word (word W) = 0 : no raw digit is 0xFFF, digits unchanged;
+ *     flag word          = 1 : [one 11-bit entry per 0xFFF digit, in increasing position: position | 0x400 if
+ *                               another entry follows][all other digits in their original order].
+ * The context must be GF(0xFFF00001) with block_bytes = 4 * (W + 1) (e.g. 4100); raw stripes are k * 4W bytes,
+ * packed stripes k * block_bytes bytes, both block-major and contiguous.  DEVICE pointers: enqueued on `stream`.
+ * fastecc_unpack_blocks also validates: a block no packer produces (flag > 1, a 0xFFF digit left, entries not
+ * strictly increasing / out of range / never ending) is copied through unchanged and counted in *bad_blocks
+ * (may be NULL = not wanted; non-NULL makes the call synchronise `stream`).
+ */
+int fastecc_pack_blocks(fastecc_ctx *ctx, const void *raw, void *packed, int mem_kind, void *stream);
+int fastecc_unpack_blocks(fastecc_ctx *ctx, const void *packed, void *raw, int mem_kind, void *stream, uint64_t *bad_blocks);
+
 /* Host-side field helpers (GF(p).cpp:254-297), used to build tables and by bindings. */
 uint32_t fastecc_gf_mul(uint32_t x, uint32_t y);
 uint32_t fastecc_gf_pow(uint32_t x, uint32_t e);

@@ -57,6 +57,8 @@ class Oracle:
         lib.orc_fill_linear.argtypes, lib.orc_fill_linear.restype = [_u32p, _sz], None
         lib.orc_fill_splitmix.argtypes, lib.orc_fill_splitmix.restype = [_u32p, _sz, ctypes.c_uint64], None
         lib.orc_num_threads.restype = ctypes.c_int
+        lib.orc_pack_blocks.argtypes, lib.orc_pack_blocks.restype = [_u32p, _sz, _sz, _u32p], None
+        lib.orc_unpack_blocks.argtypes, lib.orc_unpack_blocks.restype = [_u32p, _sz, _sz, _u32p], _sz
 
     # field
     def gf_add(self, x, y): return self.lib.orc_gf_add(x, y)
@@ -108,6 +110,20 @@ class Oracle:
         return a
 
     def num_threads(self): return int(self.lib.orc_num_threads())
+
+    # data packing (GF.md:72-104): [N, words] arbitrary uint32 <-> [N, words + 1] uint32 < P
+    def pack_blocks(self, raw):
+        a = np.ascontiguousarray(raw, dtype=np.uint32)
+        out = np.empty((a.shape[0], a.shape[1] + 1), dtype=np.uint32)
+        self.lib.orc_pack_blocks(a, a.shape[0], a.shape[1], out)
+        return out
+
+    def unpack_blocks(self, packed):
+        """-> (raw, number of blocks that no packer produces)"""
+        a = np.ascontiguousarray(packed, dtype=np.uint32)
+        out = np.empty((a.shape[0], a.shape[1] - 1), dtype=np.uint32)
+        bad = self.lib.orc_unpack_blocks(a, a.shape[0], a.shape[1] - 1, out)
+        return out, int(bad)
 
 
 P61 = (1 << 61) - 1

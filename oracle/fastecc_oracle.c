@@ -305,3 +305,94 @@ void orc_fill_splitmix(uint32_t *data, size_t nwords, uint64_t seed)
         data[i] = (uint32_t)(z % P);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Data packing, GF.md:72-104 ("Efficient data packing"): arbitrary 32-bit words -> words < P at the cost of
+ * one extra word per block.  The reference has prose only (no code), so the exact format is OURS (stated in
+ * include/fastecc.h) and PARITY IS UNPINNED; this is the plain sequential statement of it.
+ *
+ * A word is (digit << 20) | low20.  Words with digit 0xFFF are the ones that may be >= P = 0xFFF00001, so the
+ * block's `words` digits (base 4096) are recoded so that none equals 0xFFF; the low 20 bits never move.
+ *   flag 0: no digit is 0xFFF, digits unchanged.
+ *   flag 1: digits = [index entries][the digits != 0xFFF in order]; entry t = position of the t-th 0xFFF digit
+ *           (10 bits) | 0x400 if another entry follows.
+ * The flag is stored as word number `words` of the packed block (GF.md:98-100: the 1025th source word).
+ * ---------------------------------------------------------------------------------------- */
+#define PK_DIGIT(w) ((w) >> 20)
+#define PK_LOW(w) ((w) & 0xFFFFFu)
+
+void orc_pack_block(const uint32_t *raw, size_t words, uint32_t *packed)
+{
+    uint32_t digits[1024];
+    size_t m = 0, out = 0;
+    for (size_t j = 0; j < words; j++) m += PK_DIGIT(raw[j]) == 0xFFFu;
+    if (m == 0) {
+        memcpy(packed, raw, words * 4);
+        packed[words] = 0;
+        return;
+    }
+    size_t t = 0;
+    for (size_t j = 0; j < words; j++)
+        if (PK_DIGIT(raw[j]) == 0xFFFu) {
+            t++;
+            digits[out++] = (uint32_t)j | (t < m ? 0x400u : 0u);
+        }
+    for (size_t j = 0; j < words; j++)
+        if (PK_DIGIT(raw[j]) != 0xFFFu) digits[out++] = PK_DIGIT(raw[j]);
+    for (size_t j = 0; j < words; j++) packed[j] = (digits[j] << 20) | PK_LOW(raw[j]);
+    packed[words] = 1;
+}
+
+/* Returns 0, or -1 for a block no packer produces (raw then gets the first `words` packed words unchanged). */
+int orc_unpack_block(const uint32_t *packed, size_t words, uint32_t *raw)
+{
+    const uint32_t flag = packed[words];
+    int bad = flag > 1;
+    if (!bad && flag == 0) {
+        for (size_t j = 0; j < words; j++) bad |= PK_DIGIT(packed[j]) == 0xFFFu;
+    } else if (!bad) {
+        uint8_t is_fff[1024];
+        memset(is_fff, 0, sizeof is_fff);
+        size_t m = 0;
+        long prev = -1;
+        for (;;) {
+            if (m == words) { bad = 1; break; }
+            const uint32_t e = PK_DIGIT(packed[m]);
+            const long idx = (long)(e & 0x3FFu);
+            if ((e & 0x800u) || idx <= prev || (size_t)idx >= words) { bad = 1; break; }
+            is_fff[idx] = 1;
+            prev = idx;
+            m++;
+            if (!(e & 0x400u)) break;
+        }
+        if (!bad) {
+            size_t next = m;
+            for (size_t j = m; j < words; j++) bad |= PK_DIGIT(packed[j]) == 0xFFFu;
+            if (!bad)
+                for (size_t j = 0; j < words; j++) {
+                    const uint32_t d = is_fff[j] ? 0xFFFu : PK_DIGIT(packed[next++]);
+                    raw[j] = (d << 20) | PK_LOW(packed[j]);
+                }
+        }
+    }
+    if (bad) {
+        memcpy(raw, packed, words * 4);
+        return -1;
+    }
+    if (flag == 0) memcpy(raw, packed, words * 4);
+    return 0;
+}
+
+void orc_pack_blocks(const uint32_t *raw, size_t N, size_t words, uint32_t *packed)
+{
+#pragma omp parallel for
+    for (size_t i = 0; i < N; i++) orc_pack_block(raw + i * words, words, packed + i * (words + 1));
+}
+
+size_t orc_unpack_blocks(const uint32_t *packed, size_t N, size_t words, uint32_t *raw)
+{
+    size_t bad = 0;
+#pragma omp parallel for reduction(+ : bad)
+    for (size_t i = 0; i < N; i++) bad += orc_unpack_block(packed + i * (words + 1), words, raw + i * words) != 0;
+    return bad;
+}

@@ -57,6 +57,13 @@ uint32_t orc_hash(const uint32_t *data, size_t nwords);
 void orc_fill_linear(uint32_t *data, size_t nwords);                 /* i % P (RS.cpp:28-29) */
 void orc_fill_splitmix(uint32_t *data, size_t nwords, uint64_t seed); /* splitmix64 % P        */
 
+/* Data packing GF.md:72-104 (prose only upstream: format defined in include/fastecc.h, parity unpinned).
+ * raw: `words` arbitrary uint32 (words <= 1024); packed: words + 1 uint32, all < P. */
+void orc_pack_block(const uint32_t *raw, size_t words, uint32_t *packed);
+int orc_unpack_block(const uint32_t *packed, size_t words, uint32_t *raw); /* -1: not a packer output */
+void orc_pack_blocks(const uint32_t *raw, size_t N, size_t words, uint32_t *packed);
+size_t orc_unpack_blocks(const uint32_t *packed, size_t N, size_t words, uint32_t *raw); /* count of bad blocks */
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

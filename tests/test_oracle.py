@@ -155,3 +155,35 @@ def test_p61_oracle_fast_transform_is_the_definition():
     word[0::2], word[1::2] = x, par
     coef = o.ntt(word, inverse=True)
     assert (coef[N:] == 0).all() and (coef[:N] != 0).any()
+
+
+# ------------------------------------------------------------------------------------------------
+# data packing (GF.md:72-104): the C restatement against the independent pure-Python vectors
+# ------------------------------------------------------------------------------------------------
+def test_pack_oracle_against_independent_golden(oracle):
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_pack.json")))
+    assert len(doc["cases"]) >= 10
+    for case in doc["cases"]:
+        raw = np.array(case["raw"], dtype=np.uint32)[None, :]
+        want = np.array(case["packed"], dtype=np.uint32)[None, :]
+        got = oracle.pack_blocks(raw)
+        assert (got == want).all(), case["name"]
+        assert (got < P).all()
+        back, bad = oracle.unpack_blocks(got)
+        assert bad == 0 and (back == raw).all()
+
+
+def test_pack_oracle_properties(oracle):
+    rng = np.random.default_rng(1)
+    for W in (1, 7, 64, 1000, 1024):
+        raw = rng.integers(0, 1 << 32, size=(50, W), dtype=np.uint64).astype(np.uint32)
+        raw[::3] |= np.uint32(0xFFF00000) * (rng.random((len(raw[::3]), W)) < 0.1).astype(np.uint32)
+        packed = oracle.pack_blocks(raw)
+        assert (packed < P).all() and set(np.unique(packed[:, W])) <= {0, 1}
+        assert ((packed[:, :W] & 0xFFFFF) == (raw & 0xFFFFF)).all()      # low 20 bits never move
+        back, bad = oracle.unpack_blocks(packed)
+        assert bad == 0 and (back == raw).all()
+    junk = np.full((1, 9), 0, dtype=np.uint32)
+    junk[0, 8] = 7
+    assert oracle.unpack_blocks(junk)[1] == 1
