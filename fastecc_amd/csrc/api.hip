@@ -825,7 +825,7 @@ static int pack_args_ok(const fastecc_ctx* c, const void* a, const void* b)
 {
     if (!c || !a || !b || (((uintptr_t)a | (uintptr_t)b) & 3u)) return FASTECC_E_INVAL;
     if (c->p61) return FASTECC_E_UNSUPPORTED;                       // the recoding is specific to p = 0xFFF00001
-    if (c->S < 2 || c->S > 1025 || c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
+    if (c->S < 2 || c->S > 1025) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
     return FASTECC_OK;
 }
 
@@ -847,17 +847,18 @@ int fastecc_pack_blocks(fastecc_ctx* c, const void* raw, void* packed, int mem_k
     const uint64_t alg_bytes = c->N * (2ull * words + 1) * 4;
     if (mem_kind == FASTECC_MEM_DEVICE) {
         ProfScope ps(c, st, "pack_blocks", alg_bytes);
-        HIP_TRY(launch_pack_blocks((const uint32_t*)raw, (uint32_t*)packed, words, c->N, st));
+        HIP_TRY(launch_pack_blocks((const uint32_t*)raw, (uint32_t*)packed, words, (uint32_t)c->ld, c->N, st));
         return FASTECC_OK;
     }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     rc = ensure_dbuf(c);
     if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
     if (rc != FASTECC_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->rawbuf, raw, c->N * words * 4, hipMemcpyHostToDevice, st));
     {
         ProfScope ps(c, st, "pack_blocks", alg_bytes);
-        HIP_TRY(launch_pack_blocks(c->rawbuf, c->dbuf, words, c->N, st));
+        HIP_TRY(launch_pack_blocks(c->rawbuf, c->dbuf, words, (uint32_t)c->S, c->N, st));
     }
     HIP_TRY(hipMemcpyAsync(packed, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -876,6 +877,7 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
     const uint32_t* src = (const uint32_t*)packed;
     uint32_t* dst = (uint32_t*)raw;
     if (mem_kind == FASTECC_MEM_HOST) {
+        if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;
         rc = ensure_dbuf(c);
         if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
         if (rc != FASTECC_OK) return rc;
@@ -889,7 +891,7 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
     if (counter) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     {
         ProfScope ps(c, st, "unpack_blocks", alg_bytes);
-        HIP_TRY(launch_unpack_blocks(src, dst, words, c->N, counter, st));
+        HIP_TRY(launch_unpack_blocks(src, dst, words, (uint32_t)c->ld, c->N, counter, st));
     }
     unsigned long long found = 0;
     if (counter) HIP_TRY(hipMemcpyAsync(&found, counter, sizeof found, hipMemcpyDeviceToHost, st));

@@ -49,10 +49,10 @@ hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& 
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);
 hipError_t launch_count_out_of_range(const uint32_t* x, uint64_t count, unsigned long long* bad, hipStream_t st);
-// pack_kernels.hip: GF.md:72-104 recoding, `words` <= 1024 raw words per block <-> words + 1 packed words
-hipError_t launch_pack_blocks(const uint32_t* raw, uint32_t* packed, uint32_t words, uint64_t blocks, hipStream_t st);
-hipError_t launch_unpack_blocks(const uint32_t* packed, uint32_t* raw, uint32_t words, uint64_t blocks, unsigned long long* bad_blocks,
-                                hipStream_t st);
+// pack_kernels.hip: GF.md:72-104 recoding, `words` <= 1024 raw words per block <-> words + 1 packed words at row pitch ld
+hipError_t launch_pack_blocks(const uint32_t* raw, uint32_t* packed, uint32_t words, uint32_t ld, uint64_t blocks, hipStream_t st);
+hipError_t launch_unpack_blocks(const uint32_t* packed, uint32_t* raw, uint32_t words, uint32_t ld, uint64_t blocks,
+                                unsigned long long* bad_blocks, hipStream_t st);
 hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, hipStream_t st);
 
 }  // namespace fastecc

@@ -34,7 +34,7 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 __global__ __launch_bounds__(256) void pack_blocks_kernel(const uint32_t* __restrict__ raw, uint32_t* __restrict__ packed,
-                                                          uint32_t words, uint64_t blocks)
+                                                          uint32_t words, uint32_t ld, uint64_t blocks)
 {
     __shared__ uint16_t lds[4][1024];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(const uint32_t* __rest
     const uint64_t b = (uint64_t)blockIdx.x * 4u + wave;
     if (b >= blocks) return;  // wave-uniform
     const uint32_t* src = raw + b * words;
-    uint32_t* dst = packed + b * (words + 1);
+    uint32_t* dst = packed + b * ld;  // ld >= words + 1: the row pitch of the encoder's device stripes
     uint16_t* digits = lds[wave];
 
     uint32_t w[CHUNKS];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(const uint32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __restrict__ packed, uint32_t* __restrict__ raw,
-                                                            uint32_t words, uint64_t blocks, unsigned long long* bad_blocks)
+                                                            uint32_t words, uint32_t ld, uint64_t blocks, unsigned long long* bad_blocks)
 {
     __shared__ uint16_t lds[4][1024];
     __shared__ uint32_t marks[4][32];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __re
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b = (uint64_t)blockIdx.x * 4u + wave;
     if (b >= blocks) return;
-    const uint32_t* src = packed + b * (words + 1);
+    const uint32_t* src = packed + b * ld;
     uint32_t* dst = raw + b * words;
     uint16_t* digits = lds[wave];
     uint32_t* mark = marks[wave];
@@ -176,18 +176,18 @@ __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __re
 
 }  // namespace
 
-hipError_t launch_pack_blocks(const uint32_t* raw, uint32_t* packed, uint32_t words, uint64_t blocks, hipStream_t st)
+hipError_t launch_pack_blocks(const uint32_t* raw, uint32_t* packed, uint32_t words, uint32_t ld, uint64_t blocks, hipStream_t st)
 {
-    if (words == 0 || words > 64u * CHUNKS || blocks == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, raw, packed, words, blocks);
+    if (words == 0 || words > 64u * CHUNKS || ld <= words || blocks == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, raw, packed, words, ld, blocks);
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_blocks(const uint32_t* packed, uint32_t* raw, uint32_t words, uint64_t blocks, unsigned long long* bad_blocks,
-                                hipStream_t st)
+hipError_t launch_unpack_blocks(const uint32_t* packed, uint32_t* raw, uint32_t words, uint32_t ld, uint64_t blocks,
+                                unsigned long long* bad_blocks, hipStream_t st)
 {
-    if (words == 0 || words > 64u * CHUNKS || blocks == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(unpack_blocks_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, packed, raw, words, blocks, bad_blocks);
+    if (words == 0 || words > 64u * CHUNKS || ld <= words || blocks == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(unpack_blocks_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, packed, raw, words, ld, blocks, bad_blocks);
     return hipGetLastError();
 }
 

@@ -139,7 +139,9 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *     flag word          = 1 : [one 11-bit entry per 0xFFF digit, in increasing position: position | 0x400 if
  *                               another entry follows][all other digits in their original order].
  * The context must be GF(0xFFF00001) with block_bytes = 4 * (W + 1) (e.g. 4100); raw stripes are k * 4W bytes,
- * packed stripes k * block_bytes bytes, both block-major and contiguous.  DEVICE pointers: enqueued on `stream`.
+ * packed stripes k * block_bytes bytes, both block-major and contiguous — except that DEVICE packed stripes use
+ * the context's "row_pitch_words" option like fastecc_encode does (e.g. 1056: rows padded to 4224 bytes, which
+ * is what makes 4100-byte blocks encode at full speed).  DEVICE pointers: enqueued on `stream`.
  * fastecc_unpack_blocks also validates: a block no packer produces (flag > 1, a 0xFFF digit left, entries not
  * strictly increasing / out of range / never ending) is copied through unchanged and counted in *bad_blocks
  * (may be NULL = not wanted; non-NULL makes the call synchronise `stream`).

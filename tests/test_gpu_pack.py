@@ -146,6 +146,27 @@ def test_sector_pipeline_4096_to_4100(torch_cuda, fe, oracle):
         assert (raw_back == raw).all()
 
 
+def test_padded_row_pitch(torch_cuda, fe, oracle):
+    """pack -> encode -> unpack on device stripes with 4224-byte rows (row_pitch_words = 1056)."""
+    torch = torch_cuda
+    k, W, pitch = 1 << 11, 1024, 1056
+    raw = raw_stripe(np.random.default_rng(21), k, W, 1 / 2048)
+    packed_want = oracle.pack_blocks(raw)
+    parity_want = oracle.encode_fast(packed_want)
+    with fe.Encoder(2 * k, k, 4100) as enc:
+        enc.set_option("row_pitch_words", pitch)
+        d_packed = torch.full((k * pitch,), -1, dtype=torch.int32, device="cuda:0")
+        d_parity = torch.full((k * pitch,), -1, dtype=torch.int32, device="cuda:0")
+        enc.pack_blocks(to_dev(torch, raw), d_packed)
+        got = to_host(d_packed, (k, pitch))
+        assert (got[:, :W + 1] == packed_want).all() and (got[:, W + 1:] == 0xFFFFFFFF).all()  # padding untouched
+        enc.encode(d_packed, d_parity)
+        assert (to_host(d_parity, (k, pitch))[:, :W + 1] == parity_want).all()
+        back = torch.empty(k * W, dtype=torch.int32, device="cuda:0")
+        assert enc.unpack_blocks(d_packed, back) == 0
+        assert (to_host(back, (k, W)) == raw).all()
+
+
 def test_headline_size_round_trip(torch_cuda, fe):
     """k = 2^19 sectors of 4096 bytes (2 GiB): pack, range check, unpack; compared on the device."""
     torch = torch_cuda
