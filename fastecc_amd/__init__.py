@@ -120,8 +120,9 @@ def _addr(x):
 class Encoder:
     """(n,k) = (2N,N) Reed-Solomon encoder over GF(0xFFF00001): the RS.cpp:22-68 operation.
 
-    ``data``/``parity`` arguments are device tensors (or raw addresses) of k*block_bytes bytes laid out
-    block-major, exactly the ``T** data`` stripe of RS.cpp:28-33 stored back to back.
+    ``data`` is a device tensor (or raw address) of k*block_bytes bytes laid out block-major, exactly the
+    ``T** data`` stripe of RS.cpp:28-33 stored back to back; ``parity`` holds n-k blocks the same way.
+    n - k may also be k/2, k/4, k/8 or k/16: parity block j is then block j*k/(n-k) of the (2k,k) parity.
     """
 
     def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001):
@@ -145,6 +146,10 @@ class Encoder:
 
     def __exit__(self, *exc):
         self.close()
+
+    @property
+    def parity_blocks(self):
+        return self.n - self.k
 
     @property
     def words_per_block(self):

@@ -52,6 +52,14 @@ struct fastecc_ctx {
     uint64_t S = 0;   // words per block
     uint64_t ld = 0;  // words between consecutive blocks in DEVICE stripes (row pitch, >= S; S unless "row_pitch_words" is set)
     size_t stripe_bytes = 0;
+    // Fewer parity than data blocks: n - k = M = k >> fold.  Parity block j of that code is parity block j << fold of
+    // the (2k, k) code (same polynomial, a sub-coset of the evaluation points), so the DIF half is unchanged, the
+    // MID pass keeps every 2^fold-th output and the DIT passes above it run as a size-M transform on the compact buffer.
+    int fold = 0;
+    uint64_t M = 0;             // parity blocks
+    size_t parity_bytes = 0;    // M * block_bytes
+    uint32_t* scratch = nullptr;      // fold > 0: k-block work stripe for the DIF half (lazy)
+    uint32_t* tw_fold_dit = nullptr;  // fold > 0: forward roots of order M, level-packed for the DIT passes above MID
 
     // device tables (Montgomery form, see gf.hpp)
     // level-packed twiddle tables (ntt_device.hpp), N words each, rebuilt whenever the plan changes:
@@ -175,12 +183,13 @@ void build_plans(fastecc_ctx* c)
         const int want = std::min(n, c->tile_mid);
         if (!tile_fits(c, want, 0)) {
             // blocks too large for 32-bit tile offsets: register passes handle the low levels
-        } else if (tile_supported(want, !c->tile_mid_wide)) {
+        } else if (tile_supported(want, !c->tile_mid_wide) && tile_max_fold(want, !c->tile_mid_wide) >= c->fold) {
             mid = want, mid_tile = true, mid_pair = !c->tile_mid_wide;
-        } else if (tile_supported(want, c->tile_mid_wide)) {
+        } else if (tile_supported(want, c->tile_mid_wide) && tile_max_fold(want, c->tile_mid_wide) >= c->fold) {
             mid = want, mid_tile = true, mid_pair = c->tile_mid_wide;
         }
     }
+    if (!mid_tile && mid < c->fold) mid = std::min(n, c->fold);  // a register MID pass drops blocks within its own 2^mid
     const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
     const std::vector<int> outer = split_levels(n - mid, max_chunk);
     int s = n;
@@ -261,24 +270,34 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     if (width == 0) width = (uint32_t)c->S;
     in += col0;
     out += col0;
-    const int vec = pick_vec(c, in, out);
     const uint32_t* src = in;
     char name[32];
     bool first = true;
+    // fold > 0 (encode only): the DIF half works on a k-block scratch stripe, MID writes the M surviving blocks to
+    // `out`, the DIT passes above it are a size-M transform in place on `out`
+    const bool folded = c->fold > 0 && &plan == &c->encode_plan;
+    if (folded && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
+    const int vec = folded ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
 
     for (const Pass& p : plan) {
-        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), 2ull * c->N * width * 4ull);
+        const bool above_mid = folded && p.mode == MODE_DIT;
+        uint32_t* dst = folded && p.mode == MODE_DIF ? c->scratch : out;
+        const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
+        const uint32_t* twd = above_mid ? c->tw_fold_dit : tw_dit;
+        const uint64_t rows_moved = !folded ? 2 * c->N : p.mode == MODE_DIF ? 2 * c->N : p.mode == MODE_MID ? c->N + c->M : 2 * c->M;
+        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), rows_moved * width * 4ull);
         if (p.tile) {
             TileArgs a{};
             a.in = src;
-            a.out = out;
+            a.out = dst;
             a.tw_dif = tw_dif;
-            a.tw_dit = tw_dit;
+            a.tw_dit = twd;
             a.dscale = c->dscale;
             a.S = width;
             a.ld = (uint32_t)c->ld;
-            a.n = c->n;
-            a.s = p.s;
+            a.n = n_eff;
+            a.s = s_eff;
+            a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
             a.split2 = c->split2;
@@ -292,17 +311,18 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         } else {
             PassArgs a{};
             a.in = src;
-            a.out = out;
+            a.out = dst;
             a.tw_dif = tw_dif;
-            a.tw_dit = tw_dit;
+            a.tw_dit = twd;
             a.dscale = c->dscale;
             a.S = (uint32_t)c->S;
             a.ld = (uint32_t)c->ld;
-            a.n = c->n;
-            a.s = p.s;
+            a.n = n_eff;
+            a.s = s_eff;
+            a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
-        src = out;  // after the first pass everything is in place on `out`
+        src = dst;  // after the first pass everything is in place on the buffer just written
         if (first && first_done) {
             ps.finish();
             HIP_TRY(hipEventRecord(first_done, st));
@@ -361,7 +381,7 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
     }
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
     const int H = c->slabs;
-    const bool slabbed = H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
+    const bool slabbed = c->fold == 0 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
                          (c->S % (32u * H)) == 0;
     if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
 
@@ -453,6 +473,13 @@ int upload_twiddles(fastecc_ctx* c)
     if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc));  // evaluate (RS.cpp:63)
     if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
     if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
+    if (rc == FASTECC_OK && c->fold > 0) {
+        // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
+        const int nf = c->n - c->fold;
+        std::vector<int> sl(std::max(nf, 0), 0);
+        for (int l = 0; l < nf; l++) sl[l] = std::max(enc[l + c->fold] - c->fold, 0);
+        rc = upload_table(&c->tw_fold_dit, build_level_table(nf, gf::h_root((uint32_t)c->M), sl));
+    }
     return rc;
 }
 
@@ -543,9 +570,14 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     *out = nullptr;
     const bool f61 = field == FASTECC_FIELD_GF_P61_SQUARED;
     if (field != FASTECC_FIELD_GF_FFF00001 && !f61) return FASTECC_E_UNSUPPORTED;
-    if (k < 2 || n != 2 * k || block_bytes == 0 || (block_bytes % (f61 ? 16 : 4)) != 0) return FASTECC_E_INVAL;
+    if (k < 2 || n <= k || block_bytes == 0 || (block_bytes % (f61 ? 16 : 4)) != 0) return FASTECC_E_INVAL;
     const int lg = ilog2_exact(k);
     if (lg < 0) return FASTECC_E_INVAL;
+    // parity blocks: k (the reference's configuration) or k/2, k/4, k/8, k/16
+    const int lgm = ilog2_exact(n - k);
+    if (lgm < 0 || lgm > lg) return FASTECC_E_INVAL;
+    const int fold = lg - lgm;
+    if (fold > 4 || (f61 && fold != 0)) return FASTECC_E_UNSUPPORTED;
     // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51); in GF(p61^2) 2N | 2^62, the bound is table memory
     if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
@@ -566,6 +598,9 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     c->S = block_bytes / 4;
     c->ld = c->S;
     c->stripe_bytes = (size_t)k * block_bytes;
+    c->fold = fold;
+    c->M = n - k;
+    c->parity_bytes = (size_t)(n - k) * block_bytes;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
@@ -642,6 +677,8 @@ void fastecc_destroy(fastecc_ctx* c)
     if (c->factor) (void)hipFree(c->factor);
     if (c->dbuf) (void)hipFree(c->dbuf);
     if (c->rawbuf) (void)hipFree(c->rawbuf);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->tw_fold_dit) (void)hipFree(c->tw_fold_dit);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
@@ -661,7 +698,7 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
     rc = encode_device(c, c->dbuf, c->dbuf, st);
     if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->parity_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FASTECC_OK;
 }
@@ -693,8 +730,8 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
     }
     rc = encode_device(c, c->dbuf, c->dbuf, nullptr);
     if (rc != FASTECC_OK) return rc;
-    for (uint64_t i0 = 0; i0 < c->N; i0 += per_chunk) {
-        const size_t cnt = std::min<uint64_t>(per_chunk, c->N - i0);
+    for (uint64_t i0 = 0; i0 < c->M; i0 += per_chunk) {  // the first n - k blocks receive the parity
+        const size_t cnt = std::min<uint64_t>(per_chunk, c->M - i0);
         HIP_TRY(hipMemcpy(bounce, (char*)c->dbuf + i0 * bb, cnt * bb, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) memcpy(blocks[i0 + i], bounce + i * bb, bb);
     }
@@ -935,6 +972,12 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         const uint64_t pitch = value == 0 ? c->S : (uint64_t)value;
         if (value < 0 || pitch < c->S) return FASTECC_E_INVAL;
         c->ld = pitch;
+        if (c->scratch) {  // sized for the old pitch
+            DeviceGuard dgs(c->device);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(c->scratch);
+            c->scratch = nullptr;
+        }
         build_plans(c);  // tile eligibility depends on the pitch
         DeviceGuard dg(c->device);
         if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");

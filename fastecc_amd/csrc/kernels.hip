@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     }
 
     if (live) {
+        if (MODE == MODE_MID && a.fold > 0) {
+            // fewer parity than data blocks: parity block j of the (N + N/2^fold, N) code is parity block j * 2^fold of
+            // the (2N, N) code, i.e. the output positions that are multiples of 2^fold, stored compactly
+            const uint32_t drop = (1u << a.fold) - 1u;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if ((j & drop) == 0) store_vec<V>(a.out + (size_t)((base + j) >> a.fold) * a.ld + col, x[j]);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             uint32_t* row = a.out + (size_t)(base + ((uint32_t)j << s)) * a.ld;

@@ -20,6 +20,7 @@ struct PassArgs {
     int s;                   // log2 of the smallest stride of this pass
     uint32_t col_chunks;     // filled by the launcher
     uint64_t items;          // filled by the launcher
+    int fold;                // MID only: keep every 2^fold-th output block, written compactly (fewer parity than data blocks)
 };
 
 // Arguments of one LDS-tiled pass (tile_kernels.hip: ntt_tile_kernel); fields as in PassArgs.
@@ -40,11 +41,13 @@ struct TileArgs {
     bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
     bool split2;          // 1024-block pair tiles exchange 16 columns at a time (64 KiB LDS, 2 workgroups per CU)
     int cache_policy;     // bit 0: non-temporal stripe loads, bit 1: non-temporal stripe stores
+    int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
 };
 
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
 bool tile_supported(int logt, bool pair, int logr = 5);
+int tile_max_fold(int logt, bool pair, int logr = 5);
 hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st);
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);

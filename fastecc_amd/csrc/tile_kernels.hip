@@ -171,6 +171,9 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     const uint32_t half = PAIR ? (lane >> 5) : 0u;
     const uint32_t upper_mask = 0u - half;  // all ones in the high half-wave of a PAIR tile
     const int s = MODE == MODE_MID ? 0 : a.s;
+    // MID with fewer parity than data blocks: only output positions that are multiples of 2^fold are kept, stored
+    // at position >> fold.  fold <= L2, so whether a wave's blocks survive depends on g alone.
+    const int fold = MODE == MODE_MID ? a.fold : 0;
 
     // Block held in register j (layout A) / k (layout B), split into a wave-uniform part (SGPRs) and the
     // half-wave part of a PAIR tile, which is folded once into per-lane offsets.
@@ -211,7 +214,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         v.dead_mask = (cc * W + c < a.S) ? 0u : 0xFFFFFFFFu;
         const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.ld + cc * W;
         v.in = make_desc(a.in + origin);
-        v.out = make_desc(a.out + origin);
+        v.out = make_desc(a.out + (fold ? (size_t)((v.hi << LOGT) >> fold) * a.ld + cc * W : origin));
         return v;
     };
     auto load_rows = [&](uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
@@ -261,9 +264,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 #undef FASTECC_LOAD_LOOP
     };
     auto store_paired = [&](const uint32_t (&r)[R][1], const View& v) {
-        const uint32_t voff = lane_p | v.dead_mask;
-        uint32_t soff = g * row_bytes;
-        const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+        // with fold: block q = g + 2i*G (+ G) (+ T/2) goes to q >> fold; G, T/2 and (for the waves that store) g are multiples of 2^fold
+        const uint32_t voff = (fold ? ((half * (G >> fold)) * a.ld + c) * 4u : lane_p) | v.dead_mask;
+        uint32_t soff = (g >> fold) * row_bytes;
+        const uint32_t far = ((T / 2) >> fold) * row_bytes, step = ((2 * G) >> fold) * row_bytes;
 #define FASTECC_STORE_LOOP(AUX)                                                                \
     _Pragma("unroll") for (int j = 0; j < R; j += 2) {                                          \
         __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, soff, AUX);                 \
@@ -368,12 +372,14 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
                 lds_barrier();  // every lane has finished reading the first exchange
                 exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
-                dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
-                if constexpr (PAIR) {
-                    pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
-                    store_paired(x, v);
-                } else {
-                    store_rows(x, v, lane_a, qa_u, G);
+                if (fold == 0 || (g & ((1u << fold) - 1u)) == 0) {  // uniform: does this wave hold surviving blocks?
+                    dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
+                    if constexpr (PAIR) {
+                        pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+                        store_paired(x, v);
+                    } else {
+                        store_rows(x, v, lane_a, qa_u >> fold, G >> fold);
+                    }
                 }
             }
         } else {
@@ -462,6 +468,9 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     }
 }
 
+// Largest fold a MID tile supports: 2^fold must divide its wave stride G = 2^L2.
+int tile_max_fold(int logt, bool pair, int logr) { return logt - logr - (pair ? 1 : 0); }
+
 // Tile shapes that are instantiated.  logr = registers per lane (log2): 5 everywhere; 4 additionally for the
 // 8- and 9-level pair tiles of the outer passes (16 words per lane, <= 64 VGPRs, twice the waves per CU).
 bool tile_supported(int logt, bool pair, int logr)
@@ -474,6 +483,7 @@ bool tile_supported(int logt, bool pair, int logr)
 hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st)
 {
     if (!tile_supported(logt, pair, logr) || a.n < logt) return hipErrorInvalidValue;
+    if (a.fold < 0 || (a.fold > 0 && (mode != MODE_MID || a.fold > tile_max_fold(logt, pair, logr)))) return hipErrorInvalidValue;
     if (logr == 4) {
         if (mode == MODE_MID) return hipErrorInvalidValue;
         return logt == 8 ? launch_mode<8, 4, true>(mode, a, st) : launch_mode<9, 4, true>(mode, a, st);
