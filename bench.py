@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2k", type=int, default=19, help="k = 2^log2k data blocks (headline: 19)")
+    ap.add_argument("--log2m", type=int, default=None, help="parity blocks = 2^log2m (default: = k, the reference's configuration; "
+                                                            "k/2 .. k/16 are supported, not the headline metric)")
     ap.add_argument("--block-bytes", type=int, default=0, help="default 4096 (65536 with --field p61)")
     ap.add_argument("--field", choices=["fff00001", "p61"], default="fff00001",
                     help="p61 = GF((2^61-1)^2), the 64 KB-block configuration of BASELINE.json configs[4] (not the headline metric)")
@@ -159,7 +161,8 @@ def main():
     import fastecc_amd
 
     k = 1 << args.log2k
-    n = 2 * k
+    m_blocks = k if args.log2m is None else 1 << args.log2m
+    n = k + m_blocks
     p61 = args.field == "p61"
     if not args.block_bytes:
         args.block_bytes = 65536 if p61 else 4096
@@ -168,7 +171,7 @@ def main():
         data = random_stripe_p61(k * (args.block_bytes // 8), device, seed=0x1234 + rank)
     else:
         data = random_stripe(k * S, device, seed=0x1234 + rank)
-    parity = torch.empty_like(data)
+    parity = torch.empty(data.numel() // k * m_blocks, dtype=data.dtype, device=device)
     enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local,
                               field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001)
     if args.plan:
@@ -229,7 +232,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        bytes_per_encode = 2.0 * k * args.block_bytes  # data + parity, RS.cpp:38
+        bytes_per_encode = float(k + m_blocks) * args.block_bytes  # data + parity, RS.cpp:38
         ms_per_step = elapsed / args.steps * 1e3
         value = world * bytes_per_encode / (ms_per_step * 1e-3) / 1e9
         # dominant kernel by total time; a launch reads its part of the stripe once and writes it once (the
@@ -243,7 +246,8 @@ def main():
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             kernel_ms_per_step = sum(v[0] for v in kernels.values()) / args.steps  # summed durations (kernels may overlap)
             per_block = args.block_bytes // 16 if p61 else S  # field elements per block
-            bfly = (2 * args.log2k + 1) * (k / 2) * per_block / (ms_per_step * 1e-3) / 1e9
+            log2m = args.log2k if args.log2m is None else args.log2m
+            bfly = ((args.log2k + 1) * (k / 2) + log2m * (m_blocks / 2)) * per_block / (ms_per_step * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
@@ -263,12 +267,14 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cpu = {"error": repr(e)}
         line = {
-            "metric": "encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes),
+            "metric": ("encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes))
+                      if m_blocks == k else
+                      ("encode GB/s at (n,k)=(2^%d+2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k, args.log2m, args.log2k, args.block_bytes)),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
-            "config": {"workload": "RS encode (n,k)=(2^%d,2^%d), %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
-                                   % (args.log2k + 1, args.log2k, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
+            "config": {"workload": "RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
+                                   % (args.log2k, m_blocks, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
                                       k * args.block_bytes / 2**20),
                        "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
             "data_only_GBps": round(value / 2, 2),

@@ -56,6 +56,10 @@ struct fastecc_ctx {
     // the (2k, k) code (same polynomial, a sub-coset of the evaluation points), so the DIF half is unchanged, the
     // MID pass keeps every 2^fold-th output and the DIT passes above it run as a size-M transform on the compact buffer.
     int fold = 0;
+    // More parity than data blocks: n = 2^e k, e = 2 or 3.  The n - k parity blocks are the values of the same
+    // polynomial on the 2^e - 1 cosets g_t * <w_k> of the data points inside the n-th roots of unity, ordered so that
+    // codes nest: coset 0 is the reference's w_2k (the (2k,k) parity), then w_4k, w_4k^3, then w_8k, w_8k^3, w_8k^5, w_8k^7.
+    int cosets = 1;
     uint64_t M = 0;             // parity blocks
     size_t parity_bytes = 0;    // M * block_bytes
     uint32_t* scratch = nullptr;      // fold > 0: k-block work stripe for the DIF half (lazy)
@@ -70,6 +74,7 @@ struct fastecc_ctx {
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
+    uint32_t* parbuf = nullptr;  // cosets > 1: device parity for FASTECC_MEM_HOST encodes (lazy)
     uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
     void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
     size_t pinned_bytes = 0;
@@ -264,24 +269,29 @@ struct ProfScope {
 
 // Runs the passes of `plan` on columns [col0, col0 + width) of every block (the whole block by default).
 // first_done (optional) is recorded on `st` right after the first pass.
+//
+// The encode plan is [DIF passes][MID][DIT passes].  Normally the first pass reads `in`, writes `out`, and the rest
+// runs in place on `out`.  Two variations share the DIF half on a k-block scratch stripe:
+//   fold > 0   : MID keeps every 2^fold-th block (written compactly to `out`), the DIT passes above it are a size-M
+//                transform in place on `out`;
+//   cosets > 1 : [MID][DIT passes] run once per coset of evaluation points (its own per-block factor table), coset t
+//                writing blocks [t*k, (t+1)*k) of `out`.
 int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in, uint32_t* out, const uint32_t* tw_dif,
                const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr)
 {
     if (width == 0) width = (uint32_t)c->S;
     in += col0;
     out += col0;
-    const uint32_t* src = in;
     char name[32];
-    bool first = true;
-    // fold > 0 (encode only): the DIF half works on a k-block scratch stripe, MID writes the M surviving blocks to
-    // `out`, the DIT passes above it are a size-M transform in place on `out`
-    const bool folded = c->fold > 0 && &plan == &c->encode_plan;
-    if (folded && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
-    const int vec = folded ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
+    const bool is_encode = &plan == &c->encode_plan;
+    const bool folded = c->fold > 0 && is_encode;
+    const int cosets = is_encode ? c->cosets : 1;
+    const bool staged = folded || cosets > 1;
+    if (staged && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
+    const int vec = staged ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
 
-    for (const Pass& p : plan) {
+    auto run_one = [&](const Pass& p, const uint32_t* src, uint32_t* dst, const uint32_t* dscale) -> int {
         const bool above_mid = folded && p.mode == MODE_DIT;
-        uint32_t* dst = folded && p.mode == MODE_DIF ? c->scratch : out;
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
         const uint32_t* twd = above_mid ? c->tw_fold_dit : tw_dit;
         const uint64_t rows_moved = !folded ? 2 * c->N : p.mode == MODE_DIF ? 2 * c->N : p.mode == MODE_MID ? c->N + c->M : 2 * c->M;
@@ -292,7 +302,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.out = dst;
             a.tw_dif = tw_dif;
             a.tw_dit = twd;
-            a.dscale = c->dscale;
+            a.dscale = dscale;
             a.S = width;
             a.ld = (uint32_t)c->ld;
             a.n = n_eff;
@@ -314,7 +324,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.out = dst;
             a.tw_dif = tw_dif;
             a.tw_dit = twd;
-            a.dscale = c->dscale;
+            a.dscale = dscale;
             a.S = (uint32_t)c->S;
             a.ld = (uint32_t)c->ld;
             a.n = n_eff;
@@ -322,12 +332,35 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
-        src = dst;  // after the first pass everything is in place on the buffer just written
-        if (first && first_done) {
-            ps.finish();
-            HIP_TRY(hipEventRecord(first_done, st));
+        return FASTECC_OK;
+    };
+
+    const uint32_t* src = in;
+    if (!staged) {
+        bool first = true;
+        for (const Pass& p : plan) {
+            const int rc = run_one(p, src, out, c->dscale);
+            if (rc != FASTECC_OK) return rc;
+            src = out;  // after the first pass everything is in place on `out`
+            if (first && first_done) HIP_TRY(hipEventRecord(first_done, st));
+            first = false;
         }
-        first = false;
+        return FASTECC_OK;
+    }
+    size_t i = 0;
+    for (; i < plan.size() && plan[i].mode == MODE_DIF; ++i) {
+        const int rc = run_one(plan[i], src, c->scratch, c->dscale);
+        if (rc != FASTECC_OK) return rc;
+        src = c->scratch;
+    }
+    for (int t = 0; t < cosets; ++t) {
+        uint32_t* o = out + (size_t)t * c->N * c->ld;
+        const uint32_t* s2 = src;
+        for (size_t j = i; j < plan.size(); ++j) {
+            const int rc = run_one(plan[j], s2, o, c->dscale + (size_t)t * c->N);
+            if (rc != FASTECC_OK) return rc;
+            s2 = o;
+        }
     }
     return FASTECC_OK;
 }
@@ -381,7 +414,7 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
     }
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
     const int H = c->slabs;
-    const bool slabbed = c->fold == 0 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
+    const bool slabbed = c->fold == 0 && c->cosets == 1 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
                          (c->S % (32u * H)) == 0;
     if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
 
@@ -574,12 +607,20 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     const int lg = ilog2_exact(k);
     if (lg < 0) return FASTECC_E_INVAL;
     // parity blocks: k (the reference's configuration) or k/2, k/4, k/8, k/16
-    const int lgm = ilog2_exact(n - k);
-    if (lgm < 0 || lgm > lg) return FASTECC_E_INVAL;
-    const int fold = lg - lgm;
-    if (fold > 4 || (f61 && fold != 0)) return FASTECC_E_UNSUPPORTED;
+    // or 3k, 7k (n = 4k, 8k)
+    int fold = 0, cosets = 1;
+    if (n == 4 * k || n == 8 * k) {
+        cosets = (int)(n / k) - 1;
+        if (f61) return FASTECC_E_UNSUPPORTED;
+    } else {
+        const int lgm = ilog2_exact(n - k);
+        if (lgm < 0 || lgm > lg) return FASTECC_E_INVAL;
+        fold = lg - lgm;
+        if (fold > 4 || (f61 && fold != 0)) return FASTECC_E_UNSUPPORTED;
+    }
     // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51); in GF(p61^2) 2N | 2^62, the bound is table memory
     if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
+    if (!f61 && n > (1ull << 20)) return FASTECC_E_UNSUPPORTED;  // w_n must exist
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
 
     int ndev = 0;
@@ -599,6 +640,7 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     c->ld = c->S;
     c->stripe_bytes = (size_t)k * block_bytes;
     c->fold = fold;
+    c->cosets = cosets;
     c->M = n - k;
     c->parity_bytes = (size_t)(n - k) * block_bytes;
     {
@@ -630,12 +672,19 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
 
     // ---- tables: per-level twiddles for the plan, and the per-block factors w_2N^i / N of RS.cpp:51-54 ----
     const uint64_t N = k;
-    std::vector<uint32_t> dsc(N);
-    const uint32_t w2N = gf::h_root((uint32_t)(2 * N)), invN = gf::h_inv((uint32_t)N);
-    uint32_t d = invN;
-    for (uint64_t i = 0; i < N; i++) {
-        dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);  // stored by position: position p holds coefficient bitrev(p)
-        d = gf::h_mul(d, w2N);
+    std::vector<uint32_t> dsc(N * cosets);
+    const uint32_t invN = gf::h_inv((uint32_t)N);
+    for (int t = 0; t < cosets; t++) {
+        // coset t: generator w_(2^j k)^c with j = floor(log2(t + 1)) + 1 and c the (t + 2 - 2^(j-1))-th odd number
+        int j = 1;
+        while ((1 << j) - 1 <= t) j++;
+        const uint32_t cth_odd = 2u * (uint32_t)(t + 1 - (1 << (j - 1))) + 1u;
+        const uint32_t gen = gf::h_pow(gf::h_root((uint32_t)(N << j)), cth_odd);
+        uint32_t d = invN;
+        for (uint64_t i = 0; i < N; i++) {
+            dsc[t * N + bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);  // by position: position p holds coefficient bitrev(p)
+            d = gf::h_mul(d, gen);
+        }
     }
     int rc = upload_twiddles(c);
     if (rc == FASTECC_OK) rc = upload_table(&c->dscale, dsc);
@@ -678,6 +727,7 @@ void fastecc_destroy(fastecc_ctx* c)
     if (c->dbuf) (void)hipFree(c->dbuf);
     if (c->rawbuf) (void)hipFree(c->rawbuf);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->parbuf) (void)hipFree(c->parbuf);
     if (c->tw_fold_dit) (void)hipFree(c->tw_fold_dit);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -690,15 +740,21 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
+    if (c->cosets > 1 && parity == data) return FASTECC_E_INVAL;  // the parity is larger than the data
     if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     int rc = ensure_dbuf(c);
     if (rc != FASTECC_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
-    rc = encode_device(c, c->dbuf, c->dbuf, st);
+    uint32_t* dpar = c->dbuf;
+    if (c->cosets > 1) {
+        if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->parity_bytes));
+        dpar = c->parbuf;
+    }
+    rc = encode_device(c, c->dbuf, dpar, st);
     if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->parity_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(parity, dpar, c->parity_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FASTECC_OK;
 }
@@ -706,6 +762,7 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
 int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 {
     if (!c || !blocks) return FASTECC_E_INVAL;
+    if (c->cosets > 1) return FASTECC_E_UNSUPPORTED;  // the in-place form has room for at most k parity blocks
     for (uint64_t i = 0; i < c->N; i++)
         if (!blocks[i] || ((uintptr_t)blocks[i] & 3u)) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);

@@ -187,3 +187,21 @@ def test_pack_oracle_properties(oracle):
     junk = np.full((1, 9), 0, dtype=np.uint32)
     junk[0, 8] = 7
     assert oracle.unpack_blocks(junk)[1] == 1
+
+
+def test_coset_composition_is_polynomial_evaluation(oracle):
+    """iNTT, block i *= g^i / N, NTT  ==  f(g * w_N^j) for any g (here the generators of the n = 4k, 8k parity cosets)."""
+    N, S = 8, 2
+    x = oracle.fill_splitmix(N, S, 77)
+    wN, inv_n = oracle.gf_root(N), oracle.gf_inv(N)
+    coef = oracle.scale_blocks(oracle.slow_ntt(x, inverse=True), inv_n, 1)  # f's coefficients
+    for order, c in ((2 * N, 1), (4 * N, 1), (4 * N, 3), (8 * N, 5)):
+        g = oracle.gf_pow(oracle.gf_root(order), c)
+        got = oracle.ntt_fast(oracle.scale_blocks(oracle.ntt_fast(x, inverse=True), inv_n, g))
+        for j in range(N):
+            pt = oracle.gf_mul(g, oracle.gf_pow(wN, j))
+            for s in range(S):
+                acc = 0
+                for i in range(N):
+                    acc = (acc + int(coef[i, s]) * oracle.gf_pow(pt, i)) % P
+                assert got[j, s] == acc
