@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--log2k", type=int, default=19, help="k = 2^log2k data blocks (headline: 19)")
     ap.add_argument("--log2m", type=int, default=None, help="parity blocks = 2^log2m (default: = k, the reference's configuration; "
                                                             "k/2 .. k/16 are supported, not the headline metric)")
+    ap.add_argument("--log2-n-over-k", type=int, default=1, help="n = 2^e k: e = 2, 3 give 3k, 7k parity blocks (nested cosets)")
     ap.add_argument("--block-bytes", type=int, default=0, help="default 4096 (65536 with --field p61)")
     ap.add_argument("--field", choices=["fff00001", "p61"], default="fff00001",
                     help="p61 = GF((2^61-1)^2), the 64 KB-block configuration of BASELINE.json configs[4] (not the headline metric)")
@@ -162,6 +163,8 @@ def main():
 
     k = 1 << args.log2k
     m_blocks = k if args.log2m is None else 1 << args.log2m
+    if args.log2_n_over_k > 1:
+        m_blocks = ((1 << args.log2_n_over_k) - 1) * k
     n = k + m_blocks
     p61 = args.field == "p61"
     if not args.block_bytes:
@@ -246,8 +249,8 @@ def main():
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             kernel_ms_per_step = sum(v[0] for v in kernels.values()) / args.steps  # summed durations (kernels may overlap)
             per_block = args.block_bytes // 16 if p61 else S  # field elements per block
-            log2m = args.log2k if args.log2m is None else args.log2m
-            bfly = ((args.log2k + 1) * (k / 2) + log2m * (m_blocks / 2)) * per_block / (ms_per_step * 1e-3) / 1e9
+            log2m = args.log2k if args.log2m is None or m_blocks > k else args.log2m
+            bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block / (ms_per_step * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
@@ -269,7 +272,7 @@ def main():
         line = {
             "metric": ("encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes))
                       if m_blocks == k else
-                      ("encode GB/s at (n,k)=(2^%d+2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k, args.log2m, args.log2k, args.block_bytes)),
+                      ("encode GB/s at k=2^%d data + %d parity blocks, %d-byte blocks (data+parity bytes / s)" % (args.log2k, m_blocks, args.block_bytes)),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
