@@ -76,6 +76,9 @@ def lib():
     for name in ("root", "inv"):
         f = getattr(L, "fastecc_gf_" + name)
         f.argtypes, f.restype = [u32], u32
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L.fastecc_decode_prepare.argtypes, L.fastecc_decode_prepare.restype = [vp, u8p, u8p], i32
+    L.fastecc_decode.argtypes, L.fastecc_decode.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_pack_blocks.argtypes, L.fastecc_pack_blocks.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_unpack_blocks.argtypes, L.fastecc_unpack_blocks.restype = [vp, vp, vp, i32, vp, ctypes.POINTER(u64)], i32
     pair = ctypes.POINTER(u64)
@@ -189,6 +192,17 @@ class Encoder:
         bad = ctypes.c_uint64()
         _check(lib().fastecc_check_range(self._h, _addr(data), mem, stream or None, ctypes.byref(bad)), "fastecc_check_range")
         return int(bad.value)
+
+    def decode_prepare(self, data_present, parity_present):
+        """Erasure pattern: k flags each (truthy = the block survives)."""
+        dp = (ctypes.c_uint8 * self.k)(*[1 if v else 0 for v in data_present])
+        pp = (ctypes.c_uint8 * self.k)(*[1 if v else 0 for v in parity_present])
+        _check(lib().fastecc_decode_prepare(self._h, dp, pp), "fastecc_decode_prepare")
+
+    def decode(self, data, parity, stream=0, mem=MEM_DEVICE):
+        """Recover the erased data blocks in place (README.md:102-119); parity is read only."""
+        _check(lib().fastecc_decode(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_decode")
+        return data
 
     def pack_blocks(self, raw, packed, stream=0, mem=MEM_DEVICE):
         """GF.md:72-104: k blocks of block_bytes - 4 arbitrary bytes -> k encodable blocks of block_bytes."""

@@ -20,6 +20,7 @@
 #include "gf.hpp"
 #include "gf61.hpp"
 #include "gf61_path.hpp"
+#include "internal.hpp"
 #include "kernels.hpp"
 
 using namespace fastecc;
@@ -46,6 +47,7 @@ struct ProfileRec {
 struct fastecc_ctx {
     int device = 0;
     int field = FASTECC_FIELD_GF_FFF00001;
+    DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
     int n = 0;        // log2 k
@@ -539,6 +541,9 @@ struct DeviceGuard {
 
 }  // namespace
 
+static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64_t block_bytes, int field, int device, int fold,
+                       int cosets, const uint32_t* custom_factor);
+
 extern "C" {
 
 const char* fastecc_strerror(int code)
@@ -622,7 +627,17 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
     if (!f61 && n > (1ull << 20)) return FASTECC_E_UNSUPPORTED;  // w_n must exist
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
+    return create_impl(out, n, k, lg, block_bytes, field, device, fold, cosets, nullptr);
+}
 
+}  // extern "C"
+
+// Everything after argument validation.  custom_factor (k plain values by coefficient index) replaces the encoder's
+// w_2k^m / k table (create_transform_ctx).
+static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64_t block_bytes, int field, int device, int fold,
+                       int cosets, const uint32_t* custom_factor)
+{
+    const bool f61 = field == FASTECC_FIELD_GF_P61_SQUARED;
     int ndev = 0;
     {
         const hipError_t e = hipGetDeviceCount(&ndev);
@@ -674,7 +689,10 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     const uint64_t N = k;
     std::vector<uint32_t> dsc(N * cosets);
     const uint32_t invN = gf::h_inv((uint32_t)N);
-    for (int t = 0; t < cosets; t++) {
+    for (int t = 0; t < cosets && custom_factor; t++) {
+        for (uint64_t i = 0; i < N; i++) dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(custom_factor[i] % gf::P);
+    }
+    for (int t = 0; t < cosets && !custom_factor; t++) {
         // coset t: generator w_(2^j k)^c with j = floor(log2(t + 1)) + 1 and c the (t + 2 - 2^(j-1))-th odd number
         int j = 1;
         while ((1 << j) - 1 <= t) j++;
@@ -700,9 +718,38 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     return FASTECC_OK;
 }
 
+namespace fastecc {
+
+CtxInfo info_of(const fastecc_ctx* c) { return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld}; }
+DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
+void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
+
+int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device)
+{
+    if (!out || !factor || log2k < 1 || log2k > 20 || fold < 0 || fold > 4 || fold > log2k || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
+    *out = nullptr;
+    const uint64_t k = 1ull << log2k;
+    return create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, factor);
+}
+
+int scratch_of(fastecc_ctx* c, uint32_t** out)
+{
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    if (!c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
+    *out = c->scratch;
+    return FASTECC_OK;
+}
+
+}  // namespace fastecc
+
+extern "C" {
+
 void fastecc_destroy(fastecc_ctx* c)
 {
     if (!c) return;
+    destroy_decode_state(c->decoder);
+    c->decoder = nullptr;
     DeviceGuard dg(c->device);
     for (ProfileRec& r : c->prof) {
         (void)hipEventDestroy(r.start);

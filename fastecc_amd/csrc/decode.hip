@@ -1,0 +1,420 @@
+// decode.hip — erasure decoding for the (2k,k) code of RS.cpp, the "fastest" scheme of README.md:102-119 / RS.md:42-79.
+//
+// The reference documents this algorithm and does not implement it.  The codeword is f on the 2k-th roots of unity:
+// position u <-> point w^u (w = w_2k), even positions are the data blocks (u = 2i), odd ones the parity blocks
+// (u = 2j+1, RS.cpp:51-54).  With E the erased positions (|E| <= k) and l(x) = prod_{e in E} (x - w^e):
+//
+//   p = f * l has degree < 2k and KNOWN values everywhere: c[u] * l(w^u) at surviving positions, 0 at erased ones;
+//   p'(w^e) = f(w^e) * l'(w^e) at an erased position, so  f(w^e) = [x p'(x)](w^e) / (w^e * l'(w^e)).
+//
+// x p'(x) = sum m p_m x^m needs no coefficient shift, which makes the data-parallel part the SAME pipeline as the
+// encoder one size up: inverse transform of size 2k, block holding coefficient m times m / 2k, forward transform —
+// i.e. create_transform_ctx(2k, factor[m] = m / 2k) with fold = 1, because only the even (data) positions are wanted.
+// Around it: one gather pass (codeword blocks times l(w^u), zeros at erasures) and one pass that multiplies the
+// recovered rows by 1 / (w^e l'(w^e)).  Everything that depends only on the erasure PATTERN (l by a product tree,
+// its values and its derivative's values by two host transforms of size 2k, one batch inversion) is scalar work
+// done once in fastecc_decode_prepare on the host.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gf.hpp"
+#include "internal.hpp"
+#include "ntt_device.hpp"
+
+namespace fastecc {
+
+struct DecodeState {
+    fastecc_ctx* transform = nullptr;  // size-2k transform context, fold 1
+    uint32_t* fin = nullptr;           // 2k factors by codeword position: l(w^u) (Montgomery) or 0 if erased
+    uint32_t* gout = nullptr;          // k factors by data block: 1 / (w^2i l'(w^2i)) (Montgomery) if erased, else 0
+    uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
+    uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
+    uint64_t erased_data = 0, erased_total = 0;
+    bool ready = false;
+};
+
+void destroy_decode_state(DecodeState* d)
+{
+    if (!d) return;
+    if (d->transform) fastecc_destroy(d->transform);
+    if (d->fin) (void)hipFree(d->fin);
+    if (d->gout) (void)hipFree(d->gout);
+    if (d->recovered) (void)hipFree(d->recovered);
+    if (d->parity_dev) (void)hipFree(d->parity_dev);
+    delete d;
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// host arithmetic for the pattern-only part: plain values, products through a Montgomery step
+// ------------------------------------------------------------------------------------------------
+using gf::P;
+
+inline uint32_t h_add(uint32_t a, uint32_t b)
+{
+    const uint64_t s = (uint64_t)a + b;
+    return (uint32_t)(s >= P ? s - P : s);
+}
+inline uint32_t h_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
+// x * w for w given as wm = w * 2^32 mod p (same reduction as gf::mul_mont on the device)
+inline uint32_t h_mont(uint32_t x, uint32_t wm)
+{
+    const uint64_t t = (uint64_t)x * wm;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    const uint32_t m = lo + (lo << 20);
+    const uint32_t q = (uint32_t)(((uint64_t)m * P) >> 32);
+    return hi >= q ? hi - q : hi - q + P;
+}
+
+// Transforms of any power-of-two size up to 2^20 from one table of w_(2^20)^i (Montgomery form), i < 2^19.
+struct HostNtt {
+    static constexpr int MAXLOG = 20;
+    std::vector<uint32_t> fwd, inv;
+    HostNtt() : fwd(1u << (MAXLOG - 1)), inv(1u << (MAXLOG - 1))
+    {
+        const uint32_t w = gf::h_root(1u << MAXLOG), wi = gf::h_inv(w);
+        uint32_t a = 1, b = 1;
+        for (size_t i = 0; i < fwd.size(); i++) {
+            fwd[i] = gf::h_to_mont(a);
+            inv[i] = gf::h_to_mont(b);
+            a = gf::h_mul(a, w);
+            b = gf::h_mul(b, wi);
+        }
+    }
+    // decimation in frequency: natural order in, bit-reversed order out, unscaled
+    void dif(uint32_t* x, int logn, bool inverse) const
+    {
+        const std::vector<uint32_t>& tw = inverse ? inv : fwd;
+        const size_t n = (size_t)1 << logn;
+        for (size_t h = n >> 1; h >= 1; h >>= 1) {
+            const size_t step = (fwd.size() / h);  // (root of order 2h)^i = w_(2^20)^(i * 2^19 / h)
+            for (size_t base = 0; base < n; base += 2 * h)
+                for (size_t i = 0; i < h; i++) {
+                    const uint32_t a = x[base + i], b = x[base + i + h];
+                    x[base + i] = h_add(a, b);
+                    x[base + i + h] = h_mont(h_sub(a, b), tw[i * step]);
+                }
+        }
+    }
+    // decimation in time: bit-reversed order in, natural order out, unscaled
+    void dit(uint32_t* x, int logn, bool inverse) const
+    {
+        const std::vector<uint32_t>& tw = inverse ? inv : fwd;
+        const size_t n = (size_t)1 << logn;
+        for (size_t h = 1; h < n; h <<= 1) {
+            const size_t step = (fwd.size() / h);
+            for (size_t base = 0; base < n; base += 2 * h)
+                for (size_t i = 0; i < h; i++) {
+                    const uint32_t a = x[base + i], b = h_mont(x[base + i + h], tw[i * step]);
+                    x[base + i] = h_add(a, b);
+                    x[base + i + h] = h_sub(a, b);
+                }
+        }
+    }
+};
+
+const HostNtt& host_ntt()
+{
+    static const HostNtt t;
+    return t;
+}
+
+// c = a * b (coefficient vectors, lowest degree first)
+std::vector<uint32_t> poly_mul(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b)
+{
+    const size_t need = a.size() + b.size() - 1;
+    std::vector<uint32_t> c(need, 0);
+    if (std::min(a.size(), b.size()) <= 32) {
+        for (size_t i = 0; i < a.size(); i++) {
+            if (!a[i]) continue;
+            const uint32_t am = gf::h_to_mont(a[i]);
+            for (size_t j = 0; j < b.size(); j++) c[i + j] = h_add(c[i + j], h_mont(b[j], am));
+        }
+        return c;
+    }
+    int logn = 0;
+    while (((size_t)1 << logn) < need) logn++;
+    const size_t n = (size_t)1 << logn;
+    std::vector<uint32_t> fa(n, 0), fb(n, 0);
+    std::copy(a.begin(), a.end(), fa.begin());
+    std::copy(b.begin(), b.end(), fb.begin());
+    const HostNtt& t = host_ntt();
+    t.dif(fa.data(), logn, false);
+    t.dif(fb.data(), logn, false);
+    const uint32_t inv_n = gf::h_inv((uint32_t)n);
+    for (size_t i = 0; i < n; i++) fa[i] = h_mont(fa[i], gf::h_to_mont(gf::h_mul(fb[i], inv_n)));
+    t.dit(fa.data(), logn, true);  // the bit-reversed products go straight back: no permutation anywhere
+    std::copy(fa.begin(), fa.begin() + need, c.begin());
+    return c;
+}
+
+// l(x) = prod (x - roots[i]) by a balanced product tree: O(M log^2 M)
+std::vector<uint32_t> poly_from_roots(const std::vector<uint32_t>& roots)
+{
+    std::vector<std::vector<uint32_t>> level;
+    level.reserve(roots.size());
+    for (uint32_t r : roots) level.push_back({h_sub(0, r), 1u});
+    if (level.empty()) return {1u};
+    while (level.size() > 1) {
+        std::vector<std::vector<uint32_t>> next;
+        next.reserve((level.size() + 1) / 2);
+        for (size_t i = 0; i + 1 < level.size(); i += 2) next.push_back(poly_mul(level[i], level[i + 1]));
+        if (level.size() & 1) next.push_back(std::move(level.back()));
+        level.swap(next);
+    }
+    return level[0];
+}
+
+uint32_t bitrev_bits(uint32_t v, int bits)
+{
+    uint32_t r = 0;
+    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (bits - 1 - b);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: one wave per (block row, 64*V-word column chunk); the row's factor is a scalar
+// ------------------------------------------------------------------------------------------------
+// work[u] = (u even ? data[u/2] : parity[u/2]) * fin[u]; erased positions (fin == 0) are written as zeros, never read
+template <int V>
+__global__ __launch_bounds__(256) void decode_gather_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
+                                                            uint32_t* __restrict__ work, const uint32_t* __restrict__ fin, uint32_t S,
+                                                            uint32_t ld, uint32_t ld_work, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t u = (uint32_t)(item / col_chunks);
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    const uint32_t f = as_constant(fin)[u];
+    uint32_t x[V];
+    if (f != 0) {
+        const uint32_t* src = ((u & 1u) ? parity : data) + (size_t)(u >> 1) * ld + col;
+        load_vec<V>(x, src);
+#pragma unroll
+        for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
+    } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) x[v] = 0;
+    }
+    store_vec<V>(work + (size_t)u * ld_work + col, x);
+}
+
+// data[i] = recovered[i] * gout[i] for the erased data blocks (gout != 0); surviving blocks are not touched
+template <int V>
+__global__ __launch_bounds__(256) void decode_scatter_kernel(const uint32_t* __restrict__ recovered, uint32_t* __restrict__ data,
+                                                             const uint32_t* __restrict__ gout, uint32_t S, uint32_t ld_rec, uint32_t ld,
+                                                             uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t i = (uint32_t)(item / col_chunks);
+    const uint32_t f = as_constant(gout)[i];
+    if (f == 0) return;  // wave-uniform
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t x[V];
+    load_vec<V>(x, recovered + (size_t)i * ld_rec + col);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
+    store_vec<V>(data + (size_t)i * ld + col, x);
+}
+
+int hip_code(const char* what, hipError_t e)
+{
+    set_error_detail(what, e);
+    return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+}
+
+#define DEC_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return hip_code(#expr, e_);  \
+    } while (0)
+
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        (void)hipSetDevice(dev);
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+}  // namespace fastecc
+
+using namespace fastecc;
+
+extern "C" {
+
+int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
+{
+    if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
+    const CtxInfo ci = info_of(c);
+    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.fold != 0 || ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // n = 2k only
+    if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
+    const uint64_t N = ci.k, N2 = 2 * N;
+    const int lg2 = ci.log2k + 1;
+
+    std::vector<uint32_t> erased;  // codeword positions
+    uint64_t erased_data = 0;
+    for (uint64_t i = 0; i < N; i++) {
+        if (!data_present[i]) erased.push_back((uint32_t)(2 * i)), erased_data++;
+        if (!parity_present[i]) erased.push_back((uint32_t)(2 * i + 1));
+    }
+    if (erased.size() > N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
+
+    DeviceScope ds(ci.device);
+    DecodeState*& slot = decoder_of(c);
+    if (!slot) {
+        slot = new (std::nothrow) DecodeState();
+        if (!slot) return FASTECC_E_NOMEM;
+    }
+    DecodeState* d = slot;
+    d->ready = false;
+    d->erased_data = erased_data;
+    d->erased_total = erased.size();
+    if (erased_data == 0) {  // nothing to recover
+        d->ready = true;
+        return FASTECC_OK;
+    }
+
+    // ---- pattern-only scalars ----
+    const HostNtt& t = host_ntt();
+    const uint32_t w = gf::h_root((uint32_t)N2);
+    std::vector<uint32_t> wpow(N2);  // w^u
+    {
+        uint32_t a = 1;
+        for (uint64_t u = 0; u < N2; u++) {
+            wpow[u] = a;
+            a = gf::h_mul(a, w);
+        }
+    }
+    std::vector<uint32_t> roots(erased.size());
+    for (size_t i = 0; i < erased.size(); i++) roots[i] = wpow[erased[i]];
+    const std::vector<uint32_t> l = poly_from_roots(roots);  // degree |E| <= N < 2N
+    std::vector<uint32_t> lval(N2, 0), lder(N2, 0);
+    std::copy(l.begin(), l.end(), lval.begin());
+    for (size_t m = 0; m + 1 < l.size(); m++) lder[m] = gf::h_mul((uint32_t)((m + 1) % P), l[m + 1]);
+    t.dif(lval.data(), lg2, false);  // value at w^u sits at index bitrev(u)
+    t.dif(lder.data(), lg2, false);
+
+    std::vector<uint32_t> fin(N2, 0), gout(N, 0);
+    for (uint64_t u = 0; u < N2; u++) {
+        const bool present = (u & 1) ? parity_present[u >> 1] != 0 : data_present[u >> 1] != 0;
+        if (present) fin[u] = gf::h_to_mont(lval[bitrev_bits((uint32_t)u, lg2)]);
+    }
+    {
+        // 1 / (w^e l'(w^e)) for the erased data positions with ONE inversion (prefix products)
+        std::vector<uint32_t> den, prefix;
+        std::vector<uint64_t> who;
+        for (uint64_t i = 0; i < N; i++) {
+            if (data_present[i]) continue;
+            const uint32_t v = gf::h_mul(wpow[2 * i], lder[bitrev_bits((uint32_t)(2 * i), lg2)]);
+            if (v == 0) return FASTECC_E_INVAL;  // cannot happen: l has simple roots
+            den.push_back(v);
+            who.push_back(i);
+        }
+        prefix.resize(den.size());
+        uint32_t acc = 1;
+        for (size_t j = 0; j < den.size(); j++) {
+            prefix[j] = acc;
+            acc = gf::h_mul(acc, den[j]);
+        }
+        uint32_t inv = gf::h_inv(acc);
+        for (size_t j = den.size(); j-- > 0;) {
+            gout[who[j]] = gf::h_to_mont(gf::h_mul(inv, prefix[j]));
+            inv = gf::h_mul(inv, den[j]);
+        }
+    }
+
+    // ---- device state ----
+    if (!d->transform) {
+        std::vector<uint32_t> factor(N2);
+        const uint32_t inv2n = gf::h_inv((uint32_t)N2);
+        for (uint64_t m = 0; m < N2; m++) factor[m] = gf::h_mul((uint32_t)m, inv2n);  // x p'(x): coefficient m times m, and the 1/2k of the inverse transform
+        const int rc = create_transform_ctx(&d->transform, lg2, ci.words * 4, 1, factor.data(), ci.device);
+        if (rc != FASTECC_OK) return rc;
+    }
+    if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, N2 * 4));
+    if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
+    if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
+    DEC_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern
+    DEC_TRY(hipMemcpy(d->fin, fin.data(), N2 * 4, hipMemcpyHostToDevice));
+    DEC_TRY(hipMemcpy(d->gout, gout.data(), N * 4, hipMemcpyHostToDevice));
+    d->ready = true;
+    return FASTECC_OK;
+}
+
+int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream)
+{
+    if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    DecodeState* d = decoder_of(c);
+    if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first
+    if (d->erased_data == 0) return FASTECC_OK;
+    const CtxInfo ci = info_of(c);
+    DeviceScope ds(ci.device);
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t N = ci.k;
+    const size_t stripe = N * ci.words * 4;
+
+    uint32_t* ddata = (uint32_t*)data;
+    const uint32_t* dparity = (const uint32_t*)parity;
+    if (mem_kind == FASTECC_MEM_HOST) {
+        // stage both halves of the codeword
+        if (!d->parity_dev) DEC_TRY(hipMalloc((void**)&d->parity_dev, 2 * stripe));
+        DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, stripe, hipMemcpyHostToDevice, st));
+        DEC_TRY(hipMemcpyAsync(d->parity_dev + N * ci.words, data, stripe, hipMemcpyHostToDevice, st));
+        dparity = d->parity_dev;
+        ddata = d->parity_dev + N * ci.words;
+    } else if (mem_kind != FASTECC_MEM_DEVICE) {
+        return FASTECC_E_INVAL;
+    }
+
+    uint32_t* work = nullptr;
+    int rc = scratch_of(d->transform, &work);
+    if (rc != FASTECC_OK) return rc;
+    const uint32_t S = (uint32_t)ci.words;
+    const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)work | (uintptr_t)d->recovered) & 15u) == 0);
+    const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+    {
+        const uint64_t items = 2 * N * col_chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+        if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
+        else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
+        DEC_TRY(hipGetLastError());
+    }
+    rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
+    if (rc != FASTECC_OK) return rc;
+    {
+        const uint64_t items = N * col_chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+        if (v4) hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, S, S, col_chunks, items);
+        else    hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, S, S, col_chunks, items);
+        DEC_TRY(hipGetLastError());
+    }
+    if (mem_kind == FASTECC_MEM_HOST) {
+        DEC_TRY(hipMemcpyAsync(data, ddata, stripe, hipMemcpyDeviceToHost, st));
+        DEC_TRY(hipStreamSynchronize(st));
+    }
+    return FASTECC_OK;
+}
+
+}  // extern "C"

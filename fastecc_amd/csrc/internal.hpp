@@ -1,0 +1,31 @@
+// internal.hpp — what decode.hip needs from api.hip (nothing here is part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fastecc.h"
+
+namespace fastecc {
+
+struct DecodeState;                        // decode.hip: tables of one erasure pattern + the size-2k transform context
+void destroy_decode_state(DecodeState*);   // decode.hip, called by fastecc_destroy
+
+// ---- api.hip ----
+struct CtxInfo {
+    int device, field, fold, cosets, log2k;
+    uint64_t k, words, pitch;  // blocks, words per block, words between device blocks
+};
+CtxInfo info_of(const fastecc_ctx* c);
+DecodeState*& decoder_of(fastecc_ctx* c);
+void set_error_detail(const char* what, hipError_t e);
+
+// A transform context (GF(0xFFF00001)): DIF over all log2k levels with inverse roots, the block holding coefficient m
+// multiplied by factor[m] (plain representatives, k entries), DIT back with forward roots keeping every 2^fold-th
+// output block.  fastecc_encode(ctx, in, out, FASTECC_MEM_DEVICE, stream) runs it; k may be 2^20 (no root of order 2k
+// is needed).  The encoder of RS.cpp:40-63 is the case factor[m] = w_2k^m / k.
+int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device);
+// The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
+// there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
+int scratch_of(fastecc_ctx* c, uint32_t** out);
+
+}  // namespace fastecc

@@ -137,6 +137,22 @@ int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_
 int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *stream, uint64_t *bad_words);
 
 /*
+ * Erasure decoding for n = 2k contexts over GF(0xFFF00001): recover the erased DATA blocks from any k or more
+ * surviving blocks of the codeword.  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79:
+ * erasure locator l, p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part
+ * here is one transform pipeline of size 2k (the encoder's kernels) between a gather and a scale pass.
+ *   fastecc_decode_prepare : set the erasure pattern, k flags each (non-zero = block survives).  Host-side scalar work
+ *                            (product tree for l, two size-2k transforms, one inversion) and a table upload; returns
+ *                            FASTECC_E_INVAL if fewer than k blocks survive.  Reusable for any number of stripes.
+ *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
+ *                            are not written) and parity (k blocks, read only; content of erased blocks is ignored).
+ *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
+ * Erased parity blocks are not rebuilt (re-encode the repaired data for that).
+ */
+int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
+int fastecc_decode(fastecc_ctx *ctx, void *data, const void *parity, int mem_kind, void *stream);
+
+/*
  * Data packing (GF.md:72-104 "Efficient data packing", README.md:160-163): RS.cpp only encodes words < p, so
  * arbitrary bytes are first recoded with one extra word per block — 4096-byte sectors become the 4100-byte
  * blocks the encoder then works on.  The reference describes this in prose and has NO code for it; the exact

@@ -57,6 +57,8 @@ class Oracle:
         lib.orc_fill_linear.argtypes, lib.orc_fill_linear.restype = [_u32p, _sz], None
         lib.orc_fill_splitmix.argtypes, lib.orc_fill_splitmix.restype = [_u32p, _sz, ctypes.c_uint64], None
         lib.orc_num_threads.restype = ctypes.c_int
+        _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        lib.orc_decode.argtypes, lib.orc_decode.restype = [_u32p, _u32p, _u8p, _u8p, _sz, _sz], ctypes.c_int
         lib.orc_pack_blocks.argtypes, lib.orc_pack_blocks.restype = [_u32p, _sz, _sz, _u32p], None
         lib.orc_unpack_blocks.argtypes, lib.orc_unpack_blocks.restype = [_u32p, _sz, _sz, _u32p], _sz
 
@@ -110,6 +112,14 @@ class Oracle:
         return a
 
     def num_threads(self): return int(self.lib.orc_num_threads())
+
+    def decode(self, data, parity, data_present, parity_present):
+        """Erased data blocks recomputed by Lagrange interpolation (O(N^2)); returns the repaired data or None."""
+        d = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        p = np.ascontiguousarray(parity, dtype=np.uint32)
+        rc = self.lib.orc_decode(d, p, np.ascontiguousarray(data_present, dtype=np.uint8),
+                                 np.ascontiguousarray(parity_present, dtype=np.uint8), d.shape[0], d.shape[1])
+        return d if rc == 0 else None
 
     # data packing (GF.md:72-104): [N, words] arbitrary uint32 <-> [N, words + 1] uint32 < P
     def pack_blocks(self, raw):

@@ -396,3 +396,56 @@ size_t orc_unpack_blocks(const uint32_t *packed, size_t N, size_t words, uint32_
     for (size_t i = 0; i < N; i++) bad += orc_unpack_block(packed + i * (words + 1), words, raw + i * words) != 0;
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Erasure decoding, checker only.  The reference documents decoding (README.md:83-119, RS.md:42-79) and does not
+ * implement it; the product uses the O(N log N) derivative scheme.  This is the independent textbook statement:
+ * the codeword is f on the 2N-th roots of unity (position u <-> w_2N^u, data at even u, parity at odd u,
+ * RS.cpp:51-54), deg f < N, so f is the Lagrange interpolant through ANY N surviving positions and an erased data
+ * block is its value at w_2N^(2i).  O(N^2) scalar work plus O(E*N) per word.  Returns -1 if fewer than N survive.
+ * ---------------------------------------------------------------------------------------- */
+int orc_decode(uint32_t *data, const uint32_t *parity, const uint8_t *data_present, const uint8_t *parity_present, size_t N,
+               size_t size)
+{
+    const size_t N2 = 2 * N;
+    uint32_t *pt = malloc(N2 * 4);      /* w_2N^u */
+    size_t *pos = malloc(N * sizeof *pos); /* the N surviving positions used */
+    uint32_t *den = malloc(N * 4), *wgt = malloc(N * 4);
+    const uint32_t w = orc_gf_root((uint32_t)N2);
+    size_t cnt = 0;
+    pt[0] = 1;
+    for (size_t u = 1; u < N2; u++) pt[u] = orc_gf_mul(pt[u - 1], w);
+    for (size_t u = 0; u < N2 && cnt < N; u++)
+        if ((u & 1) ? parity_present[u >> 1] : data_present[u >> 1]) pos[cnt++] = u;
+    int rc = cnt == N ? 0 : -1;
+    if (rc == 0) {
+        for (size_t a = 0; a < N; a++) { /* prod_{b != a} (x_a - x_b) */
+            uint32_t d = 1;
+            for (size_t b = 0; b < N; b++)
+                if (b != a) d = orc_gf_mul(d, orc_gf_sub(pt[pos[a]], pt[pos[b]]));
+            den[a] = d;
+        }
+        uint32_t *row = malloc(size * 4);
+        for (size_t i = 0; i < N; i++) {
+            if (data_present[i]) continue;
+            const uint32_t xe = pt[2 * i];
+            uint32_t full = 1;
+            for (size_t b = 0; b < N; b++) full = orc_gf_mul(full, orc_gf_sub(xe, pt[pos[b]]));
+            for (size_t a = 0; a < N; a++)
+                wgt[a] = orc_gf_mul(full, orc_gf_inv(orc_gf_mul(orc_gf_sub(xe, pt[pos[a]]), den[a])));
+            memset(row, 0, size * 4);
+            for (size_t a = 0; a < N; a++) {
+                const size_t u = pos[a];
+                const uint32_t *src = (u & 1) ? parity + (u >> 1) * size : data + (u >> 1) * size;
+                for (size_t s = 0; s < size; s++) row[s] = orc_gf_add(row[s], orc_gf_mul(wgt[a], src[s]));
+            }
+            memcpy(data + i * size, row, size * 4); /* erased blocks are never read as sources */
+        }
+        free(row);
+    }
+    free(pt);
+    free(pos);
+    free(den);
+    free(wgt);
+    return rc;
+}

@@ -64,6 +64,11 @@ int orc_unpack_block(const uint32_t *packed, size_t words, uint32_t *raw); /* -1
 void orc_pack_blocks(const uint32_t *raw, size_t N, size_t words, uint32_t *packed);
 size_t orc_unpack_blocks(const uint32_t *packed, size_t N, size_t words, uint32_t *raw); /* count of bad blocks */
 
+/* Erasure decoding by plain Lagrange interpolation (checker for fastecc_decode; the reference has no decoder).
+ * Erased data blocks (data_present[i] == 0) are recomputed in place from the first N surviving positions. */
+int orc_decode(uint32_t *data, const uint32_t *parity, const uint8_t *data_present, const uint8_t *parity_present, size_t N,
+               size_t size);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,140 @@
+"""GPU tests (-m gpu) of the erasure decoder (fastecc_decode_prepare / fastecc_decode, n = 2k).
+
+The reference documents decoding (README.md:83-119, RS.md:42-79) and has no implementation, so there is nothing
+upstream to pin against; the checks are (1) the size-independent round trip encode -> erase -> decode == original,
+with the encoder itself pinned to the reference, and (2) the independent O(N^2) Lagrange interpolation of
+oracle/fastecc_oracle.c (orc_decode).  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFF00001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to("cuda:0")
+
+
+def to_host(t, shape):
+    return t.cpu().numpy().view(np.uint32).reshape(shape)
+
+
+def pattern(rng, N, kind):
+    """-> (data_present, parity_present) with at least N survivors"""
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    if kind == "one":
+        dp[rng.integers(N)] = 0
+    elif kind == "all_data":
+        dp[:] = 0
+    elif kind == "half_each":
+        dp[rng.permutation(N)[: N // 2]] = 0
+        pp[rng.permutation(N)[: N - N // 2]] = 0
+    elif kind == "random_max":  # exactly N erasures spread over the whole codeword
+        lost = rng.permutation(2 * N)[:N]
+        dp[lost[lost < N]] = 0
+        pp[lost[lost >= N] - N] = 0
+    elif kind == "quarter":
+        lost = rng.permutation(2 * N)[: max(1, N // 2)]
+        dp[lost[lost < N]] = 0
+        pp[lost[lost >= N] - N] = 0
+    elif kind == "burst":
+        dp[N // 4: N // 4 + max(1, N // 3)] = 0
+    return dp, pp
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 4, 5, 6, 7, 8, 10, 12])
+@pytest.mark.parametrize("kind", ["one", "all_data", "half_each", "random_max", "quarter", "burst"])
+def test_round_trip_and_lagrange(torch_cuda, fe, oracle, logn, kind):
+    torch = torch_cuda
+    N, S = 1 << logn, 77 if logn % 2 else 64
+    rng = np.random.default_rng(logn * 100 + len(kind))
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    par = oracle.encode_fast(x)
+    dp, pp = pattern(rng, N, kind)
+    damaged, dpar = x.copy(), par.copy()
+    damaged[dp == 0] = 0xFFFFFFFF   # erased blocks hold garbage (not even field elements)
+    dpar[pp == 0] = 0xDEADBEEF
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.decode_prepare(dp, pp)
+        d = to_dev(torch, damaged)
+        enc.decode(d, to_dev(torch, dpar))
+        got = to_host(d, (N, S))
+    assert (got == x).all()
+    if N <= 256:
+        assert (oracle.decode(damaged, dpar, dp, pp) == x).all()
+
+
+def test_patterns_can_change_and_errors(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    N, S = 64, 1025
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    par = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        with pytest.raises(fe.FastEccError):       # no pattern yet
+            enc.decode(to_dev(torch, x), to_dev(torch, par))
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        dp[:40] = 0
+        pp[:25] = 0                                 # 65 erasures > k
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.decode_prepare(dp, pp)
+        assert ei.value.code == fe.E_INVAL
+        for seed in range(3):                       # the same context serves pattern after pattern
+            dp, pp = pattern(np.random.default_rng(seed), N, "random_max")
+            damaged = x.copy()
+            damaged[dp == 0] = 0
+            enc.decode_prepare(dp, pp)
+            d = to_dev(torch, damaged)
+            enc.decode(d, to_dev(torch, par))
+            assert (to_host(d, (N, S)) == x).all()
+            host = damaged.copy()                   # host-memory form
+            enc.decode(host, par, mem=fe.MEM_HOST)
+            assert (host == x).all()
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        pp[::2] = 0                                 # only parity lost: nothing to do, data untouched
+        enc.decode_prepare(dp, pp)
+        d = to_dev(torch, x)
+        enc.decode(d, to_dev(torch, par))
+        assert (to_host(d, (N, S)) == x).all()
+    with fe.Encoder(N + N // 2, N, 4 * S) as enc:   # only the reference's n = 2k code has a decoder so far
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.decode_prepare(np.ones(N, np.uint8), np.ones(N, np.uint8))
+        assert ei.value.code == fe.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("lost_fraction", [0.02, 0.5])
+def test_headline_size_round_trip(torch_cuda, fe, lost_fraction):
+    """(n,k) = (2^20, 2^19), 4 KB blocks: encode, lose blocks all over the codeword, decode, compare on the device."""
+    torch = torch_cuda
+    N, S = 1 << 19, 1024
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty_like(data)
+    rng = np.random.default_rng(int(lost_fraction * 100))
+    lost = rng.permutation(2 * N)[: int(2 * N * lost_fraction)]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(data, parity)
+        damaged = data.clone().view(N, S)
+        damaged[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+        parity.view(N, S)[torch.from_numpy(pp == 0).to("cuda:0")] = 0x5A5A5A5A
+        enc.decode_prepare(dp, pp)
+        enc.decode(damaged, parity)
+        torch.cuda.synchronize()
+        assert bool((damaged.view(-1) == data).all())

@@ -205,3 +205,23 @@ def test_coset_composition_is_polynomial_evaluation(oracle):
                 for i in range(N):
                     acc = (acc + int(coef[i, s]) * oracle.gf_pow(pt, i)) % P
                 assert got[j, s] == acc
+
+
+def test_lagrange_decoder_recovers_what_the_encoder_wrote(oracle):
+    """orc_decode (checker of fastecc_decode) against the pinned encoder: any N survivors give the data back."""
+    rng = np.random.default_rng(8)
+    for N, S in ((2, 3), (8, 5), (32, 4)):
+        x = oracle.fill_splitmix(N, S, N)
+        par = oracle.encode(x)
+        for trial in range(4):
+            lost = rng.permutation(2 * N)[:N]
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            damaged = x.copy()
+            damaged[dp == 0] = 0xFFFFFFFF
+            assert (oracle.decode(damaged, par, dp, pp) == x).all()
+        dp = np.zeros(N, np.uint8)
+        pp = np.ones(N, np.uint8)
+        pp[0] = 0
+        assert oracle.decode(x, par, dp, pp) is None  # N - 1 survivors
