@@ -19,9 +19,24 @@ import os
 import sys
 import time
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (GPU boxes expose 256
+    hardware threads but may grant a container far fewer)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
 if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    # CPU baseline (single-process runs only): avoid passive-wait barrier stalls in the reference's OpenMP regions
-    # (SURVEY.md §6).  Multi-rank runs must not have hundreds of spinning OpenMP workers per rank on the host.
+    # CPU baseline (single-process runs only): one OpenMP thread per usable CPU, spinning at barriers (avoids the
+    # passive-wait stalls of the reference's many small parallel regions, SURVEY.md §6).  Must be set before libgomp
+    # loads.  Multi-rank runs must not have hundreds of spinning OpenMP workers per rank on the host.
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
     os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

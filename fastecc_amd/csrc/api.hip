@@ -47,6 +47,8 @@ struct ProfileRec {
 struct fastecc_ctx {
     int device = 0;
     int field = FASTECC_FIELD_GF_FFF00001;
+    const uint32_t* gather_odd = nullptr;     // set only inside run_gathered (decoder): see PassArgs::in_odd
+    const uint32_t* gather_factor = nullptr;
     DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
@@ -158,7 +160,8 @@ bool tile_fits(const fastecc_ctx* c, int logt, int s)
 
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
 {
-    const bool fits = tile_fits(c, bits, s);
+    // with fold > 0 the DIT passes above MID run on the compact parity stripe: their strides are 2^fold smaller
+    const bool fits = tile_fits(c, bits, mode == MODE_DIT ? s - c->fold : s);
     if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
     else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
     else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
@@ -332,6 +335,10 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.n = n_eff;
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
+            if (c->gather_factor && src == in) {  // first pass of the decoder's transform
+                a.in_odd = c->gather_odd;
+                a.row_factor = c->gather_factor;
+            }
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
         return FASTECC_OK;
@@ -456,11 +463,13 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
 }
 
 // For every level l: the stride 2^sl of the register run that executes it (see ntt_device.hpp).
-std::vector<int> level_strides(const std::vector<Pass>& plan, int n)
+// `up` selects the side of an encode plan: false = the way down (DIF passes and MID), true = the way up (MID and DIT
+// passes).  The two sides mirror each other level for level unless fold > 0 made a chunk tile-eligible on one side only.
+std::vector<int> level_strides(const std::vector<Pass>& plan, int n, bool up = false)
 {
     std::vector<int> sl(n, 0);
     for (const Pass& p : plan) {
-        if (p.mode == MODE_DIT) continue;  // DIT passes mirror the DIF ones level for level
+        if (p.mode == (up ? MODE_DIF : MODE_DIT)) continue;
         if (!p.tile) {
             for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
         } else {
@@ -504,15 +513,16 @@ int upload_twiddles(fastecc_ctx* c)
 {
     const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
     const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
+    const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
     int rc = upload_table(&c->tw_enc_dif, build_level_table(c->n, wNi, enc));  // interpolate: inverse roots (RS.cpp:41)
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc));  // evaluate (RS.cpp:63)
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc_up));  // evaluate (RS.cpp:63)
     if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
     if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
     if (rc == FASTECC_OK && c->fold > 0) {
         // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
         const int nf = c->n - c->fold;
         std::vector<int> sl(std::max(nf, 0), 0);
-        for (int l = 0; l < nf; l++) sl[l] = std::max(enc[l + c->fold] - c->fold, 0);
+        for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
         rc = upload_table(&c->tw_fold_dit, build_level_table(nf, gf::h_root((uint32_t)c->M), sl));
     }
     return rc;
@@ -730,6 +740,22 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
     *out = nullptr;
     const uint64_t k = 1ull << log2k;
     return create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, factor);
+}
+
+int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
+                 hipStream_t st)
+{
+    if (c->encode_plan.empty() || c->encode_plan[0].tile || c->encode_plan[0].mode != MODE_DIF || c->encode_plan[0].s < 1 || c->p61)
+        return FASTECC_E_UNSUPPORTED;
+    if (c->fold == 0 && c->cosets == 1) return FASTECC_E_UNSUPPORTED;  // needs the staged form (first pass writes the scratch stripe)
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    c->gather_odd = odd_blocks;
+    c->gather_factor = row_factor;
+    const int rc = run_passes(c, c->encode_plan, even_blocks, out, c->tw_enc_dif, c->tw_enc_dit, st);
+    c->gather_odd = nullptr;
+    c->gather_factor = nullptr;
+    return rc;
 }
 
 int scratch_of(fastecc_ctx* c, uint32_t** out)

@@ -388,21 +388,25 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         return FASTECC_E_INVAL;
     }
 
+    // the transform's first pass reads the two halves of the codeword itself when it can (no separate gather pass)
+    int rc = run_gathered(d->transform, ddata, dparity, d->fin, d->recovered, st);
+    const bool fused = rc == FASTECC_OK;
+    if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = nullptr;
-    int rc = scratch_of(d->transform, &work);
+    rc = scratch_of(d->transform, &work);
     if (rc != FASTECC_OK) return rc;
     const uint32_t S = (uint32_t)ci.words;
     const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)work | (uintptr_t)d->recovered) & 15u) == 0);
     const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
-    {
+    if (!fused) {
         const uint64_t items = 2 * N * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
         if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
         else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
+        rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
+        if (rc != FASTECC_OK) return rc;
     }
-    rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
-    if (rc != FASTECC_OK) return rc;
     {
         const uint64_t items = N * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));

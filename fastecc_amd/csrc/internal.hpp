@@ -24,6 +24,11 @@ void set_error_detail(const char* what, hipError_t e);
 // output block.  fastecc_encode(ctx, in, out, FASTECC_MEM_DEVICE, stream) runs it; k may be 2^20 (no root of order 2k
 // is needed).  The encoder of RS.cpp:40-63 is the case factor[m] = w_2k^m / k.
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device);
+// Decoder: when the transform's first pass is a register DIF pass it can read the codeword straight from its two
+// halves (PassArgs::in_odd / row_factor) and the separate gather pass disappears.  run_gathered does that and returns
+// FASTECC_E_UNSUPPORTED (nothing enqueued) when the plan starts with another kind of pass.
+int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
+                 hipStream_t st);
 // The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);

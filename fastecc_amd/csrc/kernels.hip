@@ -46,7 +46,22 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     const uint32_t base = (hi << (s + LOGR)) + lo;  // first block of this group
 
     uint32_t x[R][V];
-    if (live) {
+    if (MODE == MODE_DIF && a.row_factor != nullptr) {
+        // the decoder's gather fused into its first pass: codeword position u -> data or parity block u/2, times l(w^u)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t u = base + ((uint32_t)j << s);
+            const uint32_t f = as_constant(a.row_factor)[u];
+            if (live && f != 0) {
+                load_vec<V>(x[j], ((u & 1u) ? a.in_odd : a.in) + (size_t)(u >> 1) * a.ld + col);
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[j][v] = gf::mul_mont(x[j][v], f);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[j][v] = 0;
+            }
+        }
+    } else if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const uint32_t* row = a.in + (size_t)(base + ((uint32_t)j << s)) * a.ld;

@@ -21,6 +21,10 @@ struct PassArgs {
     uint32_t col_chunks;     // filled by the launcher
     uint64_t items;          // filled by the launcher
     int fold;                // MID only: keep every 2^fold-th output block, written compactly (fewer parity than data blocks)
+    // DIF only, optional (the decoder's first pass): input block u is block u/2 of `in` (u even) or of `in_odd` (u odd),
+    // multiplied by row_factor[u] (Montgomery form); a zero factor means "erased": the block is not read at all
+    const uint32_t* in_odd;
+    const uint32_t* row_factor;
 };
 
 // Arguments of one LDS-tiled pass (tile_kernels.hip: ntt_tile_kernel); fields as in PassArgs.

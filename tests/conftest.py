@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU checkers (oracle/, oracle/_ref) are OpenMP code and most tests call them on tiny stripes.  A team as wide
+# as the host (128+ threads on the GPU boxes) makes every such call pay for a full-machine barrier, and when the
+# box's CPUs are shared or quota-limited that cost explodes (seconds per call).  A moderate, fixed team keeps the
+# suite's run time predictable; it has to be set before libgomp is loaded.
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
