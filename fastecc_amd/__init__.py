@@ -18,7 +18,7 @@ P = 0xFFF00001  # RS.cpp:86
 P61 = (1 << 61) - 1
 FIELD_GF_FFF00001 = 0
 FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -90,6 +90,7 @@ struct fastecc_ctx {
     bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
+    int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
     static constexpr int MAX_SLABS = 8;
@@ -440,6 +441,48 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
         if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));
         rc = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width, c->slab_first_done[h]);
         if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipEventRecord(c->slab_done[h], sh));
+        HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
+    }
+    return FASTECC_OK;
+}
+
+int ensure_dbuf(fastecc_ctx* c);
+
+// FASTECC_MEM_HOST_PINNED: the stripe lives in pinned host memory.  Column slabs are independent transforms, so slab
+// h is uploaded (a strided 2-D copy on a copy engine: full link rate from 512-byte rows up), encoded in place in the
+// device staging stripe and downloaded on its own stream while the next slab is still arriving: the two directions of
+// the link and the kernels overlap.  Uploads are chained so that they run one after the other in slab order.
+int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    int rc = ensure_dbuf(c);
+    if (rc != FASTECC_OK) return rc;
+    int H = c->host_slabs;
+    while (H > 1 && (c->S % (32u * H)) != 0) H >>= 1;
+    if (!(plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2)) H = 1;  // register passes work on whole blocks
+    const size_t pitch = (size_t)c->S * 4;
+    if (H == 1) {
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, c->tw_enc_dif, c->tw_enc_dit, st);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+        return FASTECC_OK;
+    }
+    rc = ensure_slab_streams(c);
+    if (rc != FASTECC_OK) return rc;
+    const uint32_t width = (uint32_t)(c->S / H);
+    HIP_TRY(hipEventRecord(c->slab_fork, st));
+    for (int h = 0; h < H; h++) {
+        hipStream_t sh = c->slab_stream[h];
+        HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
+        if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));  // previous slab's upload
+        HIP_TRY(hipMemcpy2DAsync(c->dbuf + (size_t)h * width, pitch, data + (size_t)h * width, pitch, (size_t)width * 4, c->N,
+                                 hipMemcpyHostToDevice, sh));
+        HIP_TRY(hipEventRecord(c->slab_first_done[h], sh));
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpy2DAsync(parity + (size_t)h * width, pitch, c->dbuf + (size_t)h * width, pitch, (size_t)width * 4, c->N,
+                                 hipMemcpyDeviceToHost, sh));
         HIP_TRY(hipEventRecord(c->slab_done[h], sh));
         HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
     }
@@ -815,6 +858,10 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     hipStream_t st = (hipStream_t)stream;
     if (c->cosets > 1 && parity == data) return FASTECC_E_INVAL;  // the parity is larger than the data
     if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
+    if (mem_kind == FASTECC_MEM_HOST_PINNED) {
+        if (c->p61 || c->fold != 0 || c->cosets != 1 || c->ld != c->S) return FASTECC_E_UNSUPPORTED;
+        return encode_host_pinned(c, (const uint32_t*)data, (uint32_t*)parity, st);
+    }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     int rc = ensure_dbuf(c);
@@ -1122,6 +1169,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
     if (!strcmp(name, "xcd_swizzle")) {
         if (value < 0 || value > 2) return FASTECC_E_INVAL;
         c->xcd_swizzle = value;
+        return FASTECC_OK;
+    }
+    if (!strcmp(name, "host_slabs")) {
+        if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
+        c->host_slabs = value;
         return FASTECC_OK;
     }
     if (!strcmp(name, "slabs")) {

@@ -58,7 +58,15 @@ enum {
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
 };
-enum { FASTECC_MEM_HOST = 0, FASTECC_MEM_DEVICE = 1 }; /* where `data`/`parity` pointers live */
+enum {
+    FASTECC_MEM_HOST = 0,        /* ordinary host memory: staged through HBM with copies, the call is synchronous */
+    FASTECC_MEM_DEVICE = 1,      /* device memory of the context's device */
+    /* pinned host memory (hipHostMalloc / hipHostRegister): fastecc_encode pipelines the stripe through HBM in column
+     * slabs — strided copy-engine uploads, kernels and downloads of different slabs overlap, using both directions of the
+     * link at once — and is asynchronous on `stream` like FASTECC_MEM_DEVICE.  n = 2k over GF(0xFFF00001) only; the
+     * other entry points treat this kind as invalid. */
+    FASTECC_MEM_HOST_PINNED = 2
+};
 
 typedef struct fastecc_ctx fastecc_ctx;
 

@@ -474,3 +474,24 @@ def test_row_pitch(torch_cuda, fe, oracle, log2n, S, pitch):
         enc.encode(c)
         torch.cuda.synchronize()
         assert np.array_equal(to_host(c), want)
+
+
+@pytest.mark.parametrize("log2n,S,plan,slabs", [(4, 64, 0, 8), (11, 256, 0, 8), (11, 256, 0, 2), (12, 96, 0, 4), (12, 100, 0, 8), (12, 256, 52, 8), (14, 1024, 0, 8)])
+def test_pinned_host_stripes_through_the_slab_pipeline(torch_cuda, fe, oracle, log2n, S, plan, slabs):
+    """FASTECC_MEM_HOST_PINNED: strided copy-engine uploads, kernels and downloads per column slab; same parity."""
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n + S), N, S)
+    want = oracle.encode_fast(x)
+    hdata = torch.from_numpy(x.view(np.int32).copy()).pin_memory()
+    hpar = torch.zeros(N * S, dtype=torch.int32).pin_memory()
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        if plan:
+            enc.set_plan(plan)
+        enc.set_option("host_slabs", slabs)
+        enc.encode(hdata.data_ptr(), hpar.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, mem=fe.MEM_HOST_PINNED)
+        torch.cuda.synchronize()
+        assert np.array_equal(hpar.numpy().view(np.uint32).reshape(N, S), want), enc.plan()
+        assert np.array_equal(hdata.numpy().view(np.uint32).reshape(N, S), x)
+        with pytest.raises(fe.FastEccError):
+            enc.ntt(hdata.data_ptr(), mem=fe.MEM_HOST_PINNED)   # only fastecc_encode knows this kind
