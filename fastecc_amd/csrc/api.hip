@@ -34,6 +34,7 @@ struct Pass {
     bool tile;  // LDS-tiled kernel (tile_kernels.hip) instead of a register pass (kernels.hip)
     bool pair;  // tile only: 32-word rows with the cross-lane top level
     int rlog;   // tile only: log2 of the words a lane keeps in registers (5, or 4 for the slim outer tiles)
+    bool wide = false;  // tile only: the tile's blocks span 2^32..2^33 bytes and are addressed through two windows
 };
 
 struct ProfileRec {
@@ -162,8 +163,15 @@ bool tile_fits(const fastecc_ctx* c, int logt, int s)
 void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
 {
     // with fold > 0 the DIT passes above MID run on the compact parity stripe: their strides are 2^fold smaller
-    const bool fits = tile_fits(c, bits, mode == MODE_DIT ? s - c->fold : s);
-    if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
+    const int s_run = mode == MODE_DIT ? s - c->fold : s;
+    const bool fits = tile_fits(c, bits, s_run);
+    // one size up: two address windows per tile (tile_kernels.hip WIDE), only for the outer pair shapes that have it
+    const bool fits_wide = !fits && tile_fits(c, bits - 1, s_run);
+    if (c->tile_mid > 0 && fits_wide && c->slim_outer && tile_supported(bits, true, 4) && tile_wide_supported(bits, true, 4))
+        plan.push_back({mode, bits, s, true, true, 4, true});
+    else if (c->tile_mid > 0 && fits_wide && tile_supported(bits, true) && tile_wide_supported(bits, true))
+        plan.push_back({mode, bits, s, true, true, 5, true});
+    else if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
     else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
     else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
     else if (mode == MODE_DIT) {
@@ -223,7 +231,7 @@ void build_plans(fastecc_ctx* c)
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
-        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? "SW32:" : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
@@ -314,6 +322,11 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.n = n_eff;
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
+            a.wide = p.wide;
+            if (c->gather_factor && src == in) {  // first pass of the decoder's transform
+                a.in_odd = c->gather_odd;
+                a.row_factor = c->gather_factor;
+            }
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
             a.split2 = c->split2;
@@ -788,8 +801,10 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
 int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
                  hipStream_t st)
 {
-    if (c->encode_plan.empty() || c->encode_plan[0].tile || c->encode_plan[0].mode != MODE_DIF || c->encode_plan[0].s < 1 || c->p61)
-        return FASTECC_E_UNSUPPORTED;
+    // the first pass must be able to read the two half stripes itself: a register DIF pass or a two-window DIF tile
+    if (c->encode_plan.empty() || c->p61) return FASTECC_E_UNSUPPORTED;
+    const Pass& p0 = c->encode_plan[0];
+    if (p0.mode != MODE_DIF || p0.s < 1 || (p0.tile && !p0.wide)) return FASTECC_E_UNSUPPORTED;
     if (c->fold == 0 && c->cosets == 1) return FASTECC_E_UNSUPPORTED;  // needs the staged form (first pass writes the scratch stripe)
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
@@ -799,6 +814,28 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     c->gather_odd = nullptr;
     c->gather_factor = nullptr;
     return rc;
+}
+
+bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
+{
+    order.clear();
+    if (c->encode_plan.empty() || !c->encode_plan[0].tile) return false;
+    const Pass& p = c->encode_plan[0];
+    // layout of ntt_tile_kernel's paired load (PAIR tiles): tile (hi, lo), wave g, register pair i, +T/2, half-wave
+    const int logt = p.logr, l2 = p.logr - p.rlog - 1, s = p.s;
+    const uint32_t T = 1u << logt, G = 1u << l2, R = 1u << p.rlog;
+    order.resize(c->N);
+    size_t k = 0;
+    for (uint64_t tile = 0; tile < (c->N >> logt); tile++) {
+        const uint32_t lo = (uint32_t)(tile & ((1u << s) - 1u)), hi = (uint32_t)(tile >> s);
+        const uint32_t pos0 = (hi << (s + logt)) + lo;
+        for (uint32_t g = 0; g < G; g++)
+            for (uint32_t i = 0; i < R / 2; i++)
+                for (uint32_t far = 0; far < 2; far++)
+                    for (uint32_t half = 0; half < 2; half++)
+                        order[k++] = pos0 + ((g + 2 * i * G + half * G + far * (T / 2)) << s);
+    }
+    return true;
 }
 
 int scratch_of(fastecc_ctx* c, uint32_t** out)

@@ -31,6 +31,7 @@ namespace fastecc {
 struct DecodeState {
     fastecc_ctx* transform = nullptr;  // size-2k transform context, fold 1
     uint32_t* fin = nullptr;           // 2k factors by codeword position: l(w^u) (Montgomery) or 0 if erased
+    uint32_t* fin_first_pass = nullptr;  // the same in the order the transform's first pass reads them (may equal fin)
     uint32_t* gout = nullptr;          // k factors by data block: 1 / (w^2i l'(w^2i)) (Montgomery) if erased, else 0
     uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
@@ -42,6 +43,7 @@ void destroy_decode_state(DecodeState* d)
 {
     if (!d) return;
     if (d->transform) fastecc_destroy(d->transform);
+    if (d->fin_first_pass && d->fin_first_pass != d->fin) (void)hipFree(d->fin_first_pass);
     if (d->fin) (void)hipFree(d->fin);
     if (d->gout) (void)hipFree(d->gout);
     if (d->recovered) (void)hipFree(d->recovered);
@@ -358,6 +360,17 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
     DEC_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern
     DEC_TRY(hipMemcpy(d->fin, fin.data(), N2 * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> order;
+        if (gather_tile_order(d->transform, order)) {
+            std::vector<uint32_t> tiled(N2);
+            for (uint64_t i = 0; i < N2; i++) tiled[i] = fin[order[i]];
+            if (!d->fin_first_pass || d->fin_first_pass == d->fin) DEC_TRY(hipMalloc((void**)&d->fin_first_pass, N2 * 4));
+            DEC_TRY(hipMemcpy(d->fin_first_pass, tiled.data(), N2 * 4, hipMemcpyHostToDevice));
+        } else {
+            d->fin_first_pass = d->fin;
+        }
+    }
     DEC_TRY(hipMemcpy(d->gout, gout.data(), N * 4, hipMemcpyHostToDevice));
     d->ready = true;
     return FASTECC_OK;
@@ -389,7 +402,7 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     }
 
     // the transform's first pass reads the two halves of the codeword itself when it can (no separate gather pass)
-    int rc = run_gathered(d->transform, ddata, dparity, d->fin, d->recovered, st);
+    int rc = run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st);
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = nullptr;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/fastecc.h"
 
 namespace fastecc {
@@ -29,6 +31,10 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
 // FASTECC_E_UNSUPPORTED (nothing enqueued) when the plan starts with another kind of pass.
 int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
                  hipStream_t st);
+// The order in which that first pass wants row_factor: returns false when it is the natural order (register pass),
+// else fills `order` with order[i] = codeword position whose factor is entry i of the table (two-window DIF tile:
+// the factors of one wave are contiguous).
+bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
 // The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);

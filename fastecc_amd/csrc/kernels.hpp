@@ -45,6 +45,9 @@ struct TileArgs {
     bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
     bool split2;          // 1024-block pair tiles exchange 16 columns at a time (64 KiB LDS, 2 workgroups per CU)
     int cache_policy;     // bit 0: non-temporal stripe loads, bit 1: non-temporal stripe stores
+    const uint32_t* in_odd;      // wide DIF tiles, optional: as PassArgs::in_odd / row_factor (the decoder's first pass)
+    const uint32_t* row_factor;
+    bool wide;            // DIF/DIT pair tiles whose blocks span 2^32..2^33 bytes: two address windows per tile
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
 };
@@ -52,6 +55,7 @@ struct TileArgs {
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
 bool tile_supported(int logt, bool pair, int logr = 5);
 int tile_max_fold(int logt, bool pair, int logr = 5);
+bool tile_wide_supported(int logt, bool pair, int logr = 5);
 hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st);
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);

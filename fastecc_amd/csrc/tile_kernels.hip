@@ -145,6 +145,9 @@ struct TileView {
     uint32_t lo, hi;          // tile group: stripe block of tile block q is (hi << (s+LOGT)) + lo + (q << s)
     uint32_t dead_mask;       // all ones in lanes whose column does not exist
     __amdgpu_buffer_rsrc_t in, out;
+    // WIDE tiles only: descriptors of the upper half of the tile's blocks (block T/2 onwards).  A tile whose blocks span
+    // up to 2^33 bytes is then addressed as two windows of < 2^32 bytes each.
+    __amdgpu_buffer_rsrc_t in_hi, out_hi;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
@@ -157,9 +160,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0xFFFFFFFFu, 0x00020000);
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1>
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, bool WIDE = false>
 __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
+    static_assert(!WIDE || (PAIR && MODE != MODE_MID && !PREFETCH), "WIDE: outer pair tiles only");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
     using View = TileView;
     constexpr int R = C::R, G = C::G, W = C::W, L2 = C::L2, T = C::T;
@@ -174,6 +178,9 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // MID with fewer parity than data blocks: only output positions that are multiples of 2^fold are kept, stored
     // at position >> fold.  fold <= L2, so whether a wave's blocks survive depends on g alone.
     const int fold = MODE == MODE_MID ? a.fold : 0;
+    // Decoder's first pass (WIDE DIF tiles only): input block u is block u/2 of `in` (u even) or `in_odd` (u odd) times
+    // row_factor[u].  s >= 1, so a whole tile reads ONE of the two buffers, as a tile with half the block stride.
+    const bool gather = WIDE && MODE == MODE_DIF && a.row_factor != nullptr;  // uniform
 
     // Block held in register j (layout A) / k (layout B), split into a wave-uniform part (SGPRs) and the
     // half-wave part of a PAIR tile, which is folded once into per-lane offsets.
@@ -215,9 +222,27 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.ld + cc * W;
         v.in = make_desc(a.in + origin);
         v.out = make_desc(a.out + (fold ? (size_t)((v.hi << LOGT) >> fold) * a.ld + cc * W : origin));
+        if constexpr (WIDE) {
+            const size_t upper = origin + ((size_t)(T / 2) << s) * a.ld;
+            v.in_hi = make_desc(a.in + upper);
+            v.out_hi = make_desc(a.out + upper);
+            if (gather) {
+                const uint32_t* half_stripe = (v.lo & 1u) ? a.in_odd : a.in;
+                const size_t o = (size_t)((v.hi << (s + LOGT - 1)) + (v.lo >> 1)) * a.ld + cc * W;
+                v.in = make_desc(half_stripe + o);
+                v.in_hi = make_desc(half_stripe + o + ((size_t)(T / 2) << (s - 1)) * a.ld);
+            }
+        }
         return v;
     };
-    auto load_rows = [&](uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+    // WIDE, layout B (the only one that goes through load_rows/store_rows in a pair tile): a wave's blocks
+    // [2g*R, 2g*R + 2R) lie entirely in one window
+    const bool upper_wave = WIDE && g >= G / 2;
+    auto load_rows = [&](uint32_t (&r)[R][1], const View& vv, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+        View v = vv;
+        if constexpr (WIDE) {
+            if (upper_wave) v.in = vv.in_hi, q0 -= T / 2;
+        }
         const uint32_t voff = lane_off | v.dead_mask;
         // running block offset kept in ONE SGPR: the empty asm stops the compiler from materialising all R
         // offsets up front (they would sit in SGPRs for the whole kernel and spill to VGPR lanes)
@@ -234,7 +259,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         if (a.cache_policy & 1) { FASTECC_LOAD_LOOP(2) } else { FASTECC_LOAD_LOOP(0) }
 #undef FASTECC_LOAD_LOOP
     };
-    auto store_rows = [&](const uint32_t (&r)[R][1], const View& v, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+    auto store_rows = [&](const uint32_t (&r)[R][1], const View& vv, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
+        View v = vv;
+        if constexpr (WIDE) {
+            if (upper_wave) v.out = vv.out_hi, q0 -= T / 2;
+        }
         const uint32_t voff = lane_off | v.dead_mask;
         uint32_t soff = q0 * row_bytes;
         const uint32_t step = qstep * row_bytes;
@@ -250,13 +279,15 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // Paired order of a PAIR tile: register 2i <-> block g + 2i*G (+ G in the high half-wave), register 2i+1 <-> that
     // block + T/2.  Two running scalar offsets.
     auto load_paired = [&](uint32_t (&r)[R][1], const View& v) {
-        const uint32_t voff = lane_p | v.dead_mask;
-        uint32_t soff = g * row_bytes;
-        const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+        const uint32_t rb = gather ? row_bytes >> 1 : row_bytes;  // gather: the half stripes have half the block stride
+        const uint32_t voff = (gather ? ((((half * G) << (s - 1)) * a.ld) + c) * 4u : lane_p) | v.dead_mask;
+        uint32_t soff = g * rb;
+        const uint32_t far = (T / 2) * rb, step = 2 * G * rb;
 #define FASTECC_LOAD_LOOP(AUX)                                                                 \
     _Pragma("unroll") for (int j = 0; j < R; j += 2) {                                          \
         r[j][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff, AUX);                  \
-        r[j + 1][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff + far, AUX);        \
+        if constexpr (WIDE) r[j + 1][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in_hi, voff, soff, AUX);       \
+        else                r[j + 1][0] = __builtin_amdgcn_raw_buffer_load_b32(v.in, voff, soff + far, AUX);    \
         soff += step;                                                                           \
         asm volatile("" : "+s"(soff));                                                          \
     }
@@ -271,7 +302,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 #define FASTECC_STORE_LOOP(AUX)                                                                \
     _Pragma("unroll") for (int j = 0; j < R; j += 2) {                                          \
         __builtin_amdgcn_raw_buffer_store_b32(r[j][0], v.out, voff, soff, AUX);                 \
-        __builtin_amdgcn_raw_buffer_store_b32(r[j + 1][0], v.out, voff, soff + far, AUX);       \
+        if constexpr (WIDE) __builtin_amdgcn_raw_buffer_store_b32(r[j + 1][0], v.out_hi, voff, soff, AUX);      \
+        else                __builtin_amdgcn_raw_buffer_store_b32(r[j + 1][0], v.out, voff, soff + far, AUX);   \
         soff += step;                                                                           \
         asm volatile("" : "+s"(soff));                                                          \
     }
@@ -336,6 +368,22 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const uint32_t off = (g << s) + v.lo;
         const bool compute = !(a.debug & 1u), stores = !(a.debug & 2u);  // uniform; always true outside experiments
         if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
+            if constexpr (WIDE && MODE == MODE_DIF) {
+                if (gather) {
+                    // paired order: register 2i holds tile block g + 2i*G (+ G in the high half-wave), register 2i+1 that
+                    // block + T/2; a zero factor (erased block) turns whatever was read into 0
+                    // row_factor is stored in TILE order (api.hip, gather_tile_order): the 2R factors of a wave are contiguous,
+                    // [j/2][+T/2][high half-wave], so they arrive with a few wide scalar loads
+                    const_u32_ptr f = as_constant(a.row_factor) + (((size_t)(v.hi << s) + v.lo) * G + g) * (2 * R);
+#pragma unroll
+                    for (int j = 0; j < R; j += 2) {
+                        const uint32_t f0 = pair_twiddle<LOGR>(f[2 * j + 0], f[2 * j + 1], upper_mask);
+                        const uint32_t f1 = pair_twiddle<LOGR>(f[2 * j + 2], f[2 * j + 3], upper_mask);
+                        x[j][0] = gf::mul_mont(x[j][0], f0);
+                        x[j + 1][0] = gf::mul_mont(x[j + 1][0], f1);
+                    }
+                }
+            }
             if (compute) {
                 if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
                 dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
@@ -412,11 +460,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1>
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, bool WIDE = false>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT, WIDE>;
     // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
     static bool configured[64] = {};
     int dev = 0;
@@ -449,6 +497,17 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 template <int LOGT, int LOGR, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
+    if (a.wide) {
+        // two address windows per tile (blocks spanning up to 2^33 bytes): outer passes of the shapes the plans use
+        if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
+            if (mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2, true>(a, st);
+            if (mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2, true>(a, st);
+        } else if constexpr (LOGR == 4) {
+            if (mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, true>(a, st);
+            if (mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, true>(a, st);
+        }
+        return hipErrorInvalidValue;
+    }
     if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
         if (a.split2) {  // 1024-block tiles through a 64 KiB buffer: two workgroups per CU, never persistent
             switch (mode) {
@@ -467,6 +526,9 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             else return hipErrorInvalidValue;
     }
 }
+
+// Shapes with a two-window (WIDE) DIF/DIT instantiation, see launch_mode.
+bool tile_wide_supported(int logt, bool pair, int logr) { return pair && ((logr == 5 && logt == 10) || (logr == 4 && (logt == 8 || logt == 9))); }
 
 // Largest fold a MID tile supports: 2^fold must divide its wave stride G = 2^L2.
 int tile_max_fold(int logt, bool pair, int logr) { return logt - logr - (pair ? 1 : 0); }
