@@ -61,6 +61,10 @@ struct fastecc_ctx {
     // the (2k, k) code (same polynomial, a sub-coset of the evaluation points), so the DIF half is unchanged, the
     // MID pass keeps every 2^fold-th output and the DIT passes above it run as a size-M transform on the compact buffer.
     int fold = 0;
+    // Any (n,k) by zero extension (RS.md:23-33 steps 1-7): K data blocks are the first K of N = 2^ceil(log2 K) (the rest
+    // are zero blocks that never exist in memory), and the Mu requested parity blocks are the first Mu of the M = N >> fold
+    // computed ones.  K == N and Mu == M in the power-of-two configurations.
+    uint64_t K = 0, Mu = 0;
     // More parity than data blocks: n = 2^e k, e = 2 or 3.  The n - k parity blocks are the values of the same
     // polynomial on the 2^e - 1 cosets g_t * <w_k> of the data points inside the n-th roots of unity, ordered so that
     // codes nest: coset 0 is the reference's w_2k (the (2k,k) parity), then w_4k, w_4k^3, then w_8k, w_8k^3, w_8k^5, w_8k^7.
@@ -79,7 +83,8 @@ struct fastecc_ctx {
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
-    uint32_t* parbuf = nullptr;  // cosets > 1: device parity for FASTECC_MEM_HOST encodes (lazy)
+    uint32_t* parbuf = nullptr;  // Mu < M: the M computed parity blocks, of which the first Mu are handed out (lazy)
+    uint32_t* hostpar = nullptr; // device parity for FASTECC_MEM_HOST encodes with more parity than data blocks (lazy)
     uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
     void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
     size_t pinned_bytes = 0;
@@ -429,7 +434,32 @@ struct P61Hooks {
     ~P61Hooks() { delete open; }
 };
 
+int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st);
+
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
+    // any (n,k): zero-extend the data in the work stripe, compute M >= Mu parity blocks, hand out the first Mu
+    const size_t row = (size_t)c->ld * 4;
+    const uint32_t* in = data;
+    if (c->K != c->N) {
+        if (!c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * row));
+        HIP_TRY(hipMemcpyAsync(c->scratch, data, c->K * row, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync((char*)c->scratch + c->K * row, 0, (c->N - c->K) * row, st));
+        in = c->scratch;
+    }
+    uint32_t* out = parity;
+    if (c->Mu != c->M) {
+        if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->M * row));
+        out = c->parbuf;
+    }
+    const int rc = encode_pow2(c, in, out, st);
+    if (rc != FASTECC_OK) return rc;
+    if (out != parity) HIP_TRY(hipMemcpyAsync(parity, out, c->Mu * row, hipMemcpyDeviceToDevice, st));
+    return FASTECC_OK;
+}
+
+int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     if (c->p61) {
         P61Hooks hk(c);
@@ -674,26 +704,37 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     *out = nullptr;
     const bool f61 = field == FASTECC_FIELD_GF_P61_SQUARED;
     if (field != FASTECC_FIELD_GF_FFF00001 && !f61) return FASTECC_E_UNSUPPORTED;
-    if (k < 2 || n <= k || block_bytes == 0 || (block_bytes % (f61 ? 16 : 4)) != 0) return FASTECC_E_INVAL;
-    const int lg = ilog2_exact(k);
-    if (lg < 0) return FASTECC_E_INVAL;
-    // parity blocks: k (the reference's configuration) or k/2, k/4, k/8, k/16
-    // or 3k, 7k (n = 4k, 8k)
+    if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % (f61 ? 16 : 4)) != 0) return FASTECC_E_INVAL;
+    // transform size: the next power of two (RS.md:23-27 "find N1 >= N ... extend input vector with zeroes")
+    int lg = 1;
+    while ((1ull << lg) < k && lg < 63) lg++;
+    const uint64_t N1 = 1ull << lg, m = n - k;
+    const bool pow2 = N1 == k;
+    // parity blocks: k (the reference's configuration), 3k or 7k (further cosets), or any m <= N1: then the smallest
+    // power-of-two count >= m (at least N1/16) is computed and the first m blocks are the parity
     int fold = 0, cosets = 1;
-    if (n == 4 * k || n == 8 * k) {
+    if (pow2 && (n == 4 * k || n == 8 * k)) {
         cosets = (int)(n / k) - 1;
         if (f61) return FASTECC_E_UNSUPPORTED;
     } else {
-        const int lgm = ilog2_exact(n - k);
-        if (lgm < 0 || lgm > lg) return FASTECC_E_INVAL;
-        fold = lg - lgm;
-        if (fold > 4 || (f61 && fold != 0)) return FASTECC_E_UNSUPPORTED;
+        if (m > N1) return FASTECC_E_UNSUPPORTED;
+        int lgm = 0;
+        while ((1ull << lgm) < m) lgm++;
+        fold = std::min(lg - lgm, 4);
+        if (f61 && (fold != 0 || !pow2 || m != k)) return FASTECC_E_UNSUPPORTED;
     }
     // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51); in GF(p61^2) 2N | 2^62, the bound is table memory
     if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
-    if (!f61 && n > (1ull << 20)) return FASTECC_E_UNSUPPORTED;  // w_n must exist
+    if (!f61 && cosets > 1 && n > (1ull << 20)) return FASTECC_E_UNSUPPORTED;  // w_n must exist
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
-    return create_impl(out, n, k, lg, block_bytes, field, device, fold, cosets, nullptr);
+    const uint64_t n_internal = cosets > 1 ? n : N1 + (N1 >> fold);
+    const int rc = create_impl(out, n_internal, N1, lg, block_bytes, field, device, fold, cosets, nullptr);
+    if (rc == FASTECC_OK) {
+        (*out)->K = k;
+        (*out)->Mu = m;
+    }
+    return rc;
+
 }
 
 }  // extern "C"
@@ -723,6 +764,8 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
     c->fold = fold;
     c->cosets = cosets;
     c->M = n - k;
+    c->K = k;
+    c->Mu = n - k;
     c->parity_bytes = (size_t)(n - k) * block_bytes;
     {
         int cus = 0;
@@ -786,7 +829,10 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
 
 namespace fastecc {
 
-CtxInfo info_of(const fastecc_ctx* c) { return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld}; }
+CtxInfo info_of(const fastecc_ctx* c)
+{
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M};
+}
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
 
@@ -881,6 +927,7 @@ void fastecc_destroy(fastecc_ctx* c)
     if (c->rawbuf) (void)hipFree(c->rawbuf);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->parbuf) (void)hipFree(c->parbuf);
+    if (c->hostpar) (void)hipFree(c->hostpar);
     if (c->tw_fold_dit) (void)hipFree(c->tw_fold_dit);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -893,25 +940,26 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
-    if (c->cosets > 1 && parity == data) return FASTECC_E_INVAL;  // the parity is larger than the data
+    if (c->Mu > c->K && parity == data) return FASTECC_E_INVAL;  // the parity is larger than the data
     if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
     if (mem_kind == FASTECC_MEM_HOST_PINNED) {
-        if (c->p61 || c->fold != 0 || c->cosets != 1 || c->ld != c->S) return FASTECC_E_UNSUPPORTED;
+        if (c->p61 || c->fold != 0 || c->cosets != 1 || c->ld != c->S || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;
         return encode_host_pinned(c, (const uint32_t*)data, (uint32_t*)parity, st);
     }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     int rc = ensure_dbuf(c);
     if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+    const size_t block_bytes = (size_t)c->S * 4;
+    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->K * block_bytes, hipMemcpyHostToDevice, st));
     uint32_t* dpar = c->dbuf;
-    if (c->cosets > 1) {
-        if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->parity_bytes));
-        dpar = c->parbuf;
+    if (c->cosets > 1 || c->Mu > c->K) {  // more parity than the data stripe has room for
+        if (!c->hostpar) HIP_TRY(hipMalloc((void**)&c->hostpar, c->Mu * block_bytes));
+        dpar = c->hostpar;
     }
     rc = encode_device(c, c->dbuf, dpar, st);
     if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(parity, dpar, c->parity_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(parity, dpar, c->Mu * block_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FASTECC_OK;
 }
@@ -919,16 +967,16 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
 int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 {
     if (!c || !blocks) return FASTECC_E_INVAL;
-    if (c->cosets > 1) return FASTECC_E_UNSUPPORTED;  // the in-place form has room for at most k parity blocks
-    for (uint64_t i = 0; i < c->N; i++)
-        if (!blocks[i] || ((uintptr_t)blocks[i] & 3u)) return FASTECC_E_INVAL;
+    if (c->Mu > c->K) return FASTECC_E_UNSUPPORTED;  // the in-place form has room for at most k parity blocks
+    for (uint64_t i = 0; i < c->K; i++)
+        if (!blocks[i] || ((uintptr_t)blocks[i] & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     int rc = ensure_dbuf(c);
     if (rc != FASTECC_OK) return rc;
     const size_t bb = (size_t)c->S * 4;
     // bounce through a pinned buffer in chunks of whole blocks (<= 64 MiB)
-    const size_t per_chunk = std::max<size_t>(1, std::min<size_t>(c->N, (64u << 20) / bb));
+    const size_t per_chunk = std::max<size_t>(1, std::min<size_t>(c->K, (64u << 20) / bb));
     if (c->pinned_bytes < per_chunk * bb) {
         if (c->pinned) (void)hipHostFree(c->pinned);
         c->pinned = nullptr;
@@ -937,15 +985,15 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
         c->pinned_bytes = per_chunk * bb;
     }
     char* bounce = (char*)c->pinned;
-    for (uint64_t i0 = 0; i0 < c->N; i0 += per_chunk) {
-        const size_t cnt = std::min<uint64_t>(per_chunk, c->N - i0);
+    for (uint64_t i0 = 0; i0 < c->K; i0 += per_chunk) {
+        const size_t cnt = std::min<uint64_t>(per_chunk, c->K - i0);
         for (size_t i = 0; i < cnt; i++) memcpy(bounce + i * bb, blocks[i0 + i], bb);
         HIP_TRY(hipMemcpy((char*)c->dbuf + i0 * bb, bounce, cnt * bb, hipMemcpyHostToDevice));
     }
     rc = encode_device(c, c->dbuf, c->dbuf, nullptr);
     if (rc != FASTECC_OK) return rc;
-    for (uint64_t i0 = 0; i0 < c->M; i0 += per_chunk) {  // the first n - k blocks receive the parity
-        const size_t cnt = std::min<uint64_t>(per_chunk, c->M - i0);
+    for (uint64_t i0 = 0; i0 < c->Mu; i0 += per_chunk) {  // the first n - k blocks receive the parity
+        const size_t cnt = std::min<uint64_t>(per_chunk, c->Mu - i0);
         HIP_TRY(hipMemcpy(bounce, (char*)c->dbuf + i0 * bb, cnt * bb, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) memcpy(blocks[i0 + i], bounce + i * bb, bb);
     }
@@ -956,6 +1004,7 @@ int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* str
 {
     if (!c || !data || ((uintptr_t)data & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // a row pitch applies to fastecc_encode on device stripes only
+    if (c->K != c->N) return FASTECC_E_UNSUPPORTED;   // the transform length is a power of two
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -976,7 +1025,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
     if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
     if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit scalars: GF(0xFFF00001) only
-    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;
+    if (c->ld != c->S || c->K != c->N) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -1030,7 +1079,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
     if (mem_kind == FASTECC_MEM_HOST) {
         int rc = ensure_dbuf(c);
         if (rc != FASTECC_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->K * c->S * 4, hipMemcpyHostToDevice, st));
         dev = c->dbuf;
     } else if (mem_kind != FASTECC_MEM_DEVICE) {
         return FASTECC_E_INVAL;
@@ -1050,7 +1099,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
         *bad_words = found;
         return FASTECC_OK;
     }
-    uint64_t words = c->N * c->S, head = 0;
+    uint64_t words = c->K * c->S, head = 0;
     // the vector loop wants a 16-byte aligned start: count the few leading words on the host copy of them
     unsigned long long result = 0;
     while (((uintptr_t)(dev + head) & 15u) && head < words) head++;
@@ -1077,6 +1126,7 @@ static int pack_args_ok(const fastecc_ctx* c, const void* a, const void* b)
     if (!c || !a || !b || (((uintptr_t)a | (uintptr_t)b) & 3u)) return FASTECC_E_INVAL;
     if (c->p61) return FASTECC_E_UNSUPPORTED;                       // the recoding is specific to p = 0xFFF00001
     if (c->S < 2 || c->S > 1025) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
+    if (c->K != c->N) return FASTECC_E_UNSUPPORTED;             // staging buffers are sized for power-of-two k
     return FASTECC_OK;
 }
 

@@ -270,7 +270,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
 {
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
     const CtxInfo ci = info_of(c);
-    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.fold != 0 || ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // n = 2k only
+    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.fold != 0 || ci.cosets != 1 || ci.zero_extended) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m only
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
     const uint64_t N = ci.k, N2 = 2 * N;
     const int lg2 = ci.log2k + 1;

@@ -16,6 +16,7 @@ void destroy_decode_state(DecodeState*);   // decode.hip, called by fastecc_dest
 struct CtxInfo {
     int device, field, fold, cosets, log2k;
     uint64_t k, words, pitch;  // blocks, words per block, words between device blocks
+    bool zero_extended;        // k or n - k is not the power of two the transform works on
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);

@@ -81,15 +81,20 @@ int fastecc_version(void);
  * Replaces the set-up part of EncodeReedSolomon<T,P>(N,SIZE) (RS.cpp:22-37) plus the per-call root
  * tables MFA_NTT rebuilds (ntt.cpp:397-402) and the per-block GF_Pow of RS.cpp:51-54: all twiddle
  * tables are built once here and live in HBM.
- * Requires k = 2^m with 1 <= m <= 19, block_bytes > 0 and a multiple of 4, and n - k parity blocks with
- *   n = 2k                 the reference's configuration (RS.cpp:22): parity block j = f(w_2k^(2j+1));
- *   n = k + k/2^d, d<=4    fewer parity blocks (RS.md:13-33 "output some M values"): parity block j is block j*2^d of
- *                          the (2k,k) parity, i.e. f on the coset w_2k * <w_(k/2^d)>.  The DIF half is unchanged, the
+ * Requires block_bytes > 0 and a multiple of 4, 1 <= k <= 2^19 and n > k.  With N = the smallest power of two >= k:
+ *   n = 2k, k = N          the reference's configuration (RS.cpp:22): parity block j = f(w_2k^(2j+1));
+ *   n = k + N/2^d, d<=4    fewer parity blocks (RS.md:13-33 "output some M values"): parity block j is block j*2^d of
+ *                          the (2N,N) parity, i.e. f on the coset w_2N * <w_(N/2^d)>.  The DIF half is unchanged, the
  *                          evaluation half shrinks to a size-(n-k) transform;
- *   n = 4k or 8k           more parity blocks (needs n <= 2^20): the n - k parity blocks are f on the 2^e - 1 cosets of
+ *   n = 4k or 8k, k = N    more parity blocks (needs n <= 2^20): the n - k parity blocks are f on the 2^e - 1 cosets of
  *                          the data points inside the n-th roots of unity, k blocks per coset, ordered so that codes
  *                          nest: w_2k (= the (2k,k) parity), w_4k, w_4k^3, w_8k, w_8k^3, w_8k^5, w_8k^7; block j of coset
- *                          g is f(g * w_k^j).  parity == data (in place) and fastecc_encode_blocks are not possible.
+ *                          g is f(g * w_k^j).  parity == data (in place) and fastecc_encode_blocks are not possible;
+ *   any other k, n-k <= N  zero extension, exactly RS.md:23-33: the k data blocks are the first k of N (blocks k..N-1 are
+ *                          zero and never exist in memory), M = max(N/16, 2^ceil(log2(n-k))) parity blocks of the
+ *                          (N + M, N) code above are computed and the first n - k of them are the parity.  Costs one
+ *                          extra copy of the data and, when n - k < M, of the parity.  GF(0xFFF00001) only; encode,
+ *                          encode_blocks and check_range only (no ntt / scale_blocks / pack / decode).
  * `parity` buffers hold n - k blocks.
  */
 int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);

@@ -43,14 +43,16 @@ def test_argument_validation_needs_no_device(hip_lib):
     import fastecc_amd as fe
     h = ctypes.c_void_p()
     create = hip_lib.fastecc_create
-    # n != 2k, k not a power of two, k < 2, block_bytes % 4, zero block, unknown field, k > 2^19
-    assert create(ctypes.byref(h), 100, 64, 4096, 0, 0) == fe.E_INVAL
-    assert create(ctypes.byref(h), 96, 48, 4096, 0, 0) == fe.E_INVAL
-    assert create(ctypes.byref(h), 2, 1, 4096, 0, 0) == fe.E_INVAL
+    # n <= k, k = 0, block_bytes % 4, zero block, unknown field, k > 2^19, more parity than the transform size (and not 4k / 8k)
+    assert create(ctypes.byref(h), 64, 64, 4096, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 60, 64, 4096, 0, 0) == fe.E_INVAL
+    assert create(ctypes.byref(h), 2, 0, 4096, 0, 0) == fe.E_INVAL
     assert create(ctypes.byref(h), 256, 128, 4098, 0, 0) == fe.E_INVAL
     assert create(ctypes.byref(h), 256, 128, 0, 0, 0) == fe.E_INVAL
     assert create(ctypes.byref(h), 256, 128, 4096, 7, 0) == fe.E_UNSUPPORTED
     assert create(ctypes.byref(h), 1 << 21, 1 << 20, 4096, 0, 0) == fe.E_UNSUPPORTED
+    assert create(ctypes.byref(h), 100 + 129, 100, 4096, 0, 0) == fe.E_UNSUPPORTED
+    assert create(ctypes.byref(h), 3 * 128, 128, 4096, 0, 0) == fe.E_UNSUPPORTED
     assert create(None, 256, 128, 4096, 0, 0) == fe.E_INVAL
     assert not h.value
     assert hip_lib.fastecc_encode(None, None, None, 1, None) == fe.E_INVAL

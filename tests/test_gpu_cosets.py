@@ -90,4 +90,4 @@ def test_limits(fe):
     assert ei.value.code == fe.E_UNSUPPORTED
     with pytest.raises(fe.FastEccError) as ei:
         fe.Encoder(16 * 64, 64, 64)
-    assert ei.value.code == fe.E_INVAL
+    assert ei.value.code == fe.E_UNSUPPORTED

@@ -1,0 +1,94 @@
+"""GPU parity tests (-m gpu) for arbitrary (n,k) by zero extension (RS.md:23-33, steps 1-7 of the reference's own
+description): k data blocks are the first k of N = 2^ceil(log2 k), the parity is the first n-k blocks of the
+(N + M, N) code.  The checker is the PINNED oracle on the zero-padded stripe, subsampled — i.e. a subset of what
+the unmodified reference computes for the padded input.  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFF00001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to("cuda:0")
+
+
+def to_host(t, shape):
+    return t.cpu().numpy().view(np.uint32).reshape(shape)
+
+
+def expected(oracle, x, m):
+    k, S = x.shape
+    lg = max(1, int(np.ceil(np.log2(k))))
+    N = 1 << lg
+    lgm = int(np.ceil(np.log2(m))) if m > 1 else 0
+    fold = min(lg - lgm, 4)
+    padded = np.zeros((N, S), dtype=np.uint32)
+    padded[:k] = x
+    return oracle.encode_fast(padded)[:: 1 << fold][:m]
+
+
+@pytest.mark.parametrize("k,m", [(1, 1), (3, 2), (5, 5), (10, 4), (100, 30), (100, 128), (1000, 300), (1024, 1000), (1025, 1),
+                                 (3000, 3000), (5000, 1200), (10000, 2000), (65, 64)])
+def test_any_n_k(torch_cuda, fe, oracle, k, m):
+    S = 37 if k < 4000 else 16
+    x = np.random.default_rng(k * 7 + m).integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    want = expected(oracle, x, m)
+    with fe.Encoder(k + m, k, 4 * S) as enc:
+        dx = to_dev(torch_cuda, x)
+        out = torch_cuda.empty(m * S, dtype=torch_cuda.int32, device="cuda:0")
+        enc.encode(dx, out)
+        assert (to_host(out, (m, S)) == want).all(), enc.plan()
+        assert (to_host(dx, (k, S)) == x).all()
+        assert enc.check_range(dx) == 0
+        host_out = np.empty((m, S), dtype=np.uint32)
+        enc.encode_host(x, host_out)
+        assert (host_out == want).all()
+        if m <= k:
+            enc.encode(dx)  # in place: the first n - k data blocks are replaced by the parity
+            got = to_host(dx, (k, S))
+            assert (got[:m] == want).all() and (got[m:] == x[m:]).all()
+            blocks = [np.ascontiguousarray(x[i]).copy() for i in range(k)]
+            enc.encode_blocks([b.ctypes.data for b in blocks])
+            assert (np.stack(blocks[:m]) == want).all()
+        else:
+            with pytest.raises(fe.FastEccError):
+                enc.encode(dx)
+        if k & (k - 1):   # the stand-alone transform needs a power-of-two length
+            with pytest.raises(fe.FastEccError) as ei:
+                enc.ntt(dx)
+            assert ei.value.code == fe.E_UNSUPPORTED
+        if k & (k - 1) or m != k:   # only the reference's (2k,k) code has a decoder
+            with pytest.raises(fe.FastEccError) as ei:
+                enc.decode_prepare([1] * k, [1] * k)
+            assert ei.value.code == fe.E_UNSUPPORTED
+
+
+def test_matches_the_unmodified_reference_on_the_padded_stripe(torch_cuda, fe):
+    from oracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref not built")
+    ref = Reference()
+    k, m, S = 3000, 1000, 64
+    x = np.random.default_rng(2).integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    padded = np.zeros((4096, S), dtype=np.uint32)
+    padded[:k] = x
+    want = ref.encode(padded)[::4][:m]
+    with fe.Encoder(k + m, k, 4 * S) as enc:
+        out = torch_cuda.empty(m * S, dtype=torch_cuda.int32, device="cuda:0")
+        enc.encode(to_dev(torch_cuda, x), out)
+        assert (to_host(out, (m, S)) == want).all()
