@@ -138,3 +138,31 @@ def test_headline_size_round_trip(torch_cuda, fe, lost_fraction):
         enc.decode(damaged, parity)
         torch.cuda.synchronize()
         assert bool((damaged.view(-1) == data).all())
+
+
+def test_sector_pipeline_pack_encode_lose_decode_unpack(torch_cuda, fe):
+    """README.md:160-163 end to end: arbitrary 4096-byte sectors -> 4100-byte blocks -> parity; lose 30 % of the
+    codeword; decode; unpack; the sectors come back bit for bit."""
+    torch = torch_cuda
+    k, W = 1 << 12, 1024
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    sectors = torch.randint(-(1 << 31), 1 << 31, (k * W,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    sectors.view(k, W)[::7, ::3] |= -1048576   # 0xFFF00000: plenty of digits that need recoding
+    rng = np.random.default_rng(5)
+    lost = rng.permutation(2 * k)[: int(0.3 * 2 * k)]
+    dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
+    dp[lost[lost < k]] = 0
+    pp[lost[lost >= k] - k] = 0
+    with fe.Encoder(2 * k, k, 4 * (W + 1)) as enc:
+        blocks = torch.empty(k * (W + 1), dtype=torch.int32, device="cuda:0")
+        parity = torch.empty_like(blocks)
+        enc.pack_blocks(sectors, blocks)
+        assert enc.check_range(blocks) == 0
+        enc.encode(blocks, parity)
+        blocks.view(k, W + 1)[torch.from_numpy(dp == 0).to("cuda:0")] = 0x7BADF00D
+        parity.view(k, W + 1)[torch.from_numpy(pp == 0).to("cuda:0")] = -1
+        enc.decode_prepare(dp, pp)
+        enc.decode(blocks, parity)
+        back = torch.empty_like(sectors)
+        assert enc.unpack_blocks(blocks, back) == 0
+        assert bool((back == sectors).all())
