@@ -194,9 +194,11 @@ class Encoder:
         return int(bad.value)
 
     def decode_prepare(self, data_present, parity_present):
-        """Erasure pattern: k flags each (truthy = the block survives)."""
+        """Erasure pattern: k data flags and n - k parity flags (truthy = the block survives)."""
+        if len(data_present) != self.k or len(parity_present) != self.n - self.k:
+            raise ValueError("need k data flags and n - k parity flags")
         dp = (ctypes.c_uint8 * self.k)(*[1 if v else 0 for v in data_present])
-        pp = (ctypes.c_uint8 * self.k)(*[1 if v else 0 for v in parity_present])
+        pp = (ctypes.c_uint8 * (self.n - self.k))(*[1 if v else 0 for v in parity_present])
         _check(lib().fastecc_decode_prepare(self._h, dp, pp), "fastecc_decode_prepare")
 
     def decode(self, data, parity, stream=0, mem=MEM_DEVICE):

@@ -831,7 +831,7 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }

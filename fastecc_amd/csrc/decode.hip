@@ -187,7 +187,8 @@ uint32_t bitrev_bits(uint32_t v, int bits)
 template <int V>
 __global__ __launch_bounds__(256) void decode_gather_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
                                                             uint32_t* __restrict__ work, const uint32_t* __restrict__ fin, uint32_t S,
-                                                            uint32_t ld, uint32_t ld_work, uint32_t col_chunks, uint64_t items)
+                                                            uint32_t ld, uint32_t ld_work, int parity_shift, uint32_t col_chunks,
+                                                            uint64_t items)
 {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(256) void decode_gather_kernel(const uint32_t* __re
     const uint32_t f = as_constant(fin)[u];
     uint32_t x[V];
     if (f != 0) {
-        const uint32_t* src = ((u & 1u) ? parity : data) + (size_t)(u >> 1) * ld + col;
+        // parity position j of the (2N,N) code is block j >> parity_shift of a code with fewer parity blocks
+        const uint32_t* src = ((u & 1u) ? parity + (size_t)((u >> 1) >> parity_shift) * ld : data + (size_t)(u >> 1) * ld) + col;
         load_vec<V>(x, src);
 #pragma unroll
         for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
@@ -266,14 +268,22 @@ using namespace fastecc;
 
 extern "C" {
 
-int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
+int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* user_data_present, const uint8_t* user_parity_present)
 {
-    if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
+    if (!c || !user_data_present || !user_parity_present) return FASTECC_E_INVAL;
     const CtxInfo ci = info_of(c);
-    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.fold != 0 || ci.cosets != 1 || ci.zero_extended) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m only
+    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // codes inside the (2N,N) code
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
     const uint64_t N = ci.k, N2 = 2 * N;
     const int lg2 = ci.log2k + 1;
+
+    // Every supported code lives inside the reference's (2N,N) code, N = 2^ceil(log2 k): data blocks k..N-1 are known
+    // zero blocks (survivors that contribute nothing), parity block j sits at parity position j << fold, and the
+    // parity positions the code does not use count as erased.  From here on the flags are those of the (2N,N) code.
+    std::vector<uint8_t> dflag(N, 1), pflag(N, 0);
+    for (uint64_t i = 0; i < ci.user_k; i++) dflag[i] = user_data_present[i] != 0;
+    for (uint64_t j = 0; j < ci.user_m; j++) pflag[j << ci.fold] = user_parity_present[j] != 0;
+    const uint8_t *data_present = dflag.data(), *parity_present = pflag.data();
 
     std::vector<uint32_t> erased;  // codeword positions
     uint64_t erased_data = 0;
@@ -320,7 +330,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
 
     std::vector<uint32_t> fin(N2, 0), gout(N, 0);
     for (uint64_t u = 0; u < N2; u++) {
-        const bool present = (u & 1) ? parity_present[u >> 1] != 0 : data_present[u >> 1] != 0;
+        // zero blocks beyond the user's k contribute 0 * l(w^u): factor 0 keeps every kernel from reading them
+        const bool present = (u & 1) ? parity_present[u >> 1] != 0 : (data_present[u >> 1] != 0 && (u >> 1) < ci.user_k);
         if (present) fin[u] = gf::h_to_mont(lval[bitrev_bits((uint32_t)u, lg2)]);
     }
     {
@@ -386,23 +397,26 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     DeviceScope ds(ci.device);
     hipStream_t st = (hipStream_t)stream;
     const uint64_t N = ci.k;
-    const size_t stripe = N * ci.words * 4;
+    const size_t block = ci.words * 4, data_bytes = ci.user_k * block, parity_bytes = ci.user_m * block;
+    const bool sub_code = ci.zero_extended || ci.fold > 0;  // fewer blocks in memory than codeword positions
 
     uint32_t* ddata = (uint32_t*)data;
     const uint32_t* dparity = (const uint32_t*)parity;
     if (mem_kind == FASTECC_MEM_HOST) {
         // stage both halves of the codeword
-        if (!d->parity_dev) DEC_TRY(hipMalloc((void**)&d->parity_dev, 2 * stripe));
-        DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, stripe, hipMemcpyHostToDevice, st));
-        DEC_TRY(hipMemcpyAsync(d->parity_dev + N * ci.words, data, stripe, hipMemcpyHostToDevice, st));
+        if (!d->parity_dev) DEC_TRY(hipMalloc((void**)&d->parity_dev, parity_bytes + data_bytes));
+        DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, parity_bytes, hipMemcpyHostToDevice, st));
+        DEC_TRY(hipMemcpyAsync(d->parity_dev + ci.user_m * ci.words, data, data_bytes, hipMemcpyHostToDevice, st));
         dparity = d->parity_dev;
-        ddata = d->parity_dev + N * ci.words;
+        ddata = d->parity_dev + ci.user_m * ci.words;
     } else if (mem_kind != FASTECC_MEM_DEVICE) {
         return FASTECC_E_INVAL;
     }
 
     // the transform's first pass reads the two halves of the codeword itself when it can (no separate gather pass)
-    int rc = run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st);
+    // (a sub-code's buffers do not hold every position: it takes the separate gather, which never touches a block whose
+    // factor is zero, instead of the tile that reads first and multiplies by zero afterwards)
+    int rc = sub_code ? FASTECC_E_UNSUPPORTED : run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st);
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = nullptr;
@@ -414,8 +428,8 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     if (!fused) {
         const uint64_t items = 2 * N * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
-        if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
-        else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, col_chunks, items);
+        if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, ci.fold, col_chunks, items);
+        else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, ci.fold, col_chunks, items);
         DEC_TRY(hipGetLastError());
         rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
         if (rc != FASTECC_OK) return rc;
@@ -428,7 +442,7 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         DEC_TRY(hipGetLastError());
     }
     if (mem_kind == FASTECC_MEM_HOST) {
-        DEC_TRY(hipMemcpyAsync(data, ddata, stripe, hipMemcpyDeviceToHost, st));
+        DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
         DEC_TRY(hipStreamSynchronize(st));
     }
     return FASTECC_OK;

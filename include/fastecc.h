@@ -150,15 +150,18 @@ int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_
 int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *stream, uint64_t *bad_words);
 
 /*
- * Erasure decoding for n = 2k contexts over GF(0xFFF00001): recover the erased DATA blocks from any k or more
- * surviving blocks of the codeword.  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79:
- * erasure locator l, p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part
- * here is one transform pipeline of size 2k (the encoder's kernels) between a gather and a scale pass.
- *   fastecc_decode_prepare : set the erasure pattern, k flags each (non-zero = block survives).  Host-side scalar work
- *                            (product tree for l, two size-2k transforms, one inversion) and a table upload; returns
- *                            FASTECC_E_INVAL if fewer than k blocks survive.  Reusable for any number of stripes.
+ * Erasure decoding over GF(0xFFF00001): recover the erased DATA blocks from any k or more surviving blocks of the
+ * codeword.  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
+ * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
+ * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
+ * Works for every code fastecc_create accepts except n = 4k / 8k: codes with fewer parity blocks or zero-extended
+ * data are decoded inside the (2N,N) code (unused parity positions count as erased, the zero blocks as known).
+ *   fastecc_decode_prepare : set the erasure pattern, k data flags and n - k parity flags (non-zero = block survives).
+ *                            Host-side scalar work (product tree for l, two size-2N transforms, one inversion) and a
+ *                            table upload; FASTECC_E_INVAL if fewer than k blocks survive.  Reusable for any number
+ *                            of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
- *                            are not written) and parity (k blocks, read only; content of erased blocks is ignored).
+ *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
  *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
  * Erased parity blocks are not rebuilt (re-encode the repaired data for that).
  */

@@ -110,9 +110,9 @@ def test_patterns_can_change_and_errors(torch_cuda, fe, oracle):
         d = to_dev(torch, x)
         enc.decode(d, to_dev(torch, par))
         assert (to_host(d, (N, S)) == x).all()
-    with fe.Encoder(N + N // 2, N, 4 * S) as enc:   # only the reference's n = 2k code has a decoder so far
+    with fe.Encoder(4 * N, N, 4 * S) as enc:        # the multi-coset codes have no decoder yet
         with pytest.raises(fe.FastEccError) as ei:
-            enc.decode_prepare(np.ones(N, np.uint8), np.ones(N, np.uint8))
+            enc.decode_prepare(np.ones(N, np.uint8), np.ones(3 * N, np.uint8))
         assert ei.value.code == fe.E_UNSUPPORTED
 
 
@@ -166,3 +166,25 @@ def test_sector_pipeline_pack_encode_lose_decode_unpack(torch_cuda, fe):
         back = torch.empty_like(sectors)
         assert enc.unpack_blocks(blocks, back) == 0
         assert bool((back == sectors).all())
+
+
+@pytest.mark.parametrize("logn,d", [(6, 1), (10, 2), (12, 1), (12, 4), (14, 3)])
+def test_codes_with_fewer_parity_blocks(torch_cuda, fe, oracle, logn, d):
+    """(k + k/2^d, k): decoded inside the (2k,k) code, the unused parity positions counting as erased."""
+    torch = torch_cuda
+    N, S = 1 << logn, 48
+    M = N >> d
+    rng = np.random.default_rng(logn * 10 + d)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    par = oracle.encode_fast(x)[:: 1 << d]
+    lost = rng.permutation(N + M)[:M]            # as many erasures as the code can take
+    dp, pp = np.ones(N, np.uint8), np.ones(M, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    damaged = x.copy()
+    damaged[dp == 0] = 0
+    with fe.Encoder(N + M, N, 4 * S) as enc:
+        enc.decode_prepare(dp, pp)
+        dd = to_dev(torch, damaged)
+        enc.decode(dd, to_dev(torch, par))
+        assert (to_host(dd, (N, S)) == x).all()

@@ -72,10 +72,29 @@ def test_any_n_k(torch_cuda, fe, oracle, k, m):
             with pytest.raises(fe.FastEccError) as ei:
                 enc.ntt(dx)
             assert ei.value.code == fe.E_UNSUPPORTED
-        if k & (k - 1) or m != k:   # only the reference's (2k,k) code has a decoder
+        # lose as many blocks as there are parity blocks, all over the codeword, and get the data back
+        rng = np.random.default_rng(k + m)
+        lost = rng.permutation(k + m)[:m]
+        dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+        dp[lost[lost < k]] = 0
+        pp[lost[lost >= k] - k] = 0
+        damaged = x.copy()
+        damaged[dp == 0] = 0xFFFFFFFF
+        dpar = want.copy()
+        dpar[pp == 0] = 0x12345678
+        enc.decode_prepare(dp, pp)
+        dd = to_dev(torch_cuda, damaged)
+        enc.decode(dd, to_dev(torch_cuda, dpar))
+        assert (to_host(dd, (k, S)) == x).all()
+        host = damaged.copy()
+        enc.decode(host, dpar, mem=fe.MEM_HOST)
+        assert (host == x).all()
+        if m < k + m - 1 and m + 1 <= k:
+            dp2 = dp.copy()
+            dp2[np.flatnonzero(dp2)[0]] = 0          # one erasure too many
             with pytest.raises(fe.FastEccError) as ei:
-                enc.decode_prepare([1] * k, [1] * k)
-            assert ei.value.code == fe.E_UNSUPPORTED
+                enc.decode_prepare(dp2, pp)
+            assert ei.value.code == fe.E_INVAL
 
 
 def test_matches_the_unmodified_reference_on_the_padded_stripe(torch_cuda, fe):
