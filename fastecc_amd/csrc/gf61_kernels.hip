@@ -54,7 +54,8 @@ __device__ __forceinline__ const_u64_ptr as_constant(const uint64_t* p) { return
 
 __device__ __forceinline__ Elem load_elem(const uint64_t* p)
 {
-    const u64x2 t = *reinterpret_cast<const u64x2*>(p);  // global_load_dwordx4
+    // every element is read once and written once per pass: non-temporal keeps the stream from displacing itself in L2/MALL
+    const u64x2 t = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p));  // global_load_dwordx4 ... nt
     return Elem{t.x, t.y};
 }
 
@@ -63,7 +64,7 @@ __device__ __forceinline__ void store_elem(uint64_t* p, Elem e)
     u64x2 t;
     t.x = e.re;
     t.y = e.im;
-    *reinterpret_cast<u64x2*>(p) = t;
+    __builtin_nontemporal_store(t, reinterpret_cast<u64x2*>(p));
 }
 
 // Twiddles of level l = sl + T for a lane set holding blocks (.. + j*2^sl + off): entries
@@ -130,7 +131,7 @@ __device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t*
 
 // One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
 template <int LOGR, int MODE, bool CANON>
-__global__ __launch_bounds__(256) void p61_pass_kernel(const PassArgs a)
+__global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(const PassArgs a)
 {
     constexpr int R = 1 << LOGR;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
