@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--log2m", type=int, default=None, help="parity blocks = 2^log2m (default: = k, the reference's configuration; "
                                                             "k/2 .. k/16 are supported, not the headline metric)")
     ap.add_argument("--log2-n-over-k", type=int, default=1, help="n = 2^e k: e = 2, 3 give 3k, 7k parity blocks (nested cosets)")
+    ap.add_argument("--batch", type=int, default=1, help="stripes per step, stored back to back and encoded by fastecc_encode_batch "
+                                                         "(small codes; not the headline metric)")
     ap.add_argument("--block-bytes", type=int, default=0, help="default 4096 (65536 with --field p61)")
     ap.add_argument("--field", choices=["fff00001", "p61"], default="fff00001",
                     help="p61 = GF((2^61-1)^2), the 64 KB-block configuration of BASELINE.json configs[4] (not the headline metric)")
@@ -188,8 +190,12 @@ def main():
     if p61:
         data = random_stripe_p61(k * (args.block_bytes // 8), device, seed=0x1234 + rank)
     else:
-        data = random_stripe(k * S, device, seed=0x1234 + rank)
+        data = random_stripe(k * S * args.batch, device, seed=0x1234 + rank)
     parity = torch.empty(data.numel() // k * m_blocks, dtype=data.dtype, device=device)
+    if args.batch > 1:
+        step = lambda: enc.encode_batch(data, parity, args.batch, stream=stream)  # noqa: E731
+    else:
+        step = lambda: enc.encode(data, parity, stream=stream)  # noqa: E731
     enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local,
                               field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001)
     if args.plan:
@@ -207,14 +213,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        enc.encode(data, parity, stream=stream)
+        step()
     barrier()
     enc.profile(True)      # HIP events around every kernel, on the stream the kernels run on
     enc.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        enc.encode(data, parity, stream=stream)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     kernels = enc.profile_read()
@@ -250,7 +256,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        bytes_per_encode = float(k + m_blocks) * args.block_bytes  # data + parity, RS.cpp:38
+        bytes_per_encode = float(k + m_blocks) * args.block_bytes * args.batch  # data + parity, RS.cpp:38
         ms_per_step = elapsed / args.steps * 1e3
         value = world * bytes_per_encode / (ms_per_step * 1e-3) / 1e9
         # dominant kernel by total time; a launch reads its part of the stripe once and writes it once (the
@@ -265,7 +271,7 @@ def main():
             kernel_ms_per_step = sum(v[0] for v in kernels.values()) / args.steps  # summed durations (kernels may overlap)
             per_block = args.block_bytes // 16 if p61 else S  # field elements per block
             log2m = args.log2k if args.log2m is None or m_blocks > k else args.log2m
-            bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block / (ms_per_step * 1e-3) / 1e9
+            bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block * args.batch / (ms_per_step * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
@@ -294,7 +300,7 @@ def main():
             "config": {"workload": "RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
                                    % (args.log2k, m_blocks, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
                                       k * args.block_bytes / 2**20),
-                       "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
+                       "stripes_per_step": args.batch, "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
             "data_only_GBps": round(value / 2, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }

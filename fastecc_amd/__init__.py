@@ -65,6 +65,7 @@ def lib():
     L.fastecc_create.argtypes, L.fastecc_create.restype = [ctypes.POINTER(vp), u64, u64, u64, i32, i32], i32
     L.fastecc_destroy.argtypes, L.fastecc_destroy.restype = [vp], None
     L.fastecc_encode.argtypes, L.fastecc_encode.restype = [vp, vp, vp, i32, vp], i32
+    L.fastecc_encode_batch.argtypes, L.fastecc_encode_batch.restype = [vp, vp, vp, u64, vp], i32
     L.fastecc_encode_blocks.argtypes, L.fastecc_encode_blocks.restype = [vp, ctypes.POINTER(vp)], i32
     L.fastecc_ntt.argtypes, L.fastecc_ntt.restype = [vp, vp, i32, i32, vp], i32
     L.fastecc_scale_blocks.argtypes, L.fastecc_scale_blocks.restype = [vp, vp, u32, u32, i32, vp], i32
@@ -163,6 +164,13 @@ class Encoder:
         if parity is None:
             parity = data
         _check(lib().fastecc_encode(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_encode")
+        return parity
+
+    def encode_batch(self, data, parity, count, stream=0):
+        """`count` stripes stored back to back in device memory, one launch per pass."""
+        if parity is None:
+            parity = data
+        _check(lib().fastecc_encode_batch(self._h, _addr(data), _addr(parity), count, stream or None), "fastecc_encode_batch")
         return parity
 
     def encode_host(self, data_np, parity_np=None):

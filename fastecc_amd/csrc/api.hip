@@ -296,7 +296,8 @@ struct ProfScope {
 //   cosets > 1 : [MID][DIT passes] run once per coset of evaluation points (its own per-block factor table), coset t
 //                writing blocks [t*k, (t+1)*k) of `out`.
 int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in, uint32_t* out, const uint32_t* tw_dif,
-               const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr)
+               const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr,
+               uint32_t batch = 1)
 {
     if (width == 0) width = (uint32_t)c->S;
     in += col0;
@@ -314,7 +315,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
         const uint32_t* twd = above_mid ? c->tw_fold_dit : tw_dit;
         const uint64_t rows_moved = !folded ? 2 * c->N : p.mode == MODE_DIF ? 2 * c->N : p.mode == MODE_MID ? c->N + c->M : 2 * c->M;
-        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), rows_moved * width * 4ull);
+        ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), rows_moved * width * 4ull * batch);
         if (p.tile) {
             TileArgs a{};
             a.in = src;
@@ -328,6 +329,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.wide = p.wide;
+            a.batch = batch;
             if (c->gather_factor && src == in) {  // first pass of the decoder's transform
                 a.in_odd = c->gather_odd;
                 a.row_factor = c->gather_factor;
@@ -354,6 +356,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.n = n_eff;
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
+            a.batch = batch;
             if (c->gather_factor && src == in) {  // first pass of the decoder's transform
                 a.in_odd = c->gather_odd;
                 a.row_factor = c->gather_factor;
@@ -962,6 +965,17 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     HIP_TRY(hipMemcpyAsync(parity, dpar, c->Mu * block_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FASTECC_OK;
+}
+
+int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_t count, void* stream)
+{
+    if (!c || !data || !parity || count == 0 || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    if (c->p61 || c->fold != 0 || c->cosets != 1 || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m
+    if (count * c->N > 0x7FFFFFFFull || count > 0xFFFFFFFFull) return FASTECC_E_UNSUPPORTED;  // 32-bit block indices
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream, 0, 0,
+                      nullptr, (uint32_t)count);
 }
 
 int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     } else {
         dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0);
         // position p = hi*R + j holds coefficient bitrev_n(p); a.dscale is stored in position order
-        const_u32_ptr d = as_constant(a.dscale) + (size_t)hi * R;
+        const_u32_ptr d = as_constant(a.dscale) + (size_t)(hi & ((1u << (a.n - LOGR)) - 1u)) * R;  // the table repeats per stripe of a batch
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const uint32_t f = d[j];
@@ -219,7 +219,7 @@ static hipError_t launch_pass_v(int logr, int mode, const PassArgs& a, dim3 grid
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st)
 {
     a.col_chunks = (a.S + 64u * vec - 1u) / (64u * vec);
-    a.items = (uint64_t)a.col_chunks << (a.n - logr);
+    a.items = ((uint64_t)a.col_chunks * (a.batch > 1 ? a.batch : 1u)) << (a.n - logr);
     const uint64_t blocks = (a.items + 3u) / 4u;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks);

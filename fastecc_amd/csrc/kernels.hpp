@@ -21,6 +21,7 @@ struct PassArgs {
     uint32_t col_chunks;     // filled by the launcher
     uint64_t items;          // filled by the launcher
     int fold;                // MID only: keep every 2^fold-th output block, written compactly (fewer parity than data blocks)
+    uint32_t batch;          // > 1: that many stripes stored back to back are transformed by one launch
     // DIF only, optional (the decoder's first pass): input block u is block u/2 of `in` (u even) or of `in_odd` (u odd),
     // multiplied by row_factor[u] (Montgomery form); a zero factor means "erased": the block is not read at all
     const uint32_t* in_odd;
@@ -47,6 +48,7 @@ struct TileArgs {
     int cache_policy;     // bit 0: non-temporal stripe loads, bit 1: non-temporal stripe stores
     const uint32_t* in_odd;      // wide DIF tiles, optional: as PassArgs::in_odd / row_factor (the decoder's first pass)
     const uint32_t* row_factor;
+    uint32_t batch;       // > 1: that many stripes stored back to back are transformed by one launch
     bool wide;            // DIF/DIT pair tiles whose blocks span 2^32..2^33 bytes: two address windows per tile
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)

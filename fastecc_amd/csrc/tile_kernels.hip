@@ -400,7 +400,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so
                 // the R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different
                 // blocks: both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
-                const_u32_ptr d = as_constant(a.dscale) + ((size_t)v.hi << LOGT) + qb_u;
+                // (a batch stores its stripes back to back: v.hi counts tiles across all of them, the factor table repeats)
+                const_u32_ptr d = as_constant(a.dscale) + ((size_t)(v.hi & ((1u << (a.n - LOGT)) - 1u)) << LOGT) + qb_u;
                 constexpr int CH = 8;
 #pragma unroll
                 for (int k0 = 0; k0 < R; k0 += CH) {
@@ -476,7 +477,7 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     }
     TileArgs b = a;
     b.col_chunks = (a.S + C::W - 1) / C::W;
-    const uint64_t tiles = ((uint64_t)1 << (a.n - LOGT)) * b.col_chunks;
+    const uint64_t tiles = ((uint64_t)(a.batch > 1 ? a.batch : 1u) << (a.n - LOGT)) * b.col_chunks;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     b.tiles = (uint32_t)tiles;
     uint64_t blocks = tiles;

@@ -113,6 +113,15 @@ void fastecc_destroy(fastecc_ctx *ctx);
 int fastecc_encode(fastecc_ctx *ctx, const void *data, void *parity, int mem_kind, void *stream);
 
 /*
+ * Many stripes at once: `count` stripes of k blocks stored back to back in DEVICE memory (stripe b at data +
+ * b*k*block_bytes, its parity at parity + b*k*block_bytes), encoded by ONE launch per pass.  Same result as `count`
+ * fastecc_encode calls; meant for small codes — a (256,128) x 4 KB stripe is 1 MiB and a single launch of it is
+ * launch-bound, a batch of them runs at the rate of the large stripes.  n = 2k = 2^m over GF(0xFFF00001) only;
+ * parity == data encodes in place; enqueued on `stream` without synchronising.
+ */
+int fastecc_encode_batch(fastecc_ctx *ctx, const void *data, void *parity, uint64_t count, void *stream);
+
+/*
  * The reference's own calling form: an array of k HOST block pointers, transformed in place
  * (T** data of RS.cpp:31-33 / ntt.cpp:348-350).  On return blocks[j] holds parity block j (the
  * pointer array itself is left untouched, which is also what two MFA_NTT calls leave behind,

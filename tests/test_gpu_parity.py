@@ -521,3 +521,29 @@ def test_two_window_tiles_for_blocks_spanning_4_to_8_gib(torch_cuda, fe, oracle)
     for c in (0, 31, 32, 4097, S - 1):
         x = d2[:, c:c + 1].contiguous().cpu().numpy().view(np.uint32)
         assert np.array_equal(a2[:, c:c + 1].contiguous().cpu().numpy().view(np.uint32), oracle.encode_fast(x)), c
+
+
+@pytest.mark.parametrize("log2n,S,count,plan", [(1, 8, 5, 0), (4, 70, 3, 0), (7, 1024, 16, 0), (7, 1024, 7, 51), (10, 64, 9, 0), (11, 100, 4, 0),
+                                              (13, 32, 3, 0), (13, 32, 2, 1090), (12, 48, 5, 32)])
+def test_batched_stripes_equal_individual_encodes(torch_cuda, fe, oracle, log2n, S, count, plan):
+    """fastecc_encode_batch: `count` stripes back to back, one launch per pass, same parity as stripe-by-stripe."""
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(np.random.default_rng(log2n * 100 + count), N * count, S)
+    want = np.concatenate([oracle.encode_fast(x[b * N:(b + 1) * N]) for b in range(count)])
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        if plan:
+            enc.set_plan(plan)
+        d = to_dev(torch, x)
+        out = torch.empty_like(d)
+        enc.encode_batch(d, out, count)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(out).reshape(N * count, S), want), enc.plan()
+        enc.encode_batch(d, None, count)   # in place
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(d).reshape(N * count, S), want)
+    with fe.Encoder(N + max(1, N // 2), N, 4 * S) as enc:
+        if N >= 2:
+            with pytest.raises(fe.FastEccError) as ei:
+                enc.encode_batch(d, out, count)
+            assert ei.value.code == fe.E_UNSUPPORTED
