@@ -32,10 +32,13 @@ struct DecodeState {
     fastecc_ctx* transform = nullptr;  // size-2k transform context, fold 1
     uint32_t* fin = nullptr;           // 2k factors by codeword position: l(w^u) (Montgomery) or 0 if erased
     uint32_t* fin_first_pass = nullptr;  // the same in the order the transform's first pass reads them (may equal fin)
+    uint32_t* srcmap = nullptr;        // per codeword position: the block that sits there (row, bit 31 = parity stripe)
     uint32_t* gout = nullptr;          // k factors by data block: 1 / (w^2i l'(w^2i)) (Montgomery) if erased, else 0
     uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
     uint64_t erased_data = 0, erased_total = 0;
+    uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
+    bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
     bool ready = false;
 };
 
@@ -45,6 +48,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->fin_first_pass && d->fin_first_pass != d->fin) (void)hipFree(d->fin_first_pass);
     if (d->fin) (void)hipFree(d->fin);
+    if (d->srcmap) (void)hipFree(d->srcmap);
     if (d->gout) (void)hipFree(d->gout);
     if (d->recovered) (void)hipFree(d->recovered);
     if (d->parity_dev) (void)hipFree(d->parity_dev);
@@ -183,12 +187,13 @@ uint32_t bitrev_bits(uint32_t v, int bits)
 // ------------------------------------------------------------------------------------------------
 // kernels: one wave per (block row, 64*V-word column chunk); the row's factor is a scalar
 // ------------------------------------------------------------------------------------------------
-// work[u] = (u even ? data[u/2] : parity[u/2]) * fin[u]; erased positions (fin == 0) are written as zeros, never read
+// work[u] = block at codeword position u, times fin[u].  srcmap[u] names the block: row index, bit 31 set = parity
+// stripe.  Positions without a surviving block have fin == 0: they are written as zeros and nothing is read for them.
 template <int V>
 __global__ __launch_bounds__(256) void decode_gather_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
-                                                            uint32_t* __restrict__ work, const uint32_t* __restrict__ fin, uint32_t S,
-                                                            uint32_t ld, uint32_t ld_work, int parity_shift, uint32_t col_chunks,
-                                                            uint64_t items)
+                                                            uint32_t* __restrict__ work, const uint32_t* __restrict__ fin,
+                                                            const uint32_t* __restrict__ srcmap, uint32_t S, uint32_t ld, uint32_t ld_work,
+                                                            uint32_t col_chunks, uint64_t items)
 {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(256) void decode_gather_kernel(const uint32_t* __re
     const uint32_t f = as_constant(fin)[u];
     uint32_t x[V];
     if (f != 0) {
-        // parity position j of the (2N,N) code is block j >> parity_shift of a code with fewer parity blocks
-        const uint32_t* src = ((u & 1u) ? parity + (size_t)((u >> 1) >> parity_shift) * ld : data + (size_t)(u >> 1) * ld) + col;
+        const uint32_t m = as_constant(srcmap)[u];
+        const uint32_t* src = ((m >> 31) ? parity : data) + (size_t)(m & 0x7FFFFFFFu) * ld + col;
         load_vec<V>(x, src);
 #pragma unroll
         for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
@@ -268,30 +273,49 @@ using namespace fastecc;
 
 extern "C" {
 
-int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* user_data_present, const uint8_t* user_parity_present)
+int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
 {
-    if (!c || !user_data_present || !user_parity_present) return FASTECC_E_INVAL;
+    if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
     const CtxInfo ci = info_of(c);
-    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // codes inside the (2N,N) code
+    if (ci.field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
-    const uint64_t N = ci.k, N2 = 2 * N;
-    const int lg2 = ci.log2k + 1;
+    const uint64_t N = ci.k;
 
-    // Every supported code lives inside the reference's (2N,N) code, N = 2^ceil(log2 k): data blocks k..N-1 are known
-    // zero blocks (survivors that contribute nothing), parity block j sits at parity position j << fold, and the
-    // parity positions the code does not use count as erased.  From here on the flags are those of the (2N,N) code.
-    std::vector<uint8_t> dflag(N, 1), pflag(N, 0);
-    for (uint64_t i = 0; i < ci.user_k; i++) dflag[i] = user_data_present[i] != 0;
-    for (uint64_t j = 0; j < ci.user_m; j++) pflag[j << ci.fold] = user_parity_present[j] != 0;
-    const uint8_t *data_present = dflag.data(), *parity_present = pflag.data();
-
-    std::vector<uint32_t> erased;  // codeword positions
+    // Every code is f on a subset of the NC-th roots of unity, NC = N << e (position u <-> w_NC^u): data block i at
+    // i << e (blocks k..N-1 of a zero-extended code are known zero blocks), parity at the positions fastecc_create
+    // documents — odd multiples of 2^fold for the codes inside (2N,N), the cosets' offsets for n = 4k / 8k.  Positions
+    // that hold no block of the code count as erased, which is exactly what limits the losses to n - k.
+    int e = 1;
+    while ((1 << e) < ci.cosets + 1) e++;
+    const uint64_t NC = N << e;
+    const int lgc = ci.log2k + e;
+    enum : uint8_t { LOST = 0, HELD = 1, ZERO = 2 };
+    std::vector<uint8_t> state(NC, LOST);
+    std::vector<uint32_t> srcmap(NC, 0);
     uint64_t erased_data = 0;
     for (uint64_t i = 0; i < N; i++) {
-        if (!data_present[i]) erased.push_back((uint32_t)(2 * i)), erased_data++;
-        if (!parity_present[i]) erased.push_back((uint32_t)(2 * i + 1));
+        const uint64_t u = i << e;
+        if (i >= ci.user_k) state[u] = ZERO;
+        else if (data_present[i]) state[u] = HELD, srcmap[u] = (uint32_t)i;
+        else erased_data++;
     }
-    if (erased.size() > N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
+    for (uint64_t q = 0; q < ci.user_m; q++) {
+        uint64_t u;
+        if (ci.cosets > 1) {
+            const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
+            int jj = 1;
+            while ((1ull << jj) - 1 <= t) jj++;
+            const uint64_t odd = 2 * (t + 1 - (1ull << (jj - 1))) + 1;
+            u = (odd << (e - jj)) + (j << e);
+        } else {
+            u = ((q << ci.fold) << 1) + 1;
+        }
+        if (parity_present[q]) state[u] = HELD, srcmap[u] = (uint32_t)q | 0x80000000u;
+    }
+    std::vector<uint32_t> erased;
+    for (uint64_t u = 0; u < NC; u++)
+        if (state[u] == LOST) erased.push_back((uint32_t)u);
+    if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
 
     DeviceScope ds(ci.device);
     DecodeState*& slot = decoder_of(c);
@@ -303,6 +327,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* user_data_present, con
     d->ready = false;
     d->erased_data = erased_data;
     d->erased_total = erased.size();
+    d->positions = NC;
+    d->standard = ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
     if (erased_data == 0) {  // nothing to recover
         d->ready = true;
         return FASTECC_OK;
@@ -310,37 +336,35 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* user_data_present, con
 
     // ---- pattern-only scalars ----
     const HostNtt& t = host_ntt();
-    const uint32_t w = gf::h_root((uint32_t)N2);
-    std::vector<uint32_t> wpow(N2);  // w^u
+    const uint32_t w = gf::h_root((uint32_t)NC);
+    std::vector<uint32_t> wpow(NC);  // w^u
     {
         uint32_t a = 1;
-        for (uint64_t u = 0; u < N2; u++) {
+        for (uint64_t u = 0; u < NC; u++) {
             wpow[u] = a;
             a = gf::h_mul(a, w);
         }
     }
     std::vector<uint32_t> roots(erased.size());
     for (size_t i = 0; i < erased.size(); i++) roots[i] = wpow[erased[i]];
-    const std::vector<uint32_t> l = poly_from_roots(roots);  // degree |E| <= N < 2N
-    std::vector<uint32_t> lval(N2, 0), lder(N2, 0);
+    const std::vector<uint32_t> l = poly_from_roots(roots);  // degree |E| <= NC - N < NC
+    std::vector<uint32_t> lval(NC, 0), lder(NC, 0);
     std::copy(l.begin(), l.end(), lval.begin());
     for (size_t m = 0; m + 1 < l.size(); m++) lder[m] = gf::h_mul((uint32_t)((m + 1) % P), l[m + 1]);
-    t.dif(lval.data(), lg2, false);  // value at w^u sits at index bitrev(u)
-    t.dif(lder.data(), lg2, false);
+    t.dif(lval.data(), lgc, false);  // value at w^u sits at index bitrev(u)
+    t.dif(lder.data(), lgc, false);
 
-    std::vector<uint32_t> fin(N2, 0), gout(N, 0);
-    for (uint64_t u = 0; u < N2; u++) {
-        // zero blocks beyond the user's k contribute 0 * l(w^u): factor 0 keeps every kernel from reading them
-        const bool present = (u & 1) ? parity_present[u >> 1] != 0 : (data_present[u >> 1] != 0 && (u >> 1) < ci.user_k);
-        if (present) fin[u] = gf::h_to_mont(lval[bitrev_bits((uint32_t)u, lg2)]);
-    }
+    std::vector<uint32_t> fin(NC, 0), gout(N, 0);
+    for (uint64_t u = 0; u < NC; u++)  // zero blocks contribute 0 * l(w^u): factor 0 keeps every kernel from reading them
+        if (state[u] == HELD) fin[u] = gf::h_to_mont(lval[bitrev_bits((uint32_t)u, lgc)]);
     {
-        // 1 / (w^e l'(w^e)) for the erased data positions with ONE inversion (prefix products)
+        // 1 / (w^u l'(w^u)) for the erased data positions with ONE inversion (prefix products)
         std::vector<uint32_t> den, prefix;
         std::vector<uint64_t> who;
-        for (uint64_t i = 0; i < N; i++) {
+        for (uint64_t i = 0; i < ci.user_k; i++) {
             if (data_present[i]) continue;
-            const uint32_t v = gf::h_mul(wpow[2 * i], lder[bitrev_bits((uint32_t)(2 * i), lg2)]);
+            const uint64_t u = i << e;
+            const uint32_t v = gf::h_mul(wpow[u], lder[bitrev_bits((uint32_t)u, lgc)]);
             if (v == 0) return FASTECC_E_INVAL;  // cannot happen: l has simple roots
             den.push_back(v);
             who.push_back(i);
@@ -360,24 +384,27 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* user_data_present, con
 
     // ---- device state ----
     if (!d->transform) {
-        std::vector<uint32_t> factor(N2);
-        const uint32_t inv2n = gf::h_inv((uint32_t)N2);
-        for (uint64_t m = 0; m < N2; m++) factor[m] = gf::h_mul((uint32_t)m, inv2n);  // x p'(x): coefficient m times m, and the 1/2k of the inverse transform
-        const int rc = create_transform_ctx(&d->transform, lg2, ci.words * 4, 1, factor.data(), ci.device);
+        std::vector<uint32_t> factor(NC);
+        const uint32_t inv_nc = gf::h_inv((uint32_t)NC);
+        for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mul((uint32_t)m, inv_nc);  // x p'(x): coefficient m times m, and the 1/NC of the inverse transform
+        // fold e: only the data positions (multiples of 2^e) are evaluated
+        const int rc = create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
-    if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, N2 * 4));
+    if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));
+    if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
     DEC_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern
-    DEC_TRY(hipMemcpy(d->fin, fin.data(), N2 * 4, hipMemcpyHostToDevice));
+    DEC_TRY(hipMemcpy(d->fin, fin.data(), NC * 4, hipMemcpyHostToDevice));
+    DEC_TRY(hipMemcpy(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice));
     {
         std::vector<uint32_t> order;
-        if (gather_tile_order(d->transform, order)) {
-            std::vector<uint32_t> tiled(N2);
-            for (uint64_t i = 0; i < N2; i++) tiled[i] = fin[order[i]];
-            if (!d->fin_first_pass || d->fin_first_pass == d->fin) DEC_TRY(hipMalloc((void**)&d->fin_first_pass, N2 * 4));
-            DEC_TRY(hipMemcpy(d->fin_first_pass, tiled.data(), N2 * 4, hipMemcpyHostToDevice));
+        if (d->standard && gather_tile_order(d->transform, order)) {
+            std::vector<uint32_t> tiled(NC);
+            for (uint64_t i = 0; i < NC; i++) tiled[i] = fin[order[i]];
+            if (!d->fin_first_pass || d->fin_first_pass == d->fin) DEC_TRY(hipMalloc((void**)&d->fin_first_pass, NC * 4));
+            DEC_TRY(hipMemcpy(d->fin_first_pass, tiled.data(), NC * 4, hipMemcpyHostToDevice));
         } else {
             d->fin_first_pass = d->fin;
         }
@@ -398,12 +425,11 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     hipStream_t st = (hipStream_t)stream;
     const uint64_t N = ci.k;
     const size_t block = ci.words * 4, data_bytes = ci.user_k * block, parity_bytes = ci.user_m * block;
-    const bool sub_code = ci.zero_extended || ci.fold > 0;  // fewer blocks in memory than codeword positions
 
     uint32_t* ddata = (uint32_t*)data;
     const uint32_t* dparity = (const uint32_t*)parity;
     if (mem_kind == FASTECC_MEM_HOST) {
-        // stage both halves of the codeword
+        // stage both parts of the codeword
         if (!d->parity_dev) DEC_TRY(hipMalloc((void**)&d->parity_dev, parity_bytes + data_bytes));
         DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, parity_bytes, hipMemcpyHostToDevice, st));
         DEC_TRY(hipMemcpyAsync(d->parity_dev + ci.user_m * ci.words, data, data_bytes, hipMemcpyHostToDevice, st));
@@ -413,10 +439,10 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         return FASTECC_E_INVAL;
     }
 
-    // the transform's first pass reads the two halves of the codeword itself when it can (no separate gather pass)
-    // (a sub-code's buffers do not hold every position: it takes the separate gather, which never touches a block whose
-    // factor is zero, instead of the tile that reads first and multiplies by zero afterwards)
-    int rc = sub_code ? FASTECC_E_UNSUPPORTED : run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st);
+    // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).
+    // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
+    // position whose factor is zero, instead of a tile that reads first and multiplies by zero afterwards.
+    int rc = d->standard ? run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st) : FASTECC_E_UNSUPPORTED;
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = nullptr;
@@ -426,10 +452,10 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)work | (uintptr_t)d->recovered) & 15u) == 0);
     const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
     if (!fused) {
-        const uint64_t items = 2 * N * col_chunks;
+        const uint64_t items = d->positions * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
-        if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, ci.fold, col_chunks, items);
-        else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, S, S, S, ci.fold, col_chunks, items);
+        if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, d->srcmap, S, S, S, col_chunks, items);
+        else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, d->srcmap, S, S, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
         rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
         if (rc != FASTECC_OK) return rc;

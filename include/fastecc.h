@@ -163,8 +163,9 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * codeword.  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
- * Works for every code fastecc_create accepts except n = 4k / 8k: codes with fewer parity blocks or zero-extended
- * data are decoded inside the (2N,N) code (unused parity positions count as erased, the zero blocks as known).
+ * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity
+ * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
+ * as known, so exactly n - k losses are tolerated.
  *   fastecc_decode_prepare : set the erasure pattern, k data flags and n - k parity flags (non-zero = block survives).
  *                            Host-side scalar work (product tree for l, two size-2N transforms, one inversion) and a
  *                            table upload; FASTECC_E_INVAL if fewer than k blocks survive.  Reusable for any number

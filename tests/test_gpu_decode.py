@@ -110,9 +110,9 @@ def test_patterns_can_change_and_errors(torch_cuda, fe, oracle):
         d = to_dev(torch, x)
         enc.decode(d, to_dev(torch, par))
         assert (to_host(d, (N, S)) == x).all()
-    with fe.Encoder(4 * N, N, 4 * S) as enc:        # the multi-coset codes have no decoder yet
+    with fe.Encoder(2 * N, N, 16 * 8, field=fe.FIELD_GF_P61_SQUARED) as enc:   # no decoder for the 64-bit field yet
         with pytest.raises(fe.FastEccError) as ei:
-            enc.decode_prepare(np.ones(N, np.uint8), np.ones(3 * N, np.uint8))
+            enc.decode_prepare(np.ones(N, np.uint8), np.ones(N, np.uint8))
         assert ei.value.code == fe.E_UNSUPPORTED
 
 
@@ -188,3 +188,37 @@ def test_codes_with_fewer_parity_blocks(torch_cuda, fe, oracle, logn, d):
         dd = to_dev(torch, damaged)
         enc.decode(dd, to_dev(torch, par))
         assert (to_host(dd, (N, S)) == x).all()
+
+
+@pytest.mark.parametrize("logn,e", [(1, 2), (5, 2), (6, 3), (10, 2), (11, 3), (13, 2)])
+def test_codes_with_more_parity_blocks(torch_cuda, fe, oracle, logn, e):
+    """n = 4k, 8k: decoded on the n-th roots of unity; up to n - k blocks may be lost, e.g. ALL data and most parity."""
+    torch = torch_cuda
+    N, S = 1 << logn, 40
+    M = ((1 << e) - 1) * N
+    rng = np.random.default_rng(logn * 10 + e)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    with fe.Encoder(N << e, N, 4 * S) as enc:
+        dx = to_dev(torch, x)
+        par = torch.empty(M * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(dx, par)
+        for trial in range(2):
+            lost = rng.permutation(N + M)[:M] if trial == 0 else np.concatenate([np.arange(N), N + rng.permutation(M)[: M - N]])
+            dp, pp = np.ones(N, np.uint8), np.ones(M, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            damaged = x.copy()
+            damaged[dp == 0] = 0xFFFFFFFF
+            dpar = par.clone()
+            dpar.view(M, S)[torch.from_numpy(pp == 0).to("cuda:0")] = 0x0BADBEEF
+            enc.decode_prepare(dp, pp)
+            dd = to_dev(torch, damaged)
+            enc.decode(dd, dpar)
+            assert (to_host(dd, (N, S)) == x).all(), (logn, e, trial)
+        dp[:] = 0
+        pp[:] = 0
+        pp[: N - 1] = 1                      # one block short of k survivors
+        if N > 1:
+            with pytest.raises(fe.FastEccError) as ei:
+                enc.decode_prepare(dp, pp)
+            assert ei.value.code == fe.E_INVAL
