@@ -48,6 +48,10 @@ struct ProfileRec {
 struct fastecc_ctx {
     int device = 0;
     int field = FASTECC_FIELD_GF_FFF00001;
+    // set only inside encode_device for zero-extended codes: the first pass reads a stripe of bound_in_rows blocks
+    // (the rest is zero), the last pass writes the first bound_out_rows blocks of its result to bound_final_out
+    uint32_t bound_in_rows = 0, bound_out_rows = 0;
+    uint32_t* bound_final_out = nullptr;
     const uint32_t* gather_odd = nullptr;     // set only inside run_gathered (decoder): see PassArgs::in_odd
     const uint32_t* gather_factor = nullptr;
     DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
@@ -310,7 +314,13 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     if (staged && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
     const int vec = staged ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
 
-    auto run_one = [&](const Pass& p, const uint32_t* src, uint32_t* dst, const uint32_t* dscale) -> int {
+    auto run_one = [&](const Pass& p, const uint32_t* src, uint32_t* dst, const uint32_t* dscale, bool last = false) -> int {
+        const uint32_t in_rows = src == in ? c->bound_in_rows : 0;
+        uint32_t out_rows = 0;
+        if (last && c->bound_final_out) {
+            dst = c->bound_final_out + col0;
+            out_rows = c->bound_out_rows;
+        }
         const bool above_mid = folded && p.mode == MODE_DIT;
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
         const uint32_t* twd = above_mid ? c->tw_fold_dit : tw_dit;
@@ -330,6 +340,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.wide = p.wide;
             a.batch = batch;
+            a.in_rows = in_rows;
+            a.out_rows = out_rows;
             if (c->gather_factor && src == in) {  // first pass of the decoder's transform
                 a.in_odd = c->gather_odd;
                 a.row_factor = c->gather_factor;
@@ -357,6 +369,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.batch = batch;
+            a.in_rows = in_rows;
+            a.out_rows = out_rows;
             if (c->gather_factor && src == in) {  // first pass of the decoder's transform
                 a.in_odd = c->gather_odd;
                 a.row_factor = c->gather_factor;
@@ -370,7 +384,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     if (!staged) {
         bool first = true;
         for (const Pass& p : plan) {
-            const int rc = run_one(p, src, out, c->dscale);
+            const int rc = run_one(p, src, out, c->dscale, &p == &plan.back());
             if (rc != FASTECC_OK) return rc;
             src = out;  // after the first pass everything is in place on `out`
             if (first && first_done) HIP_TRY(hipEventRecord(first_done, st));
@@ -388,7 +402,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         uint32_t* o = out + (size_t)t * c->N * c->ld;
         const uint32_t* s2 = src;
         for (size_t j = i; j < plan.size(); ++j) {
-            const int rc = run_one(plan[j], s2, o, c->dscale + (size_t)t * c->N);
+            const int rc = run_one(plan[j], s2, o, c->dscale + (size_t)t * c->N, j + 1 == plan.size());
             if (rc != FASTECC_OK) return rc;
             s2 = o;
         }
@@ -442,24 +456,22 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
-    // any (n,k): zero-extend the data in the work stripe, compute M >= Mu parity blocks, hand out the first Mu
+    // any (n,k): the first pass reads the K existing data blocks and takes the rest of the stripe as zero, the last pass
+    // writes only the first Mu of the M parity blocks it computes — both through the kernels' bounds handling, no copies.
+    // The passes in between need all M blocks somewhere: the caller's parity buffer when it is that large, else parbuf.
     const size_t row = (size_t)c->ld * 4;
-    const uint32_t* in = data;
-    if (c->K != c->N) {
-        if (!c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * row));
-        HIP_TRY(hipMemcpyAsync(c->scratch, data, c->K * row, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemsetAsync((char*)c->scratch + c->K * row, 0, (c->N - c->K) * row, st));
-        in = c->scratch;
-    }
     uint32_t* out = parity;
     if (c->Mu != c->M) {
         if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->M * row));
         out = c->parbuf;
+        c->bound_final_out = parity;
+        c->bound_out_rows = (uint32_t)c->Mu;
     }
-    const int rc = encode_pow2(c, in, out, st);
-    if (rc != FASTECC_OK) return rc;
-    if (out != parity) HIP_TRY(hipMemcpyAsync(parity, out, c->Mu * row, hipMemcpyDeviceToDevice, st));
-    return FASTECC_OK;
+    c->bound_in_rows = c->K != c->N ? (uint32_t)c->K : 0;
+    const int rc = encode_pow2(c, data, out, st);
+    c->bound_in_rows = c->bound_out_rows = 0;
+    c->bound_final_out = nullptr;
+    return rc;
 }
 
 int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)

@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
                 for (int v = 0; v < V; ++v) x[j][v] = 0;
             }
         }
+    } else if (live && a.in_rows != 0) {
+        // zero-extended stripe: blocks from in_rows on do not exist and read as zero
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t blk = base + ((uint32_t)j << s);
+            if (blk < a.in_rows) {
+                load_vec<V>(x[j], a.in + (size_t)blk * a.ld + col);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[j][v] = 0;
+            }
+        }
     } else if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -100,7 +112,16 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
             const uint32_t drop = (1u << a.fold) - 1u;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                if ((j & drop) == 0) store_vec<V>(a.out + (size_t)((base + j) >> a.fold) * a.ld + col, x[j]);
+                const uint32_t blk = (base + j) >> a.fold;
+                if ((j & drop) == 0 && (a.out_rows == 0 || blk < a.out_rows)) store_vec<V>(a.out + (size_t)blk * a.ld + col, x[j]);
+            }
+            return;
+        }
+        if (a.out_rows != 0) {  // truncated result stripe
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint32_t blk = base + ((uint32_t)j << s);
+                if (blk < a.out_rows) store_vec<V>(a.out + (size_t)blk * a.ld + col, x[j]);
             }
             return;
         }

@@ -22,6 +22,8 @@ struct PassArgs {
     uint64_t items;          // filled by the launcher
     int fold;                // MID only: keep every 2^fold-th output block, written compactly (fewer parity than data blocks)
     uint32_t batch;          // > 1: that many stripes stored back to back are transformed by one launch
+    uint32_t in_rows;        // > 0: `in` holds only that many blocks, the rest of the stripe reads as zero (zero-extended codes)
+    uint32_t out_rows;       // > 0: only that many blocks of the result exist in `out`, the rest is not written
     // DIF only, optional (the decoder's first pass): input block u is block u/2 of `in` (u even) or of `in_odd` (u odd),
     // multiplied by row_factor[u] (Montgomery form); a zero factor means "erased": the block is not read at all
     const uint32_t* in_odd;
@@ -49,6 +51,8 @@ struct TileArgs {
     const uint32_t* in_odd;      // wide DIF tiles, optional: as PassArgs::in_odd / row_factor (the decoder's first pass)
     const uint32_t* row_factor;
     uint32_t batch;       // > 1: that many stripes stored back to back are transformed by one launch
+    uint32_t in_rows;     // > 0: `in` holds only that many blocks, the rest reads as zero (buffer bounds check does it)
+    uint32_t out_rows;    // > 0: only that many blocks exist in `out`, stores beyond are dropped (same mechanism)
     bool wide;            // DIF/DIT pair tiles whose blocks span 2^32..2^33 bytes: two address windows per tile
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)

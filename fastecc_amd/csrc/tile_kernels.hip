@@ -150,14 +150,14 @@ struct TileView {
     __amdgpu_buffer_rsrc_t in_hi, out_hi;
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, uint32_t num_records = 0xFFFFFFFFu)
 {
     // the pointer is wave-uniform; passing its halves through readfirstlane makes that provable to the
     // compiler, which otherwise wraps every buffer op in a waterfall loop (cdna_hip_programming.md T20)
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0xFFFFFFFFu, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(num_records), 0x00020000);
 }
 
 template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, bool WIDE = false>
@@ -220,12 +220,23 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         v.hi = grp >> s;
         v.dead_mask = (cc * W + c < a.S) ? 0u : 0xFFFFFFFFu;
         const size_t origin = (size_t)((v.hi << (s + LOGT)) + v.lo) * a.ld + cc * W;
-        v.in = make_desc(a.in + origin);
-        v.out = make_desc(a.out + (fold ? (size_t)((v.hi << LOGT) >> fold) * a.ld + cc * W : origin));
+        // A stripe that holds only `rows` blocks (zero-extended data, truncated parity): the descriptor ends after the
+        // last existing block of this column chunk, so loads beyond return 0 and stores beyond are dropped.
+        auto window = [&](uint32_t rows, size_t first_block) -> uint32_t {
+            if (rows == 0) return 0xFFFFFFFFu;
+            if (first_block >= rows) return 0u;
+            const uint64_t bytes = ((uint64_t)(rows - first_block) * a.ld - cc * W) * 4u;
+            return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes;
+        };
+        const size_t block0 = (size_t)(v.hi << (s + LOGT)) + v.lo;
+        const size_t out_block0 = fold ? (size_t)((v.hi << LOGT) >> fold) : block0;
+        v.in = make_desc(a.in + origin, window(a.in_rows, block0));
+        v.out = make_desc(a.out + (fold ? out_block0 * a.ld + cc * W : origin), window(a.out_rows, out_block0));
         if constexpr (WIDE) {
             const size_t upper = origin + ((size_t)(T / 2) << s) * a.ld;
-            v.in_hi = make_desc(a.in + upper);
-            v.out_hi = make_desc(a.out + upper);
+            const size_t upper_block0 = block0 + ((size_t)(T / 2) << s);
+            v.in_hi = make_desc(a.in + upper, window(a.in_rows, upper_block0));
+            v.out_hi = make_desc(a.out + upper, window(a.out_rows, upper_block0));
             if (gather) {
                 const uint32_t* half_stripe = (v.lo & 1u) ? a.in_odd : a.in;
                 const size_t o = (size_t)((v.hi << (s + LOGT - 1)) + (v.lo >> 1)) * a.ld + cc * W;

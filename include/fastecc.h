@@ -92,9 +92,10 @@ int fastecc_version(void);
  *                          g is f(g * w_k^j).  parity == data (in place) and fastecc_encode_blocks are not possible;
  *   any other k, n-k <= N  zero extension, exactly RS.md:23-33: the k data blocks are the first k of N (blocks k..N-1 are
  *                          zero and never exist in memory), M = max(N/16, 2^ceil(log2(n-k))) parity blocks of the
- *                          (N + M, N) code above are computed and the first n - k of them are the parity.  Costs one
- *                          extra copy of the data and, when n - k < M, of the parity.  GF(0xFFF00001) only; encode,
- *                          encode_blocks and check_range only (no ntt / scale_blocks / pack / decode).
+ *                          (N + M, N) code above are computed and the first n - k of them are the parity (no extra
+ *                          copies: the first and last kernels bound their reads / writes to the existing blocks).
+ *                          GF(0xFFF00001) only; encode, encode_blocks, check_range and decode (no ntt / scale_blocks /
+ *                          pack / encode_batch).
  * `parity` buffers hold n - k blocks.
  */
 int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);
