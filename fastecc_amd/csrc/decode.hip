@@ -30,6 +30,8 @@ namespace fastecc {
 
 struct DecodeState {
     fastecc_ctx* transform = nullptr;  // size-2k transform context, fold 1
+    fastecc_ctx* pattern_ntt = nullptr;  // same length, 2 words per block: l and l' are evaluated on the device
+    uint32_t* pattern_buf = nullptr;     // its stripe
     uint32_t* fin = nullptr;           // 2k factors by codeword position: l(w^u) (Montgomery) or 0 if erased
     uint32_t* fin_first_pass = nullptr;  // the same in the order the transform's first pass reads them (may equal fin)
     uint32_t* srcmap = nullptr;        // per codeword position: the block that sits there (row, bit 31 = parity stripe)
@@ -46,6 +48,8 @@ void destroy_decode_state(DecodeState* d)
 {
     if (!d) return;
     if (d->transform) fastecc_destroy(d->transform);
+    if (d->pattern_ntt) fastecc_destroy(d->pattern_ntt);
+    if (d->pattern_buf) (void)hipFree(d->pattern_buf);
     if (d->fin_first_pass && d->fin_first_pass != d->fin) (void)hipFree(d->fin_first_pass);
     if (d->fin) (void)hipFree(d->fin);
     if (d->srcmap) (void)hipFree(d->srcmap);
@@ -335,7 +339,6 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     }
 
     // ---- pattern-only scalars ----
-    const HostNtt& t = host_ntt();
     const uint32_t w = gf::h_root((uint32_t)NC);
     std::vector<uint32_t> wpow(NC);  // w^u
     {
@@ -348,15 +351,27 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     std::vector<uint32_t> roots(erased.size());
     for (size_t i = 0; i < erased.size(); i++) roots[i] = wpow[erased[i]];
     const std::vector<uint32_t> l = poly_from_roots(roots);  // degree |E| <= NC - N < NC
-    std::vector<uint32_t> lval(NC, 0), lder(NC, 0);
-    std::copy(l.begin(), l.end(), lval.begin());
-    for (size_t m = 0; m + 1 < l.size(); m++) lder[m] = gf::h_mul((uint32_t)((m + 1) % P), l[m + 1]);
-    t.dif(lval.data(), lgc, false);  // value at w^u sits at index bitrev(u)
-    t.dif(lder.data(), lgc, false);
+    // values of l and l' on all NC points: one forward transform of a two-column stripe (column 0 = l, column 1 = l'),
+    // on the device — the same kernels as everything else, natural order in and out
+    std::vector<uint32_t> lv(2 * NC, 0);
+    for (size_t m = 0; m < l.size(); m++) lv[2 * m] = l[m];
+    for (size_t m = 0; m + 1 < l.size(); m++) lv[2 * m + 1] = gf::h_mul((uint32_t)((m + 1) % P), l[m + 1]);
+    if (!d->pattern_ntt) {
+        const std::vector<uint32_t> ones(NC, 1u);
+        const int rc = create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
+        if (rc != FASTECC_OK) return rc;
+        DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
+    }
+    DEC_TRY(hipMemcpy(d->pattern_buf, lv.data(), 2 * NC * 4, hipMemcpyHostToDevice));
+    {
+        const int rc = fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, nullptr);
+        if (rc != FASTECC_OK) return rc;
+    }
+    DEC_TRY(hipMemcpy(lv.data(), d->pattern_buf, 2 * NC * 4, hipMemcpyDeviceToHost));
 
     std::vector<uint32_t> fin(NC, 0), gout(N, 0);
     for (uint64_t u = 0; u < NC; u++)  // zero blocks contribute 0 * l(w^u): factor 0 keeps every kernel from reading them
-        if (state[u] == HELD) fin[u] = gf::h_to_mont(lval[bitrev_bits((uint32_t)u, lgc)]);
+        if (state[u] == HELD) fin[u] = gf::h_to_mont(lv[2 * u]);
     {
         // 1 / (w^u l'(w^u)) for the erased data positions with ONE inversion (prefix products)
         std::vector<uint32_t> den, prefix;
@@ -364,7 +379,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         for (uint64_t i = 0; i < ci.user_k; i++) {
             if (data_present[i]) continue;
             const uint64_t u = i << e;
-            const uint32_t v = gf::h_mul(wpow[u], lder[bitrev_bits((uint32_t)u, lgc)]);
+            const uint32_t v = gf::h_mul(wpow[u], lv[2 * u + 1]);
             if (v == 0) return FASTECC_E_INVAL;  // cannot happen: l has simple roots
             den.push_back(v);
             who.push_back(i);
