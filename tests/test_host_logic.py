@@ -108,3 +108,17 @@ def test_level_tables_hold_the_reference_roots(hip_lib, oracle, log2k, plan):
                 pos = h + (((i & ((1 << sl[l]) - 1)) << t) | (i >> sl[l]))
                 want = (oracle.gf_pow(root, i) << 32) % P
                 assert int(tab[pos]) == want, (which, l, i)
+
+
+def test_tile_eligibility_follows_the_block_span(hip_lib):
+    """32-bit buffer offsets: an outer tile must span < 2^32 bytes, or < 2^33 with the two-window (W) form; beyond that
+    the top levels fall back to register passes with 64-bit addressing."""
+    assert describe(hip_lib, 1 << 19, 4096)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")
+    assert describe(hip_lib, 1 << 19, 8192)[1].startswith("SW32:dif9@10,T32:mid10@0,SW32:dit9@10")
+    assert describe(hip_lib, 1 << 18, 16384)[1].startswith("SW32:dif8@10,T32:mid10@0,SW32:dit8@10")
+    kinds = [p[0] for p in parse(describe(hip_lib, 1 << 19, 65536)[1])]
+    assert kinds == ["reg", "reg", "T32", "reg", "reg"]
+    assert describe(hip_lib, 128, 4096)[1].startswith("T32:mid7@0")
+    # MID (contiguous blocks) stays a tile as long as 1024 blocks fit the offsets
+    assert parse(describe(hip_lib, 1 << 12, 1 << 21)[1])[1][0] == "T32"
+    assert all(p[0] == "reg" for p in parse(describe(hip_lib, 1 << 12, 1 << 23)[1]))
