@@ -148,19 +148,32 @@ std::vector<uint32_t> poly_mul(const std::vector<uint32_t>& a, const std::vector
         }
         return c;
     }
+    // Two monic polynomials of the same power-of-two degree d (every product of the tree except at its ragged edge):
+    // (x^d + a')(x^d + b') = x^2d + x^d (a' + b') + a' b', and a' b' has degree < 2d, so a cyclic product of length 2d
+    // is enough — half the transform length of the general case below.
+    const size_t d = a.size() - 1;
+    const bool monic_pair = a.size() == b.size() && (d & (d - 1)) == 0 && a[d] == 1u && b[d] == 1u;
+    const size_t cyc = monic_pair ? 2 * d : need;
     int logn = 0;
-    while (((size_t)1 << logn) < need) logn++;
+    while (((size_t)1 << logn) < cyc) logn++;
     const size_t n = (size_t)1 << logn;
     std::vector<uint32_t> fa(n, 0), fb(n, 0);
-    std::copy(a.begin(), a.end(), fa.begin());
-    std::copy(b.begin(), b.end(), fb.begin());
+    std::copy(a.begin(), a.end() - (monic_pair ? 1 : 0), fa.begin());
+    std::copy(b.begin(), b.end() - (monic_pair ? 1 : 0), fb.begin());
     const HostNtt& t = host_ntt();
     t.dif(fa.data(), logn, false);
     t.dif(fb.data(), logn, false);
-    const uint32_t inv_n = gf::h_inv((uint32_t)n);
-    for (size_t i = 0; i < n; i++) fa[i] = h_mont(fa[i], gf::h_to_mont(gf::h_mul(fb[i], inv_n)));
+    // fa * fb / n through two Montgomery steps: (fa fb / R) * (R^2 / n) / R
+    const uint32_t scale = gf::h_to_mont(gf::h_to_mont(gf::h_inv((uint32_t)n)));
+    for (size_t i = 0; i < n; i++) fa[i] = h_mont(h_mont(fa[i], fb[i]), scale);
     t.dit(fa.data(), logn, true);  // the bit-reversed products go straight back: no permutation anywhere
-    std::copy(fa.begin(), fa.begin() + need, c.begin());
+    if (monic_pair) {
+        std::copy(fa.begin(), fa.begin() + 2 * d, c.begin());
+        for (size_t i = 0; i < d; i++) c[d + i] = h_add(c[d + i], h_add(a[i], b[i]));
+        c[2 * d] = 1u;
+    } else {
+        std::copy(fa.begin(), fa.begin() + need, c.begin());
+    }
     return c;
 }
 
