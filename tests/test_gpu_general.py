@@ -111,3 +111,32 @@ def test_matches_the_unmodified_reference_on_the_padded_stripe(torch_cuda, fe):
         out = torch_cuda.empty(m * S, dtype=torch_cuda.int32, device="cuda:0")
         enc.encode(to_dev(torch_cuda, x), out)
         assert (to_host(out, (m, S)) == want).all()
+
+
+def test_random_codes_round_trip(torch_cuda, fe, oracle):
+    """Forty random (n, k, block size, erasure pattern) combinations: encode == oracle on the padded stripe, then
+    lose up to n - k blocks and decode back."""
+    torch = torch_cuda
+    rng = np.random.default_rng(20240926)
+    for case in range(40):
+        k = int(rng.integers(1, 3000))
+        N = 1 << max(1, int(np.ceil(np.log2(k))))
+        m = int(rng.integers(1, N + 1))
+        S = int(rng.choice([1, 2, 5, 16, 33, 64, 100]))
+        x = rng.integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+        want = expected(oracle, x, m)
+        with fe.Encoder(k + m, k, 4 * S) as enc:
+            out = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+            enc.encode(to_dev(torch, x), out)
+            assert (to_host(out, (m, S)) == want).all(), (case, k, m, S, enc.plan())
+            nlost = int(rng.integers(0, m + 1))
+            lost = rng.permutation(k + m)[:nlost]
+            dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+            dp[lost[lost < k]] = 0
+            pp[lost[lost >= k] - k] = 0
+            damaged = x.copy()
+            damaged[dp == 0] = 0xA5A5A5A5
+            enc.decode_prepare(dp, pp)
+            dd = to_dev(torch, damaged)
+            enc.decode(dd, out)
+            assert (to_host(dd, (k, S)) == x).all(), (case, k, m, S, nlost)
