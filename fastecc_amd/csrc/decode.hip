@@ -194,13 +194,6 @@ std::vector<uint32_t> poly_from_roots(const std::vector<uint32_t>& roots)
     return level[0];
 }
 
-uint32_t bitrev_bits(uint32_t v, int bits)
-{
-    uint32_t r = 0;
-    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (bits - 1 - b);
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // kernels: one wave per (block row, 64*V-word column chunk); the row's factor is a scalar
 // ------------------------------------------------------------------------------------------------
