@@ -1,8 +1,9 @@
-// decode.hip — erasure decoding for the (2k,k) code of RS.cpp, the "fastest" scheme of README.md:102-119 / RS.md:42-79.
+// decode.hip — erasure decoding, the "fastest" scheme of README.md:102-119 / RS.md:42-79, for every code of this library.
 //
-// The reference documents this algorithm and does not implement it.  The codeword is f on the 2k-th roots of unity:
-// position u <-> point w^u (w = w_2k), even positions are the data blocks (u = 2i), odd ones the parity blocks
-// (u = 2j+1, RS.cpp:51-54).  With E the erased positions (|E| <= k) and l(x) = prod_{e in E} (x - w^e):
+// The reference documents this algorithm and does not implement it.  For the reference's (2k,k) code the codeword is f
+// on the 2k-th roots of unity: position u <-> point w^u (w = w_2k), even positions are the data blocks (u = 2i), odd
+// ones the parity blocks (u = 2j+1, RS.cpp:51-54).  With E the erased positions (|E| <= k) and
+// l(x) = prod_{e in E} (x - w^e):
 //
 //   p = f * l has degree < 2k and KNOWN values everywhere: c[u] * l(w^u) at surviving positions, 0 at erased ones;
 //   p'(w^e) = f(w^e) * l'(w^e) at an erased position, so  f(w^e) = [x p'(x)](w^e) / (w^e * l'(w^e)).
@@ -10,10 +11,14 @@
 // x p'(x) = sum m p_m x^m needs no coefficient shift, which makes the data-parallel part the SAME pipeline as the
 // encoder one size up: inverse transform of size 2k, block holding coefficient m times m / 2k, forward transform —
 // i.e. create_transform_ctx(2k, factor[m] = m / 2k) with fold = 1, because only the even (data) positions are wanted.
-// Around it: one gather pass (codeword blocks times l(w^u), zeros at erasures) and one pass that multiplies the
-// recovered rows by 1 / (w^e l'(w^e)).  Everything that depends only on the erasure PATTERN (l by a product tree,
-// its values and its derivative's values by two host transforms of size 2k, one batch inversion) is scalar work
-// done once in fastecc_decode_prepare on the host.
+// Around it: a gather (codeword blocks times l(w^u), zeros at erasures; fused into the transform's first pass for the
+// (2k,k) layout) and one pass that multiplies the recovered rows by 1 / (w^e l'(w^e)).
+//
+// The other codes are the same thing on the (k << e)-th roots of unity (fastecc_decode_prepare): positions that hold no
+// block of the code count as erased, zero-extended data blocks as known zeros, the transform has fold = e.
+//
+// Everything that depends only on the erasure PATTERN is done once in fastecc_decode_prepare: l by a product tree on the
+// host, its values and its derivative's values by one device transform of a two-column stripe, one batch inversion.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
