@@ -8,10 +8,11 @@
  * Conventions
  *   - Field: GF(p), p = 0xFFF00001 (RS.cpp:86).  Words are native little-endian uint32, every input
  *     word must be < p (README.md:160-162); every output word is the canonical value in [0,p).
- *   - Code: (n,k) = (2N,N), N = 2^m, 1 <= m <= 19 (RS.cpp:36,82; GF.md:20).  A "block" is
+ *   - Code: the reference's (n,k) = (2N,N), N = 2^m, 1 <= m <= 19 (RS.cpp:36,82; GF.md:20).  A "block" is
  *     block_bytes/4 consecutive words; a stripe is N blocks back to back (block-major), exactly the
  *     layout RS.cpp:28-33 builds.  parity block j = f(w_2N^(2j+1)) where f interpolates the data
- *     blocks at the powers of w_N = 19^((p-1)/N)   (RS.cpp:40-63).
+ *     blocks at the powers of w_N = 19^((p-1)/N)   (RS.cpp:40-63).  Other (n,k) — see fastecc_create — evaluate the same
+ *     f on other points; a second field (FASTECC_FIELD_GF_P61_SQUARED) exists for 64-bit words.
  *   - All functions return FASTECC_OK (0) or a negative FASTECC_E_* code; no exceptions cross the
  *     ABI and nothing is printed.  The reference returns void and has no error path (RS.cpp:26 prints
  *     and returns on allocation failure); preconditions it leaves implicit are checked here.
@@ -237,7 +238,9 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *   "row_pitch_words" = L >= block_bytes/4 (0 = contiguous): DEVICE stripes given to fastecc_encode are [k][L]
  *                  words, the first block_bytes/4 of each row valid, the rest untouched.  Lets a host that owns its
  *                  HBM layout pad odd block sizes (2052, 4100 bytes) to a multiple of 128 bytes: +50 % throughput.
- *                  Other entry points return FASTECC_E_UNSUPPORTED while a pitch is set;
+ *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
+ *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
+ *   "host_slabs" = 1, 2, 4 or 8 (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
  *   "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
  * behind the previous, so that different kinds of passes overlap on the GPU.  The call still
  * behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream`
