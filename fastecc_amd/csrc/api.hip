@@ -34,7 +34,7 @@ struct Pass {
     bool tile;  // LDS-tiled kernel (tile_kernels.hip) instead of a register pass (kernels.hip)
     bool pair;  // tile only: 32-word rows with the cross-lane top level
     int rlog;   // tile only: log2 of the words a lane keeps in registers (5, or 4 for the slim outer tiles)
-    bool wide = false;  // tile only: the tile's blocks span 2^32..2^33 bytes and are addressed through two windows
+    int wide = 0;  // tile only: the tile's blocks span >= 2^32 bytes and are addressed through this many windows (2, 4, 8)
 };
 
 struct ProfileRec {
@@ -174,12 +174,14 @@ void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastec
     // with fold > 0 the DIT passes above MID run on the compact parity stripe: their strides are 2^fold smaller
     const int s_run = mode == MODE_DIT ? s - c->fold : s;
     const bool fits = tile_fits(c, bits, s_run);
-    // one size up: two address windows per tile (tile_kernels.hip WIDE), only for the outer pair shapes that have it
-    const bool fits_wide = !fits && tile_fits(c, bits - 1, s_run);
-    if (c->tile_mid > 0 && fits_wide && c->slim_outer && tile_supported(bits, true, 4) && tile_wide_supported(bits, true, 4))
-        plan.push_back({mode, bits, s, true, true, 4, true});
-    else if (c->tile_mid > 0 && fits_wide && tile_supported(bits, true) && tile_wide_supported(bits, true))
-        plan.push_back({mode, bits, s, true, true, 5, true});
+    // larger spans: 2, 4 or 8 address windows per tile (tile_kernels.hip NWIN), only for the outer pair shapes that have them
+    int windows = 0;
+    for (int lw = 1; lw <= 3 && !fits && windows == 0; lw++)
+        if (bits - lw >= 1 && tile_fits(c, bits - lw, s_run)) windows = 1 << lw;
+    if (c->tile_mid > 0 && windows && c->slim_outer && tile_supported(bits, true, 4) && tile_max_windows(bits, true, 4) >= windows)
+        plan.push_back({mode, bits, s, true, true, 4, windows});
+    else if (c->tile_mid > 0 && windows && tile_supported(bits, true) && tile_max_windows(bits, true) >= windows)
+        plan.push_back({mode, bits, s, true, true, 5, windows});
     else if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
     else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
     else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
@@ -240,7 +242,7 @@ void build_plans(fastecc_ctx* c)
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
-        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? "SW32:" : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : "SW8x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
@@ -865,7 +867,7 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     // the first pass must be able to read the two half stripes itself: a register DIF pass or a two-window DIF tile
     if (c->encode_plan.empty() || c->p61) return FASTECC_E_UNSUPPORTED;
     const Pass& p0 = c->encode_plan[0];
-    if (p0.mode != MODE_DIF || p0.s < 1 || (p0.tile && !p0.wide)) return FASTECC_E_UNSUPPORTED;
+    if (p0.mode != MODE_DIF || p0.s < 1 || (p0.tile && p0.wide != 2)) return FASTECC_E_UNSUPPORTED;
     if (c->fold == 0 && c->cosets == 1) return FASTECC_E_UNSUPPORTED;  // needs the staged form (first pass writes the scratch stripe)
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;

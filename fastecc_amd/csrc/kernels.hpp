@@ -53,7 +53,7 @@ struct TileArgs {
     uint32_t batch;       // > 1: that many stripes stored back to back are transformed by one launch
     uint32_t in_rows;     // > 0: `in` holds only that many blocks, the rest reads as zero (buffer bounds check does it)
     uint32_t out_rows;    // > 0: only that many blocks exist in `out`, stores beyond are dropped (same mechanism)
-    bool wide;            // DIF/DIT pair tiles whose blocks span 2^32..2^33 bytes: two address windows per tile
+    int wide;             // DIF/DIT pair tiles whose blocks span >= 2^32 bytes: address windows per tile (2, 4, 8; 0 = one)
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
 };
@@ -62,6 +62,7 @@ hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
 bool tile_supported(int logt, bool pair, int logr = 5);
 int tile_max_fold(int logt, bool pair, int logr = 5);
 bool tile_wide_supported(int logt, bool pair, int logr = 5);
+int tile_max_windows(int logt, bool pair, int logr = 5);
 hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& a, hipStream_t st);
 hipError_t launch_bitrev_rows(uint32_t* data, uint32_t S, int n, int vec, hipStream_t st);
 hipError_t launch_scale_rows(uint32_t* data, const uint32_t* factor, uint32_t S, uint64_t rows, int vec, hipStream_t st);

@@ -148,6 +148,10 @@ struct TileView {
     // WIDE tiles only: descriptors of the upper half of the tile's blocks (block T/2 onwards).  A tile whose blocks span
     // up to 2^33 bytes is then addressed as two windows of < 2^32 bytes each.
     __amdgpu_buffer_rsrc_t in_hi, out_hi;
+    // MULTI tiles only: where the tile starts, descriptors are built per window (nothing but two pointers stays live)
+    const uint32_t* in_base;
+    uint32_t* out_base;
+    uint32_t first_block;  // stripe block of tile block 0 (for the in_rows / out_rows bounds)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, uint32_t num_records = 0xFFFFFFFFu)
@@ -160,10 +164,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, u
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(num_records), 0x00020000);
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, bool WIDE = false>
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, int NWIN = 1>
 __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
-    static_assert(!WIDE || (PAIR && MODE != MODE_MID && !PREFETCH), "WIDE: outer pair tiles only");
+    // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
+    // SGPRs, < 2^33), 4 / 8 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 / 2^35)
+    constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
+    static_assert(NWIN == 1 || (PAIR && MODE != MODE_MID && !PREFETCH), "windows: outer pair tiles only");
+    static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8, "1, 2, 4 or 8 windows");
+    static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
     using View = TileView;
     constexpr int R = C::R, G = C::G, W = C::W, L2 = C::L2, T = C::T;
@@ -232,6 +241,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const size_t out_block0 = fold ? (size_t)((v.hi << LOGT) >> fold) : block0;
         v.in = make_desc(a.in + origin, window(a.in_rows, block0));
         v.out = make_desc(a.out + (fold ? out_block0 * a.ld + cc * W : origin), window(a.out_rows, out_block0));
+        if constexpr (MULTI) {
+            v.in_base = a.in + origin;
+            v.out_base = a.out + origin;
+            v.first_block = (uint32_t)block0;
+        }
         if constexpr (WIDE) {
             const size_t upper = origin + ((size_t)(T / 2) << s) * a.ld;
             const size_t upper_block0 = block0 + ((size_t)(T / 2) << s);
@@ -249,10 +263,26 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // WIDE, layout B (the only one that goes through load_rows/store_rows in a pair tile): a wave's blocks
     // [2g*R, 2g*R + 2R) lie entirely in one window
     const bool upper_wave = WIDE && g >= G / 2;
+    // MULTI: window w covers tile blocks [w*T/NWIN, (w+1)*T/NWIN)
+    auto window_desc = [&](const uint32_t* base, uint32_t rows, const View& v, uint32_t w) {
+        const size_t first = (size_t)v.first_block + ((size_t)(w * (T / NWIN)) << s);
+        uint32_t nrec = 0xFFFFFFFFu;
+        if (rows != 0) {
+            const uint32_t cc_words = (uint32_t)((base - (v.first_block * (size_t)a.ld + (base == v.in_base ? a.in : a.out))));  // = cc * W
+            const uint64_t bytes = first >= rows ? 0 : ((uint64_t)(rows - first) * a.ld - cc_words) * 4u;
+            nrec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes;
+        }
+        return make_desc(base + ((size_t)(w * (T / NWIN)) << s) * a.ld, nrec);
+    };
+    const uint32_t my_window = MULTI ? g * NWIN / G : 0u;  // layout B: a wave's blocks [2g*R, 2g*R + 2R) lie in one window
     auto load_rows = [&](uint32_t (&r)[R][1], const View& vv, uint32_t lane_off, uint32_t q0, uint32_t qstep) {
         View v = vv;
         if constexpr (WIDE) {
             if (upper_wave) v.in = vv.in_hi, q0 -= T / 2;
+        }
+        if constexpr (MULTI) {
+            v.in = window_desc(vv.in_base, a.in_rows, vv, my_window);
+            q0 -= my_window * (T / NWIN);
         }
         const uint32_t voff = lane_off | v.dead_mask;
         // running block offset kept in ONE SGPR: the empty asm stops the compiler from materialising all R
@@ -275,6 +305,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         if constexpr (WIDE) {
             if (upper_wave) v.out = vv.out_hi, q0 -= T / 2;
         }
+        if constexpr (MULTI) {
+            v.out = window_desc(vv.out_base, a.out_rows, vv, my_window);
+            q0 -= my_window * (T / NWIN);
+        }
         const uint32_t voff = lane_off | v.dead_mask;
         uint32_t soff = q0 * row_bytes;
         const uint32_t step = qstep * row_bytes;
@@ -290,6 +324,26 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // Paired order of a PAIR tile: register 2i <-> block g + 2i*G (+ G in the high half-wave), register 2i+1 <-> that
     // block + T/2.  Two running scalar offsets.
     auto load_paired = [&](uint32_t (&r)[R][1], const View& v) {
+        if constexpr (MULTI) {
+            // register 2i + e <-> tile block g + 2i*G (+ G) + e*T/2: window e*NWIN/2 + i / (R/NWIN), and inside it the same
+            // running offset as the single-window form, restarted
+            constexpr int PER = R / NWIN;
+            const uint32_t voff = lane_p | v.dead_mask, step = 2 * G * row_bytes;
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) {
+                const __amdgpu_buffer_rsrc_t d = window_desc(v.in_base, a.in_rows, v, w);
+                uint32_t soff = g * row_bytes;
+#pragma unroll
+                for (int ii = 0; ii < PER; ++ii) {
+                    const int j = 2 * ((w % (NWIN / 2)) * PER + ii) + w / (NWIN / 2);
+                    r[j][0] = (a.cache_policy & 1) ? __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 2)
+                                                   : __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0);
+                    soff += step;
+                    asm volatile("" : "+s"(soff));
+                }
+            }
+            return;
+        }
         const uint32_t rb = gather ? row_bytes >> 1 : row_bytes;  // gather: the half stripes have half the block stride
         const uint32_t voff = (gather ? ((((half * G) << (s - 1)) * a.ld) + c) * 4u : lane_p) | v.dead_mask;
         uint32_t soff = g * rb;
@@ -306,6 +360,24 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 #undef FASTECC_LOAD_LOOP
     };
     auto store_paired = [&](const uint32_t (&r)[R][1], const View& v) {
+        if constexpr (MULTI) {
+            constexpr int PER = R / NWIN;
+            const uint32_t voff = lane_p | v.dead_mask, step = 2 * G * row_bytes;
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) {
+                const __amdgpu_buffer_rsrc_t d = window_desc(v.out_base, a.out_rows, v, w);
+                uint32_t soff = g * row_bytes;
+#pragma unroll
+                for (int ii = 0; ii < PER; ++ii) {
+                    const int j = 2 * ((w % (NWIN / 2)) * PER + ii) + w / (NWIN / 2);
+                    if (a.cache_policy & 2) __builtin_amdgcn_raw_buffer_store_b32(r[j][0], d, voff, soff, 2);
+                    else                    __builtin_amdgcn_raw_buffer_store_b32(r[j][0], d, voff, soff, 0);
+                    soff += step;
+                    asm volatile("" : "+s"(soff));
+                }
+            }
+            return;
+        }
         // with fold: block q = g + 2i*G (+ G) (+ T/2) goes to q >> fold; G, T/2 and (for the waves that store) g are multiples of 2^fold
         const uint32_t voff = (fold ? ((half * (G >> fold)) * a.ld + c) * 4u : lane_p) | v.dead_mask;
         uint32_t soff = (g >> fold) * row_bytes;
@@ -472,11 +544,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, bool WIDE = false>
+template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, int NWIN = 1>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT, WIDE>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT, NWIN>;
     // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
     static bool configured[64] = {};
     int dev = 0;
@@ -510,13 +582,21 @@ template <int LOGT, int LOGR, bool PAIR>
 static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 {
     if (a.wide) {
-        // two address windows per tile (blocks spanning up to 2^33 bytes): outer passes of the shapes the plans use
+        // several address windows per tile (blocks spanning up to 2^33 / 2^34 / 2^35 bytes): outer passes of the shapes the plans use
         if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
-            if (mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2, true>(a, st);
-            if (mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2, true>(a, st);
+            if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2, 2>(a, st);
+            if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2, 2>(a, st);
         } else if constexpr (LOGR == 4) {
-            if (mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, true>(a, st);
-            if (mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, true>(a, st);
+            if (mode == MODE_DIF) {
+                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 2>(a, st);
+                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 4>(a, st);
+                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 8>(a, st);
+            }
+            if (mode == MODE_DIT) {
+                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 2>(a, st);
+                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 4>(a, st);
+                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 8>(a, st);
+            }
         }
         return hipErrorInvalidValue;
     }
@@ -540,7 +620,15 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
 }
 
 // Shapes with a two-window (WIDE) DIF/DIT instantiation, see launch_mode.
-bool tile_wide_supported(int logt, bool pair, int logr) { return pair && ((logr == 5 && logt == 10) || (logr == 4 && (logt == 8 || logt == 9))); }
+// Returns the largest window count of the shape (0 = none): see launch_mode.
+int tile_max_windows(int logt, bool pair, int logr)
+{
+    if (!pair) return 0;
+    if (logr == 5 && logt == 10) return 2;
+    if (logr == 4 && (logt == 8 || logt == 9)) return 8;
+    return 0;
+}
+bool tile_wide_supported(int logt, bool pair, int logr) { return tile_max_windows(logt, pair, logr) >= 2; }
 
 // Largest fold a MID tile supports: 2^fold must divide its wave stride G = 2^L2.
 int tile_max_fold(int logt, bool pair, int logr) { return logt - logr - (pair ? 1 : 0); }

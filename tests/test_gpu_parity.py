@@ -497,28 +497,30 @@ def test_pinned_host_stripes_through_the_slab_pipeline(torch_cuda, fe, oracle, l
             enc.ntt(hdata.data_ptr(), mem=fe.MEM_HOST_PINNED)   # only fastecc_encode knows this kind
 
 
-def test_two_window_tiles_for_blocks_spanning_4_to_8_gib(torch_cuda, fe, oracle):
-    """k = 2^18 blocks of 16 KiB: the outer 8-level tiles span 2^32 bytes and use two address windows per tile
-    (TileArgs::wide).  Checked against the register-pass plan on the device and against the oracle on sampled columns."""
+@pytest.mark.parametrize("S,tag", [(4096, "SW32:"), (8192, "SW4x32:"), (16384, "SW8x32:")])
+def test_windowed_tiles_for_blocks_spanning_4_to_32_gib(torch_cuda, fe, oracle, S, tag):
+    """k = 2^18 blocks of 16 / 32 / 64 KiB: the outer 8-level tiles span 2^32 / 2^33 / 2^34 bytes and use 2 / 4 / 8
+    address windows per tile (TileArgs::wide).  Checked against the register-pass plan on the device and against the
+    oracle on sampled columns."""
     torch = torch_cuda
+    N = 1 << 18
     free, _ = torch.cuda.mem_get_info()
-    if free < 40 * (1 << 30):
-        pytest.skip("needs 16 GiB of HBM")
-    N, S = 1 << 18, 4096
+    if free < 3.3 * N * S * 4 + (2 << 30):
+        pytest.skip("needs %d GiB of HBM" % (3.3 * N * S * 4 / 2**30))
     g = torch.Generator(device="cuda:0").manual_seed(23)
     data = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
     for i in range(0, N * S, 1 << 28):
         data[i:i + (1 << 28)] = torch.randint(0, P, (min(1 << 28, N * S - i),), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
     a, b = torch.empty_like(data), torch.empty_like(data)
     with fe.Encoder(2 * N, N, 4 * S) as enc:
-        assert "W32:" in enc.plan(), enc.plan()
+        assert tag in enc.plan(), enc.plan()
         enc.encode(data, a)
         enc.set_plan(51)
         enc.encode(data, b)
         torch.cuda.synchronize()
     assert bool((a == b).all())
     d2, a2 = data.view(N, S), a.view(N, S)
-    for c in (0, 31, 32, 4097, S - 1):
+    for c in (0, 31, 32, 4097 % S, S - 1):
         x = d2[:, c:c + 1].contiguous().cpu().numpy().view(np.uint32)
         assert np.array_equal(a2[:, c:c + 1].contiguous().cpu().numpy().view(np.uint32), oracle.encode_fast(x)), c
 
