@@ -176,7 +176,7 @@ void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastec
     const bool fits = tile_fits(c, bits, s_run);
     // larger spans: 2, 4 or 8 address windows per tile (tile_kernels.hip NWIN), only for the outer pair shapes that have them
     int windows = 0;
-    for (int lw = 1; lw <= 3 && !fits && windows == 0; lw++)
+    for (int lw = 1; lw <= 4 && !fits && windows == 0; lw++)
         if (bits - lw >= 1 && tile_fits(c, bits - lw, s_run)) windows = 1 << lw;
     if (c->tile_mid > 0 && windows && c->slim_outer && tile_supported(bits, true, 4) && tile_max_windows(bits, true, 4) >= windows)
         plan.push_back({mode, bits, s, true, true, 4, windows});
@@ -242,7 +242,7 @@ void build_plans(fastecc_ctx* c)
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
-        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : "SW8x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : p.wide == 8 ? "SW8x32:" : "SW16x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }

@@ -168,10 +168,10 @@ template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1,
 __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
-    // SGPRs, < 2^33), 4 / 8 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 / 2^35)
+    // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
     static_assert(NWIN == 1 || (PAIR && MODE != MODE_MID && !PREFETCH), "windows: outer pair tiles only");
-    static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8, "1, 2, 4 or 8 windows");
+    static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
     static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
     using View = TileView;
@@ -591,11 +591,17 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
                 if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 2>(a, st);
                 if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 4>(a, st);
                 if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 8>(a, st);
+                if constexpr (LOGT == 9) {
+                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 16>(a, st);
+                }
             }
             if (mode == MODE_DIT) {
                 if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 2>(a, st);
                 if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 4>(a, st);
                 if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 8>(a, st);
+                if constexpr (LOGT == 9) {
+                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 16>(a, st);
+                }
             }
         }
         return hipErrorInvalidValue;
@@ -625,7 +631,8 @@ int tile_max_windows(int logt, bool pair, int logr)
 {
     if (!pair) return 0;
     if (logr == 5 && logt == 10) return 2;
-    if (logr == 4 && (logt == 8 || logt == 9)) return 8;
+    if (logr == 4 && logt == 9) return 16;  // G = R = 16: one register pair per window at most
+    if (logr == 4 && logt == 8) return 8;
     return 0;
 }
 bool tile_wide_supported(int logt, bool pair, int logr) { return tile_max_windows(logt, pair, logr) >= 2; }

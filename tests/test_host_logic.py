@@ -111,14 +111,15 @@ def test_level_tables_hold_the_reference_roots(hip_lib, oracle, log2k, plan):
 
 
 def test_tile_eligibility_follows_the_block_span(hip_lib):
-    """32-bit buffer offsets: an outer tile must span < 2^32 bytes, or < 2^33 / 2^34 / 2^35 with 2 / 4 / 8 address windows
+    """32-bit buffer offsets: an outer tile must span < 2^32 bytes, or up to 2^36 with 2 … 16 address windows
     (W forms); beyond that the top levels fall back to register passes with 64-bit addressing."""
     assert describe(hip_lib, 1 << 19, 4096)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")
     assert describe(hip_lib, 1 << 19, 8192)[1].startswith("SW32:dif9@10,T32:mid10@0,SW32:dit9@10")
     assert describe(hip_lib, 1 << 18, 16384)[1].startswith("SW32:dif8@10,T32:mid10@0,SW32:dit8@10")
     assert describe(hip_lib, 1 << 19, 16384)[1].startswith("SW4x32:dif9@10,T32:mid10@0,SW4x32:dit9@10")
     assert describe(hip_lib, 1 << 19, 32768)[1].startswith("SW8x32:dif9@10,T32:mid10@0,SW8x32:dit9@10")
-    kinds = [p[0] for p in parse(describe(hip_lib, 1 << 19, 65536)[1])]   # 2^35-byte spans: past eight windows of < 2^32
+    assert describe(hip_lib, 1 << 19, 65536)[1].startswith("SW16x32:dif9@10,T32:mid10@0,SW16x32:dit9@10")
+    kinds = [p[0] for p in parse(describe(hip_lib, 1 << 19, 1 << 17)[1])]   # 2^36-byte spans: past sixteen windows of < 2^32
     assert kinds == ["reg", "reg", "T32", "reg", "reg"]
     assert describe(hip_lib, 128, 4096)[1].startswith("T32:mid7@0")
     # MID (contiguous blocks) stays a tile as long as 1024 blocks fit the offsets
