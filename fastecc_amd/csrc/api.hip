@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,17 +44,30 @@ struct ProfileRec {
     uint64_t bytes;  // algorithmic bytes of the launch (stripe or slab read once + written once)
 };
 
+// What one call adds to the plain "read `in`, write `out`" form of run_passes.
+struct CallBounds {
+    // zero-extended codes: the first pass reads a stripe of in_rows blocks (the rest is zero), the last pass writes the
+    // first out_rows blocks of its result to final_out
+    uint32_t in_rows = 0, out_rows = 0;
+    uint32_t* final_out = nullptr;
+    // decoder (run_gathered): see PassArgs::in_odd / row_factor
+    const uint32_t* gather_odd = nullptr;
+    const uint32_t* gather_factor = nullptr;
+};
+
 }  // namespace
 
 struct fastecc_ctx {
     int device = 0;
     int field = FASTECC_FIELD_GF_FFF00001;
-    // set only inside encode_device for zero-extended codes: the first pass reads a stripe of bound_in_rows blocks
-    // (the rest is zero), the last pass writes the first bound_out_rows blocks of its result to bound_final_out
-    uint32_t bound_in_rows = 0, bound_out_rows = 0;
-    uint32_t* bound_final_out = nullptr;
-    const uint32_t* gather_odd = nullptr;     // set only inside run_gathered (decoder): see PassArgs::in_odd
-    const uint32_t* gather_factor = nullptr;
+    // Calls on one context are serialised on the host (every entry point that enqueues work holds `mu`), and nothing
+    // about a call is stored here: what varies per call travels in a CallBounds on the caller's stack.  Work that
+    // uses the context's internal device buffers (scratch, parbuf, dbuf, ...) on a stream other than the previous one
+    // first waits for the previous use (buf_event), so one context may be driven from several streams.
+    std::mutex mu;
+    hipEvent_t buf_event = nullptr;
+    hipStream_t buf_stream = nullptr;
+    bool buf_used = false;
     DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
@@ -276,7 +290,11 @@ struct ProfScope {
         if (!c->profiling) return;
         if (c->prof_used == c->prof.size()) {
             ProfileRec r;
-            if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+            if (hipEventCreate(&r.start) != hipSuccess) return;
+            if (hipEventCreate(&r.stop) != hipSuccess) {
+                (void)hipEventDestroy(r.start);
+                return;
+            }
             c->prof.push_back(r);
         }
         rec = &c->prof[c->prof_used++];
@@ -303,7 +321,7 @@ struct ProfScope {
 //                writing blocks [t*k, (t+1)*k) of `out`.
 int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in, uint32_t* out, const uint32_t* tw_dif,
                const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr,
-               uint32_t batch = 1)
+               uint32_t batch = 1, const CallBounds& cb = CallBounds())
 {
     if (width == 0) width = (uint32_t)c->S;
     in += col0;
@@ -314,14 +332,17 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     const int cosets = is_encode ? c->cosets : 1;
     const bool staged = folded || cosets > 1;
     if (staged && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
-    const int vec = staged ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
+    int vec = staged ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
+    // the last pass may store to another buffer and the decoder's first pass reads a second one: they bound the lane vector too
+    if (cb.final_out) vec = std::min(vec, pick_vec(c, cb.final_out + col0, cb.final_out + col0));
+    if (cb.gather_odd) vec = std::min(vec, pick_vec(c, cb.gather_odd + col0, cb.gather_odd + col0));
 
     auto run_one = [&](const Pass& p, const uint32_t* src, uint32_t* dst, const uint32_t* dscale, bool last = false) -> int {
-        const uint32_t in_rows = src == in ? c->bound_in_rows : 0;
+        const uint32_t in_rows = src == in ? cb.in_rows : 0;
         uint32_t out_rows = 0;
-        if (last && c->bound_final_out) {
-            dst = c->bound_final_out + col0;
-            out_rows = c->bound_out_rows;
+        if (last && cb.final_out) {
+            dst = cb.final_out + col0;
+            out_rows = cb.out_rows;
         }
         const bool above_mid = folded && p.mode == MODE_DIT;
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
@@ -344,9 +365,9 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.batch = batch;
             a.in_rows = in_rows;
             a.out_rows = out_rows;
-            if (c->gather_factor && src == in) {  // first pass of the decoder's transform
-                a.in_odd = c->gather_odd;
-                a.row_factor = c->gather_factor;
+            if (cb.gather_factor && src == in) {  // first pass of the decoder's transform
+                a.in_odd = cb.gather_odd;
+                a.row_factor = cb.gather_factor;
             }
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.prefetch = c->prefetch;
@@ -373,9 +394,9 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.batch = batch;
             a.in_rows = in_rows;
             a.out_rows = out_rows;
-            if (c->gather_factor && src == in) {  // first pass of the decoder's transform
-                a.in_odd = c->gather_odd;
-                a.row_factor = c->gather_factor;
+            if (cb.gather_factor && src == in) {  // first pass of the decoder's transform
+                a.in_odd = cb.gather_odd;
+                a.row_factor = cb.gather_factor;
             }
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
@@ -453,7 +474,7 @@ struct P61Hooks {
     ~P61Hooks() { delete open; }
 };
 
-int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st);
+int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st, const CallBounds& cb = CallBounds());
 
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
@@ -463,20 +484,18 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
     // The passes in between need all M blocks somewhere: the caller's parity buffer when it is that large, else parbuf.
     const size_t row = (size_t)c->ld * 4;
     uint32_t* out = parity;
+    CallBounds cb;
     if (c->Mu != c->M) {
         if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->M * row));
         out = c->parbuf;
-        c->bound_final_out = parity;
-        c->bound_out_rows = (uint32_t)c->Mu;
+        cb.final_out = parity;
+        cb.out_rows = (uint32_t)c->Mu;
     }
-    c->bound_in_rows = c->K != c->N ? (uint32_t)c->K : 0;
-    const int rc = encode_pow2(c, data, out, st);
-    c->bound_in_rows = c->bound_out_rows = 0;
-    c->bound_final_out = nullptr;
-    return rc;
+    cb.in_rows = c->K != c->N ? (uint32_t)c->K : 0;
+    return encode_pow2(c, data, out, st, cb);
 }
 
-int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st, const CallBounds& cb)
 {
     if (c->p61) {
         P61Hooks hk(c);
@@ -486,7 +505,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
     const int H = c->slabs;
     const bool slabbed = c->fold == 0 && c->cosets == 1 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
                          (c->S % (32u * H)) == 0;
-    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st);
+    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, 1, cb);
 
     // Column slabs are independent transforms.  Slab h runs on its own stream and starts when slab h-1 has
     // finished its first pass, so that at any time the GPU holds one slab in each kind of pass: the
@@ -499,7 +518,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
         hipStream_t sh = c->slab_stream[h];
         HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
         if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));
-        rc = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width, c->slab_first_done[h]);
+        rc = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width, c->slab_first_done[h], 1, cb);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipEventRecord(c->slab_done[h], sh));
         HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
@@ -637,6 +656,32 @@ int ensure_dbuf(fastecc_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->dbuf, c->stripe_bytes));
     return FASTECC_OK;
 }
+
+// Ordering of the context's internal device buffers (scratch, parbuf, dbuf, factor, ...) between streams: work that
+// touches them waits for the previous such work when that ran on another stream.  The caller holds c->mu.
+int order_internal_buffers(fastecc_ctx* c, hipStream_t st)
+{
+    if (c->buf_used && c->buf_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->buf_event, 0));
+    return FASTECC_OK;
+}
+int mark_internal_buffers(fastecc_ctx* c, hipStream_t st)
+{
+    if (!c->buf_event) HIP_TRY(hipEventCreateWithFlags(&c->buf_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->buf_event, st));
+    c->buf_stream = st;
+    c->buf_used = true;
+    return FASTECC_OK;
+}
+// Runs `body` (which enqueues work on `st` that uses internal buffers) between the two.
+template <class F> int with_internal_buffers(fastecc_ctx* c, hipStream_t st, F body)
+{
+    int rc = order_internal_buffers(c, st);
+    if (rc != FASTECC_OK) return rc;
+    rc = body();
+    const int rc2 = mark_internal_buffers(c, st);  // also after a failure: part of the work may have been enqueued
+    return rc != FASTECC_OK ? rc : rc2;
+}
+using CallLock = std::lock_guard<std::mutex>;
 
 struct DeviceGuard {
     int prev = -1;
@@ -871,12 +916,10 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     if (c->fold == 0 && c->cosets == 1) return FASTECC_E_UNSUPPORTED;  // needs the staged form (first pass writes the scratch stripe)
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
-    c->gather_odd = odd_blocks;
-    c->gather_factor = row_factor;
-    const int rc = run_passes(c, c->encode_plan, even_blocks, out, c->tw_enc_dif, c->tw_enc_dit, st);
-    c->gather_odd = nullptr;
-    c->gather_factor = nullptr;
-    return rc;
+    CallBounds cb;
+    cb.gather_odd = odd_blocks;
+    cb.gather_factor = row_factor;
+    return run_passes(c, c->encode_plan, even_blocks, out, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, 1, cb);
 }
 
 bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
@@ -899,6 +942,16 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
                         order[k++] = pos0 + ((g + 2 * i * G + half * G + far * (T / 2)) << s);
     }
     return true;
+}
+
+CallScope::CallScope(fastecc_ctx* c) : c_(c) { c_->mu.lock(); }
+CallScope::~CallScope() { c_->mu.unlock(); }
+int CallScope::begin(hipStream_t st) { return order_internal_buffers(c_, st); }
+int CallScope::end(hipStream_t st) { return mark_internal_buffers(c_, st); }
+int CallScope::wait_idle()
+{
+    if (c_->buf_used) HIP_TRY(hipEventSynchronize(c_->buf_event));
+    return FASTECC_OK;
 }
 
 int scratch_of(fastecc_ctx* c, uint32_t** out)
@@ -933,6 +986,7 @@ void fastecc_destroy(fastecc_ctx* c)
         }
         if (c->slab_fork) (void)hipEventDestroy(c->slab_fork);
     }
+    if (c->buf_event) (void)hipEventDestroy(c->buf_event);
     p61::destroy(c->p61);
     if (c->tw_enc_dif) (void)hipFree(c->tw_enc_dif);
     if (c->tw_enc_dit) (void)hipFree(c->tw_enc_dit);
@@ -958,27 +1012,36 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
     if (c->Mu > c->K && parity == data) return FASTECC_E_INVAL;  // the parity is larger than the data
-    if (mem_kind == FASTECC_MEM_DEVICE) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
+    CallLock lk(c->mu);
+    if (mem_kind == FASTECC_MEM_DEVICE) {
+        // the reference's configuration touches nothing but the caller's buffers and the read-only tables: calls on
+        // different streams may overlap on the device.  The other codes work through scratch stripes of the context.
+        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1;
+        if (!internal) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
+        return with_internal_buffers(c, st, [&] { return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st); });
+    }
     if (mem_kind == FASTECC_MEM_HOST_PINNED) {
         if (c->p61 || c->fold != 0 || c->cosets != 1 || c->ld != c->S || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;
-        return encode_host_pinned(c, (const uint32_t*)data, (uint32_t*)parity, st);
+        return with_internal_buffers(c, st, [&] { return encode_host_pinned(c, (const uint32_t*)data, (uint32_t*)parity, st); });
     }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
-    int rc = ensure_dbuf(c);
-    if (rc != FASTECC_OK) return rc;
-    const size_t block_bytes = (size_t)c->S * 4;
-    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->K * block_bytes, hipMemcpyHostToDevice, st));
-    uint32_t* dpar = c->dbuf;
-    if (c->cosets > 1 || c->Mu > c->K) {  // more parity than the data stripe has room for
-        if (!c->hostpar) HIP_TRY(hipMalloc((void**)&c->hostpar, c->Mu * block_bytes));
-        dpar = c->hostpar;
-    }
-    rc = encode_device(c, c->dbuf, dpar, st);
-    if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(parity, dpar, c->Mu * block_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return FASTECC_OK;
+    return with_internal_buffers(c, st, [&]() -> int {
+        int rc = ensure_dbuf(c);
+        if (rc != FASTECC_OK) return rc;
+        const size_t block_bytes = (size_t)c->S * 4;
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->K * block_bytes, hipMemcpyHostToDevice, st));
+        uint32_t* dpar = c->dbuf;
+        if (c->cosets > 1 || c->Mu > c->K) {  // more parity than the data stripe has room for
+            if (!c->hostpar) HIP_TRY(hipMalloc((void**)&c->hostpar, c->Mu * block_bytes));
+            dpar = c->hostpar;
+        }
+        rc = encode_device(c, c->dbuf, dpar, st);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(parity, dpar, c->Mu * block_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return FASTECC_OK;
+    });
 }
 
 int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_t count, void* stream)
@@ -986,8 +1049,10 @@ int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_
     if (!c || !data || !parity || count == 0 || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (c->p61 || c->fold != 0 || c->cosets != 1 || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m
     if (count * c->N > 0x7FFFFFFFull || count > 0xFFFFFFFFull) return FASTECC_E_UNSUPPORTED;  // 32-bit block indices
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // stripes of a batch are contiguous (b * k * block_bytes apart)
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
+    CallLock lk(c->mu);
     return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream, 0, 0,
                       nullptr, (uint32_t)count);
 }
@@ -996,11 +1061,14 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 {
     if (!c || !blocks) return FASTECC_E_INVAL;
     if (c->Mu > c->K) return FASTECC_E_UNSUPPORTED;  // the in-place form has room for at most k parity blocks
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // the staging stripe is contiguous
     for (uint64_t i = 0; i < c->K; i++)
         if (!blocks[i] || ((uintptr_t)blocks[i] & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
-    int rc = ensure_dbuf(c);
+    CallLock lk(c->mu);
+    int rc = order_internal_buffers(c, nullptr);
+    if (rc == FASTECC_OK) rc = ensure_dbuf(c);
     if (rc != FASTECC_OK) return rc;
     const size_t bb = (size_t)c->S * 4;
     // bounce through a pinned buffer in chunks of whole blocks (<= 64 MiB)
@@ -1025,7 +1093,7 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
         HIP_TRY(hipMemcpy(bounce, (char*)c->dbuf + i0 * bb, cnt * bb, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) memcpy(blocks[i0 + i], bounce + i * bb, bb);
     }
-    return FASTECC_OK;
+    return mark_internal_buffers(c, nullptr);
 }
 
 int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* stream)
@@ -1036,16 +1104,19 @@ int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* str
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
+    CallLock lk(c->mu);
     if (mem_kind == FASTECC_MEM_DEVICE) return ntt_device(c, (uint32_t*)data, inverse != 0, st);
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
-    int rc = ensure_dbuf(c);
-    if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
-    rc = ntt_device(c, c->dbuf, inverse != 0, st);
-    if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return FASTECC_OK;
+    return with_internal_buffers(c, st, [&]() -> int {
+        int rc = ensure_dbuf(c);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+        rc = ntt_device(c, c->dbuf, inverse != 0, st);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return FASTECC_OK;
+    });
 }
 
 int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t base, int mem_kind, void* stream)
@@ -1056,6 +1127,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
     if (c->ld != c->S || c->K != c->N) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
+    if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
     hipStream_t st = (hipStream_t)stream;
     std::vector<uint32_t> f(c->N);
     uint32_t cur = scale;
@@ -1063,27 +1135,28 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
         f[i] = gf::h_to_mont(cur);
         cur = gf::h_mul(cur, base);
     }
-    // the factor table is consumed by a kernel on `st`; a synchronous copy keeps the host vector's lifetime simple
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(c->factor, f.data(), c->N * 4, hipMemcpyHostToDevice));
-    uint32_t* dev = (uint32_t*)data;
-    if (mem_kind == FASTECC_MEM_HOST) {
-        int rc = ensure_dbuf(c);
-        if (rc != FASTECC_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
-        dev = c->dbuf;
-    } else if (mem_kind != FASTECC_MEM_DEVICE) {
-        return FASTECC_E_INVAL;
-    }
-    {
-        ProfScope ps(c, st, "scale_rows");
-        HIP_TRY(launch_scale_rows(dev, c->factor, (uint32_t)c->S, c->N, pick_vec(c, dev, dev), st));
-    }
-    if (mem_kind == FASTECC_MEM_HOST) {
-        HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+    CallLock lk(c->mu);
+    return with_internal_buffers(c, st, [&]() -> int {
+        // the factor table is consumed by a kernel on `st`; a synchronous copy keeps the host vector's lifetime simple
         HIP_TRY(hipStreamSynchronize(st));
-    }
-    return FASTECC_OK;
+        HIP_TRY(hipMemcpy(c->factor, f.data(), c->N * 4, hipMemcpyHostToDevice));
+        uint32_t* dev = (uint32_t*)data;
+        if (mem_kind == FASTECC_MEM_HOST) {
+            int rc = ensure_dbuf(c);
+            if (rc != FASTECC_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
+            dev = c->dbuf;
+        }
+        {
+            ProfScope ps(c, st, "scale_rows");
+            HIP_TRY(launch_scale_rows(dev, c->factor, (uint32_t)c->S, c->N, pick_vec(c, dev, dev), st));
+        }
+        if (mem_kind == FASTECC_MEM_HOST) {
+            HIP_TRY(hipMemcpyAsync(data, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        return FASTECC_OK;
+    });
 }
 
 int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, void* stream)
@@ -1092,6 +1165,7 @@ int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t*
     if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit words: GF(0xFFF00001) only
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
+    CallLock lk(c->mu);
     ProfScope ps(c, (hipStream_t)stream, "gf_binary");
     HIP_TRY(launch_gf_binary(op, x, y, out, count, (hipStream_t)stream));
     return FASTECC_OK;
@@ -1099,24 +1173,25 @@ int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t*
 
 int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* stream, uint64_t* bad_words)
 {
-    if (!c || !data || !bad_words || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
+    if (!c || !data || !bad_words || ((uintptr_t)data & (c->p61 ? 7u : 3u))) return FASTECC_E_INVAL;
+    if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
+    if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // scans k * block_bytes contiguous bytes
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
+    CallLock lk(c->mu);
+    return with_internal_buffers(c, st, [&]() -> int {
     const uint32_t* dev = (const uint32_t*)data;
     if (mem_kind == FASTECC_MEM_HOST) {
         int rc = ensure_dbuf(c);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->K * c->S * 4, hipMemcpyHostToDevice, st));
         dev = c->dbuf;
-    } else if (mem_kind != FASTECC_MEM_DEVICE) {
-        return FASTECC_E_INVAL;
     }
     // c->factor (N >= 2 words of scratch) holds the 64-bit counter
     unsigned long long* counter = reinterpret_cast<unsigned long long*>(c->factor);
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
     if (c->p61) {
-        if ((uintptr_t)data & 7u) return FASTECC_E_INVAL;
         ProfScope ps(c, st, "p61_count_out_of_range");
         const int rc = p61::count_out_of_range(c->p61, (const uint64_t*)dev, counter, st);
         if (rc != FASTECC_OK) return rc;
@@ -1146,6 +1221,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
     HIP_TRY(hipStreamSynchronize(st));
     *bad_words = result + on_device;
     return FASTECC_OK;
+    });
 }
 
 // GF.md:72-104: W = S - 1 raw words per block <-> S packed words (pack_kernels.hip)
@@ -1174,6 +1250,7 @@ int fastecc_pack_blocks(fastecc_ctx* c, const void* raw, void* packed, int mem_k
     hipStream_t st = (hipStream_t)stream;
     const uint32_t words = (uint32_t)c->S - 1;
     const uint64_t alg_bytes = c->N * (2ull * words + 1) * 4;
+    CallLock lk(c->mu);
     if (mem_kind == FASTECC_MEM_DEVICE) {
         ProfScope ps(c, st, "pack_blocks", alg_bytes);
         HIP_TRY(launch_pack_blocks((const uint32_t*)raw, (uint32_t*)packed, words, (uint32_t)c->ld, c->N, st));
@@ -1181,17 +1258,19 @@ int fastecc_pack_blocks(fastecc_ctx* c, const void* raw, void* packed, int mem_k
     }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
-    rc = ensure_dbuf(c);
-    if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
-    if (rc != FASTECC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->rawbuf, raw, c->N * words * 4, hipMemcpyHostToDevice, st));
-    {
-        ProfScope ps(c, st, "pack_blocks", alg_bytes);
-        HIP_TRY(launch_pack_blocks(c->rawbuf, c->dbuf, words, (uint32_t)c->S, c->N, st));
-    }
-    HIP_TRY(hipMemcpyAsync(packed, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return FASTECC_OK;
+    return with_internal_buffers(c, st, [&]() -> int {
+        int rc2 = ensure_dbuf(c);
+        if (rc2 == FASTECC_OK) rc2 = ensure_rawbuf(c);
+        if (rc2 != FASTECC_OK) return rc2;
+        HIP_TRY(hipMemcpyAsync(c->rawbuf, raw, c->N * words * 4, hipMemcpyHostToDevice, st));
+        {
+            ProfScope ps(c, st, "pack_blocks", alg_bytes);
+            HIP_TRY(launch_pack_blocks(c->rawbuf, c->dbuf, words, (uint32_t)c->S, c->N, st));
+        }
+        HIP_TRY(hipMemcpyAsync(packed, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return FASTECC_OK;
+    });
 }
 
 int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem_kind, void* stream, uint64_t* bad_blocks)
@@ -1205,16 +1284,18 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
     const uint64_t alg_bytes = c->N * (2ull * words + 1) * 4;
     const uint32_t* src = (const uint32_t*)packed;
     uint32_t* dst = (uint32_t*)raw;
+    if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
+    if (mem_kind == FASTECC_MEM_HOST && c->ld != c->S) return FASTECC_E_UNSUPPORTED;
+    CallLock lk(c->mu);
+    return with_internal_buffers(c, st, [&]() -> int {  // the bad-block counter lives in c->factor
+    int rc = FASTECC_OK;
     if (mem_kind == FASTECC_MEM_HOST) {
-        if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;
         rc = ensure_dbuf(c);
         if (rc == FASTECC_OK) rc = ensure_rawbuf(c);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->dbuf, packed, c->stripe_bytes, hipMemcpyHostToDevice, st));
         src = c->dbuf;
         dst = c->rawbuf;
-    } else if (mem_kind != FASTECC_MEM_DEVICE) {
-        return FASTECC_E_INVAL;
     }
     unsigned long long* counter = bad_blocks ? reinterpret_cast<unsigned long long*>(c->factor) : nullptr;  // N >= 2 words of scratch
     if (counter) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
@@ -1228,11 +1309,13 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
     if (counter || mem_kind == FASTECC_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     if (bad_blocks) *bad_blocks = found;
     return FASTECC_OK;
+    });
 }
 
 int fastecc_profile_enable(fastecc_ctx* c, int on)
 {
     if (!c) return FASTECC_E_INVAL;
+    CallLock lk(c->mu);
     c->profiling = on != 0;
     return FASTECC_OK;
 }
@@ -1241,6 +1324,7 @@ int fastecc_profile_reset(fastecc_ctx* c)
 {
     if (!c) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
+    CallLock lk(c->mu);
     (void)hipDeviceSynchronize();
     c->prof_used = 0;
     return FASTECC_OK;
@@ -1257,19 +1341,25 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
     if (c->p61) return FASTECC_E_UNSUPPORTED;  // the options below tune the GF(0xFFF00001) tile kernels
+    CallLock lk(c->mu);
     if (!strcmp(name, "row_pitch_words")) {
         // DEVICE stripes passed to fastecc_encode are then [k][pitch] words with the first block_bytes/4 of each
         // row valid: a host that owns its HBM layout can pad e.g. 4100-byte blocks to 4224 bytes so that every
         // 128-byte row segment is cache-line aligned.  0 restores the contiguous layout.
         const uint64_t pitch = value == 0 ? c->S : (uint64_t)value;
         if (value < 0 || pitch < c->S) return FASTECC_E_INVAL;
-        c->ld = pitch;
-        if (c->scratch) {  // sized for the old pitch
+        if (pitch != c->ld) {
+            // everything sized or laid out for the old pitch goes: the work stripes, and the decoder's pattern state
+            // (its transform context and tables assume the geometry they were built with)
             DeviceGuard dgs(c->device);
             (void)hipDeviceSynchronize();
-            (void)hipFree(c->scratch);
-            c->scratch = nullptr;
+            if (c->scratch) (void)hipFree(c->scratch);
+            if (c->parbuf) (void)hipFree(c->parbuf);
+            c->scratch = c->parbuf = nullptr;
+            destroy_decode_state(c->decoder);
+            c->decoder = nullptr;
         }
+        c->ld = pitch;
         build_plans(c);  // tile eligibility depends on the pitch
         DeviceGuard dg(c->device);
         if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
@@ -1303,6 +1393,7 @@ int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, u
 {
     if (!c || !names || !ms || !launches || cap <= 0) return FASTECC_E_INVAL;
     DeviceGuard dg(c->device);
+    CallLock lk(c->mu);
     HIP_TRY(hipDeviceSynchronize());
     // names returned point into the context's records (valid until the next reset/launch)
     std::map<std::string, int> slot;
@@ -1378,6 +1469,7 @@ static int apply_plan(fastecc_ctx* c, int plan)
 int fastecc_set_plan(fastecc_ctx* c, int plan)
 {
     if (!c) return FASTECC_E_INVAL;
+    CallLock lk(c->mu);
     if (c->p61) {
         // plan ids of this field: 0 = default, 1..5 = radix-2 levels per register pass
         DeviceGuard dg(c->device);

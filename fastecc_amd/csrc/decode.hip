@@ -270,10 +270,11 @@ int hip_code(const char* what, hipError_t e)
 
 struct DeviceScope {
     int prev = -1;
+    bool ok = false;
     explicit DeviceScope(int dev)
     {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        (void)hipSetDevice(dev);
+        ok = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceScope()
     {
@@ -333,6 +334,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
 
     DeviceScope ds(ci.device);
+    if (!ds.ok) return FASTECC_E_DEVICE;
+    CallScope call(c);
     DecodeState*& slot = decoder_of(c);
     if (!slot) {
         slot = new (std::nothrow) DecodeState();
@@ -371,8 +374,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         const std::vector<uint32_t> ones(NC, 1u);
         const int rc = create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
-        DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
     }
+    if (!d->pattern_buf) DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
     DEC_TRY(hipMemcpy(d->pattern_buf, lv.data(), 2 * NC * 4, hipMemcpyHostToDevice));
     {
         const int rc = fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, nullptr);
@@ -421,7 +424,10 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
-    DEC_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern
+    {
+        const int rc = call.wait_idle();  // a decode still using the previous pattern
+        if (rc != FASTECC_OK) return rc;
+    }
     DEC_TRY(hipMemcpy(d->fin, fin.data(), NC * 4, hipMemcpyHostToDevice));
     DEC_TRY(hipMemcpy(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice));
     {
@@ -443,12 +449,26 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
 int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream)
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
+    CallScope call(c);
     DecodeState* d = decoder_of(c);
     if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first
     if (d->erased_data == 0) return FASTECC_OK;
     const CtxInfo ci = info_of(c);
+    if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;  // the gather / scatter passes address contiguous stripes
     DeviceScope ds(ci.device);
+    if (!ds.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
+    struct Marker {  // the decoder's work stripes are internal buffers: order their uses between streams
+        CallScope& s;
+        hipStream_t st;
+        ~Marker() { (void)s.end(st); }
+    };
+    {
+        const int rc0 = call.begin(st);
+        if (rc0 != FASTECC_OK) return rc0;
+    }
+    Marker marker{call, st};
     const uint64_t N = ci.k;
     const size_t block = ci.words * 4, data_bytes = ci.user_k * block, parity_bytes = ci.user_m * block;
 
@@ -461,8 +481,6 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         DEC_TRY(hipMemcpyAsync(d->parity_dev + ci.user_m * ci.words, data, data_bytes, hipMemcpyHostToDevice, st));
         dparity = d->parity_dev;
         ddata = d->parity_dev + ci.user_m * ci.words;
-    } else if (mem_kind != FASTECC_MEM_DEVICE) {
-        return FASTECC_E_INVAL;
     }
 
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).

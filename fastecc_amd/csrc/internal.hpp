@@ -41,4 +41,20 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);
 
+// Calls on one context are serialised on the host, and work that uses the context's internal device buffers is ordered
+// between streams (api.hip: fastecc_ctx::mu / buf_event).  decode.hip's entry points take part through this scope:
+// the constructor locks, begin() makes `st` wait for the previous user of the internal buffers, end() records this one.
+class CallScope {
+public:
+    explicit CallScope(fastecc_ctx* c);
+    ~CallScope();
+    int begin(hipStream_t st);
+    int end(hipStream_t st);
+    int wait_idle();  // host-side wait for the last recorded use (instead of a device-wide synchronise)
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+private:
+    fastecc_ctx* c_;
+};
+
 }  // namespace fastecc
