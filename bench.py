@@ -6,9 +6,12 @@
 
 A step = one fastecc_encode of one stripe (k = 2^19 data blocks of 4 KB -> 2^19 parity blocks), inputs
 already resident in HBM, called through the C ABI (include/fastecc.h) exactly as a C++ host would.
-Multi-GPU: one process per GPU, every rank encodes its own independent stripe (the path has no exchange
-step: word columns and stripes are independent — DESIGN.md §multi-GPU), so scaling is "weak" and there is
-no collective inside the timed region; ranks only meet at the barriers that bracket it.
+Multi-GPU: one process per GPU.  `value` is the replica mode — every rank encodes its own independent stripe (the
+path has no exchange step: word columns and stripes are independent — DESIGN.md §7), scaling "weak", no collective
+inside the timed region.  The same JSON line also carries `sharded_one_stripe`: BASELINE.json configs[3], ONE stripe
+in column slabs over the ranks (strong scaling), timed compute-only and with the RCCL gather of the parity into full
+blocks on rank 0 (fastecc_amd/sharding.py).  A single-process run that sees several GPUs additionally times the
+C-ABI form of that mode (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
 
 Throughput convention = the reference's (RS.cpp:38): bytes = data + parity = 2*k*block_bytes per encode,
 reported in GB/s (1e9).  Prints ONE JSON line on rank 0.
@@ -70,7 +73,10 @@ def parse():
     ap.add_argument("--plan", type=int, default=0, help="kernel plan (0 = library default); see DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the parity (reported separately)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded_one_stripe modes")
+    ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the gather pipeline (sharded_one_stripe)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
+    ap.add_argument("--cabi-sharded-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--slabs", type=int, default=0, help="column slabs on internal streams (0 = library default)")
     ap.add_argument("--option", action="append", default=[], help="library tuning option name=value (fastecc_set_option)")
     return ap.parse_args()
@@ -156,8 +162,114 @@ def pmc_traffic(kernel):
         return None
 
 
+def parity_check(enc, log2k, block_bytes, device):
+    """The gate BASELINE.md §3.4 specifies: encode the splitmix(0x1234) stripe with the context that was just timed and
+    compare the parity hash (main.cpp:202-212) with the value recorded from the unmodified reference.  The oracle
+    only generates the input and hashes the output here (checker, outside every timed region)."""
+    import numpy as np
+    from oracle import Oracle
+    with open(os.path.join(ROOT, "tests", "golden", "golden_hashes.json")) as f:
+        gold = json.load(f)
+    N, S = 1 << log2k, block_bytes // 4
+    want = None
+    for c in gold.get("survey_appendix_b", []) + gold.get("cases", []):
+        if c.get("input") == "splitmix" and c.get("log2N") == log2k and c.get("block_bytes") == block_bytes:
+            want = c
+            break
+    if want is None:
+        return {"status": "skipped", "why": "no golden hash for k=2^%d, %d-byte blocks" % (log2k, block_bytes)}
+    orc = Oracle()
+    x = orc.fill_splitmix(N, S, gold["splitmix_seed"])
+    if orc.hash(x) != want["hash_input"]:
+        return {"status": "FAILED", "why": "input generator does not reproduce the recorded input hash"}
+    d = torch.from_numpy(x.view(np.int32)).to(device)
+    out = torch.empty_like(d)
+    enc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = orc.hash(out.cpu().numpy().view(np.uint32).reshape(N, S))
+    return {"status": "ok" if got == want["hash_parity"] else "FAILED", "hash": got, "expected": want["hash_parity"],
+            "what": "parity hash (main.cpp:202-212) of the splitmix64(0x%x) stripe vs the unmodified reference's" % gold["splitmix_seed"]}
+
+
+def time_steps(step, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def cabi_sharded_child(args):
+    """Single process, all visible GPUs: BASELINE configs[3] through fastecc_create_sharded (csrc/sharded.hip).
+    Prints one JSON object; run by the parent bench in a child process so that a failure cannot take the headline
+    number with it."""
+    import fastecc_amd
+    G = torch.cuda.device_count()
+    k, bb = 1 << args.log2k, args.block_bytes or 4096
+    S = bb // 4
+    while G > 1 and S % (G * 32):
+        G -= 1
+    ids = list(range(G))
+    w = S // G
+    out = {"n_gpus": G, "slab_bytes_per_block": 4 * w, "steps": args.steps}
+    slabs, pslabs = [], []
+    for g in ids:
+        dev = torch.device("cuda", g)
+        slabs.append(random_stripe(k * w, dev, seed=0x1234 + g))
+        pslabs.append(torch.empty(k * w, dtype=torch.int32, device=dev))
+    torch.cuda.set_device(0)
+    parity = torch.empty(k * S, dtype=torch.int32, device="cuda:0")
+    hx = torch.empty(k * S, dtype=torch.int32).pin_memory()
+    hp = torch.empty(k * S, dtype=torch.int32).pin_memory()
+    hx.copy_(torch.cat([t.view(k, w).cpu() for t in slabs], dim=1).reshape(-1))
+    enc = fastecc_amd.ShardedEncoder(2 * k, k, bb, ids)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sync_all():
+        for g in ids:
+            torch.cuda.synchronize(g)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        sync_all()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        return {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * bb / (ms * 1e-3) / 1e9, 2)}
+
+    out["plan"] = enc.plan()
+    out["compute_only"] = timed(lambda: enc.encode_sharded(slabs, pslabs, None, stream=stream))
+    for mode, name in ((1, "copy_engine"), (2, "kernel")):
+        enc.set_option("gather_mode", mode)
+        for sub in (1, 2, 4):
+            enc.set_option("sub_slabs", sub)
+            try:
+                out["with_gather_%s_sub%d" % (name, sub)] = timed(lambda: enc.encode_sharded(slabs, pslabs, parity, stream=stream))
+            except Exception as e:  # noqa: BLE001
+                out["with_gather_%s_sub%d" % (name, sub)] = {"error": repr(e)}
+    # correctness of what was just timed: the gathered parity equals the slabs that stayed on their GPUs
+    ok = all(torch.equal(parity.view(k, S)[:, g * w:(g + 1) * w].cpu(), pslabs[g].view(k, w).cpu()) for g in ids)
+    out["gather_check"] = "ok" if ok else "FAILED"
+    enc.set_option("gather_mode", 1)
+    enc.set_option("sub_slabs", 2)
+    try:
+        out["root_resident_stripe"] = timed(lambda: enc.encode(parity, parity, stream=stream))
+        out["host_pinned_stripe"] = timed(lambda: enc.encode(hx, hp, mem=fastecc_amd.MEM_HOST_PINNED, stream=stream))
+        out["host_pinned_stripe"]["what"] = "pinned host stripe in, parity out: every GPU moves its slab over its own host link"
+    except Exception as e:  # noqa: BLE001
+        out["stripe_modes_error"] = repr(e)
+    enc.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.cabi_sharded_child:
+        return cabi_sharded_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,15 +308,19 @@ def main():
         step = lambda: enc.encode_batch(data, parity, args.batch, stream=stream)  # noqa: E731
     else:
         step = lambda: enc.encode(data, parity, stream=stream)  # noqa: E731
-    enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local,
-                              field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001)
-    if args.plan:
-        enc.set_plan(args.plan)
-    if args.slabs:
-        enc.set_option("slabs", args.slabs)
-    for kv in args.option:
-        name, value = kv.split("=")
-        enc.set_option(name, int(value))
+    field = fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001
+    enc = fastecc_amd.Encoder(n, k, args.block_bytes, device=local, field=field)
+
+    def tune(e):
+        if args.plan:
+            e.set_plan(args.plan)
+        if args.slabs:
+            e.set_option("slabs", args.slabs)
+        for kv in args.option:
+            name, value = kv.split("=")
+            e.set_option(name, int(value))
+
+    tune(enc)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -212,52 +328,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the contract's timed region: W warm-up steps, then exactly K steps, nothing but the encode calls inside ----
     for _ in range(args.warmup):
         step()
-    barrier()
-    enc.profile(True)      # HIP events around every kernel, on the stream the kernels run on
+    elapsed = max_over_ranks(time_steps(step, args.steps, barrier))
+    # ---- a second, instrumented pass of K steps: HIP events around every kernel, on the stream the kernels run on ----
+    enc.profile(True)
     enc.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_prof = max_over_ranks(time_steps(step, args.steps, barrier))
     kernels = enc.profile_read()
     enc.profile(False)
 
-    # Optional second mode (reported separately, never part of `value`): ONE stripe split into column slabs,
-    # each rank encodes its slab, RCCL all_gather over xGMI re-assembles the parity on every rank.
+    # ---- BASELINE configs[3]: ONE stripe in column slabs over the ranks, gathered on rank 0 (strong scaling) ----
     sharded = None
-    if args.gather and world > 1 and S % world == 0 and not p61:
+    unit = 8 if p61 else 4  # bytes per tensor word
+    words = args.block_bytes // unit
+    shardable = (not args.no_sharded and args.batch == 1 and m_blocks == k and words % world == 0 and (not p61 or world > 1)
+                 and (args.block_bytes // world) % (16 if p61 else 4) == 0)
+    if shardable:
         from fastecc_amd import sharding
-        senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local)
-        stripe2d = data.view(k, S)
-
-        def enc_fn(slab):
-            out = torch.empty_like(slab)
-            senc.encode(slab, out, stream=torch.cuda.current_stream().cuda_stream)
-            return out
-
-        sharding.encode_column_sharded(stripe2d, enc_fn)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            sharding.encode_column_sharded(stripe2d, enc_fn)
-        barrier()
-        sh_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        sharded = {"ms_per_stripe": round(sh_ms, 4), "GBps": round(2.0 * k * args.block_bytes / (sh_ms * 1e-3) / 1e9, 2),
-                   "what": "one stripe, %d column slabs of %d B per block, encode + RCCL all_gather of the parity" % (world, args.block_bytes // world)}
+        w = words // world
+        senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local, field=field)
+        tune(senc)
+        # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM
+        slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(k, w)
+        pslab = torch.empty_like(slab)
+        sub = 1 if p61 else sharding.sub_slab_count(w, args.sub_slabs)
+        columns = sharding.hip_columns_encoder(senc)
+        wsp = {}
+        modes = {"compute_only": lambda: senc.encode(slab, pslab, stream=stream),
+                 "with_gather": lambda: sharding.encode_slab_and_gather(slab, columns, k, dst=0, sub_slabs=sub, workspace=wsp)}
+        sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank; "
+                           "with_gather adds the RCCL gather of the parity slabs into full blocks on rank 0, "
+                           "pipelined in %d sub-slab(s)" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+                   "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
+        for name, fn in modes.items():
+            for _ in range(max(1, args.warmup)):
+                fn()
+            ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
+            sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
+        # what was timed is also right: the gathered blocks on rank 0 hold this rank's slab where it belongs
+        full = wsp.get("parity_full")
+        if rank == 0 and full is not None:
+            sharded["gather_check"] = "ok" if torch.equal(full[:, :w], wsp["parity_slab"]) else "FAILED"
         senc.close()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        del wsp, slab, pslab
 
     if rank == 0:
         bytes_per_encode = float(k + m_blocks) * args.block_bytes * args.batch  # data + parity, RS.cpp:38
         ms_per_step = elapsed / args.steps * 1e3
+        ms_per_step_prof = elapsed_prof / args.steps * 1e3
         value = world * bytes_per_encode / (ms_per_step * 1e-3) / 1e9
         # dominant kernel by total time; a launch reads its part of the stripe once and writes it once (the
         # library reports those algorithmic bytes per launch: the whole stripe, or one column slab of it)
@@ -272,18 +399,42 @@ def main():
             per_block = args.block_bytes // 16 if p61 else S  # field elements per block
             log2m = args.log2k if args.log2m is None or m_blocks > k else args.log2m
             bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block * args.batch / (ms_per_step * 1e-3) / 1e9
+            traffic = pmc_traffic(name)
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(name),
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
+                                                                   "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)",
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
                     "encode": {"ms_per_step": round(ms_per_step, 4), "sum_of_kernel_ms_per_step": round(kernel_ms_per_step, 4),
                                "achieved": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9, 1),
-                               "frac": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                               "frac": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "hbm_trips": len(kernels)},
                     "valu": {"what": "radix-2 butterflies per second over the whole encode (2*log2(k)*k/2 per element column, "
                                      "plus k/2 butterfly-equivalents for the per-block factor multiply)",
                              "achieved_Gbfly_per_s": round(bfly, 1), "microbench_peak_Gbfly_per_s": None if p61 else VALU_PEAK_GBFLY,
                              "frac": None if p61 else round(bfly / VALU_PEAK_GBFLY, 4)},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
+        check = None
+        if not args.no_parity_check and not p61 and args.batch == 1 and m_blocks == k:
+            try:
+                check = parity_check(enc, args.log2k, args.block_bytes, device)
+            except Exception as e:  # noqa: BLE001
+                check = {"status": "error", "why": repr(e)}
+        cabi = None
+        if (world == 1 and torch.cuda.device_count() > 1 and not args.no_sharded and not p61 and args.batch == 1 and m_blocks == k
+                and not os.environ.get("FASTECC_BENCH_NO_CABI_SHARDED")):
+            # the single-process form of configs[3] on every visible GPU, in a child (its own HIP contexts; a failure
+            # or a hang costs this entry, not the line)
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--cabi-sharded-child", "--steps", str(min(args.steps, 10)),
+                   "--log2k", str(args.log2k), "--block-bytes", str(args.block_bytes)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                cabi = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
+            except Exception as e:  # noqa: BLE001
+                cabi = {"error": repr(e)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -295,17 +446,23 @@ def main():
                       if m_blocks == k else
                       ("encode GB/s at k=2^%d data + %d parity blocks, %d-byte blocks (data+parity bytes / s)" % (args.log2k, m_blocks, args.block_bytes)),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_instrumented": round(ms_per_step_prof, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
             "config": {"workload": "RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
                                    % (args.log2k, m_blocks, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
                                       k * args.block_bytes / 2**20),
                        "stripes_per_step": args.batch, "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
             "data_only_GBps": round(value / 2, 2),
+            "parity_check": check,
             "roofline": roof, "cpu_baseline": cpu,
+            "sharded_one_stripe": sharded,
         }
-        if sharded is not None:
-            line["column_sharded_with_rccl_gather"] = sharded
+        if p61:
+            line["parity_pin"] = ("no upstream code exists for this field: the HIP path is pinned to this repository's own oracle and "
+                                  "Python big-integer goldens (tests/test_gpu_p61.py), not to the reference")
+        if cabi is not None:
+            line["sharded_one_stripe_c_abi"] = cabi
         print(json.dumps(line), flush=True)
     enc.close()
     if world > 1:

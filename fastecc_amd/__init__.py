@@ -66,6 +66,15 @@ def lib():
     L.fastecc_destroy.argtypes, L.fastecc_destroy.restype = [vp], None
     L.fastecc_encode.argtypes, L.fastecc_encode.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_encode_batch.argtypes, L.fastecc_encode_batch.restype = [vp, vp, vp, u64, vp], i32
+    L.fastecc_encode_columns.argtypes, L.fastecc_encode_columns.restype = [vp, vp, vp, u64, u64, vp], i32
+    L.fastecc_create_sharded.argtypes = [ctypes.POINTER(vp), u64, u64, u64, i32, ctypes.POINTER(i32), i32]
+    L.fastecc_create_sharded.restype = i32
+    L.fastecc_encode_sharded.argtypes, L.fastecc_encode_sharded.restype = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp], i32
+    L.fastecc_shard_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(u64), ctypes.POINTER(i32), i32]
+    L.fastecc_shard_info.restype = i32
+    L.fastecc_plan_describe.argtypes, L.fastecc_plan_describe.restype = [u64, u64, i32, ctypes.c_char_p, ctypes.c_size_t], i32
+    L.fastecc_plan_twiddles.argtypes = [u64, u64, i32, i32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_int32)]
+    L.fastecc_plan_twiddles.restype = i32
     L.fastecc_encode_blocks.argtypes, L.fastecc_encode_blocks.restype = [vp, ctypes.POINTER(vp)], i32
     L.fastecc_ntt.argtypes, L.fastecc_ntt.restype = [vp, vp, i32, i32, vp], i32
     L.fastecc_scale_blocks.argtypes, L.fastecc_scale_blocks.restype = [vp, vp, u32, u32, i32, vp], i32
@@ -122,11 +131,14 @@ def _addr(x):
 
 
 class Encoder:
-    """(n,k) = (2N,N) Reed-Solomon encoder over GF(0xFFF00001): the RS.cpp:22-68 operation.
+    """(n,k) Reed-Solomon encoder: the RS.cpp:22-68 operation behind the C ABI (include/fastecc.h).
 
     ``data`` is a device tensor (or raw address) of k*block_bytes bytes laid out block-major, exactly the
     ``T** data`` stripe of RS.cpp:28-33 stored back to back; ``parity`` holds n-k blocks the same way.
-    n - k may also be k/2, k/4, k/8 or k/16: parity block j is then block j*k/(n-k) of the (2k,k) parity.
+    (n,k) = (2N,N), N = 2^m, is the reference's configuration (parity block j = f(w_2N^(2j+1))); fastecc_create
+    also accepts n-k = k/2 .. k/16 (a sub-coset of that parity), n = 4k / 8k (further cosets) and any other
+    (n,k) with n-k <= 2^ceil(log2 k) by zero extension, all over GF(0xFFF00001) with 4-byte words; and
+    (2N,N) over GF((2^61-1)^2) with 16-byte elements (``field=FIELD_GF_P61_SQUARED``).
     """
 
     def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001):
@@ -164,6 +176,12 @@ class Encoder:
         if parity is None:
             parity = data
         _check(lib().fastecc_encode(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_encode")
+        return parity
+
+    def encode_columns(self, data, parity, col0_words, width_words, stream=0):
+        """Encode only words [col0, col0+width) of every block (columns are independent transforms)."""
+        _check(lib().fastecc_encode_columns(self._h, _addr(data), _addr(parity), col0_words, width_words, stream or None),
+               "fastecc_encode_columns")
         return parity
 
     def encode_batch(self, data, parity, count, stream=0):
@@ -250,6 +268,49 @@ class Encoder:
         nbytes = (ctypes.c_uint64 * cap)()
         n = _check(lib().fastecc_profile_read_bytes(self._h, names, ms, cnt, nbytes, cap), "fastecc_profile_read_bytes")
         return {names[i].decode(): (ms[i], int(cnt[i]), int(nbytes[i])) for i in range(n)}
+
+
+class ShardedEncoder(Encoder):
+    """One stripe in column slabs on several GPUs driven by ONE process (fastecc_create_sharded): slab g =
+    words [g*S/G, (g+1)*S/G) of every block lives on ``gpu_ids[g]``; ``gpu_ids[0]`` is the root that holds full
+    stripes.  ``encode(data, parity)`` takes full stripes (root device or host memory);
+    ``encode_sharded(data_slabs, parity_slabs=None, parity=None)`` takes data that is already sharded."""
+
+    def __init__(self, n, k, block_bytes, gpu_ids, field=FIELD_GF_FFF00001):
+        self._h = ctypes.c_void_p()
+        self.n, self.k, self.block_bytes, self.field = n, k, block_bytes, field
+        self.gpu_ids = list(gpu_ids)
+        self.device = self.gpu_ids[0] if self.gpu_ids else 0
+        ids = (ctypes.c_int * len(self.gpu_ids))(*self.gpu_ids)
+        _check(lib().fastecc_create_sharded(ctypes.byref(self._h), n, k, block_bytes, field, ids, len(self.gpu_ids)),
+               "fastecc_create_sharded")
+
+    @property
+    def slab_block_bytes(self):
+        return self.block_bytes // len(self.gpu_ids)
+
+    def encode_sharded(self, data_slabs, parity_slabs=None, parity=None, stream=0):
+        g = len(self.gpu_ids)
+        d = (ctypes.c_void_p * g)(*[_addr(x) for x in data_slabs])
+        p = (ctypes.c_void_p * g)(*[_addr(x) for x in parity_slabs]) if parity_slabs is not None else None
+        _check(lib().fastecc_encode_sharded(self._h, d, p, _addr(parity), stream or None), "fastecc_encode_sharded")
+        return parity if parity is not None else parity_slabs
+
+
+def plan_describe(k, block_bytes, plan=0):
+    """Host-only: the pass plan fastecc_create would pick (no device is touched)."""
+    buf = ctypes.create_string_buffer(512)
+    _check(lib().fastecc_plan_describe(k, block_bytes, plan, buf, 512), "fastecc_plan_describe")
+    return buf.value.decode()
+
+
+def plan_twiddles(k, block_bytes, plan=0, which=0):
+    """Host-only: (level-packed twiddle table as a list of k ints, per-level log2 strides)."""
+    n = max(k.bit_length() - 1, 0)
+    out = (ctypes.c_uint32 * k)()
+    sl = (ctypes.c_int32 * max(n, 1))()
+    _check(lib().fastecc_plan_twiddles(k, block_bytes, plan, which, out, sl), "fastecc_plan_twiddles")
+    return list(out), list(sl)[:n]
 
 
 def gf_mul(x, y): return lib().fastecc_gf_mul(x, y)

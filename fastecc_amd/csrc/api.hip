@@ -69,6 +69,8 @@ struct fastecc_ctx {
     hipStream_t buf_stream = nullptr;
     bool buf_used = false;
     DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
+    Sharded* sharded = nullptr;      // fastecc_create_sharded: the per-device contexts of the column slabs (sharded.hip); a
+                                     // context that has it is only a shell around them
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
     int n = 0;        // log2 k
@@ -334,6 +336,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     if (staged && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * c->ld * 4));
     int vec = staged ? std::min(pick_vec(c, in, out), pick_vec(c, c->scratch, c->scratch)) : pick_vec(c, in, out);
     // the last pass may store to another buffer and the decoder's first pass reads a second one: they bound the lane vector too
+    while (vec > 1 && (width % vec) != 0) vec >>= 1;
     if (cb.final_out) vec = std::min(vec, pick_vec(c, cb.final_out + col0, cb.final_out + col0));
     if (cb.gather_odd) vec = std::min(vec, pick_vec(c, cb.gather_odd + col0, cb.gather_odd + col0));
 
@@ -386,7 +389,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.tw_dif = tw_dif;
             a.tw_dit = twd;
             a.dscale = dscale;
-            a.S = (uint32_t)c->S;
+            a.S = width;  // `in` / `out` already point at the first column of the range
             a.ld = (uint32_t)c->ld;
             a.n = n_eff;
             a.s = s_eff;
@@ -896,6 +899,26 @@ CtxInfo info_of(const fastecc_ctx* c)
     return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
+Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
+std::mutex& mutex_of(fastecc_ctx* c) { return c->mu; }
+fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes)
+{
+    fastecc_ctx* c = new (std::nothrow) fastecc_ctx();
+    if (!c) return nullptr;
+    c->device = root_device;
+    c->field = field;
+    c->N = c->K = k;
+    c->M = c->Mu = m;
+    c->S = c->ld = block_bytes / 4;
+    c->stripe_bytes = (size_t)k * block_bytes;
+    c->parity_bytes = (size_t)m * block_bytes;
+    return c;
+}
+void set_plan_text(fastecc_ctx* c, const std::string& t) { c->plan_text = t; }
+int columns_supported(const fastecc_ctx* c)
+{
+    return !c->p61 && !c->sharded && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
+}
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
 
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device)
@@ -970,6 +993,8 @@ extern "C" {
 void fastecc_destroy(fastecc_ctx* c)
 {
     if (!c) return;
+    destroy_sharded(c->sharded);
+    c->sharded = nullptr;
     destroy_decode_state(c->decoder);
     c->decoder = nullptr;
     DeviceGuard dg(c->device);
@@ -1007,7 +1032,8 @@ void fastecc_destroy(fastecc_ctx* c)
 int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind, void* stream)
 {
     if (!c || !data || !parity) return FASTECC_E_INVAL;
-    if (((uintptr_t)data | (uintptr_t)parity) & (c->p61 ? 15u : 3u)) return FASTECC_E_INVAL;
+    if (((uintptr_t)data | (uintptr_t)parity) & (c->field == FASTECC_FIELD_GF_P61_SQUARED ? 15u : 3u)) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_encode_stripe(c, data, parity, mem_kind, (hipStream_t)stream);
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -1044,9 +1070,23 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     });
 }
 
+int fastecc_encode_columns(fastecc_ctx* c, const void* data, void* parity, uint64_t col0, uint64_t width, void* stream)
+{
+    if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    if (c->sharded) return FASTECC_E_UNSUPPORTED;
+    if (width == 0 || col0 + width > c->S) return FASTECC_E_INVAL;
+    if (!columns_supported(c)) return FASTECC_E_UNSUPPORTED;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    CallLock lk(c->mu);
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream,
+                      (uint32_t)col0, (uint32_t)width);
+}
+
 int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_t count, void* stream)
 {
     if (!c || !data || !parity || count == 0 || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->p61 || c->fold != 0 || c->cosets != 1 || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m
     if (count * c->N > 0x7FFFFFFFull || count > 0xFFFFFFFFull) return FASTECC_E_UNSUPPORTED;  // 32-bit block indices
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // stripes of a batch are contiguous (b * k * block_bytes apart)
@@ -1060,6 +1100,7 @@ int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_
 int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 {
     if (!c || !blocks) return FASTECC_E_INVAL;
+    if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->Mu > c->K) return FASTECC_E_UNSUPPORTED;  // the in-place form has room for at most k parity blocks
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // the staging stripe is contiguous
     for (uint64_t i = 0; i < c->K; i++)
@@ -1099,6 +1140,7 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
 int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* stream)
 {
     if (!c || !data || ((uintptr_t)data & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
+    if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // a row pitch applies to fastecc_encode on device stripes only
     if (c->K != c->N) return FASTECC_E_UNSUPPORTED;   // the transform length is a power of two
     DeviceGuard dg(c->device);
@@ -1123,7 +1165,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
 {
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
     if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
-    if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit scalars: GF(0xFFF00001) only
+    if (c->p61 || c->sharded) return FASTECC_E_UNSUPPORTED;  // 32-bit scalars: GF(0xFFF00001) only
     if (c->ld != c->S || c->K != c->N) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
@@ -1162,7 +1204,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
 int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t* y, uint32_t* out, uint64_t count, void* stream)
 {
     if (!c || !x || !y || !out || op < 0 || op > 3) return FASTECC_E_INVAL;
-    if (c->p61) return FASTECC_E_UNSUPPORTED;  // 32-bit words: GF(0xFFF00001) only
+    if (c->p61 || c->sharded) return FASTECC_E_UNSUPPORTED;  // 32-bit words: GF(0xFFF00001) only
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     CallLock lk(c->mu);
@@ -1175,6 +1217,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
 {
     if (!c || !data || !bad_words || ((uintptr_t)data & (c->p61 ? 7u : 3u))) return FASTECC_E_INVAL;
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
+    if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // scans k * block_bytes contiguous bytes
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
@@ -1228,7 +1271,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
 static int pack_args_ok(const fastecc_ctx* c, const void* a, const void* b)
 {
     if (!c || !a || !b || (((uintptr_t)a | (uintptr_t)b) & 3u)) return FASTECC_E_INVAL;
-    if (c->p61) return FASTECC_E_UNSUPPORTED;                       // the recoding is specific to p = 0xFFF00001
+    if (c->p61 || c->sharded) return FASTECC_E_UNSUPPORTED;         // the recoding is specific to p = 0xFFF00001
     if (c->S < 2 || c->S > 1025) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
     if (c->K != c->N) return FASTECC_E_UNSUPPORTED;             // staging buffers are sized for power-of-two k
     return FASTECC_OK;
@@ -1315,6 +1358,7 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
 int fastecc_profile_enable(fastecc_ctx* c, int on)
 {
     if (!c) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_forward(c, SH_PROFILE_ENABLE, nullptr, on);
     CallLock lk(c->mu);
     c->profiling = on != 0;
     return FASTECC_OK;
@@ -1323,6 +1367,7 @@ int fastecc_profile_enable(fastecc_ctx* c, int on)
 int fastecc_profile_reset(fastecc_ctx* c)
 {
     if (!c) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_forward(c, SH_PROFILE_RESET, nullptr, 0);
     DeviceGuard dg(c->device);
     CallLock lk(c->mu);
     (void)hipDeviceSynchronize();
@@ -1340,6 +1385,7 @@ int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_
 int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_forward(c, SH_SET_OPTION, name, value);
     if (c->p61) return FASTECC_E_UNSUPPORTED;  // the options below tune the GF(0xFFF00001) tile kernels
     CallLock lk(c->mu);
     if (!strcmp(name, "row_pitch_words")) {
@@ -1392,6 +1438,7 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, uint64_t* bytes, int cap)
 {
     if (!c || !names || !ms || !launches || cap <= 0) return FASTECC_E_INVAL;
+    if (c->sharded) return fastecc_profile_read_bytes(sharded_child(c, 0), names, ms, launches, bytes, cap);
     DeviceGuard dg(c->device);
     CallLock lk(c->mu);
     HIP_TRY(hipDeviceSynchronize());
@@ -1469,6 +1516,7 @@ static int apply_plan(fastecc_ctx* c, int plan)
 int fastecc_set_plan(fastecc_ctx* c, int plan)
 {
     if (!c) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_forward(c, SH_SET_PLAN, nullptr, plan);
     CallLock lk(c->mu);
     if (c->p61) {
         // plan ids of this field: 0 = default, 1..5 = radix-2 levels per register pass

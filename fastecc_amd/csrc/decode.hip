@@ -292,6 +292,7 @@ extern "C" {
 int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
 {
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
+    if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     const CtxInfo ci = info_of(c);
     if (ci.field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
@@ -450,6 +451,7 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
+    if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     CallScope call(c);
     DecodeState* d = decoder_of(c);
     if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first

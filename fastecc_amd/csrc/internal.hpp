@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/fastecc.h"
@@ -11,6 +13,14 @@ namespace fastecc {
 
 struct DecodeState;                        // decode.hip: tables of one erasure pattern + the size-2k transform context
 void destroy_decode_state(DecodeState*);   // decode.hip, called by fastecc_destroy
+
+// ---- sharded.hip: one stripe in column slabs on several devices (fastecc_create_sharded) ----
+struct Sharded;
+void destroy_sharded(Sharded*);
+int sharded_encode_stripe(fastecc_ctx* shell, const void* data, void* parity, int mem_kind, hipStream_t st);
+enum { SH_PROFILE_ENABLE, SH_PROFILE_RESET, SH_SET_OPTION, SH_SET_PLAN };
+int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value);
+fastecc_ctx* sharded_child(fastecc_ctx* shell, int g);
 
 // ---- api.hip ----
 struct CtxInfo {
@@ -21,6 +31,12 @@ struct CtxInfo {
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);
+Sharded*& sharded_of(fastecc_ctx* c);
+std::mutex& mutex_of(fastecc_ctx* c);
+// a context that owns nothing but its geometry: fastecc_create_sharded hangs the per-device contexts on it
+fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes);
+void set_plan_text(fastecc_ctx* c, const std::string& t);
+int columns_supported(const fastecc_ctx* c);  // fastecc_encode_columns works on this context
 void set_error_detail(const char* what, hipError_t e);
 
 // A transform context (GF(0xFFF00001)): DIF over all log2k levels with inverse roots, the block holding coefficient m

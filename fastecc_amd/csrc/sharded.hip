@@ -1,0 +1,378 @@
+// sharded.hip — one stripe on several GPUs: fastecc_create_sharded / fastecc_encode_sharded (include/fastecc.h).
+//
+// The reference has no multi-device code (SURVEY.md §2 "Distributed comm backend: none"); BASELINE.json configs[3]
+// defines the mode: the blocks of ONE (n,k) stripe sharded over the GPUs of a node "with a final gather over xGMI".
+// The transform runs down the block index and the word columns of a stripe never meet (ntt.cpp:348-350 loops over
+// them independently), so the shard is a COLUMN SLAB: GPU g holds words [g*S/G, (g+1)*S/G) of every block and encodes
+// them with an ordinary per-device context for block_bytes/G — no collective inside the transform, tables replicated.
+// What is left is data movement, and that is all this file does:
+//
+//   upload    (only when the caller hands over a full stripe)  strided copy  stripe[:, slab g] -> GPU g's slab buffer
+//   compute   the device context's passes on the slab, per column sub-slab
+//   download  strided copy  GPU g's parity slab -> parity[:, slab g]   (the xGMI gather, or each GPU's own host link)
+//
+// Every GPU runs the three on its own streams, sub-slab h+1 computing while sub-slab h is being copied out; the root
+// only waits.  Copies are issued by the GPU that owns the slab (it needs peer access to the root's memory, not the
+// other way round), either on the copy engines (hipMemcpy2DAsync) or as a kernel that stores straight through the
+// peer mapping ("gather_mode" 2).  All of it is wave-agnostic plumbing: no arithmetic happens here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace fastecc {
+
+namespace {
+
+constexpr int MAX_SUB = 8;
+
+struct Shard {
+    int device = 0;
+    fastecc_ctx* ctx = nullptr;  // (n, k, block_bytes / G) on `device`
+    hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+    hipEvent_t ev_up[MAX_SUB] = {}, ev_comp[MAX_SUB] = {};
+    hipEvent_t ev_all = nullptr;  // everything this shard did for the last call
+    bool used = false;
+    char* data_slab = nullptr;    // lazy: [k][slab_bytes], for callers that hand over full stripes
+    char* parity_slab = nullptr;  // lazy: [n-k][slab_bytes], when the caller keeps no parity slabs
+};
+
+int fail(const char* what, hipError_t e)
+{
+    set_error_detail(what, e);
+    return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+}
+
+#define SH_TRY(expr)                                  \
+    do {                                              \
+        hipError_t e_ = (expr);                       \
+        if (e_ != hipSuccess) return fail(#expr, e_); \
+    } while (0)
+
+struct DeviceSwitch {
+    int prev = -1;
+    DeviceSwitch()
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceSwitch()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// dst[r][0..width) = src[r][0..width) for r < rows; pitches and width in units of T.  One thread per T, consecutive
+// threads on consecutive addresses of a row segment (256-byte segments are 16 lanes of uint4).
+template <typename T>
+__global__ __launch_bounds__(256) void copy_window_kernel(const T* __restrict__ src, T* __restrict__ dst, uint32_t width, uint64_t spitch,
+                                                          uint64_t dpitch, uint64_t total)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / width;
+        const uint32_t c = (uint32_t)(i - r * width);
+        dst[r * dpitch + c] = src[r * spitch + c];
+    }
+}
+
+}  // namespace
+
+struct Sharded {
+    std::vector<Shard> shards;
+    int root = 0;
+    int field = 0;
+    uint64_t K = 0, M = 0;  // data / parity blocks of the caller's stripes
+    uint64_t block_bytes = 0, slab_bytes = 0;
+    int sub_slabs = 2;
+    int gather_mode = 1;  // 1 = hipMemcpy2DAsync (copy engines), 2 = copy kernel on the slab's GPU
+    hipEvent_t fork = nullptr;
+    std::string text;
+};
+
+namespace {
+
+void describe(fastecc_ctx* shell)
+{
+    Sharded* s = sharded_of(shell);
+    char buf[96];
+    snprintf(buf, sizeof buf, "%d slabs x %llu B/block, sub_slabs=%d, gather=%s | ", (int)s->shards.size(), (unsigned long long)s->slab_bytes,
+             s->sub_slabs, s->gather_mode == 2 ? "kernel" : "copy-engine");
+    set_plan_text(shell, std::string(buf) + fastecc_plan_string(s->shards[0].ctx));
+}
+
+// A [rows][width bytes] window between two pitched buffers, on `st` of the current device.
+int copy_window(const Sharded* s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, bool device_both,
+                hipStream_t st)
+{
+    if (rows == 0 || width == 0) return FASTECC_OK;
+    if (s->gather_mode == 2 && device_both) {
+        const bool v16 = ((width | dpitch | spitch | (uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
+        const size_t unit = v16 ? 16 : 4;
+        const uint64_t total = (uint64_t)rows * (width / unit);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 4096);
+        if (v16)
+            hipLaunchKernelGGL(copy_window_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, (uint32_t)(width / 16),
+                               (uint64_t)(spitch / 16), (uint64_t)(dpitch / 16), total);
+        else
+            hipLaunchKernelGGL(copy_window_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst,
+                               (uint32_t)(width / 4), (uint64_t)(spitch / 4), (uint64_t)(dpitch / 4), total);
+        SH_TRY(hipGetLastError());
+        return FASTECC_OK;
+    }
+    SH_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDefault, st));
+    return FASTECC_OK;
+}
+
+// The whole data path.  Exactly one of (data_slabs, data_stripe) and at least one of (parity_slabs, parity_stripe).
+// stripe_on_host: the stripes are host memory (each GPU uses its own host link), else the root device's memory.
+int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stripe, void* const* parity_slabs, void* parity_stripe,
+        bool stripe_on_host, hipStream_t st)
+{
+    Sharded* s = sharded_of(shell);
+    const int G = (int)s->shards.size();
+    const size_t slab = s->slab_bytes, full = s->block_bytes;
+    DeviceSwitch restore;
+
+    // sub-slabs only where the device context can encode a column range
+    int H = std::max(1, std::min(s->sub_slabs, MAX_SUB));
+    const uint64_t slab_words = slab / 4;
+    while (H > 1 && (!columns_supported(s->shards[0].ctx) || (slab_words % (32u * H)) != 0)) H >>= 1;
+    const size_t wbytes = slab / H;
+
+    SH_TRY(hipSetDevice(s->root));
+    SH_TRY(hipEventRecord(s->fork, st));
+
+    for (int g = 0; g < G; g++) {
+        Shard& sh = s->shards[g];
+        SH_TRY(hipSetDevice(sh.device));
+        const char* din = data_slabs ? (const char*)data_slabs[g] : nullptr;
+        if (!din) {
+            if (!sh.data_slab) SH_TRY(hipMalloc((void**)&sh.data_slab, s->K * slab));
+            din = sh.data_slab;
+        }
+        char* pout = parity_slabs ? (char*)parity_slabs[g] : nullptr;
+        if (!pout) {
+            if (!sh.parity_slab) SH_TRY(hipMalloc((void**)&sh.parity_slab, s->M * slab));
+            pout = sh.parity_slab;
+        }
+        // this call starts after prior work on the caller's stream and after the shard's previous call
+        for (hipStream_t q : {sh.s_up, sh.s_comp}) {
+            SH_TRY(hipStreamWaitEvent(q, s->fork, 0));
+            if (sh.used) SH_TRY(hipStreamWaitEvent(q, sh.ev_all, 0));
+        }
+        for (int h = 0; h < H; h++) {
+            const size_t col = (size_t)h * wbytes;
+            if (data_stripe) {
+                const int rc = copy_window(s, sh.data_slab + col, slab, (const char*)data_stripe + (size_t)g * slab + col, full, wbytes, s->K,
+                                           !stripe_on_host, sh.s_up);
+                if (rc != FASTECC_OK) return rc;
+                SH_TRY(hipEventRecord(sh.ev_up[h], sh.s_up));
+                SH_TRY(hipStreamWaitEvent(sh.s_comp, sh.ev_up[h], 0));
+            }
+            const int rc = H > 1 ? fastecc_encode_columns(sh.ctx, din, pout, col / 4, wbytes / 4, sh.s_comp)
+                                 : fastecc_encode(sh.ctx, din, pout, FASTECC_MEM_DEVICE, sh.s_comp);
+            if (rc != FASTECC_OK) return rc;
+            SH_TRY(hipSetDevice(sh.device));  // the entry points restore the caller's device; keep ours explicit
+            SH_TRY(hipEventRecord(sh.ev_comp[h], sh.s_comp));
+            SH_TRY(hipStreamWaitEvent(sh.s_down, sh.ev_comp[h], 0));
+            if (parity_stripe) {
+                const int rc2 = copy_window(s, (char*)parity_stripe + (size_t)g * slab + col, full, pout + col, slab, wbytes, s->M,
+                                            !stripe_on_host, sh.s_down);
+                if (rc2 != FASTECC_OK) return rc2;
+            }
+        }
+        SH_TRY(hipEventRecord(sh.ev_all, sh.s_down));
+        sh.used = true;
+    }
+    SH_TRY(hipSetDevice(s->root));
+    for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
+    return FASTECC_OK;
+}
+
+}  // namespace
+
+void destroy_sharded(Sharded* s)
+{
+    if (!s) return;
+    DeviceSwitch restore;
+    for (Shard& sh : s->shards) {
+        if (hipSetDevice(sh.device) != hipSuccess) continue;
+        for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down})
+            if (q) (void)hipStreamSynchronize(q);
+        if (sh.ctx) fastecc_destroy(sh.ctx);
+        for (int h = 0; h < MAX_SUB; h++) {
+            if (sh.ev_up[h]) (void)hipEventDestroy(sh.ev_up[h]);
+            if (sh.ev_comp[h]) (void)hipEventDestroy(sh.ev_comp[h]);
+        }
+        if (sh.ev_all) (void)hipEventDestroy(sh.ev_all);
+        for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down})
+            if (q) (void)hipStreamDestroy(q);
+        if (sh.data_slab) (void)hipFree(sh.data_slab);
+        if (sh.parity_slab) (void)hipFree(sh.parity_slab);
+    }
+    if (s->fork && hipSetDevice(s->root) == hipSuccess) (void)hipEventDestroy(s->fork);
+    delete s;
+}
+
+int sharded_encode_stripe(fastecc_ctx* shell, const void* data, void* parity, int mem_kind, hipStream_t st)
+{
+    if (mem_kind != FASTECC_MEM_DEVICE && mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_HOST_PINNED) return FASTECC_E_INVAL;
+    std::lock_guard<std::mutex> lk(mutex_of(shell));
+    const int rc = run(shell, nullptr, data, nullptr, parity, mem_kind != FASTECC_MEM_DEVICE, st);
+    if (rc != FASTECC_OK || mem_kind != FASTECC_MEM_HOST) return rc;
+    // pageable host memory: the call is synchronous, like fastecc_encode on one device
+    DeviceSwitch restore;
+    SH_TRY(hipSetDevice(sharded_of(shell)->root));
+    SH_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
+
+fastecc_ctx* sharded_child(fastecc_ctx* shell, int g)
+{
+    Sharded* s = sharded_of(shell);
+    return (s && g >= 0 && g < (int)s->shards.size()) ? s->shards[g].ctx : nullptr;
+}
+
+int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value)
+{
+    Sharded* s = sharded_of(shell);
+    std::lock_guard<std::mutex> lk(mutex_of(shell));
+    if (what == SH_SET_OPTION && !strcmp(name, "sub_slabs")) {
+        if (value < 1 || value > MAX_SUB || (value & (value - 1))) return FASTECC_E_INVAL;
+        s->sub_slabs = value;
+        describe(shell);
+        return FASTECC_OK;
+    }
+    if (what == SH_SET_OPTION && !strcmp(name, "gather_mode")) {
+        if (value != 1 && value != 2) return FASTECC_E_INVAL;
+        s->gather_mode = value;
+        describe(shell);
+        return FASTECC_OK;
+    }
+    for (Shard& sh : s->shards) {
+        int rc = FASTECC_OK;
+        switch (what) {
+            case SH_PROFILE_ENABLE: rc = fastecc_profile_enable(sh.ctx, value); break;
+            case SH_PROFILE_RESET: rc = fastecc_profile_reset(sh.ctx); break;
+            case SH_SET_OPTION: rc = fastecc_set_option(sh.ctx, name, value); break;
+            case SH_SET_PLAN: rc = fastecc_set_plan(sh.ctx, value); break;
+            default: rc = FASTECC_E_INVAL;
+        }
+        if (rc != FASTECC_OK) return rc;
+    }
+    describe(shell);
+    return FASTECC_OK;
+}
+
+}  // namespace fastecc
+
+using namespace fastecc;
+
+extern "C" {
+
+int fastecc_create_sharded(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, const int* gpu_ids, int n_gpus)
+{
+    if (!out) return FASTECC_E_INVAL;
+    *out = nullptr;
+    if (!gpu_ids || n_gpus < 1 || n_gpus > 64) return FASTECC_E_INVAL;
+    const uint64_t unit = field == FASTECC_FIELD_GF_P61_SQUARED ? 16 : 4;
+    if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % (unit * n_gpus)) != 0) return FASTECC_E_INVAL;
+    int ndev = 0;
+    {
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return fail("hipGetDeviceCount", e == hipSuccess ? hipErrorNoDevice : e);
+    }
+    for (int g = 0; g < n_gpus; g++)
+        if (gpu_ids[g] < 0 || gpu_ids[g] >= ndev) return FASTECC_E_INVAL;
+
+    fastecc_ctx* shell = new_shell_ctx(gpu_ids[0], field, k, n - k, block_bytes);
+    Sharded* s = new (std::nothrow) Sharded();
+    if (!shell || !s) {
+        delete s;
+        if (shell) fastecc_destroy(shell);
+        return FASTECC_E_NOMEM;
+    }
+    sharded_of(shell) = s;  // from here on fastecc_destroy(shell) releases everything built so far
+    s->root = gpu_ids[0];
+    s->field = field;
+    s->K = k;
+    s->M = n - k;
+    s->block_bytes = block_bytes;
+    s->slab_bytes = block_bytes / n_gpus;
+    s->shards.resize(n_gpus);
+    DeviceSwitch restore;
+    auto bail = [&](int rc) {
+        fastecc_destroy(shell);
+        return rc;
+    };
+    for (int g = 0; g < n_gpus; g++) {
+        Shard& sh = s->shards[g];
+        sh.device = gpu_ids[g];
+        if (sh.device != s->root) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, sh.device, s->root) != hipSuccess || !can) {
+                set_error_detail("hipDeviceCanAccessPeer(slab device -> root)", hipErrorPeerAccessUnsupported);
+                return bail(FASTECC_E_UNSUPPORTED);
+            }
+        }
+        hipError_t e = hipSetDevice(sh.device);
+        if (e != hipSuccess) return bail(fail("hipSetDevice", e));
+        if (sh.device != s->root) {
+            e = hipDeviceEnablePeerAccess(s->root, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(fail("hipDeviceEnablePeerAccess", e));
+            (void)hipGetLastError();
+        }
+        const int rc = fastecc_create(&sh.ctx, n, k, s->slab_bytes, field, sh.device);
+        if (rc != FASTECC_OK) return bail(rc);
+        for (hipStream_t* q : {&sh.s_up, &sh.s_comp, &sh.s_down}) {
+            e = hipStreamCreateWithFlags(q, hipStreamNonBlocking);
+            if (e != hipSuccess) return bail(fail("hipStreamCreateWithFlags", e));
+        }
+        for (int h = 0; h < MAX_SUB; h++) {
+            e = hipEventCreateWithFlags(&sh.ev_up[h], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.ev_comp[h], hipEventDisableTiming);
+            if (e != hipSuccess) return bail(fail("hipEventCreateWithFlags", e));
+        }
+        e = hipEventCreateWithFlags(&sh.ev_all, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(fail("hipEventCreateWithFlags", e));
+    }
+    hipError_t e = hipSetDevice(s->root);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork, hipEventDisableTiming);
+    if (e != hipSuccess) return bail(fail("hipEventCreateWithFlags(fork)", e));
+    describe(shell);
+    *out = shell;
+    return FASTECC_OK;
+}
+
+int fastecc_encode_sharded(fastecc_ctx* c, const void* const* data_slabs, void* const* parity_slabs, void* parity, void* stream)
+{
+    if (!c || !sharded_of(c) || !data_slabs || (!parity_slabs && !parity)) return FASTECC_E_INVAL;
+    Sharded* s = sharded_of(c);
+    const uintptr_t mask = s->field == FASTECC_FIELD_GF_P61_SQUARED ? 15u : 3u;
+    if ((uintptr_t)parity & mask) return FASTECC_E_INVAL;
+    for (size_t g = 0; g < s->shards.size(); g++) {
+        if (!data_slabs[g] || ((uintptr_t)data_slabs[g] & mask)) return FASTECC_E_INVAL;
+        if (parity_slabs && (!parity_slabs[g] || ((uintptr_t)parity_slabs[g] & mask))) return FASTECC_E_INVAL;
+    }
+    std::lock_guard<std::mutex> lk(mutex_of(c));
+    return run(c, data_slabs, nullptr, parity_slabs, parity, false, (hipStream_t)stream);
+}
+
+int fastecc_shard_info(const fastecc_ctx* c, int* n_slabs, uint64_t* slab_block_bytes, int* devices, int cap)
+{
+    Sharded* s = c ? sharded_of(const_cast<fastecc_ctx*>(c)) : nullptr;
+    if (!s) return FASTECC_E_INVAL;
+    if (n_slabs) *n_slabs = (int)s->shards.size();
+    if (slab_block_bytes) *slab_block_bytes = s->slab_bytes;
+    if (devices)
+        for (int g = 0; g < cap && g < (int)s->shards.size(); g++) devices[g] = s->shards[g].device;
+    return FASTECC_OK;
+}
+
+}  // extern "C"

@@ -1,16 +1,20 @@
-"""Multi-GPU host logic for the encode path (one process per GPU, torch.distributed over RCCL).
+"""Multi-GPU host logic for the encode path when the host runs ONE PROCESS PER GPU (torch.distributed over RCCL).
 
-The encode has NO exchange step: the S word columns of a stripe are independent length-N transforms
-(ntt.cpp:348-350), and different stripes are independent jobs.  Two ways to use N GPUs:
+The encode has no exchange step: the S word columns of a stripe are independent length-N transforms
+(ntt.cpp:348-350), and different stripes are independent jobs.  Two ways to use G GPUs:
 
-  * independent stripes  — rank r encodes stripes r, r+world, ...; nothing is communicated.  This is what
-    bench.py times (weak scaling, no collective in the timed region).
-  * column slabs of ONE stripe — rank r encodes words [r*S/world, (r+1)*S/world) of every block with an
-    encoder built for block_bytes/world, then the slabs are all-gathered and re-interleaved.  The gather
-    is pure data movement (xGMI), reported separately by bench.py --gather.
+  * independent stripes ("replicas") — rank r encodes stripes r, r+G, ...; nothing is communicated;
+  * ONE stripe in column slabs (BASELINE.json configs[3]) — rank r owns words [r*S/G, (r+1)*S/G) of every block
+    (a [k, S/G] slab resident in its HBM), encodes them with an encoder for block_bytes/G, and the parity slabs are
+    gathered over xGMI into full 4 KB parity blocks on one rank: `encode_slab_and_gather`.  The gather is pipelined in
+    column sub-slabs: while sub-slab h travels (RCCL send/recv on its own stream), sub-slab h+1 is being encoded
+    (fastecc_encode_columns), and the root re-interleaves what has arrived.
 
-Everything here is index arithmetic on torch tensors; the encode itself is passed in as a callable so the
-same code runs with the HIP encoder on GPUs and — in the CPU unit tests only — with the oracle.
+The single-process form of the same thing (one host thread driving all GPUs, peer copies instead of RCCL) is
+fastecc_create_sharded / fastecc_encode_sharded in the C ABI (csrc/sharded.hip).
+
+Everything here is index arithmetic on torch tensors plus collectives; the encode itself is passed in as a callable
+so the same code runs with the HIP encoder on GPUs and — in the CPU unit tests only — with the oracle.
 """
 import torch
 
@@ -39,11 +43,107 @@ def merge_slabs(slabs):
     return torch.cat(list(slabs), dim=1).contiguous()
 
 
-def encode_column_sharded(stripe, encode_fn, group=None):
-    """Encode one stripe cooperatively: every rank holds the full `stripe` ([N, S] int32), encodes its
-    column slab with `encode_fn(slab) -> parity_slab`, and all ranks end with the full parity stripe.
+def sub_slab_count(slab_words, wanted):
+    """Largest power of two <= wanted that cuts the slab into sub-slabs of whole 32-word (128-byte) row segments."""
+    h = 1
+    while h * 2 <= wanted and slab_words % (32 * h * 2) == 0:
+        h *= 2
+    return h
 
-    encode_fn must be an encoder for blocks of S/world words (e.g. fastecc_amd.Encoder(2N, N, 4*S/world))."""
+
+def hip_columns_encoder(enc):
+    """encode_columns callable for encode_slab_and_gather from a fastecc_amd.Encoder built for the slab's block size."""
+    def fn(data_slab, parity_slab, col0, width):
+        stream = torch.cuda.current_stream(data_slab.device).cuda_stream if data_slab.is_cuda else 0
+        if col0 == 0 and width == data_slab.shape[1]:
+            enc.encode(data_slab, parity_slab, stream=stream)
+        else:
+            enc.encode_columns(data_slab, parity_slab, col0, width, stream=stream)
+    return fn
+
+
+def encode_slab_and_gather(data_slab, encode_columns, parity_rows, parity_full=None, dst=0, sub_slabs=2, group=None,
+                           collective_on_host=False, workspace=None):
+    """Encode this rank's column slab and gather all ranks' parity slabs into full parity blocks on rank `dst`.
+
+    data_slab      [k, w] int32, contiguous, on this rank's device: words [rank*w, (rank+1)*w) of the k data blocks.
+    encode_columns callable(data_slab, parity_slab, col0, width): parity_slab[:, col0:col0+width] <- encode of those
+                   columns (hip_columns_encoder(...) on GPUs).
+    parity_rows    n - k.
+    parity_full    [n-k, world*w] int32 on rank `dst` (allocated if None there); ignored elsewhere.
+    sub_slabs      pipeline depth: the slab is cut into this many column sub-slabs (rounded down to what splits
+                   into whole 128-byte row segments).
+    collective_on_host  stage the collective's buffers through host memory (CPU tests of the GPU path with gloo).
+    workspace      optional dict: the parity slab, send and receive buffers are kept in it and reused by later calls
+                   (a steady-state caller allocates nothing per stripe).
+
+    Returns (parity_slab, parity_full or None).  Order of work per sub-slab h:
+        encode h -> pack h (strided [n-k, ws] -> contiguous) -> async gather h to dst   | overlaps encode h+1
+        dst: wait gather h -> write the G received pieces into parity_full[:, g*w + h*ws : ...]
+    """
+    import torch.distributed as dist
+    ranked = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if ranked else 1
+    rank = dist.get_rank(group) if ranked else 0
+    k, w = data_slab.shape
+    H = sub_slab_count(w, sub_slabs)
+    ws = w // H
+    dev = data_slab.device
+    ws_ = workspace if workspace is not None else {}
+    key = (parity_rows, w, H, world, str(dev), collective_on_host)
+    if ws_.get("key") != key:
+        ws_.clear()
+        ws_["key"] = key
+    cdev = torch.device("cpu") if collective_on_host else dev
+
+    def buf(name, shape, device):
+        t = ws_.get(name)
+        if t is None:
+            t = ws_[name] = torch.empty(shape, dtype=data_slab.dtype, device=device)
+        return t
+
+    parity_slab = buf("parity_slab", (parity_rows, w), dev)
+    if rank == dst and parity_full is None:
+        parity_full = buf("parity_full", (parity_rows, world * w), dev)
+    pending = []
+    for h in range(H):
+        encode_columns(data_slab, parity_slab, h * ws, ws)
+        piece = parity_slab[:, h * ws:(h + 1) * ws]
+        if H > 1:                                               # pack: RCCL moves contiguous buffers
+            send = buf("send%d" % h, (parity_rows, ws), dev)
+            send.copy_(piece)
+        else:
+            send = piece
+        if collective_on_host:
+            send = send.cpu()
+        if world == 1:
+            pending.append((h, None, [send]))
+            continue
+        recv = [buf("recv%d_%d" % (h, g), (parity_rows, ws), cdev) for g in range(world)] if rank == dst else None
+        work = dist.gather(send, gather_list=recv, dst=dst, group=group, async_op=True)
+        pending.append((h, work, recv))
+        # the root re-interleaves sub-slab h-1 while sub-slab h is on the wire
+        if len(pending) >= 2:
+            _unpack(pending.pop(0), parity_full, rank, dst, w, ws)
+    while pending:
+        _unpack(pending.pop(0), parity_full, rank, dst, w, ws)
+    return parity_slab, (parity_full if rank == dst else None)
+
+
+def _unpack(item, parity_full, rank, dst, w, ws):
+    h, work, recv = item
+    if work is not None:
+        work.wait()  # device collectives: the current stream waits; host collectives: blocks
+    if rank != dst or recv is None:
+        return
+    for g, piece in enumerate(recv):
+        parity_full[:, g * w + h * ws: g * w + (h + 1) * ws].copy_(piece, non_blocking=True)
+
+
+def encode_column_sharded(stripe, encode_fn, group=None):
+    """Every rank holds the full `stripe` ([N, S] int32), encodes its column slab with `encode_fn(slab) -> parity_slab`,
+    and ALL ranks end with the full parity stripe (all_gather; the unpipelined form, kept for hosts that want the parity
+    everywhere)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0

@@ -16,8 +16,11 @@
  *   - All functions return FASTECC_OK (0) or a negative FASTECC_E_* code; no exceptions cross the
  *     ABI and nothing is printed.  The reference returns void and has no error path (RS.cpp:26 prints
  *     and returns on allocation failure); preconditions it leaves implicit are checked here.
- *   - A context is bound to one HIP device and one (n,k,block_bytes).  Use one context per host
- *     thread; distinct contexts are independent.
+ *   - A context is bound to one HIP device (fastecc_create) or to a set of devices (fastecc_create_sharded) and
+ *     one (n,k,block_bytes).  Calls on one context are serialised internally (a second thread blocks until the
+ *     first call has returned) and nothing about a call is kept in the context, so a context may be shared
+ *     between threads and streams; device work of calls that go through the context's internal buffers is
+ *     ordered between streams by the library.  Distinct contexts are independent.
  *   - There is NO CPU fallback: without a usable HIP device fastecc_create fails with
  *     FASTECC_E_DEVICE.
  */
@@ -31,14 +34,15 @@
 extern "C" {
 #endif
 
-#define FASTECC_VERSION 100 /* 0.1.0 */
+#define FASTECC_VERSION 200 /* 0.2.0 */
 
 enum {
     FASTECC_OK = 0,
     FASTECC_E_INVAL = -1,       /* bad argument (n != 2k, k not a power of two, block_bytes % 4, null pointer, ...) */
     FASTECC_E_NOMEM = -2,       /* host or device allocation failed */
     FASTECC_E_DEVICE = -3,      /* no HIP device / HIP runtime error */
-    FASTECC_E_UNSUPPORTED = -4  /* field or size outside what GF(0xFFF00001) admits (k > 2^19) */
+    FASTECC_E_UNSUPPORTED = -4  /* field or size outside what GF(0xFFF00001) admits (k > 2^19), or an entry point the
+                                   context kind does not offer */
 };
 
 enum {
@@ -113,6 +117,53 @@ void fastecc_destroy(fastecc_ctx *ctx);
  *          returns when `parity` is complete.
  */
 int fastecc_encode(fastecc_ctx *ctx, const void *data, void *parity, int mem_kind, void *stream);
+
+/*
+ * The same for the word columns [col0_words, col0_words + width_words) of every block only (DEVICE memory, both
+ * pointers are the stripes' base addresses).  The columns of a stripe are independent transforms (ntt.cpp:348-350),
+ * so a host can cut a stripe into column slabs and overlap their encodes with whatever moves the slabs — which is
+ * what fastecc_encode does for FASTECC_MEM_HOST_PINNED stripes and fastecc_encode_sharded for the xGMI gather.
+ * n = 2k = 2^m over GF(0xFFF00001); FASTECC_E_UNSUPPORTED for the other codes and the 64-bit field (they work through
+ * whole-stripe scratch buffers), and the caller encodes the stripe in one piece.  Any range is accepted; multiples of
+ * 32 words keep every 128-byte row segment whole.
+ */
+int fastecc_encode_columns(fastecc_ctx *ctx, const void *data, void *parity, uint64_t col0_words, uint64_t width_words, void *stream);
+
+/*
+ * One stripe on several GPUs (BASELINE configs[3]; the reference has no multi-device code — SURVEY.md §8e).
+ * The word columns of a stripe are independent transforms, so GPU g of G takes words [g*S/G, (g+1)*S/G) of EVERY
+ * block (S = block_bytes/4): a "column slab" of k blocks x block_bytes/G bytes, encoded by an ordinary per-device
+ * context with no communication; the only exchange is moving slabs (xGMI peer copies, or each GPU's own host link).
+ *
+ *   fastecc_create_sharded : gpu_ids[0] is the ROOT device.  block_bytes must divide by 4*n_gpus (16*n_gpus for the
+ *       64-bit field).  Ids may repeat (several slabs on one device; used by the single-GPU tests).  Every device
+ *       must be able to access the root's memory (hipDeviceCanAccessPeer), else FASTECC_E_UNSUPPORTED.  All (n,k)
+ *       of fastecc_create are accepted.  One host process drives all devices; for one-process-per-GPU hosts see
+ *       fastecc_encode_columns and fastecc_amd/sharding.py (RCCL gather).
+ *   fastecc_encode on such a context, same arguments as ever:
+ *       FASTECC_MEM_DEVICE       data / parity are full stripes in the ROOT device's memory.  Slab g is pulled by GPU g
+ *                                with a strided peer copy, encoded, and its parity pushed back into `parity`; enqueued
+ *                                on internal streams, the call behaves as one operation on `stream` (a stream of the
+ *                                root device) and does not synchronise.
+ *       FASTECC_MEM_HOST_PINNED  full stripes in pinned host memory: every GPU moves its own slab over its own host
+ *                                link (strided copies), so G links work in parallel and no xGMI traffic exists.
+ *       FASTECC_MEM_HOST         the same, synchronous.
+ *   fastecc_encode_sharded : the data is ALREADY sharded — data_slabs[g] is slab g ([k][block_bytes/G], contiguous)
+ *       in GPU g's memory.  parity_slabs (optional): G device pointers, slab g of the parity stays on GPU g.
+ *       parity (optional): full parity stripe in the ROOT's memory, gathered over xGMI ("a final gather").  At least
+ *       one of the two; with parity_slabs == NULL the library uses its own slab buffers.
+ *   Both pipeline in column sub-slabs ("sub_slabs" option, default 2; 64 words at 4 KB blocks on 8 GPUs): the copy of
+ *   one sub-slab runs behind the kernels of the next.  "gather_mode": 1 = copy engines (hipMemcpy2DAsync, default),
+ *   2 = a copy kernel on the sending GPU storing straight into the root's memory.
+ * Other entry points on a sharded context: destroy, set_option (the two above; anything else is forwarded to every
+ * device context), set_plan, plan_string, profile_* (device 0's kernels); the rest return FASTECC_E_UNSUPPORTED.
+ */
+int fastecc_create_sharded(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, const int *gpu_ids,
+                           int n_gpus);
+int fastecc_encode_sharded(fastecc_ctx *ctx, const void *const *data_slabs, void *const *parity_slabs, void *parity, void *stream);
+/* Geometry of a sharded context: slabs (= n_gpus given at creation), bytes of a block that one slab holds, and the
+ * device of slab g (any pointer may be NULL).  FASTECC_E_INVAL on an ordinary context. */
+int fastecc_shard_info(const fastecc_ctx *ctx, int *n_slabs, uint64_t *slab_block_bytes, int *devices, int cap);
 
 /*
  * Many stripes at once: `count` stripes of k blocks stored back to back in DEVICE memory (stripe b at data +

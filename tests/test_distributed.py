@@ -1,7 +1,8 @@
-"""CPU tests of the N>1 path: world_size-2 gloo processes exercising fastecc_amd.sharding.
+"""Tests of the one-process-per-GPU N>1 path: world_size-2 gloo processes exercising fastecc_amd.sharding.
 
-The encode callable is the ORACLE here (tests may use it); on GPUs bench.py passes the HIP encoder through
-the same functions."""
+Without a GPU the encode callable is the ORACLE (tests may use it) — that covers the partitioning, the sub-slab
+pipeline, the gather and the re-interleave.  With a GPU (-m gpu) the same two-rank job runs the HIP encoder through the
+C ABI (both ranks on device 0; gloo moves the pieces through host memory, where bench.py uses RCCL)."""
 import os
 import socket
 import sys
@@ -21,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, S, q):
+def _worker(rank, world, port, N, S, sub_slabs, use_gpu, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,15 +34,40 @@ def _worker(rank, world, port, N, S, q):
         rng = np.random.default_rng(123)  # same stripe on every rank
         host = rng.integers(0, 0xFFF00001, size=(N, S), dtype=np.uint64).astype(np.uint32)
         stripe = torch.from_numpy(host.view(np.int32))
-
-        def encode_fn(slab):
-            out = orc.encode_fast(slab.numpy().view(np.uint32))
-            return torch.from_numpy(out.view(np.int32))
-
-        # (1) column slabs of one stripe + all_gather == encode of the whole stripe
-        full = sharding.encode_column_sharded(stripe, encode_fn)
         want = orc.encode_fast(host)
-        ok_cols = np.array_equal(full.numpy().view(np.uint32), want)
+        w = S // world
+
+        if use_gpu:
+            import fastecc_amd
+            enc = fastecc_amd.Encoder(2 * N, N, 4 * w, device=0)
+            columns = sharding.hip_columns_encoder(enc)
+            my_slab = sharding.take_slab(stripe, rank, world).to("cuda:0")
+        else:
+            def columns(data_slab, parity_slab, col0, width):  # the oracle on a column range (columns are independent)
+                cols = np.ascontiguousarray(data_slab.numpy().view(np.uint32)[:, col0:col0 + width])
+                parity_slab[:, col0:col0 + width] = torch.from_numpy(orc.encode_fast(cols).view(np.int32))
+            my_slab = sharding.take_slab(stripe, rank, world)
+
+        # (1) one stripe in column slabs: encode + pipelined gather == encode of the whole stripe, on the root only
+        pslab, full = sharding.encode_slab_and_gather(my_slab, columns, N, dst=0, sub_slabs=sub_slabs, collective_on_host=use_gpu)
+        if use_gpu:
+            torch.cuda.synchronize()
+        ok_slab = np.array_equal(pslab.cpu().numpy().view(np.uint32), want[:, rank * w:(rank + 1) * w])
+        ok_cols = (full is None) if rank != 0 else np.array_equal(full.cpu().numpy().view(np.uint32), want)
+
+        # (1b) the all-gather form: every rank ends with the full parity
+        def encode_fn(slab):
+            out = torch.empty_like(slab)
+            if use_gpu:
+                dslab = slab.to("cuda:0")
+                dout = torch.empty_like(dslab)
+                enc.encode(dslab, dout)
+                torch.cuda.synchronize()
+                return dout.cpu()
+            out.copy_(torch.from_numpy(orc.encode_fast(slab.numpy().view(np.uint32)).view(np.int32)))
+            return out
+        everywhere = sharding.encode_column_sharded(stripe, encode_fn)
+        ok_cols = ok_cols and np.array_equal(everywhere.numpy().view(np.uint32), want)
 
         # (2) independent stripes: every stripe encoded exactly once across ranks
         mine = sharding.stripes_for_rank(5, rank, world)
@@ -54,28 +80,58 @@ def _worker(rank, world, port, N, S, q):
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ok_max = float(t.item()) == float(world)
-        q.put((rank, ok_cols, ok_stripes, ok_max))
+        if use_gpu:
+            enc.close()
+        q.put((rank, ok_slab and ok_cols, ok_stripes, ok_max))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,S", [(64, 8), (256, 6)])
-def test_two_rank_gloo_column_slabs_and_stripes(N, S):
+def _run_two_ranks(N, S, sub_slabs, use_gpu):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, S, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, S, sub_slabs, use_gpu, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == [0, 1]
     for rank, ok_cols, ok_stripes, ok_max in results:
-        assert ok_cols, "column-sharded encode + all_gather differs from the full encode (rank %d)" % rank
+        assert ok_cols, "column-sharded encode + gather differs from the full encode (rank %d)" % rank
         assert ok_stripes and ok_max
+
+
+@pytest.mark.parametrize("N,S,sub_slabs", [(64, 8, 2), (256, 6, 1), (128, 256, 2), (128, 256, 4)])
+def test_two_rank_gloo_column_slabs_and_stripes(N, S, sub_slabs):
+    _run_two_ranks(N, S, sub_slabs, use_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,sub_slabs", [(1 << 10, 1024, 2), (1 << 12, 256, 4), (64, 8, 2)])
+def test_two_rank_gloo_with_the_hip_encoder(hip_lib, N, S, sub_slabs):
+    _run_two_ranks(N, S, sub_slabs, use_gpu=True)
+
+
+@pytest.mark.gpu
+def test_single_rank_pipeline_with_the_hip_encoder(hip_lib, oracle):
+    """world = 1: the sub-slab pipeline alone (fastecc_encode_columns per sub-slab, pack, unpack) on the device."""
+    sys.path.insert(0, ROOT)
+    import fastecc_amd
+    from fastecc_amd import sharding
+    N, w = 1 << 12, 128
+    host = np.random.default_rng(3).integers(0, 0xFFF00001, size=(N, w), dtype=np.uint64).astype(np.uint32)
+    slab = torch.from_numpy(host.view(np.int32)).to("cuda:0")
+    with fastecc_amd.Encoder(2 * N, N, 4 * w, device=0) as enc:
+        for sub in (1, 2, 4):
+            pslab, full = sharding.encode_slab_and_gather(slab, sharding.hip_columns_encoder(enc), N, sub_slabs=sub)
+            torch.cuda.synchronize()
+            want = oracle.encode_fast(host)
+            assert np.array_equal(pslab.cpu().numpy().view(np.uint32), want)
+            assert np.array_equal(full.cpu().numpy().view(np.uint32), want)
 
 
 def test_slab_helpers_roundtrip():
@@ -89,3 +145,5 @@ def test_slab_helpers_roundtrip():
     with pytest.raises(ValueError):
         sharding.slab_bounds(10, 0, 4)
     assert sharding.stripes_for_rank(7, 1, 3) == [1, 4]
+    assert [sharding.sub_slab_count(w, 4) for w in (128, 64, 32, 96, 8)] == [4, 2, 1, 1, 1]
+    assert sharding.sub_slab_count(128, 1) == 1 and sharding.sub_slab_count(128, 3) == 2

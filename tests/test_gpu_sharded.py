@@ -1,0 +1,257 @@
+"""GPU tests (-m gpu) of the column-sharded encode — BASELINE.json configs[3] — through the C ABI.
+
+A GPU box for these tests has ONE device, so the slabs of fastecc_create_sharded all live on device 0
+(gpu_ids = [0]*G): the partitioning, the sub-slab pipeline, both gather mechanisms and every data-placement
+form run exactly as on G devices, only the "peer" copies stay inside one HBM.  Checked bit-for-bit against
+the single-device HIP encode, the oracle, and at the headline size the reference's golden parity hash."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFF00001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to("cuda:0")
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def rand_stripe(seed, N, S):
+    return np.random.default_rng(seed).integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+
+
+@pytest.mark.parametrize("log2n,S,col0,width", [(10, 1024, 0, 1024), (10, 1024, 64, 32), (12, 256, 128, 128), (7, 96, 32, 64), (13, 40, 5, 18), (3, 8, 2, 4)])
+def test_encode_columns_is_the_column_range_of_the_encode(torch_cuda, fe, oracle, log2n, S, col0, width):
+    torch = torch_cuda
+    N = 1 << log2n
+    x = rand_stripe(log2n * 1000 + S, N, S)
+    want = oracle.encode_fast(x)
+    d = to_dev(torch, x)
+    out = torch.full((N * S,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode_columns(d, out, col0, width)
+        torch.cuda.synchronize()
+    got = to_host(out).reshape(N, S)
+    assert np.array_equal(got[:, col0:col0 + width], want[:, col0:col0 + width])
+    untouched = np.ones(S, dtype=bool)
+    untouched[col0:col0 + width] = False
+    assert (got[:, untouched] == 0x5A5A5A5A).all()
+
+
+def test_encode_columns_rejects_what_it_cannot_do(torch_cuda, fe):
+    torch = torch_cuda
+    buf = torch.zeros(64 * 64, dtype=torch.int32, device="cuda:0")
+    with fe.Encoder(128, 64, 256) as enc:
+        for col0, width in [(0, 0), (32, 64), (0, 65)]:
+            with pytest.raises(fe.FastEccError) as ei:
+                enc.encode_columns(buf, buf, col0, width)
+            assert ei.value.code == fe.E_INVAL
+    with fe.Encoder(96 + 64, 64, 256) as enc:  # a folded code works through scratch stripes: one piece only
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.encode_columns(buf, buf, 0, 32)
+        assert ei.value.code == fe.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("G", [1, 2, 8])
+@pytest.mark.parametrize("sub_slabs,gather_mode", [(1, 1), (2, 1), (2, 2), (4, 2)])
+def test_sharded_slabs_equal_the_single_device_encode(torch_cuda, fe, oracle, G, sub_slabs, gather_mode):
+    """data already sharded (slab g on 'GPU' g) -> parity slabs and the gathered parity stripe."""
+    torch = torch_cuda
+    N, S = 1 << 10, 1024
+    x = rand_stripe(7 + G, N, S)
+    want = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:  # the single-device HIP encode
+        single = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(to_dev(torch, x), single)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(single).reshape(N, S), want)
+    w = S // G
+    slabs = [to_dev(torch, x[:, g * w:(g + 1) * w]) for g in range(G)]
+    pslabs = [torch.empty(N * w, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+    parity = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        senc.set_option("sub_slabs", sub_slabs)
+        senc.set_option("gather_mode", gather_mode)
+        assert "%d slabs" % G in senc.plan()
+        senc.encode_sharded(slabs, pslabs, parity)          # both outputs
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(parity).reshape(N, S), want)
+        for g in range(G):
+            assert np.array_equal(to_host(pslabs[g]).reshape(N, w), want[:, g * w:(g + 1) * w])
+        parity.zero_()
+        senc.encode_sharded(slabs, None, parity)            # gather only, library-owned slab buffers
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(parity).reshape(N, S), want)
+        for t in pslabs:
+            t.zero_()
+        senc.encode_sharded(slabs, pslabs, None)            # parity stays sharded
+        torch.cuda.synchronize()
+        for g in range(G):
+            assert np.array_equal(to_host(pslabs[g]).reshape(N, w), want[:, g * w:(g + 1) * w])
+        with pytest.raises(fe.FastEccError):
+            senc.encode_sharded(slabs, None, None)
+
+
+@pytest.mark.parametrize("mem", ["device", "host", "pinned"])
+def test_sharded_context_takes_full_stripes_like_fastecc_encode(torch_cuda, fe, oracle, mem):
+    torch = torch_cuda
+    N, S, G = 1 << 9, 512, 4
+    x = rand_stripe(99, N, S)
+    want = oracle.encode_fast(x)
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        if mem == "device":
+            d = to_dev(torch, x)
+            out = torch.empty_like(d)
+            senc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(out).reshape(N, S), want)
+            senc.encode(d)  # in place, like the reference
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(d).reshape(N, S), want)
+        elif mem == "host":
+            out = np.empty_like(x)
+            senc.encode(x, out, mem=fe.MEM_HOST)
+            assert np.array_equal(out, want)
+        else:
+            hx = torch.from_numpy(x.view(np.int32)).pin_memory()
+            hout = torch.empty_like(hx).pin_memory()
+            senc.encode(hx, hout, mem=fe.MEM_HOST_PINNED)
+            torch.cuda.synchronize()
+            assert np.array_equal(hout.numpy().view(np.uint32), want)
+
+
+def test_sharded_other_codes_and_the_64_bit_field(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    # fewer parity blocks (a sub-coset of the (2k,k) parity) and a zero-extended code: each slab is an ordinary context
+    N, S, G = 256, 256, 4
+    x = rand_stripe(5, N, S)
+    full = oracle.encode_fast(x)
+    with fe.ShardedEncoder(N + N // 4, N, 4 * S, [0] * G) as senc:
+        d, out = to_dev(torch, x), torch.empty(N // 4 * S, dtype=torch.int32, device="cuda:0")
+        senc.encode(d, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(out).reshape(N // 4, S), full[::4])
+    K, Mu = 200, 50
+    xz = np.zeros((N, S), dtype=np.uint32)
+    xz[:K] = x[:K]
+    fullz = oracle.encode_fast(xz)
+    with fe.ShardedEncoder(K + Mu, K, 4 * S, [0] * G) as senc:
+        d, out = to_dev(torch, x[:K]), torch.empty(Mu * S, dtype=torch.int32, device="cuda:0")
+        senc.encode(d, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(out).reshape(Mu, S), fullz[::4][:Mu])
+    # GF((2^61-1)^2): 16-byte elements, slabs of whole elements
+    from oracle import OracleP61
+    o61 = OracleP61()
+    N, elems, G = 128, 64, 4
+    h = o61.fill_splitmix(N, elems, 0x77)
+    want = o61.encode(h)
+    d = torch.from_numpy(h.view(np.int64)).to("cuda:0")
+    out = torch.empty_like(d)
+    with fe.ShardedEncoder(2 * N, N, 16 * elems, [0] * G, field=fe.FIELD_GF_P61_SQUARED) as senc:
+        senc.encode(d, out)
+        torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(want.shape), want)
+
+
+def test_sharded_argument_checks(torch_cuda, fe):
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.ShardedEncoder(256, 128, 4096, [])
+    assert ei.value.code == fe.E_INVAL
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.ShardedEncoder(256, 128, 4096 + 4, [0] * 8)  # the block does not split into 8 slabs of whole words
+    assert ei.value.code == fe.E_INVAL
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.ShardedEncoder(256, 128, 4096, [0, 99])
+    assert ei.value.code == fe.E_INVAL
+    torch = torch_cuda
+    buf = torch.zeros(128 * 1024, dtype=torch.int32, device="cuda:0")
+    with fe.ShardedEncoder(256, 128, 4096, [0, 0]) as senc:
+        for call in (lambda: senc.ntt(buf), lambda: senc.check_range(buf), lambda: senc.encode_batch(buf, buf, 1),
+                     lambda: senc.encode_columns(buf, buf, 0, 32)):
+            with pytest.raises(fe.FastEccError) as ei:
+                call()
+            assert ei.value.code == fe.E_UNSUPPORTED
+
+
+def test_headline_stripe_in_eight_slabs_reproduces_the_reference_hash(torch_cuda, fe, oracle, golden_hashes):
+    """(2^20, 2^19) x 4 KB split into 8 slabs of 512 B per block (configs[3]) == the reference's parity."""
+    torch = torch_cuda
+    N, S, G = 1 << 19, 1024, 8
+    c = [g for g in golden_hashes["survey_appendix_b"] if g["input"] == "splitmix"][0]
+    x = oracle.fill_splitmix(N, S, golden_hashes["splitmix_seed"])
+    assert oracle.hash(x) == c["hash_input"]
+    w = S // G
+    slabs = [to_dev(torch, x[:, g * w:(g + 1) * w]) for g in range(G)]
+    parity = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        for mode in (1, 2):
+            parity.zero_()
+            senc.set_option("gather_mode", mode)
+            senc.encode_sharded(slabs, None, parity)
+            torch.cuda.synchronize()
+            assert oracle.hash(to_host(parity).reshape(N, S)) == c["hash_parity"], mode
+        d = to_dev(torch, x)  # and the drop-in form: the same fastecc_encode call on full stripes
+        senc.encode(d)
+        torch.cuda.synchronize()
+        assert oracle.hash(to_host(d).reshape(N, S)) == c["hash_parity"]
+
+
+def test_one_context_shared_by_threads_and_streams(torch_cuda, fe, oracle):
+    """fastecc.h: calls on one context are serialised and carry no state in it — two threads on two streams, a plain
+    (2k,k) context (no internal buffers: device work may overlap) and a zero-extended one (internal work stripe)."""
+    torch = torch_cuda
+    N, S = 1 << 11, 256
+    xs = [rand_stripe(40 + i, N, S) for i in range(2)]
+    wants = [oracle.encode_fast(x) for x in xs]
+    K, Mu = 1500, 300
+    zs = []
+    for x in xs:
+        z = np.zeros_like(x)
+        z[:K] = x[:K]
+        zs.append(oracle.encode_fast(z)[::4][:Mu])
+    for general in (False, True):
+        enc = fe.Encoder(K + Mu, K, 4 * S) if general else fe.Encoder(2 * N, N, 4 * S)
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        ins = [to_dev(torch, x[:K] if general else x) for x in xs]
+        outs = [torch.empty((Mu if general else N) * S, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+        torch.cuda.synchronize()
+        errors = []
+
+        def work(i):
+            try:
+                for _ in range(20):
+                    enc.encode(ins[i], outs[i], stream=streams[i].cuda_stream)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for i in range(2):
+            got = to_host(outs[i]).reshape(-1, S)
+            assert np.array_equal(got, zs[i] if general else wants[i]), (general, i)
+        enc.close()
