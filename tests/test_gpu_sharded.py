@@ -65,7 +65,7 @@ def test_encode_columns_rejects_what_it_cannot_do(torch_cuda, fe):
             with pytest.raises(fe.FastEccError) as ei:
                 enc.encode_columns(buf, buf, col0, width)
             assert ei.value.code == fe.E_INVAL
-    with fe.Encoder(96 + 64, 64, 256) as enc:  # a folded code works through scratch stripes: one piece only
+    with fe.Encoder(64 + 16, 64, 256) as enc:  # a folded code works through scratch stripes: one piece only
         with pytest.raises(fe.FastEccError) as ei:
             enc.encode_columns(buf, buf, 0, 32)
         assert ei.value.code == fe.E_UNSUPPORTED
