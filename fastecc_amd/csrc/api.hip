@@ -1519,12 +1519,11 @@ int fastecc_set_plan(fastecc_ctx* c, int plan)
     if (c->sharded) return sharded_forward(c, SH_SET_PLAN, nullptr, plan);
     CallLock lk(c->mu);
     if (c->p61) {
-        // plan ids of this field: 0 = default, 1..5 = radix-2 levels per register pass
+        // plan ids of this field: gf61_path.hpp
         DeviceGuard dg(c->device);
         if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
         HIP_TRY(hipDeviceSynchronize());
-        if (plan < 0 || plan > 5) return FASTECC_E_INVAL;
-        const int rc = p61::set_levels_per_pass(c->p61, plan == 0 ? p61::DEFAULT_LEVELS : plan, g_detail, sizeof g_detail);
+        const int rc = p61::set_plan(c->p61, plan, g_detail, sizeof g_detail);
         c->plan_text = p61::plan_string(c->p61);
         return rc;
     }

@@ -75,17 +75,41 @@ inline Elem h_root(uint64_t order)
 
 #if defined(__HIPCC__)
 // ---- device arithmetic ----
+// Shaped for what hipcc emits on gfx950 (checked in the ISA, tools/count_valu.py): 58-60 VALU instructions per
+// radix-2 butterfly, 22 of them v_mad_u64_u32, no register moves.  The round-1 formulation compiled to 117 — the
+// compiler strength-reduced "x * 2^31 + acc" into 64-bit shifts, masks and adds, and built every masked 64-bit value in
+// a fresh register pair with v_mov copies.  Two constants that the compiler must not see through (Opaque) keep those
+// multiply-adds as the single instruction they are.
 #define GF61_D __device__ __forceinline__
 
-GF61_D uint64_t mad64(uint32_t a, uint32_t b, uint64_t acc) { return (uint64_t)a * b + acc; }  // v_mad_u64_u32
+struct Opaque {
+    uint32_t k31;  // 2^31
+    uint32_t one;  // 1
+};
+GF61_D Opaque make_opaque()
+{
+    Opaque k;
+    asm("s_mov_b32 %0, 0x80000000" : "=s"(k.k31));
+    asm("s_mov_b32 %0, 1" : "=s"(k.one));
+    return k;
+}
 
-// t < 2^64  ->  congruent value < 2^61 + 8
-GF61_D uint64_t fold(uint64_t t) { return (t & P) + (t >> 61); }
+GF61_D uint64_t mad64(uint32_t a, uint32_t b, uint64_t acc) { return (uint64_t)a * b + acc; }  // v_mad_u64_u32
+GF61_D uint64_t join(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// t < 2^64  ->  congruent value < 2^61 + 8:  (t mod 2^61) + (t >> 61), as  and / shift / one multiply-add by 1
+GF61_D uint64_t fold(uint64_t t, const Opaque& k)
+{
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    return mad64(hi >> 29, k.one, join(lo, hi & 0x1FFFFFFFu));
+}
 
 // lazy + lazy -> lazy
-GF61_D uint64_t add(uint64_t x, uint64_t y) { return fold(x + y); }
-// lazy - lazy -> lazy:  y < 2^61 + 16 <= 2p, so 2p - y does not wrap
-GF61_D uint64_t sub(uint64_t x, uint64_t y) { return fold(x + (2 * P - y)); }
+GF61_D uint64_t add(uint64_t x, uint64_t y, const Opaque& k) { return fold(x + y, k); }
+// lazy - lazy, NOT folded: < 2^63.  y < 2^61 + 16 <= 2p, so 2p - y does not wrap.  Feeds mul() directly.
+GF61_D uint64_t sub_raw(uint64_t x, uint64_t y) { return x + (2 * P - y); }
+// lazy - lazy -> lazy
+GF61_D uint64_t sub(uint64_t x, uint64_t y, const Opaque& k) { return fold(sub_raw(x, y), k); }
 
 // lazy (< 2^61 + 16 <= 2p) -> canonical
 GF61_D uint64_t canon(uint64_t x) { return x >= P ? x - P : x; }
@@ -111,28 +135,59 @@ GF61_D Twiddle make_twiddle(uint64_t c, uint64_t d)
     return w;
 }
 
-GF61_D uint64_t combine(uint64_t acc, uint64_t mid)
+// x < 2^63 -> limbs with x = x1 2^31 + x0 (mod p), x0 < 2^31 + 4, x1 < 2^30: bits 61, 62 (weight 2^61 = 1) join the low limb
+GF61_D void split_raw(uint64_t x, uint32_t& x0, uint32_t& x1)
 {
-    const uint32_t ml = (uint32_t)mid & 0x3FFFFFFFu;
-    uint64_t t = mad64(ml, 0x80000000u, acc);
-    t += mid >> 30;
-    return fold(t);
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    x1 = __builtin_amdgcn_alignbit(hi, lo, 31) & 0x3FFFFFFFu;
+    x0 = (lo & 0x7FFFFFFFu) + (hi >> 29);
+}
+// the same for a lazy x (< 2^61 + 16): x1 <= 2^30 needs no mask
+GF61_D void split_lazy(uint64_t x, uint32_t& x0, uint32_t& x1)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    x1 = __builtin_amdgcn_alignbit(hi, lo, 31);
+    x0 = lo & 0x7FFFFFFFu;
 }
 
-// (a + b i)(c + d i) = (a c + b e) + (a d + b c) i,  e = -d
-GF61_D Elem mul(Elem x, const Twiddle& w)
+// acc + mid 2^31 (mod p) -> lazy.  mid = mh 2^30 + ml  =>  mid 2^31 = mh + ml 2^31 (mod p); acc < 1.5 2^63 + 2^35, mid < 2^63 + 2^35
+GF61_D uint64_t combine(uint64_t acc, uint64_t mid, const Opaque& k)
 {
-    const uint32_t a0 = (uint32_t)x.re & 0x7FFFFFFFu, a1 = (uint32_t)(x.re >> 31);
-    const uint32_t b0 = (uint32_t)x.im & 0x7FFFFFFFu, b1 = (uint32_t)(x.im >> 31);
+    const uint32_t ml = (uint32_t)mid & 0x3FFFFFFFu;
+    uint64_t t = mad64(ml, k.k31, acc);
+    t += mid >> 30;
+    return fold(t, k);
+}
+
+// (a + b i)(c + d i) = (a c + b e) + (a d + b c) i,  e = -d; limbs a0, b0 < 2^31 + 4 and a1, b1 <= 2^30
+GF61_D Elem mul_limbs(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const Twiddle& w, const Opaque& k)
+{
     const uint64_t re_acc = mad64(b1, w.e1d, mad64(a1, w.c1d, mad64(b0, w.e0, mad64(a0, w.c0, 0))));
     const uint64_t re_mid = mad64(b1, w.e0, mad64(b0, w.e1, mad64(a1, w.c0, mad64(a0, w.c1, 0))));
     const uint64_t im_acc = mad64(b1, w.c1d, mad64(a1, w.d1d, mad64(b0, w.c0, mad64(a0, w.d0, 0))));
     const uint64_t im_mid = mad64(b1, w.c0, mad64(b0, w.c1, mad64(a1, w.d0, mad64(a0, w.d1, 0))));
-    return Elem{combine(re_acc, re_mid), combine(im_acc, im_mid)};
+    return Elem{combine(re_acc, re_mid, k), combine(im_acc, im_mid, k)};
+}
+// x lazy
+GF61_D Elem mul(Elem x, const Twiddle& w, const Opaque& k)
+{
+    uint32_t a0, a1, b0, b1;
+    split_lazy(x.re, a0, a1);
+    split_lazy(x.im, b0, b1);
+    return mul_limbs(a0, a1, b0, b1, w, k);
+}
+// x components < 2^63 (sub_raw results)
+GF61_D Elem mul_raw(Elem x, const Twiddle& w, const Opaque& k)
+{
+    uint32_t a0, a1, b0, b1;
+    split_raw(x.re, a0, a1);
+    split_raw(x.im, b0, b1);
+    return mul_limbs(a0, a1, b0, b1, w, k);
 }
 
-GF61_D Elem add(Elem x, Elem y) { return Elem{add(x.re, y.re), add(x.im, y.im)}; }
-GF61_D Elem sub(Elem x, Elem y) { return Elem{sub(x.re, y.re), sub(x.im, y.im)}; }
+GF61_D Elem add(Elem x, Elem y, const Opaque& k) { return Elem{add(x.re, y.re, k), add(x.im, y.im, k)}; }
+GF61_D Elem sub(Elem x, Elem y, const Opaque& k) { return Elem{sub(x.re, y.re, k), sub(x.im, y.im, k)}; }
+GF61_D Elem sub_raw(Elem x, Elem y) { return Elem{sub_raw(x.re, y.re), sub_raw(x.im, y.im)}; }
 GF61_D Elem canon(Elem x) { return Elem{canon(x.re), canon(x.im)}; }
 #endif
 

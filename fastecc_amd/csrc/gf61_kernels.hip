@@ -70,7 +70,7 @@ __device__ __forceinline__ void store_elem(uint64_t* p, Elem e)
 // Twiddles of level l = sl + T for a lane set holding blocks (.. + j*2^sl + off): entries
 // 2^l + (off << T) + m, m < 2^T, of the level-packed table (same packing as ntt_device.hpp).
 template <int LOGR, bool LO_ZERO, int T>
-__device__ __forceinline__ void dif_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl)
+__device__ __forceinline__ void dif_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
 {
     constexpr int R = 1 << LOGR, half = 1 << T;
     const_u64_ptr p = as_constant(twl) + 2 * (((size_t)1 << (sl + T)) + ((size_t)off << T));
@@ -82,15 +82,14 @@ __device__ __forceinline__ void dif_one_level(Elem (&x)[1 << LOGR], const uint64
         for (int j0 = 0; j0 < R; j0 += 2 * half) {
             const int ja = j0 + m, jb = ja + half;
             const Elem a = x[ja], b = x[jb];
-            x[ja] = gf61::add(a, b);
-            const Elem d = gf61::sub(a, b);
-            x[jb] = unit ? d : gf61::mul(d, w);
+            x[ja] = gf61::add(a, b, k);
+            x[jb] = unit ? gf61::sub(a, b, k) : gf61::mul_raw(gf61::sub_raw(a, b), w, k);
         }
     }
 }
 
 template <int LOGR, bool LO_ZERO, int T>
-__device__ __forceinline__ void dit_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl)
+__device__ __forceinline__ void dit_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
 {
     constexpr int R = 1 << LOGR, half = 1 << T;
     const_u64_ptr p = as_constant(twl) + 2 * (((size_t)1 << (sl + T)) + ((size_t)off << T));
@@ -102,31 +101,32 @@ __device__ __forceinline__ void dit_one_level(Elem (&x)[1 << LOGR], const uint64
         for (int j0 = 0; j0 < R; j0 += 2 * half) {
             const int ja = j0 + m, jb = ja + half;
             const Elem a = x[ja];
-            const Elem b = unit ? x[jb] : gf61::mul(x[jb], w);
-            x[ja] = gf61::add(a, b);
-            x[jb] = gf61::sub(a, b);
+            const Elem b = unit ? x[jb] : gf61::mul(x[jb], w, k);
+            x[ja] = gf61::add(a, b, k);
+            x[jb] = gf61::sub(a, b, k);
         }
     }
 }
 
-template <int LOGR, bool LO_ZERO>
-__device__ __forceinline__ void dif_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl)
+// LEVELS < LOGR: only the low LEVELS register bits are butterfly levels (the lane holds 2^(LOGR-LEVELS) independent groups)
+template <int LOGR, bool LO_ZERO, int LEVELS = LOGR>
+__device__ __forceinline__ void dif_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
 {
-    if constexpr (LOGR >= 5) dif_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl);
-    if constexpr (LOGR >= 4) dif_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl);
-    if constexpr (LOGR >= 3) dif_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl);
-    if constexpr (LOGR >= 2) dif_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl);
-    dif_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl);
+    if constexpr (LEVELS >= 5) dif_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 4) dif_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 3) dif_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 2) dif_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 1) dif_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl, k);
 }
 
-template <int LOGR, bool LO_ZERO>
-__device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl)
+template <int LOGR, bool LO_ZERO, int LEVELS = LOGR>
+__device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
 {
-    dit_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl);
-    if constexpr (LOGR >= 2) dit_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl);
-    if constexpr (LOGR >= 3) dit_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl);
-    if constexpr (LOGR >= 4) dit_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl);
-    if constexpr (LOGR >= 5) dit_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl);
+    if constexpr (LEVELS >= 1) dit_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 2) dit_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 3) dit_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 4) dit_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl, k);
+    if constexpr (LEVELS >= 5) dit_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl, k);
 }
 
 // One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(cons
     const uint64_t base = ((uint64_t)hi << (s + LOGR)) + lo;  // first block of this group
     const uint64_t row_words = 2ull * a.elems;
 
+    const gf61::Opaque k = gf61::make_opaque();
     Elem x[R];
     if (live) {
 #pragma unroll
@@ -159,24 +160,132 @@ __global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(cons
     }
 
     if constexpr (MODE == MODE_DIF) {
-        if (a.s == 0) dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0);
-        else          dif_levels<LOGR, false>(x, a.tw_dif, lo, s);
+        if (a.s == 0) dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0, k);
+        else          dif_levels<LOGR, false>(x, a.tw_dif, lo, s, k);
     } else if constexpr (MODE == MODE_DIT) {
-        if (a.s == 0) dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0);
-        else          dit_levels<LOGR, false>(x, a.tw_dit, lo, s);
+        if (a.s == 0) dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0, k);
+        else          dit_levels<LOGR, false>(x, a.tw_dit, lo, s, k);
     } else {
-        dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0);
+        dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0, k);
         // position p = hi*R + j holds coefficient bitrev_n(p); dscale is stored in position order
         const_u64_ptr d = as_constant(a.dscale) + 2 * ((size_t)hi * R);
 #pragma unroll
-        for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]));
-        dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0);
+        for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
+        dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0, k);
     }
 
     if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j)
             store_elem(a.out + (base + ((uint64_t)j << s)) * row_words + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled pass: LOGT = LOGR + L2 radix-2 levels per trip through HBM (register passes: at most 4).
+//
+// A workgroup owns T = 2^LOGT blocks x 64 element columns (1 KiB of every block row: contiguous in HBM).  A lane keeps
+// R = 2^LOGR elements of ONE column in VGPRs; the workgroup's G = 2^L2 waves hold
+//     layout A  blocks q = j*G + g   (j < R)  -> the high LOGR levels are in-thread, twiddles wave-uniform (off = g)
+//     layout B  blocks q = g*R + k   (k < R)  -> the low L2 levels are in-thread
+// and LDS is touched only to turn A into B or back: one ds_write_b128 / ds_read_b128 round trip per element, rows of
+// 64 (or 32: SPLIT = 2) consecutive 16-byte elements, conflict-free.  An exchange never mixes columns, so SPLIT = 2 runs
+// it one half of the columns at a time through a buffer half the size (64 KiB for the 128-block tile: two workgroups
+// per CU).  Everything else — twiddle tables, level order, lazy values — is the register pass's.
+//   DIF  load A -> LOGR levels -> A=>B -> L2 levels -> store B           (outer passes: s >= 1)
+//   DIT  load B -> L2 levels -> B=>A -> LOGR levels -> store A
+//   MID  s = 0: DIF half, multiply block p by D[bitrev(p)] (RS.cpp:51-59), DIT half: 2*LOGT levels per trip
+// With k = 2^19 the encode is dif6@13, dif6@7, mid7@0, dit6@7, dit6@13: 5 trips instead of 9.
+template <int LOGT, int LOGR, int MODE, bool CANON, int SPLIT>
+__global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(const PassArgs a)
+{
+    constexpr int R = 1 << LOGR, L2 = LOGT - LOGR, G = 1 << L2, WS = 64 / SPLIT;
+    static_assert(L2 >= 1 && L2 <= LOGR, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) u64x2 lds[];  // T rows of WS elements
+
+    const uint32_t g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t cc = tile % a.col_chunks;
+    const uint32_t grp = tile / a.col_chunks;
+    const uint32_t col = cc * 64u + lane;
+    const bool live = col < a.elems;
+    const int s = MODE == MODE_MID ? 0 : a.s;
+    const uint32_t lo = grp & ((1u << s) - 1u);
+    const uint32_t hi = grp >> s;
+    const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
+    const uint64_t row_words = 2ull * a.elems;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint32_t my_round = lane / WS;
+    u64x2* my_lds = lds + (lane % WS);
+
+    auto row_a = [&](int j) { return (uint32_t)j * G + g; };
+    auto row_b = [&](int j) { return g * R + (uint32_t)j; };
+    Elem x[R];
+    auto load = [&](auto row_of) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            x[j] = live ? load_elem(a.in + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col) : Elem{0, 0};
+    };
+    auto store = [&](auto row_of) {
+        if (!live) return;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            store_elem(a.out + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);
+    };
+    // write the registers in one layout, read them back in the other; nobody may still be reading the buffer on entry
+    auto exchange = [&](auto wrow, auto rrow) {
+#pragma unroll
+        for (int round = 0; round < SPLIT; ++round) {
+            const bool mine = SPLIT == 1 || my_round == (uint32_t)round;
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    u64x2 t;
+                    t.x = x[j].re;
+                    t.y = x[j].im;
+                    my_lds[wrow(j) * WS] = t;
+                }
+            }
+            __syncthreads();
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const u64x2 t = my_lds[rrow(j) * WS];
+                    x[j] = Elem{t.x, t.y};
+                }
+            }
+            if (round + 1 < SPLIT) __syncthreads();
+        }
+    };
+
+    const uint32_t off_a = (g << s) + lo;  // layout A: x[j] = block (.. + j * 2^(s+L2) + off_a)
+    if constexpr (MODE == MODE_DIF) {
+        load(row_a);
+        dif_levels<LOGR, false>(x, a.tw_dif, off_a, s + L2, k);
+        exchange(row_a, row_b);
+        dif_levels<LOGR, false, L2>(x, a.tw_dif, lo, s, k);
+        store(row_b);
+    } else if constexpr (MODE == MODE_DIT) {
+        load(row_b);
+        dit_levels<LOGR, false, L2>(x, a.tw_dit, lo, s, k);
+        exchange(row_b, row_a);
+        dit_levels<LOGR, false>(x, a.tw_dit, off_a, s + L2, k);
+        store(row_a);
+    } else {
+        load(row_a);
+        dif_levels<LOGR, false>(x, a.tw_dif, g, L2, k);
+        exchange(row_a, row_b);
+        dif_levels<LOGR, true, L2>(x, a.tw_dif, 0u, 0, k);
+        // position p = hi*T + g*R + j holds coefficient bitrev_n(p); dscale is stored in position order
+        const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
+        dit_levels<LOGR, true, L2>(x, a.tw_dit, 0u, 0, k);
+        __syncthreads();  // every lane has finished reading the first exchange
+        exchange(row_b, row_a);
+        dit_levels<LOGR, false>(x, a.tw_dit, g, L2, k);
+        store(row_a);
     }
 }
 
@@ -231,7 +340,40 @@ hipError_t launch_mode(int mode, bool canon, const PassArgs& a, dim3 grid, hipSt
 struct Pass {
     int mode, logr, s;
     bool canon;  // last pass of the transform: write canonical words
+    bool tile = false;  // LDS-tiled kernel covering `logr` levels (p61_tile_kernel), else a register pass
 };
+
+// Tile shapes that are instantiated: 16 elements per lane, 6 levels (4 waves, 64 KiB) or 7 levels (8 waves, 128 KiB or
+// 2 x 64 KiB with the split exchange).
+constexpr int TILE_LOGR = 4;
+bool tile_shape(int levels) { return levels == 6 || levels == 7; }
+
+template <int LOGT, int MODE, bool CANON, int SPLIT>
+hipError_t launch_tile_one(const PassArgs& a, unsigned tiles, hipStream_t st)
+{
+    auto kern = p61_tile_kernel<LOGT, TILE_LOGR, MODE, CANON, SPLIT>;
+    constexpr int lds_bytes = (1 << LOGT) * (64 / SPLIT) * 16;
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !configured[dev]) {  // > 64 KiB of dynamic LDS is opt-in per kernel and device
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) configured[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3((1 << (LOGT - TILE_LOGR)) * 64), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+template <int LOGT, int SPLIT>
+hipError_t launch_tile_mode(int mode, bool canon, const PassArgs& a, unsigned tiles, hipStream_t st)
+{
+    switch (mode) {
+    case MODE_DIF: return launch_tile_one<LOGT, MODE_DIF, false, SPLIT>(a, tiles, st);  // a DIF pass is never the last one
+    case MODE_DIT: return canon ? launch_tile_one<LOGT, MODE_DIT, true, SPLIT>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIT, false, SPLIT>(a, tiles, st);
+    default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT>(a, tiles, st);
+    }
+}
 
 }  // namespace
 
@@ -239,9 +381,13 @@ struct Path {
     int n = 0;
     uint64_t N = 0, elems = 0;
     int levels = DEFAULT_LEVELS;  // levels per register pass
+    bool tiles = true;            // LDS-tiled passes where a chunk of the plan has a tile shape
+    int split = 2;                // 7-level tiles: exchange rounds (2 = 64 KiB of LDS, two workgroups per CU)
     std::vector<Pass> enc, fwd;  // encode plan; stand-alone transform plan (all DIF, then the block permutation)
-    uint64_t* tw_fwd = nullptr;  // forward roots, level-packed
-    uint64_t* tw_inv = nullptr;  // inverse roots
+    uint64_t* tw_fwd = nullptr;  // forward roots, level-packed for the encode plan
+    uint64_t* tw_inv = nullptr;  // inverse roots, the same packing
+    uint64_t* tw_ntt_fwd = nullptr;  // the two again, packed for the stand-alone transform's plan when its register runs
+    uint64_t* tw_ntt_inv = nullptr;  // differ from the encode plan's (a MID tile there, register passes here); else null
     uint64_t* dscale = nullptr;
     std::string text;
 };
@@ -255,49 +401,130 @@ int fail(char* detail, size_t cap, hipError_t e, const char* what)
     return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
 }
 
-// MID takes the lowest min(n, L) levels; the rest is split into near-equal chunks of at most L levels.
+// The encode plan is [DIF chunks, top down][MID over the lowest m levels][DIT chunks, bottom up].  With tiles, a chunk of
+// 6 or 7 levels is one LDS-tiled pass and anything else falls back to register passes of at most L levels; the split is
+// the one with the fewest trips through HBM (ties: fewest register passes).  Without tiles: MID takes min(n, L) levels
+// and the rest is cut into near-equal chunks of at most L levels, as in round 1.
+struct Chunking {
+    int mid = 0;
+    std::vector<int> outer;  // top down
+    int trips = 1 << 30, reg = 1 << 30;
+};
+
+int reg_passes(int levels, int L) { return (levels + L - 1) / L; }
+
+Chunking choose_chunks(int n, int L, bool tiles)
+{
+    Chunking best;
+    auto consider = [&](int mid, const std::vector<int>& outer) {
+        int trips = (tiles && tile_shape(mid)) ? 1 : reg_passes(mid, L), reg = (tiles && tile_shape(mid)) ? 0 : 1;
+        for (int c : outer) {
+            const bool t = tiles && tile_shape(c);
+            trips += 2 * (t ? 1 : reg_passes(c, L));
+            reg += t ? 0 : 2;
+        }
+        if (trips < best.trips || (trips == best.trips && reg < best.reg)) {
+            best.mid = mid;
+            best.outer = outer;
+            best.trips = trips;
+            best.reg = reg;
+        }
+    };
+    const int mid_max = std::min(n, tiles ? 7 : L);
+    for (int mid = 1; mid <= mid_max; mid++) {
+        if (!tiles && mid != mid_max) continue;
+        const int rest = n - mid;
+        if (rest == 0) {
+            consider(mid, {});
+            continue;
+        }
+        const int cmax = tiles ? 7 : L;
+        for (int q = (rest + cmax - 1) / cmax; q <= rest && q <= (rest + cmax - 1) / cmax + 1; q++) {
+            // q near-equal chunks, largest first
+            std::vector<int> outer;
+            for (int i = 0; i < q; i++) outer.push_back(rest / q + (i < rest % q ? 1 : 0));
+            consider(mid, outer);
+        }
+    }
+    return best;
+}
+
+void push_chunk(std::vector<Pass>& plan, int mode, int levels, int s, int L, bool tiles)
+{
+    if (tiles && tile_shape(levels) && (mode == MODE_MID || s >= 1)) {
+        Pass q{mode, levels, s, false};
+        q.tile = true;
+        plan.push_back(q);
+        return;
+    }
+    // register passes of at most L levels: top down for DIF, bottom up for DIT
+    const int q = reg_passes(levels, L);
+    std::vector<int> parts;
+    for (int i = 0; i < q; i++) parts.push_back(levels / q + (i < levels % q ? 1 : 0));
+    if (mode == MODE_DIT) {
+        int ss = s;
+        for (size_t i = parts.size(); i-- > 0;) {
+            plan.push_back(Pass{mode, parts[i], ss, false});
+            ss += parts[i];
+        }
+    } else {
+        int ss = s + levels;
+        for (int r : parts) {
+            ss -= r;
+            plan.push_back(Pass{mode, r, ss, false});
+        }
+    }
+}
+
 void build_plans(Path* p)
 {
     const int n = p->n, L = p->levels;
-    const int m = std::min(n, L), rest = n - m;
-    std::vector<int> chunks;
-    if (rest > 0) {
-        const int q = (rest + L - 1) / L;
-        for (int i = 0; i < q; i++) chunks.push_back(rest / q + (i < rest % q ? 1 : 0));
+    Chunking ch = choose_chunks(n, L, p->tiles);
+    // a register MID pass covers at most L levels: the rest of a longer MID chunk becomes DIF / DIT passes around it
+    int mid = ch.mid;
+    std::vector<int> outer = ch.outer;
+    if (!(p->tiles && tile_shape(mid)) && mid > L) {
+        outer.push_back(mid - L);
+        mid = L;
     }
     p->enc.clear();
     p->fwd.clear();
     int top = n;
-    for (int c : chunks) {
-        p->enc.push_back(Pass{MODE_DIF, c, top - c, false});
+    for (int c : outer) {
+        push_chunk(p->enc, MODE_DIF, c, top - c, L, p->tiles);
         top -= c;
     }
+    // the stand-alone transform: the same DIF chunks, then the lowest levels as DIF register passes (natural order out
+    // needs the block permutation anyway)
     p->fwd = p->enc;
-    p->fwd.push_back(Pass{MODE_DIF, m, 0, true});
-    p->enc.push_back(Pass{MODE_MID, m, 0, false});
-    for (size_t i = chunks.size(); i-- > 0;) {
-        p->enc.push_back(Pass{MODE_DIT, chunks[i], top, false});
-        top += chunks[i];
+    push_chunk(p->fwd, MODE_DIF, mid, 0, L, false);
+    p->fwd.back().canon = true;
+    push_chunk(p->enc, MODE_MID, mid, 0, L, p->tiles);
+    for (size_t i = outer.size(); i-- > 0;) {
+        push_chunk(p->enc, MODE_DIT, outer[i], top, L, p->tiles);
+        top += outer[i];
     }
     p->enc.back().canon = true;
 
     p->text.clear();
     char buf[32];
     for (const Pass& q : p->enc) {
-        snprintf(buf, sizeof buf, "%s%s%d@%d", p->text.empty() ? "" : ",", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid",
-                 q.logr, q.s);
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", p->text.empty() ? "" : ",", q.tile ? "T64:" : "",
+                 q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr, q.s);
         p->text += buf;
     }
     p->text += " gf61^2";
 }
 
 // Level l is executed by a register run whose smallest stride is 2^sl[l] (see ntt_device.hpp).
-std::vector<int> level_strides(const Path* p)
+std::vector<int> level_strides(const Path* p, const std::vector<Pass>& plan)
 {
     std::vector<int> sl(p->n, 0);
-    for (const Pass& q : p->enc) {
+    for (const Pass& q : plan) {
         if (q.mode == MODE_DIT) continue;
-        for (int l = q.s; l < q.s + q.logr; l++) sl[l] = q.s;
+        const int l2 = q.tile ? q.logr - TILE_LOGR : q.logr;  // a tile runs its low l2 levels at stride 2^s, the rest at 2^(s+l2)
+        for (int l = q.s; l < q.s + l2; l++) sl[l] = q.s;
+        for (int l = q.s + l2; l < q.s + q.logr; l++) sl[l] = q.s + l2;
     }
     return sl;
 }
@@ -334,9 +561,17 @@ int upload(uint64_t** dst, const std::vector<uint64_t>& src, char* detail, size_
 int upload_tables(Path* p, char* detail, size_t cap)
 {
     const gf61::Elem wN = gf61::h_root(p->N), wNi = gf61::h_inv(wN);
-    const std::vector<int> sl = level_strides(p);
+    const std::vector<int> sl = level_strides(p, p->enc), sl_ntt = level_strides(p, p->fwd);
     int rc = upload(&p->tw_fwd, build_level_table(p->n, wN, sl), detail, cap);
     if (rc == FASTECC_OK) rc = upload(&p->tw_inv, build_level_table(p->n, wNi, sl), detail, cap);
+    if (sl_ntt == sl) {
+        if (p->tw_ntt_fwd) (void)hipFree(p->tw_ntt_fwd);
+        if (p->tw_ntt_inv) (void)hipFree(p->tw_ntt_inv);
+        p->tw_ntt_fwd = p->tw_ntt_inv = nullptr;
+    } else {
+        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_fwd, build_level_table(p->n, wN, sl_ntt), detail, cap);
+        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_inv, build_level_table(p->n, wNi, sl_ntt), detail, cap);
+    }
     return rc;
 }
 
@@ -368,13 +603,21 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         a.col_chunks = (uint32_t)((p->elems + 63) / 64);
         a.items = (p->N >> q.logr) * a.col_chunks;
         a.s = q.s;
-        const uint64_t blocks = (a.items + 3) / 4;
+        const uint64_t blocks = q.tile ? a.items : (a.items + 3) / 4;  // a workgroup per tile / a wave per work item
         if (blocks > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
         const dim3 grid((unsigned)blocks);
         char name[32];
-        snprintf(name, sizeof name, "p61_%s%d", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr);
+        snprintf(name, sizeof name, "p61_%s%s%d", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr);
         Scope sc(hooks, st, name, 2ull * p->N * p->elems * 16ull);
         hipError_t e;
+        if (q.tile) {
+            if (q.logr == 6) e = launch_tile_mode<6, 1>(q.mode, q.canon, a, (unsigned)blocks, st);
+            else if (p->split == 2) e = launch_tile_mode<7, 2>(q.mode, q.canon, a, (unsigned)blocks, st);
+            else e = launch_tile_mode<7, 1>(q.mode, q.canon, a, (unsigned)blocks, st);
+            if (e != hipSuccess) return fail(nullptr, 0, e, "p61 tile pass");
+            src = out;
+            continue;
+        }
         switch (q.logr) {
         case 1: e = launch_mode<1>(q.mode, q.canon, a, grid, st); break;
         case 2: e = launch_mode<2>(q.mode, q.canon, a, grid, st); break;
@@ -428,6 +671,8 @@ void destroy(Path* p)
     if (!p) return;
     if (p->tw_fwd) (void)hipFree(p->tw_fwd);
     if (p->tw_inv) (void)hipFree(p->tw_inv);
+    if (p->tw_ntt_fwd) (void)hipFree(p->tw_ntt_fwd);
+    if (p->tw_ntt_inv) (void)hipFree(p->tw_ntt_inv);
     if (p->dscale) (void)hipFree(p->dscale);
     delete p;
 }
@@ -440,7 +685,7 @@ int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, cons
 
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks)
 {
-    const uint64_t* tw = inverse ? p->tw_inv : p->tw_fwd;
+    const uint64_t* tw = inverse ? (p->tw_ntt_inv ? p->tw_ntt_inv : p->tw_inv) : (p->tw_ntt_fwd ? p->tw_ntt_fwd : p->tw_fwd);
     const int rc = run_passes(p, p->fwd, data, data, tw, tw, st, hooks);
     if (rc != FASTECC_OK) return rc;
     if (p->n >= 2) {
@@ -466,10 +711,15 @@ int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counte
     return FASTECC_OK;
 }
 
-int set_levels_per_pass(Path* p, int levels, char* detail, size_t cap)
+int set_plan(Path* p, int plan, char* detail, size_t cap)
 {
-    if (levels < 1 || levels > 5) return FASTECC_E_INVAL;
+    // 0 = default; 1..5 = register passes only, that many levels per pass; 10 + L = LDS tiles (64 KiB exchange buffer)
+    // with register passes of at most L levels where no tile shape fits; 20 + L = the same with a 128 KiB buffer
+    const int levels = plan == 0 ? DEFAULT_LEVELS : plan % 10, kind = plan / 10;
+    if (plan < 0 || kind > 2 || levels < 1 || levels > 5) return FASTECC_E_INVAL;
     p->levels = levels;
+    p->tiles = plan == 0 || kind >= 1;
+    p->split = kind == 2 ? 1 : 2;
     build_plans(p);
     return upload_tables(p, detail, cap);
 }

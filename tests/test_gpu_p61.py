@@ -85,10 +85,12 @@ def test_encode_matches_oracle(torch_cuda, fe, orc61, logn, elems):
     assert (got == want).all()
 
 
-@pytest.mark.parametrize("plan", [1, 2, 3, 4, 5])
-@pytest.mark.parametrize("logn", [3, 8, 11])
+@pytest.mark.parametrize("plan", [1, 2, 3, 4, 5, 0, 12, 13, 14, 24, 23])
+@pytest.mark.parametrize("logn", [3, 6, 7, 8, 11, 12, 13, 14])
 def test_every_plan(torch_cuda, fe, orc61, plan, logn):
-    N, elems = 1 << logn, 37
+    """register passes (1..5 levels), LDS tiles with a 64 KiB (0, 1x) and a 128 KiB (2x) exchange buffer: bit-identical;
+    the sizes cover MID tiles (6, 7), one and two tile chunks around a MID (12, 13, 14) and mixed tile / register plans"""
+    N, elems = 1 << logn, (37 if logn < 12 else 70)
     x = rand_stripe(np.random.default_rng(plan * 100 + logn), N, elems)
     want = orc61.encode(x)
     with encoder(fe, N, elems) as enc:
@@ -99,7 +101,7 @@ def test_every_plan(torch_cuda, fe, orc61, plan, logn):
         assert (to_host(out) == want).all(), enc.plan()
 
 
-@pytest.mark.parametrize("logn", [1, 4, 6, 9])
+@pytest.mark.parametrize("logn", [1, 4, 6, 9, 13])
 def test_ntt_matches_oracle_and_inverts(torch_cuda, fe, orc61, logn):
     N, elems = 1 << logn, 5
     x = rand_stripe(np.random.default_rng(logn), N, elems)
