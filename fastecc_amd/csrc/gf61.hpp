@@ -7,7 +7,7 @@
 //
 // Device arithmetic, built for a VALU whose widest multiply is v_mad_u64_u32 (32 x 32 + 64 -> 64):
 //
-//   * A data component x is kept LAZY in [0, 2^61 + 16): congruent to the value, not necessarily canonical.
+//   * A data component x is kept LAZY in [0, 2^61 + 2^33): congruent to the value, not necessarily canonical.
 //     It is split x = x1 * 2^31 + x0 with x0 < 2^31 and x1 <= 2^30.
 //   * A twiddle (c, d) is canonical and wave-uniform: its limbs c0 < 2^31, c1 < 2^30 and the doubled high
 //     limb 2*c1 live in SGPRs, as do those of e = p - d.
@@ -84,12 +84,14 @@ inline Elem h_root(uint64_t order)
 
 struct Opaque {
     uint32_t k31;  // 2^31
+    uint32_t k30;  // 2^30
     uint32_t one;  // 1
 };
 GF61_D Opaque make_opaque()
 {
     Opaque k;
     asm("s_mov_b32 %0, 0x80000000" : "=s"(k.k31));
+    asm("s_mov_b32 %0, 0x40000000" : "=s"(k.k30));
     asm("s_mov_b32 %0, 1" : "=s"(k.one));
     return k;
 }
@@ -111,7 +113,17 @@ GF61_D uint64_t sub_raw(uint64_t x, uint64_t y) { return x + (2 * P - y); }
 // lazy - lazy -> lazy
 GF61_D uint64_t sub(uint64_t x, uint64_t y, const Opaque& k) { return fold(sub_raw(x, y), k); }
 
-// lazy (< 2^61 + 16 <= 2p) -> canonical
+// 4p - y for y < 2^63: the negation of a sum of two lazy values, < 2^63
+GF61_D uint64_t neg_raw(uint64_t y) { return 4 * P - y; }
+// x < 2^63  ->  x * 2^30 (mod p), < 2^61 + 2^32:  x = xh 2^31 + xl  =>  x 2^30 = xh 2^61 + xl 2^30 = xh + xl 2^30.
+// This is what makes w_8 = 2^30 (1 + i) cheap: two multiply-adds instead of a 61 x 61-bit product.
+GF61_D uint64_t rot30(uint64_t x, const Opaque& k)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    return mad64(__builtin_amdgcn_alignbit(hi, lo, 31), k.one, mad64(lo & 0x7FFFFFFFu, k.k30, 0));
+}
+
+// lazy (< 2^61 + 2^33 <= 2p) -> canonical
 GF61_D uint64_t canon(uint64_t x) { return x >= P ? x - P : x; }
 
 // The wave-uniform half of a product: limbs of a canonical twiddle (c, d) and of e = p - d.

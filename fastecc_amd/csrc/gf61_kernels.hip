@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/fastecc.h"
@@ -34,6 +35,11 @@ namespace {
 
 enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2 };
 
+// forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
+struct SmallRoots {
+    uint64_t w16[4][2];
+};
+
 struct PassArgs {
     const uint64_t* in;
     uint64_t* out;
@@ -44,6 +50,7 @@ struct PassArgs {
     uint32_t col_chunks;     // ceil(elems / 64)
     uint64_t items;          // (N >> r) * col_chunks
     int s;                   // log2 of the smallest stride of the pass
+    SmallRoots sr;
 };
 
 using gf61::Elem;
@@ -67,71 +74,174 @@ __device__ __forceinline__ void store_elem(uint64_t* p, Elem e)
     __builtin_nontemporal_store(t, reinterpret_cast<u64x2*>(p));
 }
 
-// Twiddles of level l = sl + T for a lane set holding blocks (.. + j*2^sl + off): entries
-// 2^l + (off << T) + m, m < 2^T, of the level-packed table (same packing as ntt_device.hpp).
-template <int LOGR, bool LO_ZERO, int T>
-__device__ __forceinline__ void dif_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
+// ------------------------------------------------------------------------------------------------
+// Runs of radix-2 levels held in registers, in "radix-2^r" form (the reference's NTT2/NTT4 codelets, ntt.cpp:16-22 and
+// 50-62, are the r = 1, 2 cases; its radix-4 butterfly multiplies by the fourth root of unity just like this one).
+//
+// A lane holds x[j] = block (.. + j*2^sl + off), and `LEVELS` levels pair registers at distance 2^t, t < LEVELS.  The
+// twiddle of level t is (root of order 2^(sl+t+1))^((m << sl) + off), m = j mod 2^t (ntt.cpp:254-283).  It factors as
+//        w_(2^(t+1))^m          a SMALL root of unity: depends on the register only
+//      * w_(2^(sl+t+1))^off     the same for every butterfly of the level; commutes with all later (lower) levels
+// so the second factors are collected into ONE multiplication per element, x[j] *= w_(2^(sl+LEVELS))^(off*bitrev(j)),
+// after the levels (DIF) or before them (DIT), and the levels themselves only meet roots of order <= 16.  In this field
+// those are cheap: w_4 = i is a swap of the components inside the add/sub that follows or precedes it, w_8 = 2^30 (1 + i)
+// is two additions and two 30-bit rotations (gf61.hpp rot30); only the four odd powers of w_16 stay general.  Per 16
+// elements and 4 levels: 19 general products instead of 32 (17 -> 4 in the runs next to the per-block factor, where off = 0
+// and nothing is left to collect).  Exact arithmetic: every stored word is the same field element as before.
+//
+// Tables (host: build_run_table): the run of levels [sl, sl + r) owns entries [2^(sl+r), 2^(sl+r+1)); entry
+// (off << r) + j is (root of order 2^(sl+r))^(off * bitrev_r(j)): the 2^r - 1 values a wave needs are contiguous.
+enum { K_ONE, K_I, K_W8, K_W8I, K_GEN };
+constexpr int small_kind(int t, int m)
 {
+    if (m == 0) return K_ONE;
+    if (t >= 1 && m == (1 << (t - 1))) return K_I;
+    if (t >= 2 && m == (1 << (t - 2))) return K_W8;
+    if (t >= 2 && m == 3 * (1 << (t - 2))) return K_W8I;
+    return K_GEN;
+}
+
+// (root of order 16)^m for odd m, in the direction of the transform (INV: conjugate)
+template <bool INV>
+__device__ __forceinline__ gf61::Twiddle w16_twiddle(const SmallRoots& sr, int m)
+{
+    const uint64_t c = sr.w16[m >> 1][0], d = sr.w16[m >> 1][1];
+    return gf61::make_twiddle(c, INV ? gf61::P - d : d);  // d != 0 for these roots
+}
+
+// y = x * w_8 (KIND K_W8) or x * w_8^3 = x * w_8 * w_4 (K_W8I), x lazy -> y lazy.  Forward: w_8 = 2^30 (1 + i), w_4 = i;
+// INV: the conjugates 2^30 (1 - i) and -i.
+template <int KIND, bool INV>
+__device__ __forceinline__ Elem mul_w8(Elem x, const gf61::Opaque& k)
+{
+    const uint64_t sum = x.re + x.im;  // < 2^62 + 2^34
+    if constexpr (KIND == K_W8) {
+        if constexpr (!INV) return Elem{gf61::rot30(gf61::sub_raw(x.re, x.im), k), gf61::rot30(sum, k)};
+        else                return Elem{gf61::rot30(sum, k), gf61::rot30(gf61::sub_raw(x.im, x.re), k)};
+    } else {
+        // forward: (x i)(1 + i) = -(re + im) + (re - im) i;  INV: (x (-i))(1 - i) = (im - re) - (re + im) i
+        if constexpr (!INV) return Elem{gf61::rot30(gf61::neg_raw(sum), k), gf61::rot30(gf61::sub_raw(x.re, x.im), k)};
+        else                return Elem{gf61::rot30(gf61::sub_raw(x.im, x.re), k), gf61::rot30(gf61::neg_raw(sum), k)};
+    }
+}
+
+// Decimation in frequency: (a, b) -> (a + b, (a - b) * w), w the small root of `KIND`.
+template <int KIND, bool INV>
+__device__ __forceinline__ void dif_bfly(Elem& xa, Elem& xb, const gf61::Twiddle& w, const gf61::Opaque& k)
+{
+    const Elem a = xa, b = xb;
+    xa = gf61::add(a, b, k);
+    if constexpr (KIND == K_ONE) {
+        xb = gf61::sub(a, b, k);
+    } else if constexpr (KIND == K_I) {
+        // (a - b) i = (b.im - a.im) + (a.re - b.re) i;  (a - b)(-i) = (a.im - b.im) + (b.re - a.re) i
+        if constexpr (!INV) xb = Elem{gf61::sub(b.im, a.im, k), gf61::sub(a.re, b.re, k)};
+        else                xb = Elem{gf61::sub(a.im, b.im, k), gf61::sub(b.re, a.re, k)};
+    } else if constexpr (KIND == K_GEN) {
+        xb = gf61::mul_raw(gf61::sub_raw(a, b), w, k);
+    } else {
+        xb = mul_w8<KIND, INV>(gf61::sub(a, b, k), k);
+    }
+}
+
+// Decimation in time: (a, b) -> (a + b w, a - b w).
+template <int KIND, bool INV>
+__device__ __forceinline__ void dit_bfly(Elem& xa, Elem& xb, const gf61::Twiddle& w, const gf61::Opaque& k)
+{
+    const Elem a = xa;
+    if constexpr (KIND == K_I) {
+        const Elem b = xb;
+        // b i = -b.im + b.re i;  b (-i) = b.im - b.re i
+        const Elem plus{gf61::add(a.re, b.im, k), gf61::add(a.im, b.re, k)}, minus{gf61::sub(a.re, b.im, k), gf61::sub(a.im, b.re, k)};
+        if constexpr (!INV) {
+            xa = Elem{minus.re, plus.im};
+            xb = Elem{plus.re, minus.im};
+        } else {
+            xa = Elem{plus.re, minus.im};
+            xb = Elem{minus.re, plus.im};
+        }
+        return;
+    }
+    Elem b = xb;
+    if constexpr (KIND == K_GEN) b = gf61::mul(b, w, k);
+    if constexpr (KIND == K_W8 || KIND == K_W8I) b = mul_w8<KIND, INV>(b, k);
+    xa = gf61::add(a, b, k);
+    xb = gf61::sub(a, b, k);
+}
+
+template <int LOGR, int T, bool INV, bool DIT>
+__device__ __forceinline__ void small_level(Elem (&x)[1 << LOGR], const gf61::Opaque& k, const SmallRoots& sr)
+{
+    static_assert(T <= 3, "roots of order <= 16 inside a run");
     constexpr int R = 1 << LOGR, half = 1 << T;
-    const_u64_ptr p = as_constant(twl) + 2 * (((size_t)1 << (sl + T)) + ((size_t)off << T));
 #pragma unroll
     for (int m = 0; m < half; ++m) {
-        const bool unit = LO_ZERO && m == 0;  // exponent 0 (ntt.cpp:259-267)
-        const gf61::Twiddle w = gf61::make_twiddle(p[2 * m], p[2 * m + 1]);
+        // compile-time dispatch on the kind of w_(2^(T+1))^m (the loop is fully unrolled, m is a constant in each copy)
+        auto run = [&](auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            gf61::Twiddle w{};
+            if constexpr (KIND == K_GEN) w = w16_twiddle<INV>(sr, m);
 #pragma unroll
-        for (int j0 = 0; j0 < R; j0 += 2 * half) {
-            const int ja = j0 + m, jb = ja + half;
-            const Elem a = x[ja], b = x[jb];
-            x[ja] = gf61::add(a, b, k);
-            x[jb] = unit ? gf61::sub(a, b, k) : gf61::mul_raw(gf61::sub_raw(a, b), w, k);
+            for (int j0 = 0; j0 < R; j0 += 2 * half) {
+                if constexpr (DIT) dit_bfly<KIND, INV>(x[j0 + m], x[j0 + m + half], w, k);
+                else               dif_bfly<KIND, INV>(x[j0 + m], x[j0 + m + half], w, k);
+            }
+        };
+        switch (small_kind(T, m)) {
+        case K_ONE: run(std::integral_constant<int, K_ONE>{}); break;
+        case K_I:   run(std::integral_constant<int, K_I>{}); break;
+        case K_W8:  run(std::integral_constant<int, K_W8>{}); break;
+        case K_W8I: run(std::integral_constant<int, K_W8I>{}); break;
+        default:    run(std::integral_constant<int, K_GEN>{}); break;
         }
     }
 }
 
-template <int LOGR, bool LO_ZERO, int T>
-__device__ __forceinline__ void dit_one_level(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
+// x[j] *= (root of order 2^(sl+LEVELS))^(off * bitrev(j mod 2^LEVELS)) for the registers with j mod 2^LEVELS != 0
+template <int LOGR, int LEVELS>
+__device__ __forceinline__ void collected_twiddles(Elem (&x)[1 << LOGR], const uint64_t* tw, uint32_t off, int sl, const gf61::Opaque& k)
 {
-    constexpr int R = 1 << LOGR, half = 1 << T;
-    const_u64_ptr p = as_constant(twl) + 2 * (((size_t)1 << (sl + T)) + ((size_t)off << T));
+    constexpr int R = 1 << LOGR, W = 1 << LEVELS;
+    const_u64_ptr p = as_constant(tw) + 2 * (((size_t)1 << (sl + LEVELS)) + ((size_t)off << LEVELS));
 #pragma unroll
-    for (int m = 0; m < half; ++m) {
-        const bool unit = LO_ZERO && m == 0;
-        const gf61::Twiddle w = gf61::make_twiddle(p[2 * m], p[2 * m + 1]);
+    for (int jl = 1; jl < W; ++jl) {
+        const gf61::Twiddle w = gf61::make_twiddle(p[2 * jl], p[2 * jl + 1]);
 #pragma unroll
-        for (int j0 = 0; j0 < R; j0 += 2 * half) {
-            const int ja = j0 + m, jb = ja + half;
-            const Elem a = x[ja];
-            const Elem b = unit ? x[jb] : gf61::mul(x[jb], w, k);
-            x[ja] = gf61::add(a, b, k);
-            x[jb] = gf61::sub(a, b, k);
-        }
+        for (int j0 = 0; j0 < R; j0 += W) x[j0 + jl] = gf61::mul(x[j0 + jl], w, k);
     }
 }
 
-// LEVELS < LOGR: only the low LEVELS register bits are butterfly levels (the lane holds 2^(LOGR-LEVELS) independent groups)
-template <int LOGR, bool LO_ZERO, int LEVELS = LOGR>
-__device__ __forceinline__ void dif_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
+// LEVELS < LOGR: only the low LEVELS register bits are butterfly levels (the lane holds 2^(LOGR-LEVELS) independent groups).
+// LO_ZERO: off == 0 and sl == 0, nothing to collect (the first butterflies of a group in ntt.cpp:259-267).
+template <int LOGR, bool LO_ZERO, bool INV, int LEVELS = LOGR>
+__device__ __forceinline__ void dif_levels(Elem (&x)[1 << LOGR], const uint64_t* tw, uint32_t off, int sl, const gf61::Opaque& k,
+                                           const SmallRoots& sr)
 {
-    if constexpr (LEVELS >= 5) dif_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 4) dif_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 3) dif_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 2) dif_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 1) dif_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl, k);
+    static_assert(LEVELS <= 4, "at most 4 levels per run");
+    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, false>(x, k, sr);
+    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, false>(x, k, sr);
+    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, false>(x, k, sr);
+    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, false>(x, k, sr);
+    if constexpr (!LO_ZERO && LEVELS >= 1) collected_twiddles<LOGR, LEVELS>(x, tw, off, sl, k);
 }
 
-template <int LOGR, bool LO_ZERO, int LEVELS = LOGR>
-__device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t* twl, uint32_t off, int sl, const gf61::Opaque& k)
+template <int LOGR, bool LO_ZERO, bool INV, int LEVELS = LOGR>
+__device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t* tw, uint32_t off, int sl, const gf61::Opaque& k,
+                                           const SmallRoots& sr)
 {
-    if constexpr (LEVELS >= 1) dit_one_level<LOGR, LO_ZERO, 0>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 2) dit_one_level<LOGR, LO_ZERO, 1>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 3) dit_one_level<LOGR, LO_ZERO, 2>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 4) dit_one_level<LOGR, LO_ZERO, 3>(x, twl, off, sl, k);
-    if constexpr (LEVELS >= 5) dit_one_level<LOGR, LO_ZERO, 4>(x, twl, off, sl, k);
+    static_assert(LEVELS <= 4, "at most 4 levels per run");
+    if constexpr (!LO_ZERO && LEVELS >= 1) collected_twiddles<LOGR, LEVELS>(x, tw, off, sl, k);
+    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, true>(x, k, sr);
+    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, true>(x, k, sr);
+    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, true>(x, k, sr);
+    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, true>(x, k, sr);
 }
 
 // One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
-template <int LOGR, int MODE, bool CANON>
-__global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(const PassArgs a)
+// INV: the DIF levels use the inverse roots (the encode's way down, and the inverse stand-alone transform); DIT levels
+// always use the forward roots (the encode's way up).
+template <int LOGR, int MODE, bool CANON, bool INV>
+__global__ __launch_bounds__(256, 3) void p61_pass_kernel(const PassArgs a)
 {
     constexpr int R = 1 << LOGR;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -160,18 +270,18 @@ __global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(cons
     }
 
     if constexpr (MODE == MODE_DIF) {
-        if (a.s == 0) dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0, k);
-        else          dif_levels<LOGR, false>(x, a.tw_dif, lo, s, k);
+        if (a.s == 0) dif_levels<LOGR, true, INV>(x, a.tw_dif, 0u, 0, k, a.sr);
+        else          dif_levels<LOGR, false, INV>(x, a.tw_dif, lo, s, k, a.sr);
     } else if constexpr (MODE == MODE_DIT) {
-        if (a.s == 0) dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0, k);
-        else          dit_levels<LOGR, false>(x, a.tw_dit, lo, s, k);
+        if (a.s == 0) dit_levels<LOGR, true, false>(x, a.tw_dit, 0u, 0, k, a.sr);
+        else          dit_levels<LOGR, false, false>(x, a.tw_dit, lo, s, k, a.sr);
     } else {
-        dif_levels<LOGR, true>(x, a.tw_dif, 0u, 0, k);
+        dif_levels<LOGR, true, true>(x, a.tw_dif, 0u, 0, k, a.sr);
         // position p = hi*R + j holds coefficient bitrev_n(p); dscale is stored in position order
         const_u64_ptr d = as_constant(a.dscale) + 2 * ((size_t)hi * R);
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
-        dit_levels<LOGR, true>(x, a.tw_dit, 0u, 0, k);
+        dit_levels<LOGR, true, false>(x, a.tw_dit, 0u, 0, k, a.sr);
     }
 
     if (live) {
@@ -196,7 +306,7 @@ __global__ __launch_bounds__(256, (LOGR <= 4 ? 3 : 1)) void p61_pass_kernel(cons
 //   DIT  load B -> L2 levels -> B=>A -> LOGR levels -> store A
 //   MID  s = 0: DIF half, multiply block p by D[bitrev(p)] (RS.cpp:51-59), DIT half: 2*LOGT levels per trip
 // With k = 2^19 the encode is dif6@13, dif6@7, mid7@0, dit6@7, dit6@13: 5 trips instead of 9.
-template <int LOGT, int LOGR, int MODE, bool CANON, int SPLIT>
+template <int LOGT, int LOGR, int MODE, bool CANON, int SPLIT, bool INV>
 __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(const PassArgs a)
 {
     constexpr int R = 1 << LOGR, L2 = LOGT - LOGR, G = 1 << L2, WS = 64 / SPLIT;
@@ -262,29 +372,29 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     const uint32_t off_a = (g << s) + lo;  // layout A: x[j] = block (.. + j * 2^(s+L2) + off_a)
     if constexpr (MODE == MODE_DIF) {
         load(row_a);
-        dif_levels<LOGR, false>(x, a.tw_dif, off_a, s + L2, k);
+        dif_levels<LOGR, false, INV>(x, a.tw_dif, off_a, s + L2, k, a.sr);
         exchange(row_a, row_b);
-        dif_levels<LOGR, false, L2>(x, a.tw_dif, lo, s, k);
+        dif_levels<LOGR, false, INV, L2>(x, a.tw_dif, lo, s, k, a.sr);
         store(row_b);
     } else if constexpr (MODE == MODE_DIT) {
         load(row_b);
-        dit_levels<LOGR, false, L2>(x, a.tw_dit, lo, s, k);
+        dit_levels<LOGR, false, false, L2>(x, a.tw_dit, lo, s, k, a.sr);
         exchange(row_b, row_a);
-        dit_levels<LOGR, false>(x, a.tw_dit, off_a, s + L2, k);
+        dit_levels<LOGR, false, false>(x, a.tw_dit, off_a, s + L2, k, a.sr);
         store(row_a);
     } else {
         load(row_a);
-        dif_levels<LOGR, false>(x, a.tw_dif, g, L2, k);
+        dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
         exchange(row_a, row_b);
-        dif_levels<LOGR, true, L2>(x, a.tw_dif, 0u, 0, k);
+        dif_levels<LOGR, true, true, L2>(x, a.tw_dif, 0u, 0, k, a.sr);
         // position p = hi*T + g*R + j holds coefficient bitrev_n(p); dscale is stored in position order
         const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
-        dit_levels<LOGR, true, L2>(x, a.tw_dit, 0u, 0, k);
+        dit_levels<LOGR, true, false, L2>(x, a.tw_dit, 0u, 0, k, a.sr);
         __syncthreads();  // every lane has finished reading the first exchange
         exchange(row_b, row_a);
-        dit_levels<LOGR, false>(x, a.tw_dit, g, L2, k);
+        dit_levels<LOGR, false, false>(x, a.tw_dit, g, L2, k, a.sr);
         store(row_a);
     }
 }
@@ -319,21 +429,22 @@ __global__ __launch_bounds__(256) void p61_count_out_of_range_kernel(const uint6
     if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(counter, bad);
 }
 
-template <int LOGR, int MODE>
+template <int LOGR, int MODE, bool INV>
 hipError_t launch_canon(bool canon, const PassArgs& a, dim3 grid, hipStream_t st)
 {
-    if (canon) hipLaunchKernelGGL((p61_pass_kernel<LOGR, MODE, true>), grid, dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL((p61_pass_kernel<LOGR, MODE, false>), grid, dim3(256), 0, st, a);
+    if (canon) hipLaunchKernelGGL((p61_pass_kernel<LOGR, MODE, true, INV>), grid, dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL((p61_pass_kernel<LOGR, MODE, false, INV>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
+// inverse_roots: only DIF passes run in both directions (the stand-alone transform); see p61_pass_kernel
 template <int LOGR>
-hipError_t launch_mode(int mode, bool canon, const PassArgs& a, dim3 grid, hipStream_t st)
+hipError_t launch_mode(int mode, bool canon, bool inverse_roots, const PassArgs& a, dim3 grid, hipStream_t st)
 {
     switch (mode) {
-    case MODE_DIF: return launch_canon<LOGR, MODE_DIF>(canon, a, grid, st);
-    case MODE_DIT: return launch_canon<LOGR, MODE_DIT>(canon, a, grid, st);
-    default:       return launch_canon<LOGR, MODE_MID>(canon, a, grid, st);
+    case MODE_DIF: return inverse_roots ? launch_canon<LOGR, MODE_DIF, true>(canon, a, grid, st) : launch_canon<LOGR, MODE_DIF, false>(canon, a, grid, st);
+    case MODE_DIT: return launch_canon<LOGR, MODE_DIT, false>(canon, a, grid, st);
+    default:       return launch_canon<LOGR, MODE_MID, true>(canon, a, grid, st);
     }
 }
 
@@ -343,15 +454,17 @@ struct Pass {
     bool tile = false;  // LDS-tiled kernel covering `logr` levels (p61_tile_kernel), else a register pass
 };
 
-// Tile shapes that are instantiated: 16 elements per lane, 6 levels (4 waves, 64 KiB) or 7 levels (8 waves, 128 KiB or
-// 2 x 64 KiB with the split exchange).
-constexpr int TILE_LOGR = 4;
+// Tile shapes that are instantiated: 6 levels = 8 elements per lane, runs of 3 + 3 levels (8 waves, 64 KiB; no root of
+// order 16 inside a run, i.e. no general product besides the collected twiddles); 7 levels = 16 elements per lane, runs
+// of 4 + 3 (8 waves, 128 KiB or 2 x 64 KiB with the split exchange).
+constexpr int tile_logr(int levels) { return levels == 6 ? 3 : 4; }
 bool tile_shape(int levels) { return levels == 6 || levels == 7; }
 
-template <int LOGT, int MODE, bool CANON, int SPLIT>
+template <int LOGT, int MODE, bool CANON, int SPLIT, bool INV>
 hipError_t launch_tile_one(const PassArgs& a, unsigned tiles, hipStream_t st)
 {
-    auto kern = p61_tile_kernel<LOGT, TILE_LOGR, MODE, CANON, SPLIT>;
+    constexpr int TILE_LOGR = tile_logr(LOGT);
+    auto kern = p61_tile_kernel<LOGT, TILE_LOGR, MODE, CANON, SPLIT, INV>;
     constexpr int lds_bytes = (1 << LOGT) * (64 / SPLIT) * 16;
     static bool configured[64] = {};
     int dev = 0;
@@ -366,12 +479,12 @@ hipError_t launch_tile_one(const PassArgs& a, unsigned tiles, hipStream_t st)
 }
 
 template <int LOGT, int SPLIT>
-hipError_t launch_tile_mode(int mode, bool canon, const PassArgs& a, unsigned tiles, hipStream_t st)
+hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const PassArgs& a, unsigned tiles, hipStream_t st)
 {
-    switch (mode) {
-    case MODE_DIF: return launch_tile_one<LOGT, MODE_DIF, false, SPLIT>(a, tiles, st);  // a DIF pass is never the last one
-    case MODE_DIT: return canon ? launch_tile_one<LOGT, MODE_DIT, true, SPLIT>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIT, false, SPLIT>(a, tiles, st);
-    default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT>(a, tiles, st);
+    switch (mode) {  // a DIF tile is never the last pass of a transform (the plans end on MID, DIT or a register pass)
+    case MODE_DIF: return inverse_roots ? launch_tile_one<LOGT, MODE_DIF, false, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIF, false, SPLIT, false>(a, tiles, st);
+    case MODE_DIT: return canon ? launch_tile_one<LOGT, MODE_DIT, true, SPLIT, false>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIT, false, SPLIT, false>(a, tiles, st);
+    default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT, true>(a, tiles, st);
     }
 }
 
@@ -389,6 +502,7 @@ struct Path {
     uint64_t* tw_ntt_fwd = nullptr;  // the two again, packed for the stand-alone transform's plan when its register runs
     uint64_t* tw_ntt_inv = nullptr;  // differ from the encode plan's (a MID tile there, register passes here); else null
     uint64_t* dscale = nullptr;
+    SmallRoots sr{};  // forward w_16^(1,3,5,7)
     std::string text;
 };
 
@@ -517,32 +631,50 @@ void build_plans(Path* p)
 }
 
 // Level l is executed by a register run whose smallest stride is 2^sl[l] (see ntt_device.hpp).
-std::vector<int> level_strides(const Path* p, const std::vector<Pass>& plan)
+// The register runs of a plan's DIF side (the DIT side mirrors it): levels [sl, sl + r) each.
+struct Run {
+    int sl, r;
+    bool operator==(const Run& o) const { return sl == o.sl && r == o.r; }
+};
+
+std::vector<Run> runs_of(const std::vector<Pass>& plan)
 {
-    std::vector<int> sl(p->n, 0);
+    std::vector<Run> runs;
     for (const Pass& q : plan) {
         if (q.mode == MODE_DIT) continue;
-        const int l2 = q.tile ? q.logr - TILE_LOGR : q.logr;  // a tile runs its low l2 levels at stride 2^s, the rest at 2^(s+l2)
-        for (int l = q.s; l < q.s + l2; l++) sl[l] = q.s;
-        for (int l = q.s + l2; l < q.s + q.logr; l++) sl[l] = q.s + l2;
+        if (q.tile) {  // a tile runs its low l2 levels at stride 2^s and the high tile_logr ones at 2^(s + l2)
+            const int l2 = q.logr - tile_logr(q.logr);
+            runs.push_back(Run{q.s + l2, tile_logr(q.logr)});
+            runs.push_back(Run{q.s, l2});
+        } else {
+            runs.push_back(Run{q.s, q.logr});
+        }
     }
-    return sl;
+    return runs;
 }
 
-std::vector<uint64_t> build_level_table(int n, gf61::Elem root_of_order_N, const std::vector<int>& sl)
+// Collected twiddles (see dif_levels): the run of levels [sl, sl + r) owns entries [2^(sl+r), 2^(sl+r+1)); entry
+// (off << r) + j = (root of order 2^(sl+r))^(off * bitrev_r(j)).  2N entries of 16 bytes.  Replaces the roots[] array of
+// ntt.cpp:397-402 and the running root_i *= root of ntt.cpp:270-281.
+std::vector<uint64_t> build_run_table(int n, gf61::Elem root_of_order_N, const std::vector<Run>& runs)
 {
-    std::vector<uint64_t> tab(2 * std::max<size_t>((size_t)1 << n, 2), 0);
-    for (int l = 0; l < n; l++) {
-        const uint64_t h = 1ull << l;
-        const gf61::Elem root = gf61::h_pow(root_of_order_N, 1ull << (n - 1 - l));
-        const int t = l - sl[l];
-        const uint64_t lowmask = (1ull << sl[l]) - 1;
-        gf61::Elem w{1, 0};
-        for (uint64_t i = 0; i < h; i++) {
-            const uint64_t e = h + (((i & lowmask) << t) | (i >> sl[l]));
-            tab[2 * e] = w.re;
-            tab[2 * e + 1] = w.im;
-            w = gf61::h_mul(w, root);
+    std::vector<uint64_t> tab(4 * std::max<size_t>((size_t)1 << n, 2), 0);
+    for (const Run& run : runs) {
+        const int e = run.sl + run.r;
+        const uint64_t R = 1ull << run.r;
+        const gf61::Elem root = gf61::h_pow(root_of_order_N, 1ull << (n - e));  // order 2^e
+        gf61::Elem wo{1, 0};  // root^off
+        for (uint64_t off = 0; off < (1ull << run.sl); off++) {
+            gf61::Elem w{1, 0};  // wo^i
+            for (uint64_t i = 0; i < R; i++) {
+                uint64_t j = 0;  // i = bitrev_r(j)
+                for (int b = 0; b < run.r; b++) j |= ((i >> b) & 1ull) << (run.r - 1 - b);
+                const uint64_t entry = (1ull << e) + (off << run.r) + j;
+                tab[2 * entry] = w.re;
+                tab[2 * entry + 1] = w.im;
+                w = gf61::h_mul(w, wo);
+            }
+            wo = gf61::h_mul(wo, root);
         }
     }
     return tab;
@@ -561,16 +693,16 @@ int upload(uint64_t** dst, const std::vector<uint64_t>& src, char* detail, size_
 int upload_tables(Path* p, char* detail, size_t cap)
 {
     const gf61::Elem wN = gf61::h_root(p->N), wNi = gf61::h_inv(wN);
-    const std::vector<int> sl = level_strides(p, p->enc), sl_ntt = level_strides(p, p->fwd);
-    int rc = upload(&p->tw_fwd, build_level_table(p->n, wN, sl), detail, cap);
-    if (rc == FASTECC_OK) rc = upload(&p->tw_inv, build_level_table(p->n, wNi, sl), detail, cap);
+    const std::vector<Run> sl = runs_of(p->enc), sl_ntt = runs_of(p->fwd);
+    int rc = upload(&p->tw_fwd, build_run_table(p->n, wN, sl), detail, cap);
+    if (rc == FASTECC_OK) rc = upload(&p->tw_inv, build_run_table(p->n, wNi, sl), detail, cap);
     if (sl_ntt == sl) {
         if (p->tw_ntt_fwd) (void)hipFree(p->tw_ntt_fwd);
         if (p->tw_ntt_inv) (void)hipFree(p->tw_ntt_inv);
         p->tw_ntt_fwd = p->tw_ntt_inv = nullptr;
     } else {
-        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_fwd, build_level_table(p->n, wN, sl_ntt), detail, cap);
-        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_inv, build_level_table(p->n, wNi, sl_ntt), detail, cap);
+        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_fwd, build_run_table(p->n, wN, sl_ntt), detail, cap);
+        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_inv, build_run_table(p->n, wNi, sl_ntt), detail, cap);
     }
     return rc;
 }
@@ -588,8 +720,9 @@ struct Scope {
     }
 };
 
+// inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
 int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint64_t* out, const uint64_t* tw_dif,
-               const uint64_t* tw_dit, hipStream_t st, const LaunchHooks* hooks)
+               const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks)
 {
     const uint64_t* src = in;
     for (const Pass& q : plan) {
@@ -603,6 +736,7 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         a.col_chunks = (uint32_t)((p->elems + 63) / 64);
         a.items = (p->N >> q.logr) * a.col_chunks;
         a.s = q.s;
+        a.sr = p->sr;
         const uint64_t blocks = q.tile ? a.items : (a.items + 3) / 4;  // a workgroup per tile / a wave per work item
         if (blocks > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
         const dim3 grid((unsigned)blocks);
@@ -611,19 +745,19 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         Scope sc(hooks, st, name, 2ull * p->N * p->elems * 16ull);
         hipError_t e;
         if (q.tile) {
-            if (q.logr == 6) e = launch_tile_mode<6, 1>(q.mode, q.canon, a, (unsigned)blocks, st);
-            else if (p->split == 2) e = launch_tile_mode<7, 2>(q.mode, q.canon, a, (unsigned)blocks, st);
-            else e = launch_tile_mode<7, 1>(q.mode, q.canon, a, (unsigned)blocks, st);
+            if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else if (q.logr == 6) e = launch_tile_mode<6, 1>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else if (p->split == 2) e = launch_tile_mode<7, 2>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else e = launch_tile_mode<7, 1>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             if (e != hipSuccess) return fail(nullptr, 0, e, "p61 tile pass");
             src = out;
             continue;
         }
         switch (q.logr) {
-        case 1: e = launch_mode<1>(q.mode, q.canon, a, grid, st); break;
-        case 2: e = launch_mode<2>(q.mode, q.canon, a, grid, st); break;
-        case 3: e = launch_mode<3>(q.mode, q.canon, a, grid, st); break;
-        case 4: e = launch_mode<4>(q.mode, q.canon, a, grid, st); break;
-        case 5: e = launch_mode<5>(q.mode, q.canon, a, grid, st); break;
+        case 1: e = launch_mode<1>(q.mode, q.canon, inverse_roots, a, grid, st); break;
+        case 2: e = launch_mode<2>(q.mode, q.canon, inverse_roots, a, grid, st); break;
+        case 3: e = launch_mode<3>(q.mode, q.canon, inverse_roots, a, grid, st); break;
+        case 4: e = launch_mode<4>(q.mode, q.canon, inverse_roots, a, grid, st); break;
         default: return FASTECC_E_UNSUPPORTED;
         }
         if (e != hipSuccess) return fail(nullptr, 0, e, "p61 pass");
@@ -643,6 +777,14 @@ int create(Path** out, int n, uint64_t elems, char* detail, size_t cap)
     p->n = n;
     p->N = 1ull << n;
     p->elems = elems;
+    {
+        const gf61::Elem w16 = gf61::h_root(16);
+        for (int i = 0; i < 4; i++) {
+            const gf61::Elem w = gf61::h_pow(w16, 2 * i + 1);
+            p->sr.w16[i][0] = w.re;
+            p->sr.w16[i][1] = w.im;
+        }
+    }
     build_plans(p);
 
     // per-block factors w_2N^i / N (RS.cpp:51-54), stored by position: position q holds coefficient bitrev(q)
@@ -680,13 +822,13 @@ void destroy(Path* p)
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks)
 {
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
-    return run_passes(p, p->enc, data, parity, p->tw_inv, p->tw_fwd, st, hooks);
+    return run_passes(p, p->enc, data, parity, p->tw_inv, p->tw_fwd, true, st, hooks);
 }
 
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks)
 {
     const uint64_t* tw = inverse ? (p->tw_ntt_inv ? p->tw_ntt_inv : p->tw_inv) : (p->tw_ntt_fwd ? p->tw_ntt_fwd : p->tw_fwd);
-    const int rc = run_passes(p, p->fwd, data, data, tw, tw, st, hooks);
+    const int rc = run_passes(p, p->fwd, data, data, tw, tw, inverse, st, hooks);
     if (rc != FASTECC_OK) return rc;
     if (p->n >= 2) {
         const uint32_t col_chunks = (uint32_t)((p->elems + 63) / 64);
@@ -713,10 +855,10 @@ int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counte
 
 int set_plan(Path* p, int plan, char* detail, size_t cap)
 {
-    // 0 = default; 1..5 = register passes only, that many levels per pass; 10 + L = LDS tiles (64 KiB exchange buffer)
+    // 0 = default; 1..4 = register passes only, that many levels per pass; 10 + L = LDS tiles (64 KiB exchange buffer)
     // with register passes of at most L levels where no tile shape fits; 20 + L = the same with a 128 KiB buffer
     const int levels = plan == 0 ? DEFAULT_LEVELS : plan % 10, kind = plan / 10;
-    if (plan < 0 || kind > 2 || levels < 1 || levels > 5) return FASTECC_E_INVAL;
+    if (plan < 0 || kind > 2 || levels < 1 || levels > 4) return FASTECC_E_INVAL;
     p->levels = levels;
     p->tiles = plan == 0 || kind >= 1;
     p->split = kind == 2 ? 1 : 2;

@@ -28,7 +28,7 @@ int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks
 // words >= p among the 2 * elems * k words of a stripe; `counter` is a device uint64 the caller zeroed
 int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counter, hipStream_t st);
 
-// plan id (fastecc_set_plan): 0 = default (LDS tiles + 4-level register passes), 1..5 = register passes only with that many
+// plan id (fastecc_set_plan): 0 = default (LDS tiles + 4-level register passes), 1..4 = register passes only with that many
 // levels, 10 + L / 20 + L = tiles with a 64 / 128 KiB exchange buffer; rebuilds the tables.  The device must be idle.
 int set_plan(Path* p, int plan, char* detail, size_t detail_cap);
 const char* plan_string(const Path* p);

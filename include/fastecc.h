@@ -58,7 +58,8 @@ enum {
      *   - the encoder is the same composition as RS.cpp:40-63 over this field: parity block j is the value at
      *     w_2N^(2j+1) of the polynomial of degree < N whose value at w_N^i is data block i.
      * Supported by create/destroy/encode/encode_blocks/ntt/check_range/profile/plan_string and
-     * fastecc_set_plan (plan = radix-2 levels per pass, 1..5; 0 = default); the 32-bit-word entry points
+     * fastecc_set_plan (0 = default: LDS tiles; 1..4 = register passes with that many radix-2 levels; 10+L / 20+L = tiles with a
+     * 64 / 128 KiB exchange buffer); the 32-bit-word entry points
      * (scale_blocks, gf_binary, set_option) return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
