@@ -19,6 +19,7 @@ P61 = (1 << 61) - 1
 FIELD_GF_FFF00001 = 0
 FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+CODE_MIXED_RADIX = 1  # fastecc_create_ex flag: transform order q * 2^m, q in {1, 3, 5, 7, 9}
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -63,6 +64,7 @@ def lib():
     L.fastecc_version.argtypes, L.fastecc_version.restype = [], i32
     L.fastecc_last_error_detail.argtypes, L.fastecc_last_error_detail.restype = [], ctypes.c_char_p
     L.fastecc_create.argtypes, L.fastecc_create.restype = [ctypes.POINTER(vp), u64, u64, u64, i32, i32], i32
+    L.fastecc_create_ex.argtypes, L.fastecc_create_ex.restype = [ctypes.POINTER(vp), u64, u64, u64, i32, i32, ctypes.c_uint], i32
     L.fastecc_destroy.argtypes, L.fastecc_destroy.restype = [vp], None
     L.fastecc_encode.argtypes, L.fastecc_encode.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_encode_batch.argtypes, L.fastecc_encode_batch.restype = [vp, vp, vp, u64, vp], i32
@@ -141,10 +143,13 @@ class Encoder:
     (2N,N) over GF((2^61-1)^2) with 16-byte elements (``field=FIELD_GF_P61_SQUARED``).
     """
 
-    def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001):
+    def __init__(self, n, k, block_bytes, device=0, field=FIELD_GF_FFF00001, flags=0):
         self._h = ctypes.c_void_p()
         self.n, self.k, self.block_bytes, self.device, self.field = n, k, block_bytes, device, field
-        _check(lib().fastecc_create(ctypes.byref(self._h), n, k, block_bytes, field, device), "fastecc_create")
+        if flags:
+            _check(lib().fastecc_create_ex(ctypes.byref(self._h), n, k, block_bytes, field, device, flags), "fastecc_create_ex")
+        else:
+            _check(lib().fastecc_create(ctypes.byref(self._h), n, k, block_bytes, field, device), "fastecc_create")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -295,6 +300,17 @@ class ShardedEncoder(Encoder):
         p = (ctypes.c_void_p * g)(*[_addr(x) for x in parity_slabs]) if parity_slabs is not None else None
         _check(lib().fastecc_encode_sharded(self._h, d, p, _addr(parity), stream or None), "fastecc_encode_sharded")
         return parity if parity is not None else parity_slabs
+
+
+def mixed_radix_order(k):
+    """Transform order fastecc_create_ex(..., CODE_MIXED_RADIX) picks for k data blocks: the smallest q * 2^m >= k,
+    q in {1, 3, 5, 7, 9}, 1 <= m <= 19 (None if there is none)."""
+    best = None
+    for q in (1, 3, 5, 7, 9):
+        for m in range(1, 20):
+            if (q << m) >= k and (best is None or (q << m) < best):
+                best = q << m
+    return best
 
 
 def plan_describe(k, block_bytes, plan=0):

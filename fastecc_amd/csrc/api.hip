@@ -53,6 +53,7 @@ struct CallBounds {
     // decoder (run_gathered): see PassArgs::in_odd / row_factor
     const uint32_t* gather_odd = nullptr;
     const uint32_t* gather_factor = nullptr;
+    bool dscale_whole = false;  // batch > 1: the per-block factor table covers the whole batch (mixed-radix transforms)
 };
 
 }  // namespace
@@ -89,6 +90,15 @@ struct fastecc_ctx {
     // polynomial on the 2^e - 1 cosets g_t * <w_k> of the data points inside the n-th roots of unity, ordered so that
     // codes nest: coset 0 is the reference's w_2k (the (2k,k) parity), then w_4k, w_4k^3, then w_8k, w_8k^3, w_8k^5, w_8k^7.
     int cosets = 1;
+    // Transform order q * N with an odd q (3, 5, 7, 9): the odd-radix level is the outermost one (mixed_kernels.hip) and
+    // N = 2^n is what everything else in this structure describes — q stripes of N blocks back to back.  K <= q*N data
+    // blocks (zero-extended), the first Mu <= q*N parity blocks are handed out.  q = 1: an ordinary context.
+    int q = 1;
+    uint32_t* q_tw_dif = nullptr;   // N x (q-1): w_(qN)^-(i2*j)
+    uint32_t* q_tw_dit = nullptr;   // N x (q-1): w_(qN)^+(i2*j)
+    uint32_t* q_dft_inv = nullptr;  // q x q: w_q^-(i*j)
+    uint32_t* q_dft_fwd = nullptr;  // q x q: w_q^+(i*j)
+    uint32_t* mixbuf = nullptr;     // q*N-block work stripe for callers whose parity buffer is shorter (lazy)
     uint64_t M = 0;             // parity blocks
     size_t parity_bytes = 0;    // M * block_bytes
     uint32_t* scratch = nullptr;      // fold > 0: k-block work stripe for the DIF half (lazy)
@@ -366,6 +376,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.wide = p.wide;
             a.batch = batch;
+            a.dscale_whole = cb.dscale_whole ? 1u : 0u;
             a.in_rows = in_rows;
             a.out_rows = out_rows;
             if (cb.gather_factor && src == in) {  // first pass of the decoder's transform
@@ -395,6 +406,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             a.s = s_eff;
             a.fold = folded && p.mode == MODE_MID ? c->fold : 0;
             a.batch = batch;
+            a.dscale_whole = cb.dscale_whole ? 1u : 0u;
             a.in_rows = in_rows;
             a.out_rows = out_rows;
             if (cb.gather_factor && src == in) {  // first pass of the decoder's transform
@@ -479,8 +491,57 @@ struct P61Hooks {
 
 int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st, const CallBounds& cb = CallBounds());
 
+// Transform order q * N: [radix-q pass down][the power-of-two pipeline on q stripes of N blocks][radix-q pass up].
+// The first pass reads the K existing data blocks (the rest is zero), the last one writes the first Mu parity blocks.
+int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    const uint64_t N1 = (uint64_t)c->q * c->N;
+    uint32_t* work = parity;
+    if (c->Mu != N1) {
+        if (!c->mixbuf) HIP_TRY(hipMalloc((void**)&c->mixbuf, N1 * c->ld * 4));
+        work = c->mixbuf;
+    }
+    // these passes are free to go as wide as the block size and the three pointers allow (the plan's `vec` is about its own passes)
+    int vec = 4;
+    const uintptr_t bits = (uintptr_t)data | (uintptr_t)work | (uintptr_t)parity;
+    while (vec > 1 && ((c->S % vec) != 0 || (c->ld % vec) != 0 || (bits % (4u * vec)) != 0)) vec >>= 1;
+    char name[32];
+    RadixArgs a{};
+    a.S = (uint32_t)c->S;
+    a.ld = (uint32_t)c->ld;
+    a.M = (uint32_t)c->N;
+    {
+        a.in = data;
+        a.out = work;
+        a.dft = c->q_dft_inv;
+        a.tw = c->q_tw_dif;
+        a.in_rows = c->K != N1 ? (uint32_t)c->K : 0;
+        a.out_rows = 0;
+        snprintf(name, sizeof name, "radix%d_dif", c->q);
+        ProfScope ps(c, st, name, (c->K + N1) * c->S * 4ull);
+        HIP_TRY(launch_radix(c->q, false, vec, a, st));
+    }
+    CallBounds cb;
+    cb.dscale_whole = true;
+    const int rc = run_passes(c, c->encode_plan, work, work, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, (uint32_t)c->q, cb);
+    if (rc != FASTECC_OK) return rc;
+    {
+        a.in = work;
+        a.out = parity;
+        a.dft = c->q_dft_fwd;
+        a.tw = c->q_tw_dit;
+        a.in_rows = 0;
+        a.out_rows = c->Mu != N1 ? (uint32_t)c->Mu : 0;
+        snprintf(name, sizeof name, "radix%d_dit", c->q);
+        ProfScope ps(c, st, name, (N1 + c->Mu) * c->S * 4ull);
+        HIP_TRY(launch_radix(c->q, true, vec, a, st));
+    }
+    return FASTECC_OK;
+}
+
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
+    if (c->q > 1) return encode_mixed(c, data, parity, st);
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
     // any (n,k): the first pass reads the K existing data blocks and takes the rest of the stripe as zero, the last pass
     // writes only the first Mu of the M parity blocks it computes — both through the kernels' bounds handling, no copies.
@@ -705,6 +766,65 @@ struct DeviceGuard {
 static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64_t block_bytes, int field, int device, int fold,
                        int cosets, const uint32_t* custom_factor);
 
+// Turns a fresh (2N, N) context into the power-of-two core of a transform of order q * N: the per-block factors for all
+// q stripes (position j1*N + r holds coefficient q*bitrev(r) + j1 -> w_(2qN)^coefficient / (qN), RS.cpp:51-54 with qN for
+// N) and the tables of the two odd-radix passes (mixed_kernels.hip).
+static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user)
+{
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+    const uint64_t M = c->N, N1 = (uint64_t)q * M;
+    const uint32_t wN1 = gf::h_root((uint32_t)N1), wN1i = gf::h_inv(wN1), w2 = gf::h_root((uint32_t)(2 * N1));
+    const uint32_t inv = gf::h_inv((uint32_t)N1);
+    std::vector<uint32_t> dsc(N1), twd((size_t)M * (q - 1)), twu((size_t)M * (q - 1)), dfi((size_t)q * q), dff((size_t)q * q);
+    {
+        std::vector<uint32_t> pw(N1);  // w_(2 N1)^j / N1 by coefficient index
+        uint32_t d = inv;
+        for (uint64_t j = 0; j < N1; j++) {
+            pw[j] = gf::h_to_mont(d);
+            d = gf::h_mul(d, w2);
+        }
+        for (uint64_t j1 = 0; j1 < (uint64_t)q; j1++)
+            for (uint64_t r = 0; r < M; r++) dsc[j1 * M + r] = pw[(uint64_t)q * bitrev_host((uint32_t)r, c->n) + j1];
+    }
+    for (uint64_t i2 = 0; i2 < M; i2++) {
+        const uint32_t a = gf::h_pow(wN1, i2), b = gf::h_pow(wN1i, i2);
+        uint32_t x = 1, y = 1;
+        for (int j = 1; j < q; j++) {
+            x = gf::h_mul(x, a);
+            y = gf::h_mul(y, b);
+            twu[i2 * (q - 1) + j - 1] = gf::h_to_mont(x);
+            twd[i2 * (q - 1) + j - 1] = gf::h_to_mont(y);
+        }
+    }
+    const uint32_t wq = gf::h_pow(wN1, M), wqi = gf::h_inv(wq);
+    for (int i = 0; i < q; i++)
+        for (int j = 0; j < q; j++) {
+            dff[(size_t)i * q + j] = gf::h_to_mont(gf::h_pow(wq, (uint64_t)(i * j) % q));
+            dfi[(size_t)i * q + j] = gf::h_to_mont(gf::h_pow(wqi, (uint64_t)(i * j) % q));
+        }
+    (void)hipFree(c->dscale);  // sized for one stripe by create_impl
+    c->dscale = nullptr;
+    int rc = upload_table(&c->dscale, dsc);
+    if (rc == FASTECC_OK) rc = upload_table(&c->q_tw_dif, twd);
+    if (rc == FASTECC_OK) rc = upload_table(&c->q_tw_dit, twu);
+    if (rc == FASTECC_OK) rc = upload_table(&c->q_dft_inv, dfi);
+    if (rc == FASTECC_OK) rc = upload_table(&c->q_dft_fwd, dff);
+    if (rc != FASTECC_OK) return rc;
+    c->q = q;
+    c->K = k_user;
+    c->Mu = m_user;
+    c->stripe_bytes = (size_t)N1 * c->S * 4;  // the staging stripe of the host-memory calls holds all q * N blocks
+    c->parity_bytes = (size_t)m_user * c->S * 4;
+    char buf[48];
+    snprintf(buf, sizeof buf, "R%d:dif1@%d,", q, c->n);
+    c->plan_text = std::string(buf) + c->plan_text;
+    snprintf(buf, sizeof buf, ",R%d:dit1@%d", q, c->n);
+    const size_t sp = c->plan_text.rfind(" v");
+    c->plan_text.insert(sp == std::string::npos ? c->plan_text.size() : sp, buf);
+    return FASTECC_OK;
+}
+
 extern "C" {
 
 const char* fastecc_strerror(int code)
@@ -802,6 +922,37 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
 
 }
 
+int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device, unsigned flags)
+{
+    if (!out) return FASTECC_E_INVAL;
+    *out = nullptr;
+    if (flags & ~(unsigned)FASTECC_CODE_MIXED_RADIX) return FASTECC_E_INVAL;
+    if (!(flags & FASTECC_CODE_MIXED_RADIX)) return fastecc_create(out, n, k, block_bytes, field, device);
+    if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
+    if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
+    // transform order: the smallest q * 2^m >= k with q in {1, 3, 5, 7, 9}, m >= 1 (NTT.md:43-46: "the next divider of
+    // 0xFFF00000 is only a few percents larger than N itself"); w_(2 q 2^m) must exist: 2^(m+1) | 2^20
+    uint64_t best = 0;
+    int bq = 1, bm = 0;
+    for (int q : {1, 3, 5, 7, 9})
+        for (int m = 1; m <= 19; m++) {
+            const uint64_t N1 = (uint64_t)q << m;
+            if (N1 >= k && (best == 0 || N1 < best)) best = N1, bq = q, bm = m;
+        }
+    if (best == 0 || n - k > best) return FASTECC_E_UNSUPPORTED;
+    if (bq == 1) return fastecc_create(out, n, k, block_bytes, field, device);
+    if (block_bytes / 4 > 0xFFFFFFFFull / 2 || best * (block_bytes / 4) > 0xFFFFFFFFull * 4) return FASTECC_E_UNSUPPORTED;
+    const uint64_t M = 1ull << bm;
+    int rc = create_impl(out, 2 * M, M, bm, block_bytes, field, device, 0, 1, nullptr);
+    if (rc != FASTECC_OK) return rc;
+    rc = setup_mixed(*out, bq, k, n - k);
+    if (rc != FASTECC_OK) {
+        fastecc_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
 }  // extern "C"
 
 // Everything after argument validation.  custom_factor (k plain values by coefficient index) replaces the encoder's
@@ -896,7 +1047,7 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
@@ -917,7 +1068,7 @@ fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, u
 void set_plan_text(fastecc_ctx* c, const std::string& t) { c->plan_text = t; }
 int columns_supported(const fastecc_ctx* c)
 {
-    return !c->p61 && !c->sharded && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
+    return !c->p61 && !c->sharded && c->q == 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
 }
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
 
@@ -1025,6 +1176,8 @@ void fastecc_destroy(fastecc_ctx* c)
     if (c->parbuf) (void)hipFree(c->parbuf);
     if (c->hostpar) (void)hipFree(c->hostpar);
     if (c->tw_fold_dit) (void)hipFree(c->tw_fold_dit);
+    for (uint32_t* t : {c->q_tw_dif, c->q_tw_dit, c->q_dft_inv, c->q_dft_fwd, c->mixbuf})
+        if (t) (void)hipFree(t);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
@@ -1042,12 +1195,12 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     if (mem_kind == FASTECC_MEM_DEVICE) {
         // the reference's configuration touches nothing but the caller's buffers and the read-only tables: calls on
         // different streams may overlap on the device.  The other codes work through scratch stripes of the context.
-        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1;
+        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1 || c->q > 1;
         if (!internal) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
         return with_internal_buffers(c, st, [&] { return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st); });
     }
     if (mem_kind == FASTECC_MEM_HOST_PINNED) {
-        if (c->p61 || c->fold != 0 || c->cosets != 1 || c->ld != c->S || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;
+        if (c->p61 || c->q > 1 || c->fold != 0 || c->cosets != 1 || c->ld != c->S || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;
         return with_internal_buffers(c, st, [&] { return encode_host_pinned(c, (const uint32_t*)data, (uint32_t*)parity, st); });
     }
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
@@ -1087,7 +1240,7 @@ int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_
 {
     if (!c || !data || !parity || count == 0 || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (c->sharded) return FASTECC_E_UNSUPPORTED;
-    if (c->p61 || c->fold != 0 || c->cosets != 1 || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m
+    if (c->p61 || c->q > 1 || c->fold != 0 || c->cosets != 1 || c->K != c->N || c->Mu != c->M) return FASTECC_E_UNSUPPORTED;  // n = 2k = 2^m
     if (count * c->N > 0x7FFFFFFFull || count > 0xFFFFFFFFull) return FASTECC_E_UNSUPPORTED;  // 32-bit block indices
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // stripes of a batch are contiguous (b * k * block_bytes apart)
     DeviceGuard dg(c->device);
@@ -1142,7 +1295,7 @@ int fastecc_ntt(fastecc_ctx* c, void* data, int inverse, int mem_kind, void* str
     if (!c || !data || ((uintptr_t)data & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;
     if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // a row pitch applies to fastecc_encode on device stripes only
-    if (c->K != c->N) return FASTECC_E_UNSUPPORTED;   // the transform length is a power of two
+    if (c->K != c->N || c->q > 1) return FASTECC_E_UNSUPPORTED;   // the stand-alone transform has power-of-two length
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;
@@ -1166,7 +1319,7 @@ int fastecc_scale_blocks(fastecc_ctx* c, void* data, uint32_t scale, uint32_t ba
     if (!c || !data || ((uintptr_t)data & 3u)) return FASTECC_E_INVAL;
     if (scale >= gf::P || base >= gf::P) return FASTECC_E_INVAL;
     if (c->p61 || c->sharded) return FASTECC_E_UNSUPPORTED;  // 32-bit scalars: GF(0xFFF00001) only
-    if (c->ld != c->S || c->K != c->N) return FASTECC_E_UNSUPPORTED;
+    if (c->ld != c->S || c->K != c->N || c->q > 1) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
@@ -1273,7 +1426,7 @@ static int pack_args_ok(const fastecc_ctx* c, const void* a, const void* b)
     if (!c || !a || !b || (((uintptr_t)a | (uintptr_t)b) & 3u)) return FASTECC_E_INVAL;
     if (c->p61 || c->sharded) return FASTECC_E_UNSUPPORTED;         // the recoding is specific to p = 0xFFF00001
     if (c->S < 2 || c->S > 1025) return FASTECC_E_UNSUPPORTED;  // positions are 10-bit
-    if (c->K != c->N) return FASTECC_E_UNSUPPORTED;             // staging buffers are sized for power-of-two k
+    if (c->K != c->N || c->q > 1) return FASTECC_E_UNSUPPORTED;  // staging buffers are sized for power-of-two k
     return FASTECC_OK;
 }
 
@@ -1401,7 +1554,8 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
             (void)hipDeviceSynchronize();
             if (c->scratch) (void)hipFree(c->scratch);
             if (c->parbuf) (void)hipFree(c->parbuf);
-            c->scratch = c->parbuf = nullptr;
+            if (c->mixbuf) (void)hipFree(c->mixbuf);
+            c->scratch = c->parbuf = c->mixbuf = nullptr;
             destroy_decode_state(c->decoder);
             c->decoder = nullptr;
         }

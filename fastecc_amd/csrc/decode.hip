@@ -294,7 +294,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
     if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     const CtxInfo ci = info_of(c);
-    if (ci.field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
+    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.q > 1) return FASTECC_E_UNSUPPORTED;  // the decoder's transform is a power of two
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
     const uint64_t N = ci.k;
 

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassArgs a)
     } else {
         dif_levels<LOGR, V, true>(x, a.tw_dif, 0u, 0);
         // position p = hi*R + j holds coefficient bitrev_n(p); a.dscale is stored in position order
-        const_u32_ptr d = as_constant(a.dscale) + (size_t)(hi & ((1u << (a.n - LOGR)) - 1u)) * R;  // the table repeats per stripe of a batch
+        // the table repeats per stripe of a batch unless it covers the whole batch (mixed-radix transforms)
+        const_u32_ptr d = as_constant(a.dscale) + (size_t)(a.dscale_whole ? hi : (hi & ((1u << (a.n - LOGR)) - 1u))) * R;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const uint32_t f = d[j];

@@ -24,6 +24,8 @@ struct PassArgs {
     uint32_t batch;          // > 1: that many stripes stored back to back are transformed by one launch
     uint32_t in_rows;        // > 0: `in` holds only that many blocks, the rest of the stripe reads as zero (zero-extended codes)
     uint32_t out_rows;       // > 0: only that many blocks of the result exist in `out`, the rest is not written
+    uint32_t dscale_whole;   // MID with batch > 1: != 0 = `dscale` covers all stripes of the batch (batch * 2^n entries by
+                             // position: the q sub-transforms of an order q * 2^n transform), 0 = it repeats per stripe
     // DIF only, optional (the decoder's first pass): input block u is block u/2 of `in` (u even) or of `in_odd` (u odd),
     // multiplied by row_factor[u] (Montgomery form); a zero factor means "erased": the block is not read at all
     const uint32_t* in_odd;
@@ -56,7 +58,25 @@ struct TileArgs {
     int wide;             // DIF/DIT pair tiles whose blocks span >= 2^32 bytes: address windows per tile (2, 4, 8; 0 = one)
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
+    uint32_t dscale_whole;  // as PassArgs::dscale_whole
 };
+
+// Arguments of the odd-radix pass of a transform of order q * 2^m (mixed_kernels.hip: radix_kernel).
+struct RadixArgs {
+    const uint32_t* in;   // stripe of q * M blocks read by this pass
+    uint32_t* out;        // stripe written (may equal `in`: a wave reads and writes the same q rows)
+    const uint32_t* dft;  // q x q: w_q^(+-i*j), Montgomery form
+    const uint32_t* tw;   // M x (q-1): w_(q*M)^(+-i2*j), j = 1..q-1, Montgomery form
+    uint32_t S;           // words per block
+    uint32_t ld;          // words between consecutive blocks
+    uint32_t M;           // 2^m: the block distance of the radix-q butterflies
+    uint32_t in_rows;     // > 0: `in` holds only that many blocks, the rest reads as zero
+    uint32_t out_rows;    // > 0: only that many blocks of the result are written
+    uint32_t col_chunks;  // filled by the launcher
+    uint64_t items;       // filled by the launcher
+};
+bool radix_supported(int q);
+hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st);
 
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
 bool tile_supported(int logt, bool pair, int logr = 5);

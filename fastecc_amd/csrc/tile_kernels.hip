@@ -484,7 +484,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 // the R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different
                 // blocks: both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
                 // (a batch stores its stripes back to back: v.hi counts tiles across all of them, the factor table repeats)
-                const_u32_ptr d = as_constant(a.dscale) + ((size_t)(v.hi & ((1u << (a.n - LOGT)) - 1u)) << LOGT) + qb_u;
+                const uint32_t stripe_tile = a.dscale_whole ? v.hi : (v.hi & ((1u << (a.n - LOGT)) - 1u));
+                const_u32_ptr d = as_constant(a.dscale) + ((size_t)stripe_tile << LOGT) + qb_u;
                 constexpr int CH = 8;
 #pragma unroll
                 for (int k0 = 0; k0 < R; k0 += CH) {

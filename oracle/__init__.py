@@ -44,11 +44,11 @@ class Oracle:
         for name in ("root", "inv"):
             f = getattr(lib, "orc_gf_" + name)
             f.argtypes, f.restype = [_u32], _u32
-        for name in ("slow_ntt", "ntt", "ntt_fast"):
+        for name in ("slow_ntt", "ntt", "ntt_fast", "ntt_mixed"):
             f = getattr(lib, "orc_" + name)
             f.argtypes, f.restype = [_u32p, _sz, _sz, ctypes.c_int], None
         lib.orc_scale_blocks.argtypes, lib.orc_scale_blocks.restype = [_u32p, _sz, _sz, _u32, _u32], None
-        for name in ("encode", "encode_fast"):
+        for name in ("encode", "encode_fast", "encode_slow", "encode_mixed"):
             f = getattr(lib, "orc_" + name)
             f.argtypes, f.restype = [_u32p, _sz, _sz], None
         lib.orc_encode_by_definition.argtypes = [_u32p, _u32p, _sz, _sz]
@@ -84,6 +84,17 @@ class Oracle:
     def scale_blocks(self, data, scale, base): return self._run(self.lib.orc_scale_blocks, data, scale, base)
     def encode(self, data): return self._run(self.lib.orc_encode, data)
     def encode_fast(self, data): return self._run(self.lib.orc_encode_fast, data)
+    # any transform order N | p-1 (mixed radix, N = q 2^m): by definition, and with the odd factor outermost
+    def encode_slow(self, data): return self._run(self.lib.orc_encode_slow, data)
+    def encode_mixed(self, data): return self._run(self.lib.orc_encode_mixed, data)
+    def ntt_mixed(self, data, inverse=False): return self._run(self.lib.orc_ntt_mixed, data, int(inverse))
+
+    def encode_mixed_code(self, data, n, order):
+        """The (n,k) code FASTECC_CODE_MIXED_RADIX builds on transform order `order` >= k: zero-extend, encode, truncate."""
+        k, size = data.shape
+        x = np.zeros((order, size), dtype=np.uint32)
+        x[:k] = data
+        return self.encode_mixed(x)[: n - k]
 
     def encode_fast_inplace(self, a):
         """In-place variant for large buffers (no copy)."""
@@ -232,6 +243,8 @@ class Reference:
         lib.ref_ntt.argtypes, lib.ref_ntt.restype = [_u32p, _sz, _sz, ctypes.c_int, ctypes.c_int], None
         lib.ref_encode.argtypes, lib.ref_encode.restype = [_u32p, _sz, _sz], None
         lib.ref_hash.argtypes, lib.ref_hash.restype = [_u32p, _sz, _sz], _u32
+        if hasattr(lib, "ref_small_ntt"):
+            lib.ref_small_ntt.argtypes, lib.ref_small_ntt.restype = [_u32p, ctypes.c_int, ctypes.c_int], ctypes.c_int
         lib.ref_simd_level.restype = ctypes.c_int
 
     def gf_add(self, x, y): return self.lib.ref_gf_add(x, y)
@@ -251,6 +264,13 @@ class Reference:
     def encode(self, data):
         a = np.ascontiguousarray(data, dtype=np.uint32).copy()
         self.lib.ref_encode(a, a.shape[0], a.shape[1])
+        return a
+
+    def small_ntt(self, f, inverse=False):
+        """The reference's NTT3 / NTT9 codelet (ntt.cpp:25-44, 113-146) on a vector of 3 or 9 words."""
+        a = np.ascontiguousarray(f, dtype=np.uint32).copy()
+        if self.lib.ref_small_ntt(a, a.size, int(inverse)) != 0:
+            raise ValueError("the reference has codelets of order 3 and 9 only")
         return a
 
     def encode_inplace(self, a):

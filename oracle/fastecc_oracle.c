@@ -247,6 +247,61 @@ static void encode_with(void (*ntt)(uint32_t *, size_t, size_t, int), uint32_t *
 void orc_encode(uint32_t *data, size_t N, size_t size) { encode_with(orc_ntt, data, N, size); }
 void orc_encode_fast(uint32_t *data, size_t N, size_t size) { encode_with(orc_ntt_fast, data, N, size); }
 
+/* The same composition by the O(N^2) definition (ntt.cpp:451-483): valid for ANY order N | p-1, which is what pins the
+ * mixed-radix codes (N = q 2^m, q odd) — the reference's Slow_NTT is the only transform of it that accepts such N. */
+void orc_encode_slow(uint32_t *data, size_t N, size_t size) { encode_with(orc_slow_ntt, data, N, size); }
+
+/* Transform of order N = q * M, M = 2^m, q odd (NTT.md:43-46), natural order in and out: Cooley-Tukey with the odd factor
+ * outermost, X[q j2 + j1] = sum_i2 w_M^(i2 j2) [ w_N^(i2 j1) sum_i1 x[i1 M + i2] w_q^(i1 j1) ].  The inner odd-order sums
+ * are taken by definition (for q = 3, 9 the reference has the codelets NTT3 / NTT9, ntt.cpp:25-44, 113-146: same values,
+ * tests/test_oracle.py checks them against each other through oracle/_ref). */
+void orc_ntt_mixed(uint32_t *data, size_t N, size_t size, int inverse)
+{
+    size_t M = 1;
+    while ((N % (2 * M)) == 0) M *= 2;
+    const size_t q = N / M;
+    if (q == 1) {
+        orc_ntt_fast(data, N, size, inverse);
+        return;
+    }
+    const int m = ilog2(M);
+    uint32_t wN = orc_gf_root((uint32_t)N);
+    if (inverse) wN = orc_gf_inv(wN);
+    const uint32_t wq = orc_gf_pow(wN, (uint32_t)M), wM = orc_gf_pow(wN, (uint32_t)q);
+    uint32_t stage_root[32];
+    for (int l = 0; l < m; l++) stage_root[l] = orc_gf_pow(wM, (uint32_t)(M >> (l + 1)));
+#pragma omp parallel
+    {
+        uint32_t *col = (uint32_t *)malloc(N * sizeof(uint32_t)), *y = (uint32_t *)malloc(N * sizeof(uint32_t));
+#pragma omp for schedule(dynamic, 4)
+        for (ptrdiff_t k = 0; k < (ptrdiff_t)size; k++) {
+            for (size_t i = 0; i < N; i++) col[i] = data[i * size + k];
+            for (size_t i2 = 0; i2 < M; i2++) {
+                const uint32_t t = orc_gf_pow(wN, (uint32_t)i2);
+                uint32_t tj = 1; /* w_N^(i2 j1) */
+                for (size_t j1 = 0; j1 < q; j1++) {
+                    const uint32_t wj = orc_gf_pow(wq, (uint32_t)j1);
+                    uint32_t acc = 0, wij = 1; /* w_q^(i1 j1) */
+                    for (size_t i1 = 0; i1 < q; i1++) {
+                        acc = orc_gf_add(acc, orc_gf_mul(wij, col[i1 * M + i2]));
+                        wij = orc_gf_mul(wij, wj);
+                    }
+                    y[j1 * M + i2] = orc_gf_mul(acc, tj);
+                    tj = orc_gf_mul(tj, t);
+                }
+            }
+            for (size_t j1 = 0; j1 < q; j1++) {
+                if (M > 1) column_ntt(y + j1 * M, M, m, stage_root);
+                for (size_t j2 = 0; j2 < M; j2++) data[(q * j2 + j1) * size + k] = y[j1 * M + j2];
+            }
+        }
+        free(col);
+        free(y);
+    }
+}
+
+void orc_encode_mixed(uint32_t *data, size_t N, size_t size) { encode_with(orc_ntt_mixed, data, N, size); }
+
 /* SURVEY.md §0.6 (derived from RS.cpp:40-63, ntt.cpp:450-483): with f the degree<N polynomial
  * through f(w_N^m) = data[m], parity[j] = f(w_2N^(2j+1)).  Evaluated directly via Lagrange-free
  * route: coefficients c = (1/N) * sum_m data[m] w_N^(-m i), then Horner-free O(N^2) evaluation. */

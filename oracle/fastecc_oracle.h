@@ -47,6 +47,11 @@ void orc_scale_blocks(uint32_t *data, size_t N, size_t size, uint32_t scale, uin
 void orc_encode(uint32_t *data, size_t N, size_t size);
 /* Same result through orc_ntt_fast (used for large N). */
 void orc_encode_fast(uint32_t *data, size_t N, size_t size);
+/* any order N | p-1 (mixed radix): the composition of RS.cpp:40-63 by the O(N^2) definition, and through a transform of
+ * order q 2^m with the odd factor outermost; orc_ntt_mixed is that transform (natural order in and out) */
+void orc_encode_slow(uint32_t *data, size_t N, size_t size);
+void orc_ntt_mixed(uint32_t *data, size_t N, size_t size, int inverse);
+void orc_encode_mixed(uint32_t *data, size_t N, size_t size);
 /* Parity straight from the mathematical contract parity[j] = f(w_2N^(2j+1)), O(N^2). */
 void orc_encode_by_definition(const uint32_t *data, uint32_t *parity, size_t N, size_t size);
 

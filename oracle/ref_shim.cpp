@@ -80,6 +80,23 @@ void ref_encode(uint32_t* data, size_t N, size_t size)
     gather_logical(data, ptrs, size);
 }
 
+// The reference's odd-order codelets (ntt.cpp:25-44, 113-146), which none of its drivers reaches: f[0..order) in place.
+// order 3 or 9; anything else leaves f untouched and returns -1.
+int ref_small_ntt(uint32_t* f, int order, int inverse)
+{
+    if (order == 3) {
+        if (inverse) NTT3<T, P, true>(f[0], f[1], f[2]);
+        else         NTT3<T, P, false>(f[0], f[1], f[2]);
+        return 0;
+    }
+    if (order == 9) {
+        if (inverse) NTT9<T, P, true>(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8]);
+        else         NTT9<T, P, false>(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8]);
+        return 0;
+    }
+    return -1;
+}
+
 // main.cpp:202-212 through the reference's own template.
 uint32_t ref_hash(uint32_t* data, size_t N, size_t size)
 {

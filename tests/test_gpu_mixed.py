@@ -1,0 +1,161 @@
+"""GPU tests (-m gpu) of the mixed-radix codes: transform order q * 2^m, q in {3, 5, 7, 9} (fastecc_create_ex with
+FASTECC_CODE_MIXED_RADIX; NTT.md:43-46, the reference's NTT3/NTT9 codelets ntt.cpp:25-146).
+
+Checker: the oracle's mixed-radix encode, itself pinned to the reference's Slow_NTT — the one reference transform that
+takes such orders — and to its NTT3 / NTT9 codelets in tests/test_oracle.py.  Bit-exact, no tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFF00001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fe(hip_lib):
+    import fastecc_amd
+    return fastecc_amd
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to("cuda:0")
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def rand_stripe(seed, N, S):
+    x = np.random.default_rng(seed).integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    x.reshape(-1)[:4] = [0, 1, P - 1, 0x000FFFFF][: min(4, x.size)]
+    return x
+
+
+def test_order_selection(fe):
+    assert [fe.mixed_radix_order(k) for k in (1, 2, 3, 5, 6, 7, 9, 11, 13, 17, 96, 97, 1000, 393216, 393217)] == \
+        [2, 2, 4, 6, 6, 8, 10, 12, 14, 18, 96, 112, 1024, 393216, 458752]
+
+
+@pytest.mark.parametrize("q", [3, 5, 7, 9])
+@pytest.mark.parametrize("m,S", [(1, 1), (2, 7), (5, 64), (6, 33), (7, 256), (10, 128), (11, 40)])
+def test_full_codes_match_the_oracle(torch_cuda, fe, oracle, q, m, S):
+    """n = 2k, k = q * 2^m exactly: parity block j = f(w_2k^(2j+1)), data at the powers of w_k."""
+    torch = torch_cuda
+    k = q << m
+    assert fe.mixed_radix_order(k) == k
+    x = rand_stripe(q * 100 + m, k, S)
+    want = oracle.encode_mixed(x)
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        assert ("R%d:" % q) in enc.plan()
+        d = to_dev(torch, x)
+        out = torch.empty_like(d)
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(out).reshape(k, S), want), enc.plan()
+        assert np.array_equal(to_host(d).reshape(k, S), x)  # out of place leaves the data alone
+        enc.encode(d)  # in place, the reference's behaviour
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(d).reshape(k, S), want)
+
+
+@pytest.mark.parametrize("k,m", [(3, 3), (5, 1), (11, 12), (100, 37), (111, 112), (1000, 24), (1500, 1536), (3000, 1)])
+def test_any_k_zero_extension_and_fewer_parity_blocks(torch_cuda, fe, oracle, k, m):
+    torch = torch_cuda
+    S = 24
+    order = fe.mixed_radix_order(k)
+    x = rand_stripe(k + m, k, S)
+    if order & (order - 1):
+        want = oracle.encode_mixed_code(x, k + m, order)
+    else:
+        # a power of two is the ordinary fastecc_create code: the smallest power-of-two count >= m (at least order/16) of
+        # evenly spaced parity blocks of the (2 order, order) code is computed, the first m are the parity
+        count = max(order // 16, 1 << max(m - 1, 0).bit_length())
+        z = np.zeros((order, S), dtype=np.uint32)
+        z[:k] = x
+        want = oracle.encode_fast(z)[:: order // count][:m]
+    try:
+        enc = fe.Encoder(k + m, k, 4 * S, flags=fe.CODE_MIXED_RADIX)
+    except fe.FastEccError as e:
+        assert m > order and e.code == fe.E_UNSUPPORTED
+        return
+    with enc:
+        d = to_dev(torch, x)
+        out = torch.full((m * S,), 0x77777777, dtype=torch.int32, device="cuda:0")
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(out).reshape(m, S), want), enc.plan()
+        host_out = np.empty((m, S), dtype=np.uint32)
+        enc.encode_host(x, host_out)
+        assert np.array_equal(host_out, want)
+
+
+def test_every_plan_and_block_pointers(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    k, S = 3 << 11, 96
+    x = rand_stripe(5, k, S)
+    want = oracle.encode_mixed(x)
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        for plan in (0, 51, 42, 34, 1100, 2080, 3100):
+            enc.set_plan(plan)
+            d = to_dev(torch, x)
+            enc.encode(d)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(d).reshape(k, S), want), (plan, enc.plan())
+        blocks = [np.ascontiguousarray(x[i]).copy() for i in range(k)]
+        enc.encode_blocks([b.ctypes.data for b in blocks])
+        assert np.array_equal(np.stack(blocks), want)
+        assert enc.check_range(to_dev(torch, x)) == 0
+        for call in (lambda: enc.ntt(to_dev(torch, x)), lambda: enc.encode_columns(d, d, 0, 32),
+                     lambda: enc.decode_prepare([1] * k, [1] * k)):
+            with pytest.raises(fe.FastEccError) as ei:
+                call()
+            assert ei.value.code == fe.E_UNSUPPORTED
+
+
+def test_flags_validation(torch_cuda, fe):
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.Encoder(8, 4, 64, flags=2)
+    assert ei.value.code == fe.E_INVAL
+    with pytest.raises(fe.FastEccError) as ei:
+        fe.Encoder(2 * 96, 96, 64, field=fe.FIELD_GF_P61_SQUARED, flags=fe.CODE_MIXED_RADIX)
+    assert ei.value.code == fe.E_UNSUPPORTED
+    with fe.Encoder(256, 128, 64, flags=fe.CODE_MIXED_RADIX) as enc:  # a power of two: the ordinary context
+        assert "R" not in enc.plan().split(" v")[0]
+
+
+def test_large_orders_linearity_and_sampled_columns(torch_cuda, fe, oracle):
+    """k = 3 * 2^17 and 9 * 2^16 x 4 KB (1.5 and 2.25 GiB stripes): eight columns re-encoded by the oracle, and linearity."""
+    torch = torch_cuda
+    S = 1024
+    for q, m in ((3, 17), (9, 16)):
+        k = q << m
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(q)
+        a = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+        b = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+        pa, pb, ps = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+            enc.encode(a, pa)
+            enc.encode(b, pb)
+            ua = a.to(torch.int64) & 0xFFFFFFFF
+            ub = b.to(torch.int64) & 0xFFFFFFFF
+            s = ((ua + ub) % P).to(torch.int32)
+            del ua, ub
+            enc.encode(s, ps)
+            torch.cuda.synchronize()
+        lhs = ((pa.to(torch.int64) & 0xFFFFFFFF) + (pb.to(torch.int64) & 0xFFFFFFFF)) % P
+        assert torch.equal(lhs, ps.to(torch.int64) & 0xFFFFFFFF)
+        del lhs, s, ps, pb, b
+        cols = [0, 1, 31, 32, 500, 777, 1022, 1023]
+        sample = to_host(a.view(k, S)[:, cols].contiguous()).reshape(k, len(cols))
+        want = oracle.encode_mixed(sample)
+        assert np.array_equal(to_host(pa.view(k, S)[:, cols].contiguous()).reshape(k, len(cols)), want), (q, m)
+        del a, pa
+        torch.cuda.empty_cache()

@@ -3,6 +3,7 @@ unmodified reference.  These pin the checker that the -m gpu parity tests rely o
 import os
 
 import numpy as np
+import pytest
 
 P = 0xFFF00001
 
@@ -225,3 +226,45 @@ def test_lagrange_decoder_recovers_what_the_encoder_wrote(oracle):
         pp = np.ones(N, np.uint8)
         pp[0] = 0
         assert oracle.decode(x, par, dp, pp) is None  # N - 1 survivors
+
+
+# ------------------------------------------------------------------------------------------------
+# mixed-radix orders (NTT.md:43-46): the oracle's transforms of order q * 2^m against the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [3, 6, 12, 5, 10, 40, 7, 28, 9, 18, 72, 96, 160])
+def test_mixed_radix_transform_matches_the_definition(oracle, N):
+    """orc_ntt_mixed (odd factor outermost + radix-2) == the O(N^2) definition orc_slow_ntt, both directions."""
+    x = np.random.default_rng(N).integers(0, P, size=(N, 3), dtype=np.uint64).astype(np.uint32)
+    for inverse in (False, True):
+        assert np.array_equal(oracle.ntt_mixed(x, inverse), oracle.slow_ntt(x, inverse)), (N, inverse)
+    assert np.array_equal(oracle.encode_mixed(x), oracle.encode_slow(x))
+
+
+@pytest.mark.parametrize("N", [3, 12, 24, 9, 36, 5, 20, 7, 14])
+def test_mixed_radix_is_pinned_to_the_reference(oracle, reference, N):
+    """Slow_NTT (ntt.cpp:451-483) is the one reference transform that accepts a non-power-of-two order; the encode is the
+    RS.cpp:40-63 composition around it.  Both must agree with the oracle's fast mixed-radix path."""
+    from oracle import Reference
+    x = np.random.default_rng(100 + N).integers(0, P, size=(N, 2), dtype=np.uint64).astype(np.uint32)
+    for inverse in (False, True):
+        assert np.array_equal(reference.ntt(x, inverse, Reference.SLOW), oracle.ntt_mixed(x, inverse)), (N, inverse)
+    # RS.cpp:41-63 with Slow_NTT: inverse transform, block i *= root(2N)^i / N, forward transform
+    c = reference.ntt(x, True, Reference.SLOW).astype(object)
+    w2n, inv_n = reference.gf_root(2 * N), reference.gf_inv(N)
+    for i in range(N):
+        c[i] = (c[i] * (inv_n * pow(w2n, i, P) % P)) % P
+    want = reference.ntt(c.astype(np.uint32), False, Reference.SLOW)
+    assert np.array_equal(oracle.encode_mixed(x), want)
+
+
+def test_reference_codelets_of_order_3_and_9(oracle, reference):
+    """NTT3 / NTT9 (ntt.cpp:25-44, 113-146) compute the order-3 / order-9 transform of the definition: the values the
+    odd-radix pass of the HIP path is built on.  (NTT9 leaves its outputs in natural order: its last step transposes.)"""
+    if not hasattr(reference.lib, "ref_small_ntt"):
+        pytest.skip("oracle/_ref predates ref_small_ntt: rebuild it where /root/reference exists")
+    rng = np.random.default_rng(39)
+    for order in (3, 9):
+        for inverse in (False, True):
+            f = rng.integers(0, P, size=order, dtype=np.uint64).astype(np.uint32)
+            want = oracle.slow_ntt(f.reshape(order, 1), inverse).reshape(-1)
+            assert np.array_equal(reference.small_ntt(f, inverse), want), (order, inverse)
