@@ -228,9 +228,16 @@ class Encoder:
         """Erasure pattern: k data flags and n - k parity flags (truthy = the block survives)."""
         if len(data_present) != self.k or len(parity_present) != self.n - self.k:
             raise ValueError("need k data flags and n - k parity flags")
-        dp = (ctypes.c_uint8 * self.k)(*[1 if v else 0 for v in data_present])
-        pp = (ctypes.c_uint8 * (self.n - self.k))(*[1 if v else 0 for v in parity_present])
+        def flags(v, count):
+            # a contiguous uint8 numpy array goes through as it is (the C ABI takes plain byte arrays); anything else is converted
+            if hasattr(v, "ctypes") and getattr(v, "dtype", None) is not None and v.dtype.itemsize == 1 and v.flags["C_CONTIGUOUS"]:
+                return v, ctypes.cast(v.ctypes.data, ctypes.POINTER(ctypes.c_uint8))
+            arr = (ctypes.c_uint8 * count)(*[1 if x else 0 for x in v])
+            return arr, arr
+        keep_d, dp = flags(data_present, self.k)
+        keep_p, pp = flags(parity_present, self.n - self.k)
         _check(lib().fastecc_decode_prepare(self._h, dp, pp), "fastecc_decode_prepare")
+        del keep_d, keep_p
 
     def decode(self, data, parity, stream=0, mem=MEM_DEVICE):
         """Recover the erased data blocks in place (README.md:102-119); parity is read only."""

@@ -1080,6 +1080,20 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
     return create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, factor);
 }
 
+int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit, bool inverse_roots, uint32_t width, hipStream_t st)
+{
+    if (c->p61 || c->sharded || c->q > 1 || c->ntt_plan.empty() || width == 0 || width > c->S) return FASTECC_E_UNSUPPORTED;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    const uint32_t* tw = inverse_roots ? c->tw_ntt_inv : c->tw_ntt_fwd;
+    if (!dit) return run_passes(c, c->ntt_plan, in, out, tw, tw, st, 0, width);
+    // the stand-alone plan mirrored: the same chunks bottom up as DIT passes; level for level the same register runs, so
+    // the level-packed tables of the DIF plan serve both
+    std::vector<Pass> up(c->ntt_plan.rbegin(), c->ntt_plan.rend());
+    for (Pass& p : up) p.mode = MODE_DIT;
+    return run_passes(c, up, in, out, tw, tw, st, 0, width);
+}
+
 int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
                  hipStream_t st)
 {

@@ -17,8 +17,10 @@
 // The other codes are the same thing on the (k << e)-th roots of unity (fastecc_decode_prepare): positions that hold no
 // block of the code count as erased, zero-extended data blocks as known zeros, the transform has fold = e.
 //
-// Everything that depends only on the erasure PATTERN is done once in fastecc_decode_prepare: l by a product tree on the
-// host, its values and its derivative's values by one device transform of a two-column stripe, one batch inversion.
+// Everything that depends only on the erasure PATTERN is done once in fastecc_decode_prepare, on the device: the locator by
+// a product tree whose every level is ONE batch of cyclic products through the library's own transforms (all polynomials
+// of a level side by side as the word columns of a stripe), its values and its derivative's values by one transform of a
+// two-column stripe, the inverses by Fermat powers.  The host only classifies the positions (one pass over the flags).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,6 +45,19 @@ struct DecodeState {
     uint32_t* gout = nullptr;          // k factors by data block: 1 / (w^2i l'(w^2i)) (Montgomery) if erased, else 0
     uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
+    // fastecc_decode_prepare's device state (lazy): the product tree of the locator
+    uint64_t tree_T = 0;                   // padded number of roots: the smallest power of two >= the most losses a code tolerates
+    std::vector<fastecc_ctx*> tree_ctx;    // level k (polynomials of degree d = 2^k): transforms of length 2d, T/d columns
+    uint32_t* tree_x = nullptr;            // 2T words: the level's polynomials, [coefficient][polynomial]
+    uint32_t* tree_f = nullptr;            // 2T words: their transforms
+    uint32_t* tree_y = nullptr;            // 2T words: the next level's polynomials (swaps roles with tree_x)
+    uint32_t* tree_p = nullptr;            // 2T words: pairwise products
+    uint32_t* wpow = nullptr;              // NC words: w^u (plain)
+    uint32_t* roots = nullptr;             // T words: the erased points, zero-padded
+    uint32_t* dev_state = nullptr;         // NC bytes (as words/4): LOST / HELD / ZERO per position
+    uint32_t* dev_erased = nullptr;        // T words: erased positions
+    uint32_t* tile_order = nullptr;        // NC words: first-pass order of the factors (only for the (2k,k) layout)
+    bool tile_order_valid = false;
     uint64_t erased_data = 0, erased_total = 0;
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
@@ -61,142 +76,140 @@ void destroy_decode_state(DecodeState* d)
     if (d->gout) (void)hipFree(d->gout);
     if (d->recovered) (void)hipFree(d->recovered);
     if (d->parity_dev) (void)hipFree(d->parity_dev);
+    for (fastecc_ctx* t : d->tree_ctx)
+        if (t) fastecc_destroy(t);
+    for (uint32_t* b : {d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
+        if (b) (void)hipFree(b);
     delete d;
 }
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// host arithmetic for the pattern-only part: plain values, products through a Montgomery step
+// fastecc_decode_prepare on the device.  All values are plain representatives unless a table is consumed by
+// gf::mul_mont, in which case it is stored in Montgomery form (x * 2^32 mod p = gf::mul(x, MONT_ONE)).
 // ------------------------------------------------------------------------------------------------
-using gf::P;
+enum : uint32_t { ST_LOST = 0, ST_HELD = 1, ST_ZERO = 2 };
+constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;  // the lowest levels of the tree are one schoolbook kernel: 16 roots per thread
 
-inline uint32_t h_add(uint32_t a, uint32_t b)
+__device__ __forceinline__ uint32_t dev_pow(uint32_t x, uint32_t e)
 {
-    const uint64_t s = (uint64_t)a + b;
-    return (uint32_t)(s >= P ? s - P : s);
-}
-inline uint32_t h_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
-// x * w for w given as wm = w * 2^32 mod p (same reduction as gf::mul_mont on the device)
-inline uint32_t h_mont(uint32_t x, uint32_t wm)
-{
-    const uint64_t t = (uint64_t)x * wm;
-    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-    const uint32_t m = lo + (lo << 20);
-    const uint32_t q = (uint32_t)(((uint64_t)m * P) >> 32);
-    return hi >= q ? hi - q : hi - q + P;
+    uint32_t r = 1;
+    for (; e; e >>= 1) {
+        if (e & 1u) r = gf::mul(r, x);
+        x = gf::mul(x, x);
+    }
+    return r;
 }
 
-// Transforms of any power-of-two size up to 2^20 from one table of w_(2^20)^i (Montgomery form), i < 2^19.
-struct HostNtt {
-    static constexpr int MAXLOG = 20;
-    std::vector<uint32_t> fwd, inv;
-    HostNtt() : fwd(1u << (MAXLOG - 1)), inv(1u << (MAXLOG - 1))
-    {
-        const uint32_t w = gf::h_root(1u << MAXLOG), wi = gf::h_inv(w);
-        uint32_t a = 1, b = 1;
-        for (size_t i = 0; i < fwd.size(); i++) {
-            fwd[i] = gf::h_to_mont(a);
-            inv[i] = gf::h_to_mont(b);
-            a = gf::h_mul(a, w);
-            b = gf::h_mul(b, wi);
-        }
-    }
-    // decimation in frequency: natural order in, bit-reversed order out, unscaled
-    void dif(uint32_t* x, int logn, bool inverse) const
-    {
-        const std::vector<uint32_t>& tw = inverse ? inv : fwd;
-        const size_t n = (size_t)1 << logn;
-        for (size_t h = n >> 1; h >= 1; h >>= 1) {
-            const size_t step = (fwd.size() / h);  // (root of order 2h)^i = w_(2^20)^(i * 2^19 / h)
-            for (size_t base = 0; base < n; base += 2 * h)
-                for (size_t i = 0; i < h; i++) {
-                    const uint32_t a = x[base + i], b = x[base + i + h];
-                    x[base + i] = h_add(a, b);
-                    x[base + i + h] = h_mont(h_sub(a, b), tw[i * step]);
-                }
-        }
-    }
-    // decimation in time: bit-reversed order in, natural order out, unscaled
-    void dit(uint32_t* x, int logn, bool inverse) const
-    {
-        const std::vector<uint32_t>& tw = inverse ? inv : fwd;
-        const size_t n = (size_t)1 << logn;
-        for (size_t h = 1; h < n; h <<= 1) {
-            const size_t step = (fwd.size() / h);
-            for (size_t base = 0; base < n; base += 2 * h)
-                for (size_t i = 0; i < h; i++) {
-                    const uint32_t a = x[base + i], b = h_mont(x[base + i + h], tw[i * step]);
-                    x[base + i] = h_add(a, b);
-                    x[base + i + h] = h_sub(a, b);
-                }
-        }
-    }
-};
-
-const HostNtt& host_ntt()
+// wpow[u] = w^u
+__global__ __launch_bounds__(256) void wpow_kernel(uint32_t* __restrict__ wpow, uint32_t w, uint32_t count)
 {
-    static const HostNtt t;
-    return t;
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < count) wpow[u] = dev_pow(w, u);
 }
 
-// c = a * b (coefficient vectors, lowest degree first)
-std::vector<uint32_t> poly_mul(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b)
+// roots[i] = w^erased[i] for i < n_erased, 0 for the padding up to T (a factor x: it only shifts the locator)
+__global__ __launch_bounds__(256) void roots_kernel(uint32_t* __restrict__ roots, const uint32_t* __restrict__ erased,
+                                                    const uint32_t* __restrict__ wpow, uint32_t n_erased, uint32_t T)
 {
-    const size_t need = a.size() + b.size() - 1;
-    std::vector<uint32_t> c(need, 0);
-    if (std::min(a.size(), b.size()) <= 32) {
-        for (size_t i = 0; i < a.size(); i++) {
-            if (!a[i]) continue;
-            const uint32_t am = gf::h_to_mont(a[i]);
-            for (size_t j = 0; j < b.size(); j++) c[i + j] = h_add(c[i + j], h_mont(b[j], am));
-        }
-        return c;
-    }
-    // Two monic polynomials of the same power-of-two degree d (every product of the tree except at its ragged edge):
-    // (x^d + a')(x^d + b') = x^2d + x^d (a' + b') + a' b', and a' b' has degree < 2d, so a cyclic product of length 2d
-    // is enough — half the transform length of the general case below.
-    const size_t d = a.size() - 1;
-    const bool monic_pair = a.size() == b.size() && (d & (d - 1)) == 0 && a[d] == 1u && b[d] == 1u;
-    const size_t cyc = monic_pair ? 2 * d : need;
-    int logn = 0;
-    while (((size_t)1 << logn) < cyc) logn++;
-    const size_t n = (size_t)1 << logn;
-    std::vector<uint32_t> fa(n, 0), fb(n, 0);
-    std::copy(a.begin(), a.end() - (monic_pair ? 1 : 0), fa.begin());
-    std::copy(b.begin(), b.end() - (monic_pair ? 1 : 0), fb.begin());
-    const HostNtt& t = host_ntt();
-    t.dif(fa.data(), logn, false);
-    t.dif(fb.data(), logn, false);
-    // fa * fb / n through two Montgomery steps: (fa fb / R) * (R^2 / n) / R
-    const uint32_t scale = gf::h_to_mont(gf::h_to_mont(gf::h_inv((uint32_t)n)));
-    for (size_t i = 0; i < n; i++) fa[i] = h_mont(h_mont(fa[i], fb[i]), scale);
-    t.dit(fa.data(), logn, true);  // the bit-reversed products go straight back: no permutation anywhere
-    if (monic_pair) {
-        std::copy(fa.begin(), fa.begin() + 2 * d, c.begin());
-        for (size_t i = 0; i < d; i++) c[d + i] = h_add(c[d + i], h_add(a[i], b[i]));
-        c[2 * d] = 1u;
-    } else {
-        std::copy(fa.begin(), fa.begin() + need, c.begin());
-    }
-    return c;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T) roots[i] = i < n_erased ? wpow[erased[i]] : 0u;
 }
 
-// l(x) = prod (x - roots[i]) by a balanced product tree: O(M log^2 M)
-std::vector<uint32_t> poly_from_roots(const std::vector<uint32_t>& roots)
+// Leaves: polynomial p = prod_{j < leaf} (x - roots[p*leaf + j]), monic of degree `leaf`; its other coefficients go to
+// x[i * m + p], i < leaf (m = T / leaf polynomials side by side).
+__global__ __launch_bounds__(256) void leaf_products_kernel(const uint32_t* __restrict__ roots, uint32_t* __restrict__ x, uint32_t leaf, uint32_t m)
 {
-    std::vector<std::vector<uint32_t>> level;
-    level.reserve(roots.size());
-    for (uint32_t r : roots) level.push_back({h_sub(0, r), 1u});
-    if (level.empty()) return {1u};
-    while (level.size() > 1) {
-        std::vector<std::vector<uint32_t>> next;
-        next.reserve((level.size() + 1) / 2);
-        for (size_t i = 0; i + 1 < level.size(); i += 2) next.push_back(poly_mul(level[i], level[i + 1]));
-        if (level.size() & 1) next.push_back(std::move(level.back()));
-        level.swap(next);
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    uint32_t c[LEAF + 1];
+#pragma unroll
+    for (int i = 0; i <= LEAF; ++i) c[i] = i == 0 ? 1u : 0u;
+    for (uint32_t j = 0; j < leaf; ++j) {
+        const uint32_t r = roots[p * leaf + j];
+#pragma unroll
+        for (int i = LEAF; i >= 1; --i) c[i] = gf::sub(c[i - 1], gf::mul(r, c[i]));  // c <- c * (x - r)
+        c[0] = gf::sub(0u, gf::mul(r, c[0]));
     }
-    return level[0];
+    for (uint32_t i = 0; i < leaf; ++i) x[i * m + p] = c[i];
+}
+
+// y[i][q] = f[i][2q] * f[i][2q+1] * scale (rows of pitch m, m/2 results per row); scale = 1 / (2d) in Montgomery form
+__global__ __launch_bounds__(256) void pointwise_pairs_kernel(const uint32_t* __restrict__ f, uint32_t* __restrict__ y, uint32_t m, uint64_t total,
+                                                              uint32_t scale_mont)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t half = m >> 1;
+    const uint64_t i = t / half;
+    const uint32_t q = (uint32_t)(t - i * half);
+    const uint2 v = *reinterpret_cast<const uint2*>(f + i * m + 2 * q);
+    y[i * m + q] = gf::mul_mont(gf::mul(v.x, v.y), scale_mont);
+}
+
+// (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b: the next level's polynomials from the cyclic products a b (y, rows of
+// pitch m) and this level's a, b (xold, [d][m]); xnew is [4d][m/2] with the upper 2d rows zero (room for the next product)
+__global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ y, const uint32_t* __restrict__ xold, uint32_t* __restrict__ xnew,
+                                                      uint32_t d, uint32_t m, uint64_t total, bool top)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t half = m >> 1;
+    const uint64_t i = t / half;
+    const uint32_t q = (uint32_t)(t - i * half);
+    uint32_t v = 0;
+    if (i < 2ull * d) {
+        v = y[i * m + q];
+        if (i >= d) v = gf::add(v, gf::add(xold[(i - d) * m + 2 * q], xold[(i - d) * m + 2 * q + 1]));
+    } else if (top) {
+        return;  // the last level has no upper half
+    }
+    xnew[i * half + q] = v;
+}
+
+// lv[m][0] = c_m, lv[m][1] = m c_m for the locator L = x^T + sum_{m<T} c_m x^m taken modulo x^NC - 1 (exact on the NC-th
+// roots of unity): the two columns whose transforms are L(w^u) and (x L')(w^u)
+__global__ __launch_bounds__(256) void locator_columns_kernel(const uint32_t* __restrict__ c, uint32_t* __restrict__ lv, uint32_t T, uint32_t NC)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= NC) return;
+    uint32_t v0 = m < T ? c[m] : 0u;
+    uint32_t v1 = gf::mul(m, v0);
+    if (m == T % NC) {  // the monic term x^T (T == NC wraps onto x^0)
+        v0 = gf::add(v0, 1u);
+        v1 = gf::add(v1, T % gf::P);
+    }
+    lv[2 * m] = v0;
+    lv[2 * m + 1] = v1;
+}
+
+// From the values L(w^u), (x L')(w^u) of the padded locator L = x^pad l to the decoder's tables:
+//   fin[u]  = l(w^u) (Montgomery) on surviving positions, 0 elsewhere           l(w^u) = L(w^u) w^(-u pad)
+//   gout[i] = 1 / (w^u l'(w^u)) (Montgomery) for erased data block i at u = i << e   (x l')(w^u) = (x L')(w^u) w^(-u pad) there
+__global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __restrict__ lv, const uint32_t* __restrict__ state,
+                                                            const uint32_t* __restrict__ wpow, uint32_t* __restrict__ fin, uint32_t* __restrict__ gout,
+                                                            uint32_t NC, uint32_t pad, int e, uint32_t user_k)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= NC) return;
+    const uint32_t st = (state[u >> 2] >> (8 * (u & 3u))) & 0xFFu;
+    const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
+    const uint32_t corr = wpow[back == 0 ? 0 : NC - back];  // w^(-u pad)
+    fin[u] = st == ST_HELD ? gf::mul(gf::mul(lv[2 * u], corr), gf::MONT_ONE) : 0u;
+    if ((u & ((1u << e) - 1u)) == 0) {
+        const uint32_t i = u >> e;
+        uint32_t g = 0;
+        if (st == ST_LOST && i < user_k) g = gf::mul(dev_pow(gf::mul(lv[2 * u + 1], corr), gf::P - 2u), gf::MONT_ONE);
+        gout[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ order, uint32_t* __restrict__ dst,
+                                                      uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[order[i]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,7 +319,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while ((1 << e) < ci.cosets + 1) e++;
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
-    enum : uint8_t { LOST = 0, HELD = 1, ZERO = 2 };
+    enum : uint8_t { LOST = ST_LOST, HELD = ST_HELD, ZERO = ST_ZERO };
     std::vector<uint8_t> state(NC, LOST);
     std::vector<uint32_t> srcmap(NC, 0);
     uint64_t erased_data = 0;
@@ -353,66 +366,21 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         return FASTECC_OK;
     }
 
-    // ---- pattern-only scalars ----
+    // ---- device state of the decoder (built once) ----
+    // T = padded root count: the smallest power of two that holds the most losses the code tolerates, NC - N
+    uint64_t T = 1;
+    while (T < NC - N) T <<= 1;
+    int lgT = 0;
+    while ((1ull << lgT) < T) lgT++;
+    const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
-    std::vector<uint32_t> wpow(NC);  // w^u
-    {
-        uint32_t a = 1;
-        for (uint64_t u = 0; u < NC; u++) {
-            wpow[u] = a;
-            a = gf::h_mul(a, w);
-        }
-    }
-    std::vector<uint32_t> roots(erased.size());
-    for (size_t i = 0; i < erased.size(); i++) roots[i] = wpow[erased[i]];
-    const std::vector<uint32_t> l = poly_from_roots(roots);  // degree |E| <= NC - N < NC
-    // values of l and l' on all NC points: one forward transform of a two-column stripe (column 0 = l, column 1 = l'),
-    // on the device — the same kernels as everything else, natural order in and out
-    std::vector<uint32_t> lv(2 * NC, 0);
-    for (size_t m = 0; m < l.size(); m++) lv[2 * m] = l[m];
-    for (size_t m = 0; m + 1 < l.size(); m++) lv[2 * m + 1] = gf::h_mul((uint32_t)((m + 1) % P), l[m + 1]);
+    hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
     if (!d->pattern_ntt) {
         const std::vector<uint32_t> ones(NC, 1u);
         const int rc = create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
     if (!d->pattern_buf) DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
-    DEC_TRY(hipMemcpy(d->pattern_buf, lv.data(), 2 * NC * 4, hipMemcpyHostToDevice));
-    {
-        const int rc = fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, nullptr);
-        if (rc != FASTECC_OK) return rc;
-    }
-    DEC_TRY(hipMemcpy(lv.data(), d->pattern_buf, 2 * NC * 4, hipMemcpyDeviceToHost));
-
-    std::vector<uint32_t> fin(NC, 0), gout(N, 0);
-    for (uint64_t u = 0; u < NC; u++)  // zero blocks contribute 0 * l(w^u): factor 0 keeps every kernel from reading them
-        if (state[u] == HELD) fin[u] = gf::h_to_mont(lv[2 * u]);
-    {
-        // 1 / (w^u l'(w^u)) for the erased data positions with ONE inversion (prefix products)
-        std::vector<uint32_t> den, prefix;
-        std::vector<uint64_t> who;
-        for (uint64_t i = 0; i < ci.user_k; i++) {
-            if (data_present[i]) continue;
-            const uint64_t u = i << e;
-            const uint32_t v = gf::h_mul(wpow[u], lv[2 * u + 1]);
-            if (v == 0) return FASTECC_E_INVAL;  // cannot happen: l has simple roots
-            den.push_back(v);
-            who.push_back(i);
-        }
-        prefix.resize(den.size());
-        uint32_t acc = 1;
-        for (size_t j = 0; j < den.size(); j++) {
-            prefix[j] = acc;
-            acc = gf::h_mul(acc, den[j]);
-        }
-        uint32_t inv = gf::h_inv(acc);
-        for (size_t j = den.size(); j-- > 0;) {
-            gout[who[j]] = gf::h_to_mont(gf::h_mul(inv, prefix[j]));
-            inv = gf::h_mul(inv, den[j]);
-        }
-    }
-
-    // ---- device state ----
     if (!d->transform) {
         std::vector<uint32_t> factor(NC);
         const uint32_t inv_nc = gf::h_inv((uint32_t)NC);
@@ -421,28 +389,99 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         const int rc = create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
+    if (d->tree_T != T) {
+        // level k >= leaf_log multiplies pairs of degree-2^k polynomials: transforms of length 2^(k+1) on T / 2^k columns
+        for (fastecc_ctx* t : d->tree_ctx)
+            if (t) fastecc_destroy(t);
+        d->tree_ctx.assign(lgT, nullptr);
+        const std::vector<uint32_t> ones((size_t)T, 1u);
+        for (int k = leaf_log; k < lgT; k++) {
+            const int rc = create_transform_ctx(&d->tree_ctx[k], k + 1, 4 * (T >> k), 0, ones.data(), ci.device);
+            if (rc != FASTECC_OK) return rc;
+        }
+        for (uint32_t** b : {&d->tree_x, &d->tree_f, &d->tree_y, &d->tree_p, &d->roots, &d->dev_erased}) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
+        DEC_TRY(hipMalloc((void**)&d->tree_x, 2 * T * 4));
+        DEC_TRY(hipMalloc((void**)&d->tree_f, 2 * T * 4));
+        DEC_TRY(hipMalloc((void**)&d->tree_y, 2 * T * 4));
+        DEC_TRY(hipMalloc((void**)&d->tree_p, 2 * T * 4));
+        DEC_TRY(hipMalloc((void**)&d->roots, T * 4));
+        DEC_TRY(hipMalloc((void**)&d->dev_erased, T * 4));
+        d->tree_T = T;
+    }
+    if (!d->wpow) {
+        DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
+        hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
+        DEC_TRY(hipGetLastError());
+    }
+    if (!d->dev_state) DEC_TRY(hipMalloc((void**)&d->dev_state, NC));
     if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));
     if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
+    if (d->standard && !d->tile_order_valid) {
+        std::vector<uint32_t> order;
+        if (gather_tile_order(d->transform, order)) {
+            DEC_TRY(hipMalloc((void**)&d->tile_order, NC * 4));
+            DEC_TRY(hipMemcpy(d->tile_order, order.data(), NC * 4, hipMemcpyHostToDevice));
+            DEC_TRY(hipMalloc((void**)&d->fin_first_pass, NC * 4));
+        } else {
+            d->fin_first_pass = d->fin;
+        }
+        d->tile_order_valid = true;
+    }
+    if (!d->standard) d->fin_first_pass = d->fin;
     {
         const int rc = call.wait_idle();  // a decode still using the previous pattern
         if (rc != FASTECC_OK) return rc;
     }
-    DEC_TRY(hipMemcpy(d->fin, fin.data(), NC * 4, hipMemcpyHostToDevice));
-    DEC_TRY(hipMemcpy(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice));
-    {
-        std::vector<uint32_t> order;
-        if (d->standard && gather_tile_order(d->transform, order)) {
-            std::vector<uint32_t> tiled(NC);
-            for (uint64_t i = 0; i < NC; i++) tiled[i] = fin[order[i]];
-            if (!d->fin_first_pass || d->fin_first_pass == d->fin) DEC_TRY(hipMalloc((void**)&d->fin_first_pass, NC * 4));
-            DEC_TRY(hipMemcpy(d->fin_first_pass, tiled.data(), NC * 4, hipMemcpyHostToDevice));
-        } else {
-            d->fin_first_pass = d->fin;
-        }
+
+    // ---- this pattern ----
+    DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
+    DEC_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, st));
+    DEC_TRY(hipMemcpyAsync(d->dev_erased, erased.data(), erased.size() * 4, hipMemcpyHostToDevice, st));
+    auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    hipLaunchKernelGGL(roots_kernel, grid(T), dim3(256), 0, st, d->roots, d->dev_erased, d->wpow, (uint32_t)erased.size(), (uint32_t)T);
+    // leaves: T / leaf polynomials of degree `leaf`, side by side ([coefficient][polynomial]); the upper half of the
+    // 2*leaf rows the first product needs is zero
+    DEC_TRY(hipMemsetAsync(d->tree_x, 0, 2 * T * 4, st));
+    hipLaunchKernelGGL(leaf_products_kernel, grid(T >> leaf_log), dim3(256), 0, st, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
+    DEC_TRY(hipGetLastError());
+    uint32_t* x = d->tree_x;
+    uint32_t* spare = d->tree_y;  // x / spare swap roles level by level; tree_f always holds the transforms
+    for (int k = leaf_log; k < lgT; k++) {
+        const uint64_t deg = 1ull << k, m = T >> k;  // m polynomials of degree deg in x: [2 deg][m], rows deg.. are zero
+        fastecc_ctx* t = d->tree_ctx[k];
+        int rc = transform_bitrev(t, x, d->tree_f, false, false, (uint32_t)m, st);                     // all of them at once
+        if (rc != FASTECC_OK) return rc;
+        const uint32_t scale = gf::h_to_mont(gf::h_inv((uint32_t)(2 * deg)));
+        hipLaunchKernelGGL(pointwise_pairs_kernel, grid(2 * deg * (m / 2)), dim3(256), 0, st, d->tree_f, d->tree_p, (uint32_t)m, 2 * deg * (m / 2), scale);
+        DEC_TRY(hipGetLastError());
+        rc = transform_bitrev(t, d->tree_p, d->tree_p, true, true, (uint32_t)(m / 2), st);             // the products, back in natural order
+        if (rc != FASTECC_OK) return rc;
+        const bool top = k + 1 == lgT;
+        const uint64_t rows = top ? 2 * deg : 4 * deg;
+        hipLaunchKernelGGL(combine_kernel, grid(rows * (m / 2)), dim3(256), 0, st, d->tree_p, x, spare, (uint32_t)deg, (uint32_t)m, rows * (m / 2), top);
+        DEC_TRY(hipGetLastError());
+        std::swap(x, spare);
     }
-    DEC_TRY(hipMemcpy(d->gout, gout.data(), N * 4, hipMemcpyHostToDevice));
+    // x now holds the T lower coefficients of L = x^pad * l (monic of degree T), pad = T - |E|
+    hipLaunchKernelGGL(locator_columns_kernel, grid(NC), dim3(256), 0, st, x, d->pattern_buf, (uint32_t)T, (uint32_t)NC);
+    DEC_TRY(hipGetLastError());
+    {
+        const int rc = fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, st);
+        if (rc != FASTECC_OK) return rc;
+    }
+    hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
+                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k);
+    DEC_TRY(hipGetLastError());
+    if (d->fin_first_pass != d->fin) {
+        hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);
+        DEC_TRY(hipGetLastError());
+    }
+    DEC_TRY(hipStreamSynchronize(st));
     d->ready = true;
     return FASTECC_OK;
 }

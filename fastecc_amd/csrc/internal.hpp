@@ -50,6 +50,11 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
 // FASTECC_E_UNSUPPORTED (nothing enqueued) when the plan starts with another kind of pass.
 int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* odd_blocks, const uint32_t* row_factor, uint32_t* out,
                  hipStream_t st);
+// Half a stand-alone transform of a transform context, on the word columns [0, width) of every block: dit = false runs the
+// DIF passes (natural order in, bit-reversed order out), dit = true the mirrored DIT passes (bit-reversed in, natural out);
+// unscaled, forward roots or (inverse_roots) their inverses.  A product of transforms does not care about the order, so
+// polynomial products on the device need no permutation pass (decode.hip: the erasure locator's product tree).
+int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit, bool inverse_roots, uint32_t width, hipStream_t st);
 // The order in which that first pass wants row_factor: returns false when it is the natural order (register pass),
 // else fills `order` with order[i] = codeword position whose factor is entry i of the table (two-window DIF tile:
 // the factors of one wave are contiguous).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the erasure decoder at the headline code: (n,k) = (2^20, 2^19), 4 KB blocks, HBM-resident codeword.
-For each loss rate: host-side pattern preparation (ms, once per erasure pattern) and the per-stripe decode on the GPU
+For each loss rate: pattern preparation (fastecc_decode_prepare: ms, once per erasure pattern; device product tree) and the per-stripe decode on the GPU
 (HIP events on the stream the kernels run on).  GB/s uses the codeword bytes a decode reads (data + parity = 4 GiB).
 One JSON line."""
 import json
@@ -37,6 +37,9 @@ def main():
             pp[lost[lost >= N] - N] = 0
             t0 = time.perf_counter()
             enc.decode_prepare(dp, pp)
+            first_ms = (time.perf_counter() - t0) * 1e3  # the very first call also builds the decoder's contexts and tables
+            t0 = time.perf_counter()
+            enc.decode_prepare(dp, pp)
             prep_ms = (time.perf_counter() - t0) * 1e3
             work = data.clone()
             work.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
@@ -51,7 +54,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / steps
             out["cases"].append({"lost_fraction": frac, "erased_blocks": int(lost.size), "erased_data_blocks": int((dp == 0).sum()),
-                                 "prepare_host_ms": round(prep_ms, 1), "decode_ms": round(ms, 3),
+                                 "prepare_ms": round(prep_ms, 2), "prepare_first_call_ms": round(first_ms, 1), "decode_ms": round(ms, 3),
                                  "codeword_GBps": round(2.0 * N * S * 4 / (ms * 1e-3) / 1e9, 1)})
     print(json.dumps(out))
 
