@@ -91,6 +91,7 @@ def lib():
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.fastecc_decode_prepare.argtypes, L.fastecc_decode_prepare.restype = [vp, u8p, u8p], i32
     L.fastecc_decode.argtypes, L.fastecc_decode.restype = [vp, vp, vp, i32, vp], i32
+    L.fastecc_repair.argtypes, L.fastecc_repair.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_pack_blocks.argtypes, L.fastecc_pack_blocks.restype = [vp, vp, vp, i32, vp], i32
     L.fastecc_unpack_blocks.argtypes, L.fastecc_unpack_blocks.restype = [vp, vp, vp, i32, vp, ctypes.POINTER(u64)], i32
     pair = ctypes.POINTER(u64)
@@ -243,6 +244,11 @@ class Encoder:
         """Recover the erased data blocks in place (README.md:102-119); parity is read only."""
         _check(lib().fastecc_decode(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_decode")
         return data
+
+    def repair(self, data, parity, stream=0, mem=MEM_DEVICE):
+        """decode, then rebuild the erased parity blocks as well (both buffers are written where blocks were lost)."""
+        _check(lib().fastecc_repair(self._h, _addr(data), _addr(parity), mem, stream or None), "fastecc_repair")
+        return data, parity
 
     def pack_blocks(self, raw, packed, stream=0, mem=MEM_DEVICE):
         """GF.md:72-104: k blocks of block_bytes - 4 arbitrary bytes -> k encodable blocks of block_bytes."""

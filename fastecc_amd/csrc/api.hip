@@ -1142,6 +1142,13 @@ int CallScope::wait_idle()
     return FASTECC_OK;
 }
 
+int encode_unlocked(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    return encode_device(c, data, parity, st);
+}
+
 int scratch_of(fastecc_ctx* c, uint32_t** out)
 {
     DeviceGuard dg(c->device);

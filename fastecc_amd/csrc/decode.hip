@@ -58,6 +58,10 @@ struct DecodeState {
     uint32_t* dev_erased = nullptr;        // T words: erased positions
     uint32_t* tile_order = nullptr;        // NC words: first-pass order of the factors (only for the (2k,k) layout)
     bool tile_order_valid = false;
+    // fastecc_repair: which parity blocks are lost (one word each), and the stripe the re-encode writes to
+    uint32_t* parity_lost = nullptr;
+    uint32_t* parity_again = nullptr;
+    uint64_t erased_parity = 0;
     uint64_t erased_data = 0, erased_total = 0;
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
@@ -78,7 +82,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->parity_dev) (void)hipFree(d->parity_dev);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
-    for (uint32_t* b : {d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
+    for (uint32_t* b : {d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
         if (b) (void)hipFree(b);
     delete d;
 }
@@ -269,6 +273,25 @@ __global__ __launch_bounds__(256) void decode_scatter_kernel(const uint32_t* __r
     store_vec<V>(data + (size_t)i * ld + col, x);
 }
 
+// parity[q] = again[q] for the parity blocks that were lost (lost[q] != 0); the others are not touched
+template <int V>
+__global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __restrict__ again, uint32_t* __restrict__ parity,
+                                                             const uint32_t* __restrict__ lost, uint32_t S, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t q = (uint32_t)(item / col_chunks);
+    if (as_constant(lost)[q] == 0) return;  // wave-uniform
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t x[V];
+    load_vec<V>(x, again + (size_t)q * S + col);
+    store_vec<V>(parity + (size_t)q * S + col, x);
+}
+
 int hip_code(const char* what, hipError_t e)
 {
     set_error_detail(what, e);
@@ -361,7 +384,16 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     d->erased_total = erased.size();
     d->positions = NC;
     d->standard = ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
-    if (erased_data == 0) {  // nothing to recover
+    {
+        std::vector<uint32_t> plost(ci.user_m);
+        d->erased_parity = 0;
+        for (uint64_t q = 0; q < ci.user_m; q++) d->erased_parity += (plost[q] = parity_present[q] ? 0u : 1u);
+        if (!d->parity_lost) DEC_TRY(hipMalloc((void**)&d->parity_lost, ci.user_m * 4));
+        const int rc = call.wait_idle();  // a repair still reading the previous pattern
+        if (rc != FASTECC_OK) return rc;
+        DEC_TRY(hipMemcpy(d->parity_lost, plost.data(), ci.user_m * 4, hipMemcpyHostToDevice));
+    }
+    if (erased_data == 0) {  // no data block to recover
         d->ready = true;
         return FASTECC_OK;
     }
@@ -486,7 +518,20 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     return FASTECC_OK;
 }
 
+static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream, void* parity_out);
+
 int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream)
+{
+    return decode_impl(c, data, parity, mem_kind, stream, nullptr);
+}
+
+int fastecc_repair(fastecc_ctx* c, void* data, void* parity, int mem_kind, void* stream)
+{
+    return decode_impl(c, data, parity, mem_kind, stream, parity);
+}
+
+// parity_out != null (== parity): also rebuild the lost parity blocks from the repaired data
+static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream, void* parity_out)
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
@@ -494,7 +539,8 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
     CallScope call(c);
     DecodeState* d = decoder_of(c);
     if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first
-    if (d->erased_data == 0) return FASTECC_OK;
+    const bool rebuild = parity_out != nullptr && d->erased_parity != 0;
+    if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
     const CtxInfo ci = info_of(c);
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;  // the gather / scatter passes address contiguous stripes
     DeviceScope ds(ci.device);
@@ -524,6 +570,7 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         ddata = d->parity_dev + ci.user_m * ci.words;
     }
 
+    if (d->erased_data != 0) {
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).
     // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
     // position whose factor is zero, instead of a tile that reads first and multiplies by zero afterwards.
@@ -552,8 +599,26 @@ int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind,
         else    hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, S, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
     }
+    }
+    if (rebuild) {
+        // the lost parity blocks are whatever the encoder makes of the (now complete) data: one more encode into a stripe
+        // of the decoder's, from which only the lost blocks are copied — the surviving ones are left as they are
+        if (!d->parity_again) DEC_TRY(hipMalloc((void**)&d->parity_again, parity_bytes));
+        const int rc = encode_unlocked(c, ddata, d->parity_again, st);
+        if (rc != FASTECC_OK) return rc;
+        const uint32_t S = (uint32_t)ci.words;
+        uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
+        const bool v4 = (S % 4) == 0 && ((((uintptr_t)dpar_out | (uintptr_t)d->parity_again) & 15u) == 0);
+        const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+        const uint64_t items = ci.user_m * col_chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+        if (v4) hipLaunchKernelGGL(restore_parity_kernel<4>, grid, dim3(256), 0, st, d->parity_again, dpar_out, d->parity_lost, S, col_chunks, items);
+        else    hipLaunchKernelGGL(restore_parity_kernel<1>, grid, dim3(256), 0, st, d->parity_again, dpar_out, d->parity_lost, S, col_chunks, items);
+        DEC_TRY(hipGetLastError());
+    }
     if (mem_kind == FASTECC_MEM_HOST) {
-        DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
+        if (d->erased_data != 0) DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
+        if (rebuild) DEC_TRY(hipMemcpyAsync(parity_out, d->parity_dev, parity_bytes, hipMemcpyDeviceToHost, st));
         DEC_TRY(hipStreamSynchronize(st));
     }
     return FASTECC_OK;

@@ -62,6 +62,8 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
 // The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);
+// fastecc_encode on DEVICE memory for a caller that already holds the context's call lock (decode.hip: fastecc_repair)
+int encode_unlocked(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st);
 
 // Calls on one context are serialised on the host, and work that uses the context's internal device buffers is ordered
 // between streams (api.hip: fastecc_ctx::mu / buf_event).  decode.hip's entry points take part through this scope:

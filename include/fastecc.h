@@ -235,16 +235,20 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
  * as known, so exactly n - k losses are tolerated.
  *   fastecc_decode_prepare : set the erasure pattern, k data flags and n - k parity flags (non-zero = block survives).
- *                            Host-side scalar work (product tree for l, two size-2N transforms, one inversion) and a
- *                            table upload; FASTECC_E_INVAL if fewer than k blocks survive.  Reusable for any number
- *                            of stripes.
+ *                            The host classifies the positions; the locator's product tree, its two size-NC transforms
+ *                            and the inversions run on the device (2-8 ms at (2^20,2^19); the first call also builds the
+ *                            decoder's contexts).  Synchronous.  FASTECC_E_INVAL if fewer than k blocks survive.
+ *                            Reusable for any number of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
  *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
- * Erased parity blocks are not rebuilt (re-encode the repaired data for that).
+ * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
 int fastecc_decode(fastecc_ctx *ctx, void *data, const void *parity, int mem_kind, void *stream);
+/* fastecc_decode, then the erased PARITY blocks as well: the repaired data is encoded once more and the lost parity blocks
+ * (only those) are written into `parity` — the whole codeword is whole again ("repair").  Same arguments otherwise. */
+int fastecc_repair(fastecc_ctx *ctx, void *data, void *parity, int mem_kind, void *stream);
 
 /*
  * Data packing (GF.md:72-104 "Efficient data packing", README.md:160-163): RS.cpp only encodes words < p, so

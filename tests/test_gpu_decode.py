@@ -222,3 +222,52 @@ def test_codes_with_more_parity_blocks(torch_cuda, fe, oracle, logn, e):
             with pytest.raises(fe.FastEccError) as ei:
                 enc.decode_prepare(dp, pp)
             assert ei.value.code == fe.E_INVAL
+
+
+# ------------------------------------------------------------------------------------------------
+# fastecc_repair: the lost parity blocks come back too
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_over_k,k,S", [(2.0, 1 << 10, 64), (2.0, 1 << 13, 33), (1.25, 1 << 8, 64), (4.0, 1 << 6, 16), (1.2, 1000, 24)])
+def test_repair_restores_data_and_parity(torch_cuda, fe, oracle, n_over_k, k, S):
+    torch = torch_cuda
+    n = int(k * n_over_k)
+    m = n - k
+    rng = np.random.default_rng(k + m)
+    x = rng.integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    with fe.Encoder(n, k, 4 * S) as enc:
+        d = to_dev(torch, x)
+        par_dev = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(d, par_dev)  # the codeword by the (pinned) encoder itself: every code family has its own parity
+        torch.cuda.synchronize()
+        par = to_host(par_dev, (m, S))
+        lost = rng.permutation(n)[:m]  # as many losses as the code tolerates, over data and parity
+        dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+        dp[lost[lost < k]] = 0
+        pp[lost[lost >= k] - k] = 0
+        damaged, dpar = x.copy(), par.copy()
+        damaged[dp == 0] = 0xFFFFFFFF
+        dpar[pp == 0] = 0xDEADBEEF
+        enc.decode_prepare(dp, pp)
+        dd, dq = to_dev(torch, damaged), to_dev(torch, dpar)
+        enc.repair(dd, dq)
+        torch.cuda.synchronize()
+        assert (to_host(dd, (k, S)) == x).all()
+        assert (to_host(dq, (m, S)) == par).all()
+        # host memory form
+        hd, hp = damaged.copy(), dpar.copy()
+        enc.repair(hd, hp, mem=fe.MEM_HOST)
+        assert (hd == x).all() and (hp == par).all()
+        # only parity lost: nothing to decode, the parity is simply encoded again
+        dp2, pp2 = np.ones(k, np.uint8), np.ones(m, np.uint8)
+        pp2[: max(1, m // 3)] = 0
+        enc.decode_prepare(dp2, pp2)
+        dq2 = to_dev(torch, np.where(pp2[:, None] == 0, np.uint32(7), par))
+        enc.repair(to_dev(torch, x), dq2)
+        torch.cuda.synchronize()
+        assert (to_host(dq2, (m, S)) == par).all()
+        # plain decode leaves the parity alone
+        enc.decode_prepare(dp, pp)
+        dq3 = to_dev(torch, dpar)
+        enc.decode(to_dev(torch, damaged), dq3)
+        torch.cuda.synchronize()
+        assert (to_host(dq3, (m, S)) == dpar).all()
