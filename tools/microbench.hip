@@ -190,6 +190,21 @@ __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b)
     const bool c2 = __builtin_uadd_overflow(s, 0xFFFFFu, &u);
     return (c1 | c2) ? u : s;
 }
+// Lazy representatives (round 2): any uint32 congruent to the value.  With the other operand canonical (a fresh product)
+// one carry correction is exact: a + t - 2^32 = a + t - p - (2^20 - 1), and the sum stays below 2^32.
+__device__ __forceinline__ uint32_t add_lazy(uint32_t a, uint32_t t)
+{
+    uint32_t s;
+    const bool c = __builtin_uadd_overflow(a, t, &s);
+    return s + (c ? 0xFFFFFu : 0u);
+}
+__device__ __forceinline__ uint32_t sub_lazy(uint32_t a, uint32_t t)
+{
+    uint32_t d;
+    const bool b = __builtin_usub_overflow(a, t, &d);
+    return d - (b ? 0xFFFFFu : 0u);
+}
+__device__ __forceinline__ uint32_t canon(uint32_t x) { return x >= gf::P ? x - gf::P : x; }
 }  // namespace v
 
 template <int VAR>
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
             if constexpr (VAR == 8) t = v::mont_neg(b[i], w);
             if constexpr (VAR == 9) t = v::mont_d(b[i], w);
             if constexpr (VAR == 10) t = v::mont_h(b[i], w, w * 0x00100001u);
+            if constexpr (VAR == 11) t = v::mont_f(b[i], w);
             const uint32_t x = a[i];
             if constexpr (VAR == 5 || VAR == 6 || VAR == 10) {
                 a[i] = v::add2(x, t);
@@ -224,6 +240,9 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
             } else if constexpr (VAR == 7 || VAR == 9) {
                 a[i] = v::sub1(x, gf::P - t);  // add as subtract of the negation
                 b[i] = v::sub1(x, t);
+            } else if constexpr (VAR == 11) {
+                a[i] = v::add_lazy(x, t);  // lazy outputs: canonicalised once at the end
+                b[i] = v::sub_lazy(x, t);
             } else if constexpr (VAR == 8) {
                 a[i] = v::sub1(x, t);          // t holds p - b*w: x + b*w
                 b[i] = v::sub1(x, gf::P - t);  // x - b*w   (t == 0 -> p - 0 = p -> x - p wraps -> +p -> x)
@@ -237,14 +256,15 @@ __global__ __launch_bounds__(256) void bfly_kernel(uint32_t* out, int iters, uin
     }
     uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc ^= a[i] ^ b[i];
+    for (int i = 0; i < 8; i++) acc ^= VAR == 11 ? (v::canon(a[i]) ^ v::canon(b[i])) : (a[i] ^ b[i]);
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
 static const char* BFLY_NAME[] = {"mont:mad64+mulhi (gf.hpp)", "mont:mullo+mulhi+mulhi,usub_overflow", "mont:mad64+shift-form hi(m*p)",
                                   "mont:2x mad64", "barrett (reference form)", "mont B + carry-form add",
                                   "mont F(mad64+mulhi) + carry-form add", "mont F + add-as-sub(p-t)", "mont NEG + sub-only",
-                                  "mont D(2x mad64) + add-as-sub(p-t)", "mont H(two-word twiddle, 3 mul32) + carry-form add"};
+                                  "mont D(2x mad64) + add-as-sub(p-t)", "mont H(two-word twiddle, 3 mul32) + carry-form add",
+                                  "mont F + LAZY add/sub (any uint32 representative, one carry correction, canonical at the end)"};
 
 template <int VAR>
 static void run_bfly(uint32_t* d_out, int blocks, std::vector<uint32_t>* first)
@@ -369,6 +389,7 @@ int main(int argc, char** argv)
         run_bfly<8>(d_out, blocks, &first);
         run_bfly<9>(d_out, blocks, &first);
         run_bfly<10>(d_out, blocks, &first);
+        run_bfly<11>(d_out, blocks, &first);
         run_bfly<6>(d_out, blocks, &first);
     }
     if (do_copy) {
