@@ -72,6 +72,7 @@ struct fastecc_ctx {
     DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
     Sharded* sharded = nullptr;      // fastecc_create_sharded: the per-device contexts of the column slabs (sharded.hip); a
                                      // context that has it is only a shell around them
+    p61::Decoder* decoder61 = nullptr;  // the same for FASTECC_FIELD_GF_P61_SQUARED (gf61_decode.hip)
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
     int n = 0;        // log2 k
@@ -1051,6 +1052,8 @@ CtxInfo info_of(const fastecc_ctx* c)
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
+p61::Decoder*& decoder61_of(fastecc_ctx* c) { return c->decoder61; }
+p61::Path* p61_path_of(fastecc_ctx* c) { return c->p61; }
 std::mutex& mutex_of(fastecc_ctx* c) { return c->mu; }
 fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes)
 {
@@ -1170,6 +1173,8 @@ void fastecc_destroy(fastecc_ctx* c)
     destroy_decode_state(c->decoder);
     c->decoder = nullptr;
     DeviceGuard dg(c->device);
+    p61::destroy_decoder(c->decoder61);
+    c->decoder61 = nullptr;
     for (ProfileRec& r : c->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);

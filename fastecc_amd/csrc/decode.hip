@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gf.hpp"
+#include "gf61_path.hpp"
 #include "internal.hpp"
 #include "ntt_device.hpp"
 
@@ -330,6 +331,16 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
     if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     const CtxInfo ci = info_of(c);
+    if (ci.field == FASTECC_FIELD_GF_P61_SQUARED) {
+        // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are always (2k,k) with k a power of two
+        DeviceScope ds61(ci.device);
+        if (!ds61.ok) return FASTECC_E_DEVICE;
+        CallScope call61(c);
+        char detail[160] = "";
+        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, detail, sizeof detail);
+        if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
+        return rc;
+    }
     if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.q > 1) return FASTECC_E_UNSUPPORTED;  // the decoder's transform is a power of two
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
     const uint64_t N = ci.k;
@@ -537,6 +548,15 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
     if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     CallScope call(c);
+    if (info_of(c).field == FASTECC_FIELD_GF_P61_SQUARED) {
+        if ((((uintptr_t)data | (uintptr_t)parity) & 15u)) return FASTECC_E_INVAL;
+        if (mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_UNSUPPORTED;  // this field's decoder works on device stripes
+        p61::Decoder* d61 = decoder61_of(c);
+        if (!p61::decoder_ready(d61)) return FASTECC_E_INVAL;
+        DeviceScope ds61(info_of(c).device);
+        if (!ds61.ok) return FASTECC_E_DEVICE;
+        return p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
+    }
     DecodeState* d = decoder_of(c);
     if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first
     const bool rebuild = parity_out != nullptr && d->erased_parity != 0;

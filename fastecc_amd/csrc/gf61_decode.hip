@@ -1,0 +1,433 @@
+// gf61_decode.hip — erasure decoding over GF((2^61-1)^2): the scheme of decode.hip (README.md:102-119 "Fastest",
+// RS.md:42-79; documented by the reference, implemented nowhere upstream) for the 64-bit field of BASELINE configs[4].
+//
+// Codeword of the (2k,k) code = f on the 2k-th roots of unity: position u <-> w^u (w = w_2k), data block i at u = 2i, parity
+// block j at u = 2j+1.  With E the erased positions and l = prod_{e in E} (x - w^e):  p = f l has degree < 2k and known values
+// everywhere (c[u] l(w^u) on survivors, 0 on erasures), and f(w^e) = [x p'(x)](w^e) / (w^e l'(w^e)).  Data-parallel part:
+//   gather   work[u] = codeword[u] * l(w^u)                              (erased positions: zeros, nothing is read)
+//   x p'(x)  one pass of the encoder's own pipeline one size up: inverse transform of size 2k, the block holding coefficient
+//            m times m / 2k, forward transform  (gf61_kernels.hip with a custom factor table: p61::create_transform)
+//   scatter  data[i] = work[2i] / (w^2i l'(w^2i))  for the erased data blocks
+// Pattern-only part (decode_prepare), on the device: l by a full product tree over the zero-padded erasure list (a zero root is
+// a factor x, undone by a table lookup per position), every level ONE batch of cyclic products — all polynomials of a level
+// are the element columns of a stripe that the path's own stand-alone transform handles; the values of L and x L' by one
+// transform of a two-column stripe; inverses as conj / norm with the norm inverted by a Fermat power in GF(p).
+//
+// Parity: nothing upstream to pin to (there is no code for the field at all); the checks are the size-independent round trip
+// encode -> erase -> decode = original, and the oracle's O(N^2) Lagrange decoder (tests/test_gpu_p61.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <new>
+#include <vector>
+
+#include "../../include/fastecc.h"
+#include "gf61.hpp"
+#include "gf61_path.hpp"
+
+namespace fastecc {
+namespace p61 {
+
+namespace {
+
+using gf61::Elem;
+using gf61::P;
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+enum : uint32_t { ST_LOST = 0, ST_HELD = 1 };
+constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;
+
+__device__ __forceinline__ Elem ld(const uint64_t* p)
+{
+    const u64x2 t = *reinterpret_cast<const u64x2*>(p);
+    return Elem{t.x, t.y};
+}
+__device__ __forceinline__ void st(uint64_t* p, Elem e)
+{
+    u64x2 t;
+    t.x = e.re;
+    t.y = e.im;
+    *reinterpret_cast<u64x2*>(p) = t;
+}
+// canonical x canonical -> canonical (both operands per lane: the twiddle limbs live in VGPRs here)
+__device__ __forceinline__ Elem mulc(Elem x, Elem y, const gf61::Opaque& k) { return gf61::canon(gf61::mul(x, gf61::make_twiddle(y.re, y.im), k)); }
+__device__ __forceinline__ uint64_t addc(uint64_t x, uint64_t y)
+{
+    const uint64_t s = x + y;
+    return s >= P ? s - P : s;
+}
+__device__ __forceinline__ uint64_t subc(uint64_t x, uint64_t y) { return x >= y ? x - y : x + P - y; }
+__device__ __forceinline__ Elem addc(Elem x, Elem y) { return Elem{addc(x.re, y.re), addc(x.im, y.im)}; }
+__device__ __forceinline__ Elem powc(Elem x, uint64_t e, const gf61::Opaque& k)
+{
+    Elem r{1, 0};
+    for (; e; e >>= 1) {
+        if (e & 1u) r = mulc(r, x, k);
+        x = mulc(x, x, k);
+    }
+    return r;
+}
+// 1 / x = conj(x) / (re^2 + im^2); the norm lies in GF(p) and is inverted by norm^(p-2)
+__device__ __forceinline__ Elem invc(Elem x, const gf61::Opaque& k)
+{
+    const Elem re2 = mulc(Elem{x.re, 0}, Elem{x.re, 0}, k), im2 = mulc(Elem{x.im, 0}, Elem{x.im, 0}, k);
+    const Elem ninv = powc(Elem{addc(re2.re, im2.re), 0}, P - 2, k);
+    return mulc(Elem{x.re, subc(0, x.im)}, ninv, k);
+}
+
+__global__ __launch_bounds__(256) void k_wpow(uint64_t* __restrict__ wpow, uint64_t wre, uint64_t wim, uint32_t count)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= count) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    st(wpow + 2ull * u, powc(Elem{wre, wim}, u, k));
+}
+
+__global__ __launch_bounds__(256) void k_roots(uint64_t* __restrict__ roots, const uint32_t* __restrict__ erased, const uint64_t* __restrict__ wpow,
+                                               uint32_t n_erased, uint32_t T)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    st(roots + 2ull * i, i < n_erased ? ld(wpow + 2ull * erased[i]) : Elem{0, 0});
+}
+
+// polynomial p = prod_{j < leaf} (x - roots[p*leaf + j]); coefficient i (< leaf; the monic one is implied) -> x[i*m + p]
+__global__ __launch_bounds__(64) void k_leaves(const uint64_t* __restrict__ roots, uint64_t* __restrict__ x, uint32_t leaf, uint32_t m)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    Elem c[LEAF + 1];
+#pragma unroll
+    for (int i = 0; i <= LEAF; ++i) c[i] = Elem{i == 0 ? 1ull : 0ull, 0};
+    for (uint32_t j = 0; j < leaf; ++j) {
+        const Elem r = ld(roots + 2ull * (p * leaf + j));
+#pragma unroll
+        for (int i = LEAF; i >= 1; --i) {  // c <- c * (x - r)
+            const Elem t = mulc(r, c[i], k);
+            c[i] = Elem{subc(c[i - 1].re, t.re), subc(c[i - 1].im, t.im)};
+        }
+        const Elem t = mulc(r, c[0], k);
+        c[0] = Elem{subc(0, t.re), subc(0, t.im)};
+    }
+    for (uint32_t i = 0; i < leaf; ++i) st(x + 2ull * ((uint64_t)i * m + p), c[i]);
+}
+
+// y[i][q] = f[i][2q] * f[i][2q+1] * scale for q < m/2, zero for the other columns (rows of m elements)
+__global__ __launch_bounds__(256) void k_pairs(const uint64_t* __restrict__ f, uint64_t* __restrict__ y, uint32_t m, uint64_t total, uint64_t sre,
+                                               uint64_t sim)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t i = t / m;
+    const uint32_t q = (uint32_t)(t - i * m);
+    Elem v{0, 0};
+    if (q < m / 2) v = mulc(mulc(ld(f + 2 * (i * m + 2 * q)), ld(f + 2 * (i * m + 2 * q + 1)), k), Elem{sre, sim}, k);
+    st(y + 2 * (i * m + q), v);
+}
+
+// (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b: xnew [4d][m/2] (upper 2d rows zero) from the cyclic products y (rows of m) and xold [d][m]
+__global__ __launch_bounds__(256) void k_combine(const uint64_t* __restrict__ y, const uint64_t* __restrict__ xold, uint64_t* __restrict__ xnew,
+                                                 uint32_t d, uint32_t m, uint64_t total, bool top)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t half = m >> 1;
+    const uint64_t i = t / half;
+    const uint32_t q = (uint32_t)(t - i * half);
+    Elem v{0, 0};
+    if (i < 2ull * d) {
+        v = ld(y + 2 * (i * m + q));
+        if (i >= d) v = addc(v, addc(ld(xold + 2 * ((i - d) * m + 2 * q)), ld(xold + 2 * ((i - d) * m + 2 * q + 1))));
+    } else if (top) {
+        return;
+    }
+    st(xnew + 2 * (i * half + q), v);
+}
+
+// lv[m][0] = c_m, lv[m][1] = m c_m for L = x^T + sum c_m x^m modulo x^NC - 1
+__global__ __launch_bounds__(256) void k_locator_columns(const uint64_t* __restrict__ c, uint64_t* __restrict__ lv, uint32_t T, uint32_t NC)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= NC) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    Elem v0 = m < T ? ld(c + 2ull * m) : Elem{0, 0};
+    Elem v1 = mulc(v0, Elem{m, 0}, k);
+    if (m == T % NC) {
+        v0.re = addc(v0.re, 1);
+        v1.re = addc(v1.re, T);
+    }
+    st(lv + 4ull * m, v0);
+    st(lv + 4ull * m + 2, v1);
+}
+
+// fin[u] = l(w^u) on surviving positions (0 elsewhere); gout[i] = 1 / (w^2i l'(w^2i)) for erased data block i (0 elsewhere);
+// l = L w^(-u pad) on the points (the padding), see decode.hip finish_tables_kernel
+__global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv, const uint8_t* __restrict__ state, const uint64_t* __restrict__ wpow,
+                                                uint64_t* __restrict__ fin, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= NC) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
+    const Elem corr = ld(wpow + 2ull * (back == 0 ? 0 : NC - back));
+    const bool held = state[u] == ST_HELD;
+    st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * u), corr, k) : Elem{0, 0});
+    if ((u & 1u) == 0) st(gout + 2ull * (u >> 1), held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * u + 2), corr, k), k));
+}
+
+// One wave per (row, 64-element column chunk); the row's factor is wave-uniform.
+using const_u64_ptr = const uint64_t __attribute__((address_space(4)))*;
+__device__ __forceinline__ const_u64_ptr as_constant(const uint64_t* p) { return (const_u64_ptr)(reinterpret_cast<uintptr_t>(p)); }
+
+// work[u] = (u even ? data[u/2] : parity[u/2]) * fin[u]; zero rows where fin == 0 (nothing is read there)
+__global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ data, const uint64_t* __restrict__ parity, uint64_t* __restrict__ work,
+                                                const uint64_t* __restrict__ fin, uint32_t elems, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t u = (uint32_t)(item / col_chunks);
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t fre = as_constant(fin)[2ull * u], fim = as_constant(fin)[2ull * u + 1];
+    Elem v{0, 0};
+    if ((fre | fim) != 0) {
+        const uint64_t* src = ((u & 1u) ? parity : data) + ((uint64_t)(u >> 1) * elems + col) * 2;
+        v = gf61::mul(ld(src), gf61::make_twiddle(fre, fim), k);  // lazy: the transform's first pass takes it
+    }
+    st(work + ((uint64_t)u * elems + col) * 2, v);
+}
+
+// data[i] = work[2i] * gout[i] for the erased data blocks (gout != 0)
+__global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ work, uint64_t* __restrict__ data, const uint64_t* __restrict__ gout,
+                                                 uint32_t elems, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t i = (uint32_t)(item / col_chunks);
+    const uint64_t gre = as_constant(gout)[2ull * i], gim = as_constant(gout)[2ull * i + 1];
+    if ((gre | gim) == 0) return;  // wave-uniform
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const Elem v = gf61::mul(ld(work + ((uint64_t)(2u * i) * elems + col) * 2), gf61::make_twiddle(gre, gim), k);
+    st(data + ((uint64_t)i * elems + col) * 2, gf61::canon(v));
+}
+
+// parity[j] = again[j] for the lost parity blocks
+__global__ __launch_bounds__(256) void k_restore(const uint64_t* __restrict__ again, uint64_t* __restrict__ parity, const uint8_t* __restrict__ state,
+                                                 uint32_t elems, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t j = (uint32_t)(item / col_chunks);
+    if (state[2u * j + 1u] == ST_HELD) return;
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    st(parity + ((uint64_t)j * elems + col) * 2, ld(again + ((uint64_t)j * elems + col) * 2));
+}
+
+int fail(char* detail, size_t cap, hipError_t e, const char* what)
+{
+    if (detail && cap) snprintf(detail, cap, "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
+}
+
+#define D61_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return fail(detail, cap, e_, #expr); \
+    } while (0)
+
+}  // namespace
+
+struct Decoder {
+    int log2k = 0;
+    uint64_t N = 0, NC = 0, T = 0, elems = 0;
+    Path* transform = nullptr;         // size 2k, factor m / 2k, `elems` columns: x p'(x) on a whole stripe
+    Path* pattern = nullptr;           // size 2k, 2 columns: L and x L' on the points
+    std::vector<Path*> tree;           // level k >= LEAF_LOG: size 2^(k+1), T >> k columns
+    uint64_t *tree_x = nullptr, *tree_y = nullptr, *tree_f = nullptr;  // 2T elements each
+    uint64_t *wpow = nullptr, *roots = nullptr, *lv = nullptr, *fin = nullptr, *gout = nullptr;
+    uint32_t* erased = nullptr;
+    uint8_t* state = nullptr;
+    uint64_t* work = nullptr;          // 2k blocks (lazy)
+    uint64_t* again = nullptr;         // k parity blocks of the re-encode (lazy, repair only)
+    uint64_t erased_data = 0, erased_parity = 0;
+    bool ready = false;
+};
+
+bool decoder_ready(const Decoder* d) { return d && d->ready; }
+
+void destroy_decoder(Decoder* d)
+{
+    if (!d) return;
+    destroy(d->transform);
+    destroy(d->pattern);
+    for (Path* t : d->tree) destroy(t);
+    for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
+                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again})
+        if (b) (void)hipFree(b);
+    delete d;
+}
+
+int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, char* detail, size_t cap)
+{
+    const uint64_t N = 1ull << log2k, NC = 2 * N;
+    std::vector<uint8_t> state(NC);
+    std::vector<uint32_t> erased;
+    uint64_t erased_data = 0, erased_parity = 0;
+    for (uint64_t i = 0; i < N; i++) {
+        state[2 * i] = data_present[i] ? ST_HELD : ST_LOST;
+        state[2 * i + 1] = parity_present[i] ? ST_HELD : ST_LOST;
+        erased_data += !data_present[i];
+        erased_parity += !parity_present[i];
+    }
+    for (uint64_t u = 0; u < NC; u++)
+        if (state[u] == ST_LOST) erased.push_back((uint32_t)u);
+    if (erased.size() > N) return FASTECC_E_INVAL;  // fewer than k blocks survive
+
+    if (!*slot) {
+        *slot = new (std::nothrow) Decoder();
+        if (!*slot) return FASTECC_E_NOMEM;
+    }
+    Decoder* d = *slot;
+    d->ready = false;
+    d->log2k = log2k;
+    d->N = N;
+    d->NC = NC;
+    d->elems = elems;
+    d->erased_data = erased_data;
+    d->erased_parity = erased_parity;
+    const uint64_t T = N;  // the most losses the code tolerates, a power of two already
+    int lgT = log2k;
+    const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
+
+    // ---- built once ----
+    if (!d->transform) {
+        std::vector<uint64_t> factor(2 * NC);
+        const gf61::Elem inv_nc = gf61::h_inv(gf61::Elem{NC % P, 0});
+        for (uint64_t m = 0; m < NC; m++) {
+            const gf61::Elem f = gf61::h_mul(gf61::Elem{m % P, 0}, inv_nc);
+            factor[2 * m] = f.re;
+            factor[2 * m + 1] = f.im;
+        }
+        int rc = create_transform(&d->transform, log2k + 1, elems, factor.data(), detail, cap);
+        if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + 1, 2, detail, cap);  // only its stand-alone transform is used
+        if (rc != FASTECC_OK) return rc;
+        d->tree.assign(lgT, nullptr);
+        for (int k = leaf_log; k < lgT; k++) {
+            rc = create(&d->tree[k], k + 1, T >> k, detail, cap);
+            if (rc != FASTECC_OK) return rc;
+        }
+        d->T = T;
+        D61_TRY(hipMalloc((void**)&d->tree_x, 2 * T * 16));
+        D61_TRY(hipMalloc((void**)&d->tree_y, 2 * T * 16));
+        D61_TRY(hipMalloc((void**)&d->tree_f, 2 * T * 16));
+        D61_TRY(hipMalloc((void**)&d->wpow, NC * 16));
+        D61_TRY(hipMalloc((void**)&d->roots, T * 16));
+        D61_TRY(hipMalloc((void**)&d->lv, NC * 32));
+        D61_TRY(hipMalloc((void**)&d->fin, NC * 16));
+        D61_TRY(hipMalloc((void**)&d->gout, N * 16));
+        D61_TRY(hipMalloc((void**)&d->erased, T * 4));
+        D61_TRY(hipMalloc((void**)&d->state, NC));
+        const gf61::Elem w = gf61::h_root(NC);
+        hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, nullptr, d->wpow, w.re, w.im, (uint32_t)NC);
+        D61_TRY(hipGetLastError());
+    }
+    hipStream_t s0 = nullptr;
+    D61_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern (set-up is rare; the device-wide wait is acceptable here)
+    D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
+    if (erased_data == 0 && erased_parity == 0) {
+        D61_TRY(hipStreamSynchronize(s0));
+        d->ready = true;
+        return FASTECC_OK;
+    }
+    D61_TRY(hipMemcpyAsync(d->erased, erased.data(), erased.size() * 4, hipMemcpyHostToDevice, s0));
+    auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    hipLaunchKernelGGL(k_roots, grid(T), dim3(256), 0, s0, d->roots, d->erased, d->wpow, (uint32_t)erased.size(), (uint32_t)T);
+    D61_TRY(hipMemsetAsync(d->tree_x, 0, 2 * T * 16, s0));
+    hipLaunchKernelGGL(k_leaves, dim3((unsigned)(((T >> leaf_log) + 63) / 64)), dim3(64), 0, s0, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
+    D61_TRY(hipGetLastError());
+    // three 2T-element buffers change roles level by level: a = this level's polynomials [2 deg][m] (rows deg.. zero),
+    // b = their transforms and then the next level's polynomials, c = the pairwise products
+    uint64_t *a = d->tree_x, *b = d->tree_f, *c = d->tree_y;
+    for (int k = leaf_log; k < lgT; k++) {
+        const uint64_t deg = 1ull << k, m = T >> k;
+        D61_TRY(hipMemcpyAsync(b, a, 2 * T * 16, hipMemcpyDeviceToDevice, s0));  // a survives for the combine step
+        int rc = ntt(d->tree[k], b, false, s0, nullptr);                          // all m polynomials at once
+        if (rc != FASTECC_OK) return rc;
+        const gf61::Elem scale = gf61::h_inv(gf61::Elem{(2 * deg) % P, 0});
+        hipLaunchKernelGGL(k_pairs, grid(2 * deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, 2 * deg * m, scale.re, scale.im);
+        D61_TRY(hipGetLastError());
+        rc = ntt(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero)
+        if (rc != FASTECC_OK) return rc;
+        const bool top = k + 1 == lgT;
+        const uint64_t rows = top ? 2 * deg : 4 * deg;
+        hipLaunchKernelGGL(k_combine, grid(rows * (m / 2)), dim3(256), 0, s0, c, a, b, (uint32_t)deg, (uint32_t)m, rows * (m / 2), top);
+        D61_TRY(hipGetLastError());
+        std::swap(a, b);
+    }
+    uint64_t* x = a;  // the T lower coefficients of L = x^pad l
+    hipLaunchKernelGGL(k_locator_columns, grid(NC), dim3(256), 0, s0, x, d->lv, (uint32_t)T, (uint32_t)NC);
+    D61_TRY(hipGetLastError());
+    {
+        const int rc = ntt(d->pattern, d->lv, false, s0, nullptr);
+        if (rc != FASTECC_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()));
+    D61_TRY(hipGetLastError());
+    D61_TRY(hipStreamSynchronize(s0));
+    d->ready = true;
+    return FASTECC_OK;
+}
+
+int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hipStream_t s0, const LaunchHooks* hooks)
+{
+    if (!d || !d->ready) return FASTECC_E_INVAL;
+    char* detail = nullptr;
+    const size_t cap = 0;
+    const uint32_t elems = (uint32_t)d->elems, col_chunks = (elems + 63) / 64;
+    const bool rebuild = rebuild_with != nullptr && d->erased_parity != 0;
+    if (d->erased_data != 0) {
+        if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
+        {
+            const uint64_t items = d->NC * col_chunks;
+            hipLaunchKernelGGL(k_gather, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, elems, col_chunks, items);
+            D61_TRY(hipGetLastError());
+        }
+        const int rc = encode(d->transform, d->work, d->work, s0, hooks);  // x p'(x) on all 2k points; the even ones are wanted
+        if (rc != FASTECC_OK) return rc;
+        {
+            const uint64_t items = d->N * col_chunks;
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->work, data, d->gout, elems, col_chunks, items);
+            D61_TRY(hipGetLastError());
+        }
+    }
+    if (rebuild) {
+        if (!d->again) D61_TRY(hipMalloc((void**)&d->again, d->N * d->elems * 16));
+        const int rc = encode(rebuild_with, data, d->again, s0, hooks);
+        if (rc != FASTECC_OK) return rc;
+        const uint64_t items = d->N * col_chunks;
+        hipLaunchKernelGGL(k_restore, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->state, elems, col_chunks, items);
+        D61_TRY(hipGetLastError());
+    }
+    return FASTECC_OK;
+}
+
+}  // namespace p61
+}  // namespace fastecc

@@ -768,7 +768,9 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
 
 }  // namespace
 
-int create(Path** out, int n, uint64_t elems, char* detail, size_t cap)
+int create(Path** out, int n, uint64_t elems, char* detail, size_t cap) { return create_transform(out, n, elems, nullptr, detail, cap); }
+
+int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t cap)
 {
     *out = nullptr;
     if (n < 1 || n > MAX_LOG2_K || elems == 0 || elems > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
@@ -794,8 +796,8 @@ int create(Path** out, int n, uint64_t elems, char* detail, size_t cap)
     for (uint64_t i = 0; i < p->N; i++) {
         uint64_t r = 0;
         for (int b = 0; b < n; b++) r |= ((i >> b) & 1ull) << (n - 1 - b);
-        dsc[2 * r] = d.re;
-        dsc[2 * r + 1] = d.im;
+        dsc[2 * r] = factor ? factor[2 * i] % gf61::P : d.re;  // a custom per-coefficient factor (the decoder's m / N), else the encoder's
+        dsc[2 * r + 1] = factor ? factor[2 * i + 1] % gf61::P : d.im;
         d = gf61::h_mul(d, w2N);
     }
     int rc = upload_tables(p, detail, cap);

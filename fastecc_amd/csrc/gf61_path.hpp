@@ -21,6 +21,10 @@ struct LaunchHooks {
 constexpr int MAX_LOG2_K = 24;   // 3 tables of 16 * k bytes
 constexpr int DEFAULT_LEVELS = 4;
 int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
+// The same pipeline — DIF over all levels with the inverse roots, the block holding coefficient m times factor[m], DIT back
+// with the forward roots — with a caller's factors (2 * 2^n words, (re, im) by coefficient index) instead of the encoder's
+// w_2N^m / N; no root of order 2^(n+1) is needed.  The decoder's x p'(x) transform (gf61_decode.hip) is factor[m] = m / 2^n.
+int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t detail_cap);
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);
@@ -32,6 +36,18 @@ int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counte
 // levels, 10 + L / 20 + L = tiles with a 64 / 128 KiB exchange buffer; rebuilds the tables.  The device must be idle.
 int set_plan(Path* p, int plan, char* detail, size_t detail_cap);
 const char* plan_string(const Path* p);
+
+// ---- erasure decoder over this field (gf61_decode.hip): the same scheme as decode.hip, (2k,k) codes ----
+struct Decoder;
+void destroy_decoder(Decoder* d);
+// data_present / parity_present: k flags each (non-zero = the block survives).  Synchronous.  The current device must be
+// the target device.  *slot is created on first use and reused.
+int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, char* detail,
+                   size_t detail_cap);
+// Recover the erased data blocks in place (device pointers, enqueued on st); rebuild_with != null: also re-encode with that
+// path (the context's encoder) and write the lost parity blocks into `parity`.
+int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hipStream_t st, const LaunchHooks* hooks);
+bool decoder_ready(const Decoder* d);
 
 }  // namespace p61
 }  // namespace fastecc

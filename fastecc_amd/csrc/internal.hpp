@@ -33,6 +33,12 @@ struct CtxInfo {
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);
 Sharded*& sharded_of(fastecc_ctx* c);
+namespace p61 {
+struct Decoder;
+struct Path;
+}
+p61::Decoder*& decoder61_of(fastecc_ctx* c);  // the erasure decoder of a GF((2^61-1)^2) context (gf61_decode.hip)
+p61::Path* p61_path_of(fastecc_ctx* c);       // its encoder
 std::mutex& mutex_of(fastecc_ctx* c);
 // a context that owns nothing but its geometry: fastecc_create_sharded hangs the per-device contexts on it
 fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes);

@@ -57,7 +57,7 @@ enum {
      *     order 2^t is w_(2^62)^(2^(62-t)); so w_4 = i and w_8 = 2^30 (1 + i);
      *   - the encoder is the same composition as RS.cpp:40-63 over this field: parity block j is the value at
      *     w_2N^(2j+1) of the polynomial of degree < N whose value at w_N^i is data block i.
-     * Supported by create/destroy/encode/encode_blocks/ntt/check_range/profile/plan_string and
+     * Supported by create/destroy/encode/encode_blocks/ntt/check_range/decode_prepare/decode/repair/profile/plan_string and
      * fastecc_set_plan (0 = default: LDS tiles; 1..4 = register passes with that many radix-2 levels; 10+L / 20+L = tiles with a
      * 64 / 128 KiB exchange buffer); the 32-bit-word entry points
      * (scale_blocks, gf_binary, set_option) return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
@@ -227,8 +227,9 @@ int fastecc_gf_binary(fastecc_ctx *ctx, int op, const uint32_t *x, const uint32_
 int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *stream, uint64_t *bad_words);
 
 /*
- * Erasure decoding over GF(0xFFF00001): recover the erased DATA blocks from any k or more surviving blocks of the
- * codeword.  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
+ * Erasure decoding: recover the erased DATA blocks from any k or more surviving blocks of the codeword.  Both fields:
+ * GF(0xFFF00001) as described below; GF((2^61-1)^2) for its (2k,k) codes with the same scheme on 16-byte elements
+ * (gf61_decode.hip; FASTECC_MEM_DEVICE stripes only).  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity

@@ -176,6 +176,8 @@ class OracleP61:
         lib.orc61_encode.argtypes, lib.orc61_encode.restype = [_u64p, _sz, _sz], None
         lib.orc61_encode_by_definition.argtypes, lib.orc61_encode_by_definition.restype = [_u64p, _u64p, _sz, _sz], None
         lib.orc61_fill_splitmix.argtypes, lib.orc61_fill_splitmix.restype = [_u64p, _sz, _u64], None
+        _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        lib.orc61_decode.argtypes, lib.orc61_decode.restype = [_u64p, _u64p, _u8p, _u8p, _sz, _sz], ctypes.c_int
 
     def cmul(self, x, y):
         out = _pair()
@@ -208,6 +210,16 @@ class OracleP61:
 
     def scale_blocks(self, data, scale, base):
         return self._run(self.lib.orc61_scale_blocks, data, _pair(*scale), _pair(*base))
+
+    def decode(self, data, parity, data_present, parity_present):
+        """O(N^2) Lagrange erasure decoding; returns the repaired data stripe."""
+        a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        par = np.ascontiguousarray(parity, dtype=np.uint64)
+        dp = np.ascontiguousarray(data_present, dtype=np.uint8)
+        pp = np.ascontiguousarray(parity_present, dtype=np.uint8)
+        if self.lib.orc61_decode(a, par, dp, pp, a.shape[0], a.shape[1] // 2) != 0:
+            raise ValueError("fewer than N blocks survive")
+        return a
 
     def encode_by_definition(self, data):
         a = np.ascontiguousarray(data, dtype=np.uint64)

@@ -234,3 +234,76 @@ void orc61_fill_splitmix(uint64_t *data, size_t nwords, uint64_t seed)
         data[i] = z % P;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Erasure decoding by Lagrange interpolation, O(N^2): the oracle of gf61_decode.hip (the reference only describes
+ * decoding, README.md:83-119).  Codeword position u <-> w_2N^u: data block i at u = 2i, parity block j at u = 2j+1.  The
+ * erased data blocks are rebuilt from the first N surviving positions; returns -1 when fewer than N survive.  Same
+ * structure as orc_decode over GF(0xFFF00001).
+ * ---------------------------------------------------------------------------------------- */
+static void c_sub(const uint64_t x[2], const uint64_t y[2], uint64_t out[2])
+{
+    out[0] = orc61_sub(x[0], y[0]);
+    out[1] = orc61_sub(x[1], y[1]);
+}
+
+int orc61_decode(uint64_t *data, const uint64_t *parity, const uint8_t *data_present, const uint8_t *parity_present, size_t N, size_t elems)
+{
+    const size_t N2 = 2 * N;
+    uint64_t(*pt)[2] = malloc(N2 * 16), (*den)[2] = malloc(N * 16), (*wgt)[2] = malloc(N * 16);
+    size_t *pos = malloc(N * sizeof *pos);
+    uint64_t w[2];
+    orc61c_root(N2, w);
+    pt[0][0] = 1;
+    pt[0][1] = 0;
+    for (size_t u = 1; u < N2; u++) orc61c_mul(pt[u - 1], w, pt[u]);
+    size_t cnt = 0;
+    for (size_t u = 0; u < N2 && cnt < N; u++)
+        if ((u & 1) ? parity_present[u >> 1] : data_present[u >> 1]) pos[cnt++] = u;
+    const int rc = cnt == N ? 0 : -1;
+    if (rc == 0) {
+        for (size_t a = 0; a < N; a++) { /* prod_{b != a} (x_a - x_b) */
+            uint64_t d[2] = {1, 0}, t[2];
+            for (size_t b = 0; b < N; b++)
+                if (b != a) {
+                    c_sub(pt[pos[a]], pt[pos[b]], t);
+                    orc61c_mul(d, t, d);
+                }
+            den[a][0] = d[0];
+            den[a][1] = d[1];
+        }
+        uint64_t *row = malloc(elems * 16);
+        for (size_t i = 0; i < N; i++) {
+            if (data_present[i]) continue;
+            const uint64_t *xe = pt[2 * i];
+            uint64_t full[2] = {1, 0}, t[2];
+            for (size_t b = 0; b < N; b++) {
+                c_sub(xe, pt[pos[b]], t);
+                orc61c_mul(full, t, full);
+            }
+            for (size_t a = 0; a < N; a++) {
+                c_sub(xe, pt[pos[a]], t);
+                orc61c_mul(t, den[a], t);
+                orc61c_inv(t, t);
+                orc61c_mul(full, t, wgt[a]);
+            }
+            memset(row, 0, elems * 16);
+            for (size_t a = 0; a < N; a++) {
+                const size_t u = pos[a];
+                const uint64_t *src = (u & 1) ? parity + (u >> 1) * elems * 2 : data + (u >> 1) * elems * 2;
+                for (size_t s = 0; s < elems; s++) {
+                    orc61c_mul(wgt[a], src + 2 * s, t);
+                    row[2 * s] = orc61_add(row[2 * s], t[0]);
+                    row[2 * s + 1] = orc61_add(row[2 * s + 1], t[1]);
+                }
+            }
+            memcpy(data + i * elems * 2, row, elems * 16); /* erased blocks are never read as sources */
+        }
+        free(row);
+    }
+    free(pt);
+    free(den);
+    free(wgt);
+    free(pos);
+    return rc;
+}

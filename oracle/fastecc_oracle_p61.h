@@ -51,6 +51,10 @@ void orc61_scale_blocks(uint64_t *data, size_t N, size_t elems, const uint64_t s
 void orc61_encode(uint64_t *data, size_t N, size_t elems);                /* RS.cpp:40-63 composition, in place */
 void orc61_encode_by_definition(const uint64_t *data, uint64_t *parity, size_t N, size_t elems);
 
+/* O(N^2) Lagrange erasure decoder of the (2N,N) code (position u <-> w_2N^u; data at even, parity at odd positions):
+ * rewrites the erased data blocks in place from the first N survivors; -1 when fewer than N blocks survive */
+int orc61_decode(uint64_t *data, const uint64_t *parity, const uint8_t *data_present, const uint8_t *parity_present, size_t N, size_t elems);
+
 /* splitmix64 % p fill (same generator as the 32-bit oracle) */
 void orc61_fill_splitmix(uint64_t *data, size_t nwords, uint64_t seed);
 

@@ -203,3 +203,103 @@ def test_headline_size_sampled_columns(torch_cuda, fe, orc61):
     for c in cols:
         got = par[:, 2 * c:2 * c + 2].contiguous().cpu().numpy().view(np.uint64)
         assert (got == orc61.encode(keep[c])).all(), c
+
+
+# ------------------------------------------------------------------------------------------------
+# erasure decoder over this field (gf61_decode.hip): round trips and the oracle's O(N^2) Lagrange decoder
+# ------------------------------------------------------------------------------------------------
+def loss_pattern(rng, N, kind):
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    if kind == "one":
+        dp[rng.integers(N)] = 0
+    elif kind == "all_data":
+        dp[:] = 0
+    elif kind == "random_max":
+        lost = rng.permutation(2 * N)[:N]
+        dp[lost[lost < N]] = 0
+        pp[lost[lost >= N] - N] = 0
+    elif kind == "quarter":
+        lost = rng.permutation(2 * N)[: max(1, N // 2)]
+        dp[lost[lost < N]] = 0
+        pp[lost[lost >= N] - N] = 0
+    elif kind == "burst":
+        dp[N // 4: N // 4 + max(1, N // 3)] = 0
+    return dp, pp
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 4, 5, 6, 8, 10, 12])
+@pytest.mark.parametrize("kind", ["one", "all_data", "random_max", "quarter", "burst"])
+def test_decode_round_trip_and_lagrange(torch_cuda, fe, orc61, logn, kind):
+    torch = torch_cuda
+    N, elems = 1 << logn, 5 if logn % 2 else 70
+    rng = np.random.default_rng(logn * 10 + len(kind))
+    x = rand_stripe(rng, N, elems)
+    par = orc61.encode(x)
+    dp, pp = loss_pattern(rng, N, kind)
+    damaged, dpar = x.copy(), par.copy()
+    damaged[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)   # erased blocks hold garbage (not even field elements)
+    dpar[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+    with encoder(fe, N, elems) as enc:
+        enc.decode_prepare(dp, pp)
+        d, q = to_dev(torch, damaged), to_dev(torch, dpar)
+        enc.decode(d, q)
+        torch.cuda.synchronize()
+        assert (to_host(d).reshape(x.shape) == x).all()
+        assert (to_host(q).reshape(par.shape) == dpar).all()  # decode leaves the parity alone
+        enc.repair(to_dev(torch, damaged), q)
+        torch.cuda.synchronize()
+        assert (to_host(q).reshape(par.shape) == par).all()   # repair brings the lost parity blocks back too
+    if N <= 64:
+        assert (orc61.decode(damaged, dpar, dp, pp) == x).all()
+
+
+def test_decode_patterns_change_and_errors(torch_cuda, fe, orc61):
+    torch = torch_cuda
+    N, elems = 128, 9
+    rng = np.random.default_rng(99)
+    x = rand_stripe(rng, N, elems)
+    par = orc61.encode(x)
+    with encoder(fe, N, elems) as enc:
+        with pytest.raises(fe.FastEccError):
+            enc.decode(to_dev(torch, x), to_dev(torch, par))  # no pattern set
+        for kind in ("one", "random_max", "burst", "one"):
+            dp, pp = loss_pattern(rng, N, kind)
+            damaged = x.copy()
+            damaged[dp == 0] = 7
+            enc.decode_prepare(dp, pp)
+            d = to_dev(torch, damaged)
+            enc.decode(d, to_dev(torch, par))
+            torch.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all(), kind
+        dp, pp = np.zeros(N, np.uint8), np.ones(N, np.uint8)
+        pp[0] = 0
+        with pytest.raises(fe.FastEccError) as ei:  # N + 1 losses
+            enc.decode_prepare(dp, pp)
+        assert ei.value.code == fe.E_INVAL
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.decode(x, par, mem=fe.MEM_HOST)
+        assert ei.value.code in (fe.E_UNSUPPORTED, fe.E_INVAL)
+
+
+def test_decode_at_2_16_blocks(torch_cuda, fe):
+    """(2^17, 2^16) x 1 KiB blocks, half of the codeword lost: encode -> erase -> repair == original (no oracle at this size)."""
+    torch = torch_cuda
+    N, elems = 1 << 16, 64
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    x = torch.randint(0, P61, (N * 2 * elems,), dtype=torch.int64, device="cuda:0", generator=g)
+    par = torch.empty_like(x)
+    rng = np.random.default_rng(3)
+    lost = rng.permutation(2 * N)[:N]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    with encoder(fe, N, elems) as enc:
+        enc.encode(x, par)
+        d, q = x.clone(), par.clone()
+        d.view(N, 2 * elems)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+        q.view(N, 2 * elems)[torch.from_numpy(pp == 0).to("cuda:0")] = -1
+        enc.decode_prepare(dp, pp)
+        enc.repair(d, q)
+        torch.cuda.synchronize()
+        assert torch.equal(d, x) and torch.equal(q, par)

@@ -268,3 +268,20 @@ def test_reference_codelets_of_order_3_and_9(oracle, reference):
             f = rng.integers(0, P, size=order, dtype=np.uint64).astype(np.uint32)
             want = oracle.slow_ntt(f.reshape(order, 1), inverse).reshape(-1)
             assert np.array_equal(reference.small_ntt(f, inverse), want), (order, inverse)
+
+
+def test_p61_oracle_decoder_round_trip():
+    """orc61_decode (O(N^2) Lagrange) restores what orc61_encode produced: the checker of the GF(p61^2) HIP decoder."""
+    from oracle import OracleP61
+    o = OracleP61()
+    rng = np.random.default_rng(61)
+    for N, elems in ((2, 1), (8, 3), (32, 2)):
+        x = o.fill_splitmix(N, elems, 0x61 + N)
+        par = o.encode(x)
+        lost = rng.permutation(2 * N)[:N]
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        dp[lost[lost < N]] = 0
+        pp[lost[lost >= N] - N] = 0
+        damaged = x.copy()
+        damaged[dp == 0] = 12345
+        assert np.array_equal(o.decode(damaged, par, dp, pp), x)

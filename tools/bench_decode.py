@@ -21,13 +21,18 @@ P = 0xFFF00001
 
 def main():
     log2k = int(sys.argv[1]) if len(sys.argv) > 1 else 19
-    N, S, steps = 1 << log2k, 1024, 10
+    p61 = len(sys.argv) > 2 and sys.argv[2] == "p61"   # GF((2^61-1)^2): S counts 64-bit words, 4096-byte blocks as well
+    N, S, steps = 1 << log2k, (512 if p61 else 1024), 10
     g = torch.Generator(device="cuda:0").manual_seed(11)
-    data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    if p61:
+        data = torch.randint(0, (1 << 61) - 1, (N * S,), dtype=torch.int64, device="cuda:0", generator=g)
+    else:
+        data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
     parity = torch.empty_like(data)
-    out = {"workload": "(n,k)=(2^%d,2^%d), 4096 B blocks, random erasures over the whole codeword" % (log2k + 1, log2k), "cases": []}
+    out = {"workload": "(n,k)=(2^%d,2^%d), 4096 B blocks, %s, random erasures over the whole codeword"
+                       % (log2k + 1, log2k, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)"), "cases": []}
     stream = torch.cuda.current_stream().cuda_stream
-    with fastecc_amd.Encoder(2 * N, N, 4 * S) as enc:
+    with fastecc_amd.Encoder(2 * N, N, 4096, field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001) as enc:
         enc.encode(data, parity, stream=stream)
         for frac in (0.001, 0.02, 0.25, 0.5):
             rng = np.random.default_rng(int(frac * 1000))
@@ -55,7 +60,7 @@ def main():
             ms = e0.elapsed_time(e1) / steps
             out["cases"].append({"lost_fraction": frac, "erased_blocks": int(lost.size), "erased_data_blocks": int((dp == 0).sum()),
                                  "prepare_ms": round(prep_ms, 2), "prepare_first_call_ms": round(first_ms, 1), "decode_ms": round(ms, 3),
-                                 "codeword_GBps": round(2.0 * N * S * 4 / (ms * 1e-3) / 1e9, 1)})
+                                 "codeword_GBps": round(2.0 * N * 4096 / (ms * 1e-3) / 1e9, 1)})
     print(json.dumps(out))
 
 
