@@ -942,7 +942,7 @@ int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_
         }
     if (best == 0 || n - k > best) return FASTECC_E_UNSUPPORTED;
     if (bq == 1) return fastecc_create(out, n, k, block_bytes, field, device);
-    if (block_bytes / 4 > 0xFFFFFFFFull / 2 || best * (block_bytes / 4) > 0xFFFFFFFFull * 4) return FASTECC_E_UNSUPPORTED;
+    if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;
     const uint64_t M = 1ull << bm;
     int rc = create_impl(out, 2 * M, M, bm, block_bytes, field, device, 0, 1, nullptr);
     if (rc != FASTECC_OK) return rc;
