@@ -369,8 +369,8 @@ def main():
             # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM
             slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(k, w)
             pslab = torch.empty_like(slab)
-            sub = 1 if p61 else sharding.sub_slab_count(w, args.sub_slabs)
-            columns = sharding.hip_columns_encoder(senc)
+            sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
+            columns = sharding.hip_columns_encoder(senc, unit // 4)
             wsp = {}
             modes = {"compute_only": lambda: senc.encode(slab, pslab, stream=stream),
                      "with_gather": lambda: sharding.encode_slab_and_gather(slab, columns, k, dst=0, sub_slabs=sub, workspace=wsp,

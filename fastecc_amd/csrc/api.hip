@@ -1071,7 +1071,7 @@ fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, u
 void set_plan_text(fastecc_ctx* c, const std::string& t) { c->plan_text = t; }
 int columns_supported(const fastecc_ctx* c)
 {
-    return !c->p61 && !c->sharded && c->q == 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
+    return !c->sharded && c->q == 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
 }
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
 
@@ -1258,6 +1258,12 @@ int fastecc_encode_columns(fastecc_ctx* c, const void* data, void* parity, uint6
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     CallLock lk(c->mu);
+    if (c->p61) {  // the range is given in 4-byte words like everywhere in this ABI: whole 16-byte elements only
+        if ((col0 % 4) != 0 || (width % 4) != 0 || ((((uintptr_t)data | (uintptr_t)parity)) & 15u)) return FASTECC_E_INVAL;
+        P61Hooks hk(c);
+        return p61::encode_columns(c->p61, (const uint64_t*)data, (uint64_t*)parity, col0 / 4, width / 4, (hipStream_t)stream,
+                                   c->profiling ? &hk.h : nullptr);
+    }
     return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream,
                       (uint32_t)col0, (uint32_t)width);
 }

@@ -46,7 +46,8 @@ struct PassArgs {
     const uint64_t* tw_dif;  // level-packed twiddles for the DIF levels (16 bytes per entry)
     const uint64_t* tw_dit;  // ... for the DIT levels
     const uint64_t* dscale;  // position p -> w_2N^bitrev(p) / N
-    uint32_t elems;          // elements per block
+    uint32_t elems;          // elements per block covered by this launch (a column range may be narrower than a block)
+    uint32_t pitch;          // elements between consecutive blocks in memory (the full block)
     uint32_t col_chunks;     // ceil(elems / 64)
     uint64_t items;          // (N >> r) * col_chunks
     int s;                   // log2 of the smallest stride of the pass
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 3) void p61_pass_kernel(const PassArgs a)
     const uint32_t lo = g & ((1u << s) - 1u);
     const uint32_t hi = g >> s;
     const uint64_t base = ((uint64_t)hi << (s + LOGR)) + lo;  // first block of this group
-    const uint64_t row_words = 2ull * a.elems;
+    const uint64_t row_words = 2ull * a.pitch;
 
     const gf61::Opaque k = gf61::make_opaque();
     Elem x[R];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
     const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
-    const uint64_t row_words = 2ull * a.elems;
+    const uint64_t row_words = 2ull * a.pitch;
     const gf61::Opaque k = gf61::make_opaque();
     const uint32_t my_round = lane / WS;
     u64x2* my_lds = lds + (lane % WS);
@@ -722,8 +723,11 @@ struct Scope {
 
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
 int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint64_t* out, const uint64_t* tw_dif,
-               const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks)
+               const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks, uint64_t col0 = 0, uint64_t width = 0)
 {
+    if (width == 0) width = p->elems;
+    in += 2 * col0;  // element columns [col0, col0 + width) of every block: independent transforms
+    out += 2 * col0;
     const uint64_t* src = in;
     for (const Pass& q : plan) {
         PassArgs a{};
@@ -732,8 +736,9 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         a.tw_dif = tw_dif;
         a.tw_dit = tw_dit;
         a.dscale = p->dscale;
-        a.elems = (uint32_t)p->elems;
-        a.col_chunks = (uint32_t)((p->elems + 63) / 64);
+        a.elems = (uint32_t)width;
+        a.pitch = (uint32_t)p->elems;
+        a.col_chunks = (uint32_t)((width + 63) / 64);
         a.items = (p->N >> q.logr) * a.col_chunks;
         a.s = q.s;
         a.sr = p->sr;
@@ -742,7 +747,7 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         const dim3 grid((unsigned)blocks);
         char name[32];
         snprintf(name, sizeof name, "p61_%s%s%d", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr);
-        Scope sc(hooks, st, name, 2ull * p->N * p->elems * 16ull);
+        Scope sc(hooks, st, name, 2ull * p->N * width * 16ull);
         hipError_t e;
         if (q.tile) {
             if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
@@ -819,6 +824,12 @@ void destroy(Path* p)
     if (p->tw_ntt_inv) (void)hipFree(p->tw_ntt_inv);
     if (p->dscale) (void)hipFree(p->dscale);
     delete p;
+}
+
+int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col0, uint64_t width, hipStream_t st, const LaunchHooks* hooks)
+{
+    if (width == 0 || col0 + width > p->elems) return FASTECC_E_INVAL;
+    return run_passes(p, p->enc, data, parity, p->tw_inv, p->tw_fwd, true, st, hooks, col0, width);
 }
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks)

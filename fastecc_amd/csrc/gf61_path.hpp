@@ -28,6 +28,8 @@ int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, 
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);
+// the element columns [col0, col0 + width) of every block only (data / parity are the stripes' base addresses)
+int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col0, uint64_t width, hipStream_t st, const LaunchHooks* hooks);
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);
 // words >= p among the 2 * elems * k words of a stripe; `counter` is a device uint64 the caller zeroed
 int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counter, hipStream_t st);

@@ -43,22 +43,24 @@ def merge_slabs(slabs):
     return torch.cat(list(slabs), dim=1).contiguous()
 
 
-def sub_slab_count(slab_words, wanted):
-    """Largest power of two <= wanted that cuts the slab into sub-slabs of whole 32-word (128-byte) row segments."""
+def sub_slab_count(slab_words, wanted, words_per_column=1):
+    """Largest power of two <= wanted that cuts the slab into sub-slabs of whole 32-word (128-byte) row segments.
+    slab_words counts tensor columns of words_per_column 4-byte words each."""
     h = 1
-    while h * 2 <= wanted and slab_words % (32 * h * 2) == 0:
+    while h * 2 <= wanted and (slab_words * words_per_column) % (32 * h * 2) == 0:
         h *= 2
     return h
 
 
-def hip_columns_encoder(enc):
-    """encode_columns callable for encode_slab_and_gather from a fastecc_amd.Encoder built for the slab's block size."""
+def hip_columns_encoder(enc, words_per_column=1):
+    """encode_columns callable for encode_slab_and_gather from a fastecc_amd.Encoder built for the slab's block size.
+    words_per_column: 4-byte words per tensor column (1 for int32 slabs, 2 for the int64 slabs of the 64-bit field)."""
     def fn(data_slab, parity_slab, col0, width):
         stream = torch.cuda.current_stream(data_slab.device).cuda_stream if data_slab.is_cuda else 0
         if col0 == 0 and width == data_slab.shape[1]:
             enc.encode(data_slab, parity_slab, stream=stream)
         else:
-            enc.encode_columns(data_slab, parity_slab, col0, width, stream=stream)
+            enc.encode_columns(data_slab, parity_slab, col0 * words_per_column, width * words_per_column, stream=stream)
     return fn
 
 
@@ -86,7 +88,7 @@ def encode_slab_and_gather(data_slab, encode_columns, parity_rows, parity_full=N
     world = dist.get_world_size(group) if ranked else 1
     rank = dist.get_rank(group) if ranked else 0
     k, w = data_slab.shape
-    H = sub_slab_count(w, sub_slabs)
+    H = sub_slab_count(w, sub_slabs, data_slab.element_size() // 4)
     ws = w // H
     dev = data_slab.device
     ws_ = workspace if workspace is not None else {}

@@ -138,9 +138,9 @@ int fastecc_encode(fastecc_ctx *ctx, const void *data, void *parity, int mem_kin
  * pointers are the stripes' base addresses).  The columns of a stripe are independent transforms (ntt.cpp:348-350),
  * so a host can cut a stripe into column slabs and overlap their encodes with whatever moves the slabs — which is
  * what fastecc_encode does for FASTECC_MEM_HOST_PINNED stripes and fastecc_encode_sharded for the xGMI gather.
- * n = 2k = 2^m over GF(0xFFF00001); FASTECC_E_UNSUPPORTED for the other codes and the 64-bit field (they work through
- * whole-stripe scratch buffers), and the caller encodes the stripe in one piece.  Any range is accepted; multiples of
- * 32 words keep every 128-byte row segment whole.
+ * n = 2k = 2^m in either field (the 64-bit field: ranges of whole 16-byte elements, i.e. multiples of 4 words);
+ * FASTECC_E_UNSUPPORTED for the other codes (they work through whole-stripe scratch buffers), and the caller encodes the
+ * stripe in one piece.  Any range is accepted; multiples of 32 words keep every 128-byte row segment whole.
  */
 int fastecc_encode_columns(fastecc_ctx *ctx, const void *data, void *parity, uint64_t col0_words, uint64_t width_words, void *stream);
 

@@ -168,9 +168,22 @@ def test_sharded_other_codes_and_the_64_bit_field(torch_cuda, fe, oracle):
     d = torch.from_numpy(h.view(np.int64)).to("cuda:0")
     out = torch.empty_like(d)
     with fe.ShardedEncoder(2 * N, N, 16 * elems, [0] * G, field=fe.FIELD_GF_P61_SQUARED) as senc:
-        senc.encode(d, out)
+        for sub in (1, 2):  # 16 elements per slab: one or two sub-slabs of whole 128-byte row segments
+            senc.set_option("sub_slabs", sub)
+            out.zero_()
+            senc.encode(d, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(want.shape), want), sub
+    # fastecc_encode_columns in this field: ranges of whole 16-byte elements (given in 4-byte words)
+    with fe.Encoder(2 * N, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        part = torch.full_like(d, 0x1234)
+        enc.encode_columns(d, part, 4 * 8, 4 * 24)
         torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(want.shape), want)
+        got = part.cpu().numpy().view(np.uint64).reshape(want.shape)
+        assert np.array_equal(got[:, 16:64], want[:, 16:64]) and (got[:, :16] == 0x1234).all() and (got[:, 64:] == 0x1234).all()
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.encode_columns(d, part, 2, 8)  # not whole elements
+        assert ei.value.code == fe.E_INVAL
 
 
 def test_sharded_argument_checks(torch_cuda, fe):
