@@ -19,7 +19,7 @@ P61 = (1 << 61) - 1
 FIELD_GF_FFF00001 = 0
 FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
-CODE_MIXED_RADIX = 1  # fastecc_create_ex flag: transform order q * 2^m, q in {1, 3, 5, 7, 9}
+CODE_MIXED_RADIX = 1  # fastecc_create_ex flag: transform order q * 2^m, q in {1, 3, 5, 7, 9, 13, 15}
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -317,9 +317,9 @@ class ShardedEncoder(Encoder):
 
 def mixed_radix_order(k):
     """Transform order fastecc_create_ex(..., CODE_MIXED_RADIX) picks for k data blocks: the smallest q * 2^m >= k,
-    q in {1, 3, 5, 7, 9}, 1 <= m <= 19 (None if there is none)."""
+    q in {1, 3, 5, 7, 9, 13, 15}, 1 <= m <= 19 (None if there is none)."""
     best = None
-    for q in (1, 3, 5, 7, 9):
+    for q in (1, 3, 5, 7, 9, 13, 15):
         for m in range(1, 20):
             if (q << m) >= k and (best is None or (q << m) < best):
                 best = q << m

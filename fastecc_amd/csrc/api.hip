@@ -931,11 +931,11 @@ int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_
     if (!(flags & FASTECC_CODE_MIXED_RADIX)) return fastecc_create(out, n, k, block_bytes, field, device);
     if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
-    // transform order: the smallest q * 2^m >= k with q in {1, 3, 5, 7, 9}, m >= 1 (NTT.md:43-46: "the next divider of
+    // transform order: the smallest q * 2^m >= k with q in {1, 3, 5, 7, 9, 13, 15}, m >= 1 (NTT.md:43-46: "the next divider of
     // 0xFFF00000 is only a few percents larger than N itself"); w_(2 q 2^m) must exist: 2^(m+1) | 2^20
     uint64_t best = 0;
     int bq = 1, bm = 0;
-    for (int q : {1, 3, 5, 7, 9})
+    for (int q : {1, 3, 5, 7, 9, 13, 15})
         for (int m = 1; m <= 19; m++) {
             const uint64_t N1 = (uint64_t)q << m;
             if (N1 >= k && (best == 0 || N1 < best)) best = N1, bq = q, bm = m;

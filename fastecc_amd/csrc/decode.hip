@@ -336,6 +336,10 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DeviceScope ds61(ci.device);
         if (!ds61.ok) return FASTECC_E_DEVICE;
         CallScope call61(c);
+        {
+            const int rc0 = call61.wait_idle();  // a decode still using the previous pattern
+            if (rc0 != FASTECC_OK) return rc0;
+        }
         char detail[160] = "";
         const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, detail, sizeof detail);
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
@@ -555,7 +559,11 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         if (!p61::decoder_ready(d61)) return FASTECC_E_INVAL;
         DeviceScope ds61(info_of(c).device);
         if (!ds61.ok) return FASTECC_E_DEVICE;
-        return p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
+        int rc61 = call.begin((hipStream_t)stream);  // the decoder's work stripe and tables are internal buffers
+        if (rc61 != FASTECC_OK) return rc61;
+        rc61 = p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
+        const int rc_end = call.end((hipStream_t)stream);
+        return rc61 != FASTECC_OK ? rc61 : rc_end;
     }
     DecodeState* d = decoder_of(c);
     if (!d || !d->ready) return FASTECC_E_INVAL;  // fastecc_decode_prepare first

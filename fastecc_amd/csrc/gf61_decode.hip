@@ -350,7 +350,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         D61_TRY(hipGetLastError());
     }
     hipStream_t s0 = nullptr;
-    D61_TRY(hipDeviceSynchronize());  // a decode still using the previous pattern (set-up is rare; the device-wide wait is acceptable here)
+    // (the caller has waited for the last decode that used the previous pattern)
     D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
     if (erased_data == 0 && erased_parity == 0) {
         D61_TRY(hipStreamSynchronize(s0));

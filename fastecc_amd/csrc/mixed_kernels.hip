@@ -1,4 +1,4 @@
-// mixed_kernels.hip — the odd-radix level of a transform of order q * 2^m, q in {3, 5, 7, 9}.
+// mixed_kernels.hip — the odd-radix level of a transform of order q * 2^m, q in {3, 5, 7, 9, 13, 15}.
 //
 // The reference's roadmap for block counts that are not powers of two (NTT.md:43-46, README.md:175: "PFA NTT as well
 // as NTT kernels of orders 3,5,7,9,13, since 0xFFF00000 = 2^20*3*3*5*7*13"; its codelets NTT3 / NTT9, ntt.cpp:25-146,
@@ -16,7 +16,8 @@
 // A wave owns one i2 (one row of each of the q stripes) and a 64*V-word column chunk: the q blocks are in VGPRs, the
 // twiddles w_N^(i2*j1) and the q x q matrix w_q^(i*j) are wave-uniform scalars.  The odd-order DFT is the plain matrix
 // product: (q-1)^2 products per q words — 6 VALU instructions each — stay below the HBM time of the pass for q <= 7
-// and about match it for q = 9; NTT3's (ntt.cpp:25-44) two-product form only trades products for additions.
+// and about match it for q = 9; q = 13 and 15 (the remaining small divisors of p - 1 = 2^20 3^2 5 7 13) are VALU-bound by
+// about 2x and exist for completeness.  NTT3's (ntt.cpp:25-44) two-product form only trades products for additions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -107,16 +108,23 @@ static hipError_t launch_v(int q, bool dit, const RadixArgs& a, dim3 grid, hipSt
         case 5: return launch_q<5, V>(dit, a, grid, st);
         case 7: return launch_q<7, V>(dit, a, grid, st);
         case 9: return launch_q<9, V>(dit, a, grid, st);
+        case 13:
+            if constexpr (V == 1) return launch_q<13, 1>(dit, a, grid, st);
+            else return hipErrorInvalidValue;
+        case 15:
+            if constexpr (V == 1) return launch_q<15, 1>(dit, a, grid, st);
+            else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
 
-bool radix_supported(int q) { return q == 3 || q == 5 || q == 7 || q == 9; }
+bool radix_supported(int q) { return q == 3 || q == 5 || q == 7 || q == 9 || q == 13 || q == 15; }
 
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st)
 {
     if (!radix_supported(q) || a.M == 0) return hipErrorInvalidValue;
     if (q == 9 && vec == 4) vec = 2;  // 9 blocks of 4 words per lane (twice: in and out) do not fit the register budget
+    if (q > 9) vec = 1;
     a.col_chunks = (a.S + 64u * vec - 1u) / (64u * vec);
     a.items = (uint64_t)a.col_chunks * a.M;
     const uint64_t blocks = (a.items + 3u) / 4u;

@@ -249,6 +249,7 @@ int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value)
         describe(shell);
         return FASTECC_OK;
     }
+    if (what == SH_SET_OPTION && !strcmp(name, "row_pitch_words")) return FASTECC_E_UNSUPPORTED;  // slabs are contiguous [k][block_bytes / G]
     if (what == SH_SET_OPTION && !strcmp(name, "gather_mode")) {
         if (value != 1 && value != 2) return FASTECC_E_INVAL;
         s->gather_mode = value;

@@ -107,13 +107,13 @@ int fastecc_version(void);
 int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);
 /*
  * fastecc_create with flags.  FASTECC_CODE_MIXED_RADIX: the transform order is the smallest N1 = q * 2^m >= k with q in
- * {1, 3, 5, 7, 9} instead of the next power of two — the reference's roadmap for block counts that are not powers of two
+ * {1, 3, 5, 7, 9, 13, 15} instead of the next power of two — the reference's roadmap for block counts that are not powers of two
  * (NTT.md:43-46, README.md:175; its NTT3 / NTT9 codelets, ntt.cpp:25-146, are never reached by its drivers).  The data
  * points are then the powers of w_N1 = 19^((p-1)/N1) and parity block j = f(w_(2 N1)^(2j+1)): the composition of
  * RS.cpp:40-63 with N1 for N (k < N1: zero extension as in RS.md:23-33; the first n - k <= N1 of the N1 parity blocks
  * are the parity).  With q = 1 this IS fastecc_create; otherwise it is a different code than the zero-extended power-of-
  * two one fastecc_create builds for the same (n,k) — a stripe must be decoded with the flags it was encoded with.
- * k <= 9 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile (no decoder yet).  The odd-radix
+ * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile (no decoder yet).  The odd-radix
  * level costs two more trips through HBM than the power-of-two pipeline; measured against zero extension in
  * profiles/r02/mixed_radix_bench.json.
  */

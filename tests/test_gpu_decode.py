@@ -110,9 +110,9 @@ def test_patterns_can_change_and_errors(torch_cuda, fe, oracle):
         d = to_dev(torch, x)
         enc.decode(d, to_dev(torch, par))
         assert (to_host(d, (N, S)) == x).all()
-    with fe.Encoder(2 * N, N, 16 * 8, field=fe.FIELD_GF_P61_SQUARED) as enc:   # no decoder for the 64-bit field yet
+    with fe.Encoder(2 * 96, 96, 64, flags=fe.CODE_MIXED_RADIX) as enc:   # no decoder for the mixed-radix codes yet
         with pytest.raises(fe.FastEccError) as ei:
-            enc.decode_prepare(np.ones(N, np.uint8), np.ones(N, np.uint8))
+            enc.decode_prepare(np.ones(96, np.uint8), np.ones(96, np.uint8))
         assert ei.value.code == fe.E_UNSUPPORTED
 
 

@@ -39,11 +39,11 @@ def rand_stripe(seed, N, S):
 
 
 def test_order_selection(fe):
-    assert [fe.mixed_radix_order(k) for k in (1, 2, 3, 5, 6, 7, 9, 11, 13, 17, 96, 97, 1000, 393216, 393217)] == \
-        [2, 2, 4, 6, 6, 8, 10, 12, 14, 18, 96, 112, 1024, 393216, 458752]
+    assert [fe.mixed_radix_order(k) for k in (1, 2, 3, 5, 6, 7, 9, 11, 13, 17, 96, 97, 105, 1000, 393216, 393217, 430000)] == \
+        [2, 2, 4, 6, 6, 8, 10, 12, 14, 18, 96, 104, 112, 1024, 393216, 425984, 458752]
 
 
-@pytest.mark.parametrize("q", [3, 5, 7, 9])
+@pytest.mark.parametrize("q", [3, 5, 7, 9, 13, 15])
 @pytest.mark.parametrize("m,S", [(1, 1), (2, 7), (5, 64), (6, 33), (7, 256), (10, 128), (11, 40)])
 def test_full_codes_match_the_oracle(torch_cuda, fe, oracle, q, m, S):
     """n = 2k, k = q * 2^m exactly: parity block j = f(w_2k^(2j+1)), data at the powers of w_k."""

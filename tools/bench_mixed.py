@@ -16,7 +16,7 @@ import fastecc_amd as fe  # noqa: E402
 P = 0xFFF00001
 S = 1024
 rows = []
-for q, m in ((3, 17), (5, 16), (7, 16), (9, 15), (3, 10), (9, 16)):
+for q, m in ((3, 17), (5, 16), (7, 16), (9, 15), (13, 15), (15, 15), (3, 10), (9, 16), (15, 19)):
     k = q << m
     data = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0").to(torch.int32)
     parity = torch.empty_like(data)
