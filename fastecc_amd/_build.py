@@ -44,15 +44,23 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     objs = []
     headers = [os.path.join(ROOT, "include", "fastecc.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    jobs = []
     for src in HIP_SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if not (force or _newer(obj, headers + [os.path.join(CSRC, src)])):
             continue  # this translation unit is up to date
-        cmd = [hipcc()] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        jobs.append([hipcc()] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def compile_one(cmd):
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, jobs))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
