@@ -1,7 +1,9 @@
 // rs_main.cpp — `rs`-compatible host driver over the C ABI (include/fastecc.h).
 //
 // Keeps the command line of the reference benchmark (RS.cpp:71-87, RS.md:4):
-//     rs_hip [.][log2(N) [block_bytes]]          defaults: N = 2^19, 2052-byte blocks, "." = quiet
+//     rs_hip [.][log2(N) [block_bytes [gpus=g0,g1,...]]]    defaults: N = 2^19, 2052-byte blocks, "." = quiet
+// (gpus=...: one stripe in column slabs on several GPUs through fastecc_create_sharded — BASELINE configs[3]; the same
+// fastecc_encode calls, g0 is the root.  Ids may repeat, e.g. gpus=0,0,0,0 on a one-GPU box.)
 // fills the stripe with the reference's i % p pattern (RS.cpp:28-29), encodes it on the GPU through
 // fastecc_encode, and reports time / MiB/s in the reference's convention (data + parity bytes per
 // second, RS.cpp:38, wall_clock_timer.h:91).  Unlike the reference it also prints the parity checksum
@@ -16,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "fastecc.h"
@@ -46,16 +49,27 @@ int main(int argc, char** argv)
     }
     if (argc > arg) logn = atoi(argv[arg++]);
     if (argc > arg) block_bytes = (size_t)atoll(argv[arg++]);
+    std::vector<int> gpus;
+    if (argc > arg && !strncmp(argv[arg], "gpus=", 5)) {
+        for (const char* p = argv[arg] + 5; *p;) {
+            gpus.push_back(atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        arg++;
+    }
     const uint64_t N = 1ull << logn;
     const size_t words = block_bytes / 4;  // RS.cpp:86 truncates the same way
     const size_t total = N * words;
 
     fastecc_ctx* ctx = nullptr;
-    int rc = fastecc_create(&ctx, 2 * N, N, words * 4, FASTECC_FIELD_GF_FFF00001, 0);
+    int rc = gpus.empty() ? fastecc_create(&ctx, 2 * N, N, words * 4, FASTECC_FIELD_GF_FFF00001, 0)
+                          : fastecc_create_sharded(&ctx, 2 * N, N, words * 4, FASTECC_FIELD_GF_FFF00001, gpus.data(), (int)gpus.size());
     if (rc != FASTECC_OK) {
-        fprintf(stderr, "fastecc_create: %s\n", fastecc_strerror(rc));
+        fprintf(stderr, "%s: %s (%s)\n", gpus.empty() ? "fastecc_create" : "fastecc_create_sharded", fastecc_strerror(rc), fastecc_last_error_detail());
         return 1;
     }
+    if (!gpus.empty() && hipSetDevice(gpus[0]) != hipSuccess) return 1;  // stripes live on the root
 
     std::vector<uint32_t> host(total);
     for (size_t i = 0; i < total; i++) host[i] = (uint32_t)(i % 0xFFF00001ull);
@@ -112,7 +126,17 @@ int main(int argc, char** argv)
                t_h2d1 - t_h2d0, t_d2h1 - t_d2h0);
         printf("  parity checksum: %u\n", rolling_hash(host.data(), total));
     }
-    if (verbose) {
+    if (verbose && !gpus.empty()) {
+        // the host-memory form on a sharded context: every GPU moves its own column slab over its own host link
+        std::vector<uint32_t> in(total), out(total);
+        for (size_t i = 0; i < total; i++) in[i] = (uint32_t)(i % 0xFFF00001ull);
+        const double h0 = now_ms();
+        rc = fastecc_encode(ctx, in.data(), out.data(), FASTECC_MEM_HOST, nullptr);
+        const double h1 = now_ms();
+        printf("  host stripe through %d slabs (each GPU its own host link, pageable memory): %.0lf ms = %.0lf MiB/s, parity %s\n",
+               (int)gpus.size(), h1 - h0, bytes / (h1 - h0) * 1000 / (1 << 20), rc == FASTECC_OK && out == host ? "identical" : "MISMATCH");
+    }
+    if (verbose && gpus.empty()) {
         // Beyond the reference (it documents decoding, README.md:83-119, and has no code for it): lose every third data
         // block and every fifth parity block of the codeword just produced, and repair the data on the GPU.
         uint32_t* ddata = nullptr;

@@ -14,3 +14,4 @@ timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > "$OUT/smoke.log
 timeout 600 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; echo "bench rc=$?"; cat "$OUT/bench_default.json"
 timeout 600 bash tools/prof_stats.sh "$OUT/stats" > "$OUT/stats.txt" 2>&1; grep -E "fastecc|Name" "$OUT/stats.txt" | head -12
 timeout 300 fastecc_amd/lib/rs_hip 19 4096 > "$OUT/rs_hip.log" 2>&1; tail -3 "$OUT/rs_hip.log"
+timeout 300 fastecc_amd/lib/rs_hip 19 4096 gpus=0,0,0,0,0,0,0,0 > "$OUT/rs_hip_sharded.log" 2>&1; tail -4 "$OUT/rs_hip_sharded.log"
