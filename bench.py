@@ -191,6 +191,21 @@ def parity_check(enc, log2k, block_bytes, device):
             "what": "parity hash (main.cpp:202-212) of the splitmix64(0x%x) stripe vs the unmodified reference's" % gold["splitmix_seed"]}
 
 
+def parity_check_p61(data, parity, k, block_bytes):
+    """No reference output exists for this field (parity unpinned upstream): the gate re-encodes two element columns of
+    the stripe that was just timed with this repository's oracle (checker only) and compares them with the parity."""
+    import numpy as np
+    from oracle import OracleP61
+    elems = block_bytes // 16
+    cols = [0, elems - 1]
+    idx = torch.tensor([2 * c + j for c in cols for j in (0, 1)], device=data.device)
+    x = data.view(k, 2 * elems)[:, idx].cpu().numpy().view(np.uint64)
+    got = parity.view(k, 2 * elems)[:, idx].cpu().numpy().view(np.uint64)
+    want = OracleP61().encode(np.ascontiguousarray(x))
+    return {"status": "ok" if np.array_equal(got, want) else "FAILED",
+            "what": "element columns %s of the timed stripe re-encoded by oracle/fastecc_oracle_p61.c (no upstream output exists for this field)" % cols}
+
+
 def time_steps(step, steps, barrier):
     barrier()
     t0 = time.perf_counter()
@@ -428,9 +443,9 @@ def main():
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
         check = None
-        if not args.no_parity_check and not p61 and args.batch == 1 and m_blocks == k:
+        if not args.no_parity_check and args.batch == 1 and m_blocks == k:
             try:
-                check = parity_check(enc, args.log2k, args.block_bytes, device)
+                check = parity_check_p61(data, parity, k, args.block_bytes) if p61 else parity_check(enc, args.log2k, args.block_bytes, device)
             except Exception as e:  # noqa: BLE001
                 check = {"status": "error", "why": repr(e)}
         cabi = None
