@@ -273,6 +273,12 @@ void build_plans(fastecc_ctx* c)
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
+    if (c->q > 1) {  // the odd-radix level around the power-of-two pipeline (mixed_kernels.hip)
+        snprintf(buf, sizeof buf, "R%d:dif1@%d,", c->q, c->n);
+        c->plan_text = std::string(buf) + c->plan_text;
+        snprintf(buf, sizeof buf, ",R%d:dit1@%d", c->q, c->n);
+        c->plan_text += buf;
+    }
     snprintf(buf, sizeof buf, " v%d", c->vec);
     c->plan_text += buf;
 }
@@ -817,12 +823,7 @@ static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user)
     c->Mu = m_user;
     c->stripe_bytes = (size_t)N1 * c->S * 4;  // the staging stripe of the host-memory calls holds all q * N blocks
     c->parity_bytes = (size_t)m_user * c->S * 4;
-    char buf[48];
-    snprintf(buf, sizeof buf, "R%d:dif1@%d,", q, c->n);
-    c->plan_text = std::string(buf) + c->plan_text;
-    snprintf(buf, sizeof buf, ",R%d:dit1@%d", q, c->n);
-    const size_t sp = c->plan_text.rfind(" v");
-    c->plan_text.insert(sp == std::string::npos ? c->plan_text.size() : sp, buf);
+    build_plans(c);  // the same passes; the plan text now names the two odd-radix passes
     return FASTECC_OK;
 }
 
