@@ -112,6 +112,10 @@ GF61_D uint64_t add(uint64_t x, uint64_t y, const Opaque& k) { return fold(x + y
 GF61_D uint64_t sub_raw(uint64_t x, uint64_t y) { return x + (2 * P - y); }
 // lazy - lazy -> lazy
 GF61_D uint64_t sub(uint64_t x, uint64_t y, const Opaque& k) { return fold(sub_raw(x, y), k); }
+// "Loose" values: the unfolded sums and differences of two lazy values, < 1.5 * 2^62 + 2^34.  They may be added once more
+// (< 2^64) or subtracted with a 4p offset (y <= 4p = 2^63 - 4; the result stays below 3.5 * 2^62 + 2^35 < 2^64) before the
+// next fold; mul_raw's limb split takes any 64-bit value.
+GF61_D uint64_t sub_raw4(uint64_t x, uint64_t y) { return x + (4 * P - y); }
 
 // 4p - y for y < 2^63: the negation of a sum of two lazy values, < 2^63
 GF61_D uint64_t neg_raw(uint64_t y) { return 4 * P - y; }
@@ -200,6 +204,8 @@ GF61_D Elem mul_raw(Elem x, const Twiddle& w, const Opaque& k)
 GF61_D Elem add(Elem x, Elem y, const Opaque& k) { return Elem{add(x.re, y.re, k), add(x.im, y.im, k)}; }
 GF61_D Elem sub(Elem x, Elem y, const Opaque& k) { return Elem{sub(x.re, y.re, k), sub(x.im, y.im, k)}; }
 GF61_D Elem sub_raw(Elem x, Elem y) { return Elem{sub_raw(x.re, y.re), sub_raw(x.im, y.im)}; }
+GF61_D Elem sub_raw4(Elem x, Elem y) { return Elem{sub_raw4(x.re, y.re), sub_raw4(x.im, y.im)}; }
+GF61_D Elem fold(Elem x, const Opaque& k) { return Elem{fold(x.re, k), fold(x.im, k)}; }
 GF61_D Elem canon(Elem x) { return Elem{canon(x.re), canon(x.im)}; }
 #endif
 

@@ -126,34 +126,44 @@ __device__ __forceinline__ Elem mul_w8(Elem x, const gf61::Opaque& k)
     }
 }
 
+// Folding only every other level.  A level whose outputs the NEXT level of the same run consumes may leave them "loose"
+// (LOOSE_OUT: plain 64-bit sums / differences, gf61.hpp); the next level (LOOSE_IN) adds them once more or subtracts them with
+// a 4p offset and folds then.  The last level of a run always folds: collected twiddles, the LDS exchange and HBM see lazy
+// values only.  Saves 12 of the 20 add/sub instructions of a butterfly on every other level.
+template <bool LOOSE_IN>
+__device__ __forceinline__ uint64_t diff(uint64_t x, uint64_t y) { return LOOSE_IN ? gf61::sub_raw4(x, y) : gf61::sub_raw(x, y); }
+template <bool LOOSE_OUT>
+__device__ __forceinline__ uint64_t settle(uint64_t t, const gf61::Opaque& k) { return LOOSE_OUT ? t : gf61::fold(t, k); }
+
 // Decimation in frequency: (a, b) -> (a + b, (a - b) * w), w the small root of `KIND`.
-template <int KIND, bool INV>
+template <int KIND, bool INV, bool LOOSE_IN, bool LOOSE_OUT>
 __device__ __forceinline__ void dif_bfly(Elem& xa, Elem& xb, const gf61::Twiddle& w, const gf61::Opaque& k)
 {
     const Elem a = xa, b = xb;
-    xa = gf61::add(a, b, k);
+    xa = Elem{settle<LOOSE_OUT>(a.re + b.re, k), settle<LOOSE_OUT>(a.im + b.im, k)};
     if constexpr (KIND == K_ONE) {
-        xb = gf61::sub(a, b, k);
+        xb = Elem{settle<LOOSE_OUT>(diff<LOOSE_IN>(a.re, b.re), k), settle<LOOSE_OUT>(diff<LOOSE_IN>(a.im, b.im), k)};
     } else if constexpr (KIND == K_I) {
         // (a - b) i = (b.im - a.im) + (a.re - b.re) i;  (a - b)(-i) = (a.im - b.im) + (b.re - a.re) i
-        if constexpr (!INV) xb = Elem{gf61::sub(b.im, a.im, k), gf61::sub(a.re, b.re, k)};
-        else                xb = Elem{gf61::sub(a.im, b.im, k), gf61::sub(b.re, a.re, k)};
+        if constexpr (!INV) xb = Elem{settle<LOOSE_OUT>(diff<LOOSE_IN>(b.im, a.im), k), settle<LOOSE_OUT>(diff<LOOSE_IN>(a.re, b.re), k)};
+        else                xb = Elem{settle<LOOSE_OUT>(diff<LOOSE_IN>(a.im, b.im), k), settle<LOOSE_OUT>(diff<LOOSE_IN>(b.re, a.re), k)};
     } else if constexpr (KIND == K_GEN) {
-        xb = gf61::mul_raw(gf61::sub_raw(a, b), w, k);
+        xb = gf61::mul_raw(Elem{diff<LOOSE_IN>(a.re, b.re), diff<LOOSE_IN>(a.im, b.im)}, w, k);  // the limb split takes any 64-bit value
     } else {
-        xb = mul_w8<KIND, INV>(gf61::sub(a, b, k), k);
+        xb = mul_w8<KIND, INV>(Elem{gf61::fold(diff<LOOSE_IN>(a.re, b.re), k), gf61::fold(diff<LOOSE_IN>(a.im, b.im), k)}, k);
     }
 }
 
 // Decimation in time: (a, b) -> (a + b w, a - b w).
-template <int KIND, bool INV>
+template <int KIND, bool INV, bool LOOSE_IN, bool LOOSE_OUT>
 __device__ __forceinline__ void dit_bfly(Elem& xa, Elem& xb, const gf61::Twiddle& w, const gf61::Opaque& k)
 {
     const Elem a = xa;
     if constexpr (KIND == K_I) {
         const Elem b = xb;
         // b i = -b.im + b.re i;  b (-i) = b.im - b.re i
-        const Elem plus{gf61::add(a.re, b.im, k), gf61::add(a.im, b.re, k)}, minus{gf61::sub(a.re, b.im, k), gf61::sub(a.im, b.re, k)};
+        const Elem plus{settle<LOOSE_OUT>(a.re + b.im, k), settle<LOOSE_OUT>(a.im + b.re, k)};
+        const Elem minus{settle<LOOSE_OUT>(diff<LOOSE_IN>(a.re, b.im), k), settle<LOOSE_OUT>(diff<LOOSE_IN>(a.im, b.re), k)};
         if constexpr (!INV) {
             xa = Elem{minus.re, plus.im};
             xb = Elem{plus.re, minus.im};
@@ -164,13 +174,20 @@ __device__ __forceinline__ void dit_bfly(Elem& xa, Elem& xb, const gf61::Twiddle
         return;
     }
     Elem b = xb;
-    if constexpr (KIND == K_GEN) b = gf61::mul(b, w, k);
-    if constexpr (KIND == K_W8 || KIND == K_W8I) b = mul_w8<KIND, INV>(b, k);
-    xa = gf61::add(a, b, k);
-    xb = gf61::sub(a, b, k);
+    if constexpr (KIND == K_ONE) {
+        xa = Elem{settle<LOOSE_OUT>(a.re + b.re, k), settle<LOOSE_OUT>(a.im + b.im, k)};
+        xb = Elem{settle<LOOSE_OUT>(diff<LOOSE_IN>(a.re, b.re), k), settle<LOOSE_OUT>(diff<LOOSE_IN>(a.im, b.im), k)};
+        return;
+    }
+    // the product is lazy whatever came in; a loose b goes through the limb split that takes any 64-bit value (K_GEN) or is
+    // folded first (w_8: its rotations want values below 2^63)
+    if constexpr (KIND == K_GEN) b = LOOSE_IN ? gf61::mul_raw(b, w, k) : gf61::mul(b, w, k);
+    if constexpr (KIND == K_W8 || KIND == K_W8I) b = mul_w8<KIND, INV>(LOOSE_IN ? gf61::fold(b, k) : b, k);
+    xa = Elem{settle<LOOSE_OUT>(a.re + b.re, k), settle<LOOSE_OUT>(a.im + b.im, k)};
+    xb = Elem{settle<LOOSE_OUT>(gf61::sub_raw(a.re, b.re), k), settle<LOOSE_OUT>(gf61::sub_raw(a.im, b.im), k)};  // b is lazy here: 2p suffices
 }
 
-template <int LOGR, int T, bool INV, bool DIT>
+template <int LOGR, int T, bool INV, bool DIT, bool LOOSE_IN, bool LOOSE_OUT>
 __device__ __forceinline__ void small_level(Elem (&x)[1 << LOGR], const gf61::Opaque& k, const SmallRoots& sr)
 {
     static_assert(T <= 3, "roots of order <= 16 inside a run");
@@ -184,8 +201,8 @@ __device__ __forceinline__ void small_level(Elem (&x)[1 << LOGR], const gf61::Op
             if constexpr (KIND == K_GEN) w = w16_twiddle<INV>(sr, m);
 #pragma unroll
             for (int j0 = 0; j0 < R; j0 += 2 * half) {
-                if constexpr (DIT) dit_bfly<KIND, INV>(x[j0 + m], x[j0 + m + half], w, k);
-                else               dif_bfly<KIND, INV>(x[j0 + m], x[j0 + m + half], w, k);
+                if constexpr (DIT) dit_bfly<KIND, INV, LOOSE_IN, LOOSE_OUT>(x[j0 + m], x[j0 + m + half], w, k);
+                else               dif_bfly<KIND, INV, LOOSE_IN, LOOSE_OUT>(x[j0 + m], x[j0 + m + half], w, k);
             }
         };
         switch (small_kind(T, m)) {
@@ -214,15 +231,21 @@ __device__ __forceinline__ void collected_twiddles(Elem (&x)[1 << LOGR], const u
 
 // LEVELS < LOGR: only the low LEVELS register bits are butterfly levels (the lane holds 2^(LOGR-LEVELS) independent groups).
 // LO_ZERO: off == 0 and sl == 0, nothing to collect (the first butterflies of a group in ntt.cpp:259-267).
+// Which levels of a run leave their outputs loose: every other one, counted from the first level the run executes, never the
+// last.  DIF runs execute T = LEVELS-1 .. 0, DIT runs T = 0 .. LEVELS-1; `step` is the position in that order.
+constexpr bool loose_out(int step, int levels) { return (step % 2) == 0 && step + 1 < levels; }
+constexpr bool loose_in(int step, int levels) { return step >= 1 && loose_out(step - 1, levels); }
+
 template <int LOGR, bool LO_ZERO, bool INV, int LEVELS = LOGR>
 __device__ __forceinline__ void dif_levels(Elem (&x)[1 << LOGR], const uint64_t* tw, uint32_t off, int sl, const gf61::Opaque& k,
                                            const SmallRoots& sr)
 {
     static_assert(LEVELS <= 4, "at most 4 levels per run");
-    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, false>(x, k, sr);
-    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, false>(x, k, sr);
-    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, false>(x, k, sr);
-    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, false>(x, k, sr);
+    // step s executes level T = LEVELS - 1 - s
+    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, false, loose_in(LEVELS - 4, LEVELS), loose_out(LEVELS - 4, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, false, loose_in(LEVELS - 3, LEVELS), loose_out(LEVELS - 3, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, false, loose_in(LEVELS - 2, LEVELS), loose_out(LEVELS - 2, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, false, loose_in(LEVELS - 1, LEVELS), loose_out(LEVELS - 1, LEVELS)>(x, k, sr);
     if constexpr (!LO_ZERO && LEVELS >= 1) collected_twiddles<LOGR, LEVELS>(x, tw, off, sl, k);
 }
 
@@ -232,10 +255,11 @@ __device__ __forceinline__ void dit_levels(Elem (&x)[1 << LOGR], const uint64_t*
 {
     static_assert(LEVELS <= 4, "at most 4 levels per run");
     if constexpr (!LO_ZERO && LEVELS >= 1) collected_twiddles<LOGR, LEVELS>(x, tw, off, sl, k);
-    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, true>(x, k, sr);
-    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, true>(x, k, sr);
-    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, true>(x, k, sr);
-    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, true>(x, k, sr);
+    // step s executes level T = s
+    if constexpr (LEVELS >= 1) small_level<LOGR, 0, INV, true, loose_in(0, LEVELS), loose_out(0, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 2) small_level<LOGR, 1, INV, true, loose_in(1, LEVELS), loose_out(1, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 3) small_level<LOGR, 2, INV, true, loose_in(2, LEVELS), loose_out(2, LEVELS)>(x, k, sr);
+    if constexpr (LEVELS >= 4) small_level<LOGR, 3, INV, true, loose_in(3, LEVELS), loose_out(3, LEVELS)>(x, k, sr);
 }
 
 // One register pass.  Work item = (block group g, column chunk cc); a wave owns one work item.
