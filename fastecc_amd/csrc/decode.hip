@@ -329,7 +329,7 @@ extern "C" {
 int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
 {
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
-    if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
+    if (sharded_of(c)) return sharded_decode_prepare(c, data_present, parity_present);
     const CtxInfo ci = info_of(c);
     if (ci.field == FASTECC_FIELD_GF_P61_SQUARED) {
         // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are always (2k,k) with k a power of two
@@ -549,8 +549,8 @@ int fastecc_repair(fastecc_ctx* c, void* data, void* parity, int mem_kind, void*
 static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream, void* parity_out)
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
+    if (sharded_of(c)) return sharded_decode_stripe(c, data, const_cast<void*>(parity), mem_kind, parity_out != nullptr, (hipStream_t)stream);
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
-    if (sharded_of(c)) return FASTECC_E_UNSUPPORTED;
     CallScope call(c);
     if (info_of(c).field == FASTECC_FIELD_GF_P61_SQUARED) {
         if ((((uintptr_t)data | (uintptr_t)parity) & 15u)) return FASTECC_E_INVAL;

@@ -20,6 +20,8 @@ void destroy_sharded(Sharded*);
 int sharded_encode_stripe(fastecc_ctx* shell, const void* data, void* parity, int mem_kind, hipStream_t st);
 enum { SH_PROFILE_ENABLE, SH_PROFILE_RESET, SH_SET_OPTION, SH_SET_PLAN };
 int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value);
+int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, const uint8_t* parity_present);
+int sharded_decode_stripe(fastecc_ctx* shell, void* data, void* parity, int mem_kind, bool repair, hipStream_t st);
 fastecc_ctx* sharded_child(fastecc_ctx* shell, int g);
 
 // ---- api.hip ----

@@ -195,7 +195,78 @@ int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stri
     return FASTECC_OK;
 }
 
+// Decoding on a sharded context: erasures hit whole blocks, so every slab sees the same pattern and repairs its own columns
+// with its device context's decoder.  Full stripes (root memory or host): slab g of data and parity is pulled to GPU g,
+// repaired in place, and the data slab (with `repair`: the parity slab too) pushed back; only the columns move, no exchange
+// between slabs.  data_slabs / parity_slabs given: the slabs are repaired where they live.
+int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void* const* data_slabs, void* const* parity_slabs, bool stripe_on_host,
+               bool repair, hipStream_t st)
+{
+    Sharded* s = sharded_of(shell);
+    const int G = (int)s->shards.size();
+    const size_t slab = s->slab_bytes, full = s->block_bytes;
+    DeviceSwitch restore;
+    SH_TRY(hipSetDevice(s->root));
+    SH_TRY(hipEventRecord(s->fork, st));
+    for (int g = 0; g < G; g++) {
+        Shard& sh = s->shards[g];
+        SH_TRY(hipSetDevice(sh.device));
+        char* d = data_slabs ? (char*)data_slabs[g] : nullptr;
+        char* p = parity_slabs ? (char*)parity_slabs[g] : nullptr;
+        if (!d) {
+            if (!sh.data_slab) SH_TRY(hipMalloc((void**)&sh.data_slab, s->K * slab));
+            if (!sh.parity_slab) SH_TRY(hipMalloc((void**)&sh.parity_slab, s->M * slab));
+            d = sh.data_slab;
+            p = sh.parity_slab;
+        }
+        hipStream_t q = sh.s_comp;  // one stream per slab: pull, repair, push
+        SH_TRY(hipStreamWaitEvent(q, s->fork, 0));
+        if (sh.used) SH_TRY(hipStreamWaitEvent(q, sh.ev_all, 0));
+        if (!data_slabs) {
+            int rc = copy_window(s, d, slab, (const char*)data_stripe + (size_t)g * slab, full, slab, s->K, !stripe_on_host, q);
+            if (rc == FASTECC_OK) rc = copy_window(s, p, slab, (const char*)parity_stripe + (size_t)g * slab, full, slab, s->M, !stripe_on_host, q);
+            if (rc != FASTECC_OK) return rc;
+        }
+        const int rc = repair ? fastecc_repair(sh.ctx, d, p, FASTECC_MEM_DEVICE, q) : fastecc_decode(sh.ctx, d, p, FASTECC_MEM_DEVICE, q);
+        if (rc != FASTECC_OK) return rc;
+        SH_TRY(hipSetDevice(sh.device));
+        if (!data_slabs) {
+            int rc2 = copy_window(s, (char*)data_stripe + (size_t)g * slab, full, d, slab, slab, s->K, !stripe_on_host, q);
+            if (rc2 == FASTECC_OK && repair) rc2 = copy_window(s, (char*)parity_stripe + (size_t)g * slab, full, p, slab, slab, s->M, !stripe_on_host, q);
+            if (rc2 != FASTECC_OK) return rc2;
+        }
+        SH_TRY(hipEventRecord(sh.ev_all, q));
+        sh.used = true;
+    }
+    SH_TRY(hipSetDevice(s->root));
+    for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
+    return FASTECC_OK;
+}
+
 }  // namespace
+
+int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, const uint8_t* parity_present)
+{
+    Sharded* s = sharded_of(shell);
+    std::lock_guard<std::mutex> lk(mutex_of(shell));
+    for (Shard& sh : s->shards) {  // the same pattern for every slab (each context keeps its own tables on its own device)
+        const int rc = fastecc_decode_prepare(sh.ctx, data_present, parity_present);
+        if (rc != FASTECC_OK) return rc;
+    }
+    return FASTECC_OK;
+}
+
+int sharded_decode_stripe(fastecc_ctx* shell, void* data, void* parity, int mem_kind, bool repair, hipStream_t st)
+{
+    if (mem_kind != FASTECC_MEM_DEVICE && mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_HOST_PINNED) return FASTECC_E_INVAL;
+    std::lock_guard<std::mutex> lk(mutex_of(shell));
+    const int rc = run_decode(shell, data, parity, nullptr, nullptr, mem_kind != FASTECC_MEM_DEVICE, repair, st);
+    if (rc != FASTECC_OK || mem_kind != FASTECC_MEM_HOST) return rc;
+    DeviceSwitch restore;
+    SH_TRY(hipSetDevice(sharded_of(shell)->root));
+    SH_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
 
 void destroy_sharded(Sharded* s)
 {

@@ -170,6 +170,9 @@ int fastecc_encode_columns(fastecc_ctx *ctx, const void *data, void *parity, uin
  *   Both pipeline in column sub-slabs ("sub_slabs" option, default 2; 64 words at 4 KB blocks on 8 GPUs): the copy of
  *   one sub-slab runs behind the kernels of the next.  "gather_mode": 1 = copy engines (hipMemcpy2DAsync, default),
  *   2 = a copy kernel on the sending GPU storing straight into the root's memory.
+ *   fastecc_decode_prepare / fastecc_decode / fastecc_repair work on a sharded context as well: a lost block is lost in every
+ *   slab, so each slab repairs its own columns with the same pattern; full stripes (root or host memory) are moved slab-wise
+ *   like for the encode.
  * Other entry points on a sharded context: destroy, set_option (the two above; anything else is forwarded to every
  * device context), set_plan, plan_string, profile_* (device 0's kernels); the rest return FASTECC_E_UNSUPPORTED.
  */

@@ -268,3 +268,51 @@ def test_one_context_shared_by_threads_and_streams(torch_cuda, fe, oracle):
             got = to_host(outs[i]).reshape(-1, S)
             assert np.array_equal(got, zs[i] if general else wants[i]), (general, i)
         enc.close()
+
+
+@pytest.mark.parametrize("field", ["u32", "p61"])
+def test_sharded_decode_and_repair(torch_cuda, fe, oracle, field):
+    """A lost block is lost in every slab: each slab repairs its own columns with the same pattern."""
+    torch = torch_cuda
+    N, G = 512, 4
+    rng = np.random.default_rng(17)
+    if field == "u32":
+        S = 256
+        x = rand_stripe(3, N, S)
+        par = oracle.encode_fast(x)
+        mk = lambda a: to_dev(torch, a)  # noqa: E731
+        back = lambda t: to_host(t).reshape(N, -1)  # noqa: E731
+        ctx = fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G)
+        bad = np.uint32(0xFFFFFFFF)
+    else:
+        from oracle import OracleP61
+        o61 = OracleP61()
+        x = o61.fill_splitmix(N, 32, 0x99)
+        par = o61.encode(x)
+        mk = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")  # noqa: E731
+        back = lambda t: t.cpu().numpy().view(np.uint64).reshape(N, -1)  # noqa: E731
+        ctx = fe.ShardedEncoder(2 * N, N, 16 * 32, [0] * G, field=fe.FIELD_GF_P61_SQUARED)
+        bad = np.uint64(0xFFFFFFFFFFFFFFFF)
+    lost = rng.permutation(2 * N)[:N]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    damaged, dpar = x.copy(), par.copy()
+    damaged[dp == 0] = bad
+    dpar[pp == 0] = bad
+    with ctx as senc:
+        with pytest.raises(fe.FastEccError):
+            senc.decode(mk(damaged), mk(dpar))  # no pattern yet
+        senc.decode_prepare(dp, pp)
+        d, q = mk(damaged), mk(dpar)
+        senc.decode(d, q)
+        torch.cuda.synchronize()
+        assert np.array_equal(back(d), x) and np.array_equal(back(q), dpar)
+        d, q = mk(damaged), mk(dpar)
+        senc.repair(d, q)
+        torch.cuda.synchronize()
+        assert np.array_equal(back(d), x) and np.array_equal(back(q), par)
+        if field == "u32":  # host stripes: every slab travels over its GPU's own link
+            hd, hq = damaged.copy(), dpar.copy()
+            senc.repair(hd, hq, mem=fe.MEM_HOST)
+            assert np.array_equal(hd, x) and np.array_equal(hq, par)
