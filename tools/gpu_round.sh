@@ -15,3 +15,4 @@ timeout 600 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.e
 timeout 600 bash tools/prof_stats.sh "$OUT/stats" > "$OUT/stats.txt" 2>&1; grep -E "fastecc|Name" "$OUT/stats.txt" | head -12
 timeout 300 fastecc_amd/lib/rs_hip 19 4096 > "$OUT/rs_hip.log" 2>&1; tail -3 "$OUT/rs_hip.log"
 timeout 300 fastecc_amd/lib/rs_hip 19 4096 gpus=0,0,0,0,0,0,0,0 > "$OUT/rs_hip_sharded.log" 2>&1; tail -4 "$OUT/rs_hip_sharded.log"
+[ -x oracle/_ref/rs-hip-patched ] && { timeout 300 oracle/_ref/rs-hip-patched 19 4096 > "$OUT/rs_hip_patched.log" 2>&1; tail -2 "$OUT/rs_hip_patched.log"; }
