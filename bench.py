@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 def usable_cpus():
@@ -74,6 +75,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded_one_stripe modes")
+    ap.add_argument("--sharded-timeout", type=int, default=300,
+                    help="N > 1: seconds the sharded_one_stripe measurement may take before the line is printed without it (0 = wait forever)")
     ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the gather pipeline (sharded_one_stripe)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
     ap.add_argument("--cabi-sharded-child", action="store_true", help=argparse.SUPPRESS)
@@ -256,19 +259,31 @@ def cabi_sharded_child(args):
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         return {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * bb / (ms * 1e-3) / 1e9, 2)}
 
+    def progress():
+        # one line per finished measurement: the parent keeps the last complete one, so a device fault or a hang in a
+        # later mode (peer copies have never run on this code before the first multi-GPU box) costs only that mode
+        print(json.dumps(out), flush=True)
+
+    def gathered_ok():
+        return all(torch.equal(parity.view(k, S)[:, g * w:(g + 1) * w].cpu(), pslabs[g].view(k, w).cpu()) for g in ids)
+
     out["plan"] = enc.plan()
     out["compute_only"] = timed(lambda: enc.encode_sharded(slabs, pslabs, None, stream=stream))
-    for mode, name in ((1, "copy_engine"), (2, "kernel")):
+    progress()
+    for mode, name in ((2, "kernel"), (1, "copy_engine")):
         enc.set_option("gather_mode", mode)
         for sub in (1, 2, 4):
             enc.set_option("sub_slabs", sub)
             try:
+                parity.zero_()
                 out["with_gather_%s_sub%d" % (name, sub)] = timed(lambda: enc.encode_sharded(slabs, pslabs, parity, stream=stream))
+                # correctness of what was just timed: the gathered parity equals the slabs that stayed on their GPUs
+                out["with_gather_%s_sub%d" % (name, sub)]["gather_check"] = "ok" if gathered_ok() else "FAILED"
             except Exception as e:  # noqa: BLE001
                 out["with_gather_%s_sub%d" % (name, sub)] = {"error": repr(e)}
-    # correctness of what was just timed: the gathered parity equals the slabs that stayed on their GPUs
-    ok = all(torch.equal(parity.view(k, S)[:, g * w:(g + 1) * w].cpu(), pslabs[g].view(k, w).cpu()) for g in ids)
-    out["gather_check"] = "ok" if ok else "FAILED"
+            progress()
+    checks = [v.get("gather_check") for kname, v in out.items() if kname.startswith("with_gather_") and "gather_check" in v]
+    out["gather_check"] = "ok" if checks and all(c == "ok" for c in checks) else "FAILED"
     enc.set_option("gather_mode", 1)
     enc.set_option("sub_slabs", 2)
     try:
@@ -277,8 +292,9 @@ def cabi_sharded_child(args):
         out["host_pinned_stripe"]["what"] = "pinned host stripe in, parity out: every GPU moves its slab over its own host link"
     except Exception as e:  # noqa: BLE001
         out["stripe_modes_error"] = repr(e)
+    out["complete"] = True
+    progress()
     enc.close()
-    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -369,45 +385,8 @@ def main():
     kernels = enc.profile_read()
     enc.profile(False)
 
-    # ---- BASELINE configs[3]: ONE stripe in column slabs over the ranks, gathered on rank 0 (strong scaling) ----
-    sharded = None
-    unit = 8 if p61 else 4  # bytes per tensor word
-    words = args.block_bytes // unit
-    shardable = (not args.no_sharded and args.batch == 1 and m_blocks == k and words % world == 0 and (not p61 or world > 1)
-                 and (args.block_bytes // world) % (16 if p61 else 4) == 0)
-    if shardable:
-        try:
-            from fastecc_amd import sharding
-            w = words // world
-            senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local, field=field)
-            tune(senc)
-            # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM
-            slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(k, w)
-            pslab = torch.empty_like(slab)
-            sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
-            columns = sharding.hip_columns_encoder(senc, unit // 4)
-            wsp = {}
-            modes = {"compute_only": lambda: senc.encode(slab, pslab, stream=stream),
-                     "with_gather": lambda: sharding.encode_slab_and_gather(slab, columns, k, dst=0, sub_slabs=sub, workspace=wsp,
-                                                                           collective_on_host=backend != "nccl")}
-            sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank; "
-                               "with_gather adds the RCCL gather of the parity slabs into full blocks on rank 0, "
-                               "pipelined in %d sub-slab(s)" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
-                       "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
-            for name, fn in modes.items():
-                for _ in range(max(1, args.warmup)):
-                    fn()
-                ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
-                sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
-            # what was timed is also right: the gathered blocks on rank 0 hold this rank's slab where it belongs
-            full = wsp.get("parity_full")
-            if rank == 0 and full is not None:
-                sharded["gather_check"] = "ok" if torch.equal(full[:, :w], wsp["parity_slab"]) else "FAILED"
-            senc.close()
-            del wsp, slab, pslab
-        except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of this mode
-            sharded = {"error": repr(e)}
-
+    # ---- everything the line needs from the replica measurement, before anything that could stall ----
+    roof = check = None
     if rank == 0:
         bytes_per_encode = float(k + m_blocks) * args.block_bytes * args.batch  # data + parity, RS.cpp:38
         ms_per_step = elapsed / args.steps * 1e3
@@ -416,7 +395,6 @@ def main():
         # dominant kernel by total time; a launch reads its part of the stripe once and writes it once (the
         # library reports those algorithmic bytes per launch: the whole stripe, or one column slab of it)
         dom = max(kernels.items(), key=lambda kv: kv[1][0]) if kernels else None
-        roof = None
         if dom:
             name, (ms_total, launches, nbytes) = dom
             avg_ms = ms_total / launches
@@ -442,32 +420,18 @@ def main():
                              "frac": None if p61 else round(bfly / VALU_PEAK_GBFLY, 4)},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
-        check = None
         if not args.no_parity_check and args.batch == 1 and m_blocks == k:
             try:
                 check = parity_check_p61(data, parity, k, args.block_bytes) if p61 else parity_check(enc, args.log2k, args.block_bytes, device)
             except Exception as e:  # noqa: BLE001
                 check = {"status": "error", "why": repr(e)}
-        cabi = None
-        if (world == 1 and torch.cuda.device_count() > 1 and not args.no_sharded and not p61 and args.batch == 1 and m_blocks == k
-                and not os.environ.get("FASTECC_BENCH_NO_CABI_SHARDED")):
-            # the single-process form of configs[3] on every visible GPU, in a child (its own HIP contexts; a failure
-            # or a hang costs this entry, not the line)
-            import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--cabi-sharded-child", "--steps", str(min(args.steps, 10)),
-                   "--log2k", str(args.log2k), "--block-bytes", str(args.block_bytes)]
-            try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                cabi = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
-            except Exception as e:  # noqa: BLE001
-                cabi = {"error": repr(e)}
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                cpu = (cpu_baseline_p61 if p61 else cpu_baseline)(args.cpu_log2k or args.log2k, args.block_bytes)
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                cpu = {"error": repr(e)}
+
+    emitted = threading.Event()
+
+    def emit(sharded, cabi=None, cpu=None):
+        if rank != 0 or emitted.is_set():
+            return
+        emitted.set()
         line = {
             "metric": ("encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes))
                       if m_blocks == k else
@@ -491,6 +455,116 @@ def main():
         if cabi is not None:
             line["sharded_one_stripe_c_abi"] = cabi
         print(json.dumps(line), flush=True)
+
+    # N > 1: the sharded mode below is the first thing in this file that needs every rank to make progress together inside
+    # RCCL transfers of whole parity slabs.  If it stalls, the replica number measured above must still reach the driver:
+    # after --sharded-timeout seconds rank 0 prints the line without it and every rank leaves.
+    def give_up():
+        emit({"error": "sharded_one_stripe did not finish within %d s; the line carries the replica measurement only" % args.sharded_timeout})
+        sys.stdout.flush()
+        if rank != 0:
+            time.sleep(3)  # let rank 0 print before its collectives see a peer disappear
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and args.sharded_timeout > 0:
+        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- BASELINE configs[3]: ONE stripe in column slabs over the ranks, gathered on rank 0 (strong scaling) ----
+    sharded = None
+    unit = 8 if p61 else 4  # bytes per tensor word
+    words = args.block_bytes // unit
+    shardable = (not args.no_sharded and args.batch == 1 and m_blocks == k and words % world == 0 and (not p61 or world > 1)
+                 and (args.block_bytes // world) % (16 if p61 else 4) == 0)
+    if shardable:
+        try:
+            from fastecc_amd import sharding
+            if os.environ.get("FASTECC_BENCH_TEST_STALL") and rank == world - 1:
+                time.sleep(1e6)  # test hook for the watchdog above: one rank never reaches the collectives
+            w = words // world
+            senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local, field=field)
+            tune(senc)
+            # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM
+            slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(k, w)
+            pslab = torch.empty_like(slab)
+            sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
+            columns = sharding.hip_columns_encoder(senc, unit // 4)
+            wsp = {}
+            modes = {"compute_only": lambda: senc.encode(slab, pslab, stream=stream),
+                     "with_gather": lambda: sharding.encode_slab_and_gather(slab, columns, k, dst=0, sub_slabs=sub, workspace=wsp,
+                                                                           collective_on_host=backend != "nccl")}
+            sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank; "
+                               "with_gather adds the RCCL gather of the parity slabs into full blocks on rank 0, "
+                               "pipelined in %d sub-slab(s)" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+                       "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
+            for name, fn in modes.items():
+                for _ in range(max(1, args.warmup)):
+                    fn()
+                ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
+                sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
+            # what was timed is also right: the gathered blocks on rank 0 hold this rank's slab where it belongs
+            full = wsp.get("parity_full")
+            mine = wsp["parity_slab"].to(torch.int64)
+            sums = torch.stack([mine.sum(), (mine * torch.arange(1, w + 1, device=device)).sum()])  # wraps mod 2^64: fine for a checksum
+            if world > 1:
+                sums = sums.to(device if backend == "nccl" else "cpu")
+                every = [torch.empty_like(sums) for _ in range(world)]
+                dist.all_gather(every, sums)
+            else:
+                every = [sums]
+            if rank == 0 and full is not None:
+                ok = torch.equal(full[:, :w], wsp["parity_slab"])
+                for g in range(world):  # every rank's slab arrived in its columns of the full blocks
+                    part = full[:, g * w:(g + 1) * w].to(torch.int64)
+                    want = every[g].to(part.device)
+                    ok = ok and int(part.sum()) == int(want[0]) and int((part * torch.arange(1, w + 1, device=part.device)).sum()) == int(want[1])
+                sharded["gather_check"] = "ok" if ok else "FAILED"
+            senc.close()
+            del wsp, slab, pslab
+        except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of this mode
+            sharded = {"error": repr(e)}
+
+    if watchdog is not None:
+        watchdog.cancel()
+
+    cabi = cpu = None
+    if rank == 0:
+        if (world == 1 and torch.cuda.device_count() > 1 and not args.no_sharded and not p61 and args.batch == 1 and m_blocks == k
+                and not os.environ.get("FASTECC_BENCH_NO_CABI_SHARDED")):
+            # the single-process form of configs[3] on every visible GPU, in a child (its own HIP contexts; a failure
+            # or a hang costs this entry, not the line)
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--cabi-sharded-child", "--steps", str(min(args.steps, 10)),
+                   "--log2k", str(args.log2k), "--block-bytes", str(args.block_bytes)]
+            def last_json(text):
+                if isinstance(text, bytes):
+                    text = text.decode("utf-8", "replace")
+                for ln in reversed((text or "").splitlines()):
+                    if ln.startswith("{"):
+                        try:
+                            return json.loads(ln)
+                        except ValueError:  # a line cut off by the fault that ended the child
+                            continue
+                return None
+
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+                cabi = last_json(r.stdout) or {"error": (r.stderr or r.stdout)[-400:]}
+                if not cabi.get("complete") and "error" not in cabi:
+                    cabi["incomplete"] = "child exited with code %d after these measurements: %s" % (r.returncode, (r.stderr or "")[-300:])
+            except subprocess.TimeoutExpired as e:
+                cabi = last_json(e.stdout) or {}
+                cabi["incomplete"] = "child timed out after these measurements"
+            except Exception as e:  # noqa: BLE001
+                cabi = {"error": repr(e)}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = (cpu_baseline_p61 if p61 else cpu_baseline)(args.cpu_log2k or args.log2k, args.block_bytes)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                cpu = {"error": repr(e)}
+    emit(sharded, cabi, cpu)
     enc.close()
     if world > 1:
         dist.barrier()

@@ -91,6 +91,7 @@ struct Sharded {
     uint64_t block_bytes = 0, slab_bytes = 0;
     int sub_slabs = 2;
     int gather_mode = 1;  // 1 = hipMemcpy2DAsync (copy engines), 2 = copy kernel on the slab's GPU
+    bool copy_engine_refused = false;  // mode 2 was forced by an error return of hipMemcpy2DAsync
     hipEvent_t fork = nullptr;
     std::string text;
 };
@@ -100,32 +101,38 @@ namespace {
 void describe(fastecc_ctx* shell)
 {
     Sharded* s = sharded_of(shell);
-    char buf[96];
+    char buf[128];
     snprintf(buf, sizeof buf, "%d slabs x %llu B/block, sub_slabs=%d, gather=%s | ", (int)s->shards.size(), (unsigned long long)s->slab_bytes,
-             s->sub_slabs, s->gather_mode == 2 ? "kernel" : "copy-engine");
+             s->sub_slabs, s->gather_mode == 2 ? (s->copy_engine_refused ? "kernel (copy engine refused)" : "kernel") : "copy-engine");
     set_plan_text(shell, std::string(buf) + fastecc_plan_string(s->shards[0].ctx));
 }
 
-// A [rows][width bytes] window between two pitched buffers, on `st` of the current device.
-int copy_window(const Sharded* s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, bool device_both,
+// A [rows][width bytes] window between two pitched buffers, on `st` of the current device.  Between device buffers the
+// copy engines are the default; a runtime that refuses a pitched peer copy outright switches the context to the copy
+// kernel for good (recorded in the plan string), so that the first multi-GPU box decides, not this file.
+int copy_window(Sharded* s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, bool device_both,
                 hipStream_t st)
 {
     if (rows == 0 || width == 0) return FASTECC_OK;
-    if (s->gather_mode == 2 && device_both) {
-        const bool v16 = ((width | dpitch | spitch | (uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
-        const size_t unit = v16 ? 16 : 4;
-        const uint64_t total = (uint64_t)rows * (width / unit);
-        const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 4096);
-        if (v16)
-            hipLaunchKernelGGL(copy_window_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, (uint32_t)(width / 16),
-                               (uint64_t)(spitch / 16), (uint64_t)(dpitch / 16), total);
-        else
-            hipLaunchKernelGGL(copy_window_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst,
-                               (uint32_t)(width / 4), (uint64_t)(spitch / 4), (uint64_t)(dpitch / 4), total);
-        SH_TRY(hipGetLastError());
-        return FASTECC_OK;
+    if (s->gather_mode != 2 || !device_both) {
+        const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDefault, st);
+        if (e == hipSuccess) return FASTECC_OK;
+        if (!device_both) return fail("hipMemcpy2DAsync", e);
+        (void)hipGetLastError();
+        s->gather_mode = 2;
+        s->copy_engine_refused = true;
     }
-    SH_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDefault, st));
+    const bool v16 = ((width | dpitch | spitch | (uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
+    const size_t unit = v16 ? 16 : 4;
+    const uint64_t total = (uint64_t)rows * (width / unit);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 4096);
+    if (v16)
+        hipLaunchKernelGGL(copy_window_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, (uint32_t)(width / 16),
+                           (uint64_t)(spitch / 16), (uint64_t)(dpitch / 16), total);
+    else
+        hipLaunchKernelGGL(copy_window_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst,
+                           (uint32_t)(width / 4), (uint64_t)(spitch / 4), (uint64_t)(dpitch / 4), total);
+    SH_TRY(hipGetLastError());
     return FASTECC_OK;
 }
 
@@ -192,6 +199,7 @@ int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stri
     }
     SH_TRY(hipSetDevice(s->root));
     for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
+    if (s->copy_engine_refused) describe(shell);
     return FASTECC_OK;
 }
 
@@ -240,6 +248,7 @@ int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void*
     }
     SH_TRY(hipSetDevice(s->root));
     for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
+    if (s->copy_engine_refused) describe(shell);
     return FASTECC_OK;
 }
 
@@ -324,6 +333,7 @@ int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value)
     if (what == SH_SET_OPTION && !strcmp(name, "gather_mode")) {
         if (value != 1 && value != 2) return FASTECC_E_INVAL;
         s->gather_mode = value;
+        s->copy_engine_refused = false;
         describe(shell);
         return FASTECC_OK;
     }
