@@ -776,20 +776,25 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
 // Turns a fresh (2N, N) context into the power-of-two core of a transform of order q * N: the per-block factors for all
 // q stripes (position j1*N + r holds coefficient q*bitrev(r) + j1 -> w_(2qN)^coefficient / (qN), RS.cpp:51-54 with qN for
 // N) and the tables of the two odd-radix passes (mixed_kernels.hip).
-static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user)
+static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user, const uint32_t* custom_factor = nullptr)
 {
     DeviceGuard dg(c->device);
     if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
     const uint64_t M = c->N, N1 = (uint64_t)q * M;
-    const uint32_t wN1 = gf::h_root((uint32_t)N1), wN1i = gf::h_inv(wN1), w2 = gf::h_root((uint32_t)(2 * N1));
+    const uint32_t wN1 = gf::h_root((uint32_t)N1), wN1i = gf::h_inv(wN1);
     const uint32_t inv = gf::h_inv((uint32_t)N1);
     std::vector<uint32_t> dsc(N1), twd((size_t)M * (q - 1)), twu((size_t)M * (q - 1)), dfi((size_t)q * q), dff((size_t)q * q);
     {
-        std::vector<uint32_t> pw(N1);  // w_(2 N1)^j / N1 by coefficient index
-        uint32_t d = inv;
-        for (uint64_t j = 0; j < N1; j++) {
-            pw[j] = gf::h_to_mont(d);
-            d = gf::h_mul(d, w2);
+        std::vector<uint32_t> pw(N1);  // w_(2 N1)^j / N1 by coefficient index, or the caller's factors (a transform context)
+        if (custom_factor) {
+            for (uint64_t j = 0; j < N1; j++) pw[j] = gf::h_to_mont(custom_factor[j] % gf::P);
+        } else {
+            const uint32_t w2 = gf::h_root((uint32_t)(2 * N1));
+            uint32_t d = inv;
+            for (uint64_t j = 0; j < N1; j++) {
+                pw[j] = gf::h_to_mont(d);
+                d = gf::h_mul(d, w2);
+            }
         }
         for (uint64_t j1 = 0; j1 < (uint64_t)q; j1++)
             for (uint64_t r = 0; r < M; r++) dsc[j1 * M + r] = pw[(uint64_t)q * bitrev_host((uint32_t)r, c->n) + j1];
@@ -1082,6 +1087,42 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
     *out = nullptr;
     const uint64_t k = 1ull << log2k;
     return create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, factor);
+}
+
+int create_mixed_transform_ctx(fastecc_ctx** out, int q, int log2m, uint64_t block_bytes, const uint32_t* factor, int device)
+{
+    if (!out || !factor || !radix_supported(q) || log2m < 1 || log2m > 20 || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
+    *out = nullptr;
+    const uint64_t M = 1ull << log2m;
+    const std::vector<uint32_t> ones((size_t)M, 1u);  // replaced by setup_mixed below
+    int rc = create_impl(out, 2 * M, M, log2m, block_bytes, FASTECC_FIELD_GF_FFF00001, device, 0, 1, ones.data());
+    if (rc != FASTECC_OK) return rc;
+    rc = setup_mixed(*out, q, (uint64_t)q * M, (uint64_t)q * M, factor);
+    if (rc != FASTECC_OK) {
+        fastecc_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int mixed_dif(fastecc_ctx* c, const uint32_t* in, uint32_t* out, hipStream_t st)
+{
+    if (c->q <= 1 || c->ntt_plan.empty()) return FASTECC_E_UNSUPPORTED;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    int vec = 4;
+    const uintptr_t bits = (uintptr_t)in | (uintptr_t)out;
+    while (vec > 1 && ((c->S % vec) != 0 || (c->ld % vec) != 0 || (bits % (4u * vec)) != 0)) vec >>= 1;
+    RadixArgs a{};
+    a.S = (uint32_t)c->S;
+    a.ld = (uint32_t)c->ld;
+    a.M = (uint32_t)c->N;
+    a.in = in;
+    a.out = out;
+    a.dft = c->q_dft_inv;
+    a.tw = c->q_tw_dif;
+    HIP_TRY(launch_radix(c->q, false, vec, a, st));
+    return run_passes(c, c->ntt_plan, out, out, c->tw_ntt_inv, c->tw_ntt_inv, st, 0, 0, nullptr, (uint32_t)c->q);
 }
 
 int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit, bool inverse_roots, uint32_t width, hipStream_t st)

@@ -65,6 +65,7 @@ struct DecodeState {
     uint64_t erased_parity = 0;
     uint64_t erased_data = 0, erased_total = 0;
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
+    bool mixed = false;                // mixed-radix code: `recovered` is the whole work stripe (all positions), transformed in place
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
     bool ready = false;
 };
@@ -194,18 +195,25 @@ __global__ __launch_bounds__(256) void locator_columns_kernel(const uint32_t* __
 //   gout[i] = 1 / (w^u l'(w^u)) (Montgomery) for erased data block i at u = i << e   (x l')(w^u) = (x L')(w^u) w^(-u pad) there
 __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __restrict__ lv, const uint32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ wpow, uint32_t* __restrict__ fin, uint32_t* __restrict__ gout,
-                                                            uint32_t NC, uint32_t pad, int e, uint32_t user_k)
+                                                            uint32_t NC, uint32_t pad, int e, uint32_t user_k, uint32_t q, int lg2)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
     const uint32_t st = (state[u >> 2] >> (8 * (u & 3u))) & 0xFFu;
     const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
     const uint32_t corr = wpow[back == 0 ? 0 : NC - back];  // w^(-u pad)
-    fin[u] = st == ST_HELD ? gf::mul(gf::mul(lv[2 * u], corr), gf::MONT_ONE) : 0u;
+    // where the two values for w^u sit in lv: position u for the power-of-two transform (natural order out); the way down
+    // of a mixed-radix context (mixed_dif) leaves the value at w^(-v), v = q * bitrev(r) + j1, in block j1 * 2^lg2 + r
+    uint32_t at = u;
+    if (q > 1) {
+        const uint32_t v = u == 0 ? 0u : NC - u;
+        at = (v % q << lg2) + (__brev(v / q) >> (32 - lg2));
+    }
+    fin[u] = st == ST_HELD ? gf::mul(gf::mul(lv[2 * at], corr), gf::MONT_ONE) : 0u;
     if ((u & ((1u << e) - 1u)) == 0) {
         const uint32_t i = u >> e;
         uint32_t g = 0;
-        if (st == ST_LOST && i < user_k) g = gf::mul(dev_pow(gf::mul(lv[2 * u + 1], corr), gf::P - 2u), gf::MONT_ONE);
+        if (st == ST_LOST && i < user_k) g = gf::mul(dev_pow(gf::mul(lv[2 * at + 1], corr), gf::P - 2u), gf::MONT_ONE);
         gout[i] = g;
     }
 }
@@ -345,9 +353,12 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
         return rc;
     }
-    if (ci.field != FASTECC_FIELD_GF_FFF00001 || ci.q > 1) return FASTECC_E_UNSUPPORTED;  // the decoder's transform is a power of two
+    if (ci.field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (ci.pitch != ci.words) return FASTECC_E_UNSUPPORTED;
-    const uint64_t N = ci.k;
+    // mixed-radix codes (fastecc_create_ex): the same scheme on the (2 q 2^m)-th roots of unity; the decoder's transform is a
+    // mixed-radix context one size up, the locator's values come from the way down of another one (mixed_dif)
+    const bool mixed = ci.q > 1;
+    const uint64_t N = mixed ? (uint64_t)ci.q * ci.k : ci.k;
 
     // Every code is f on a subset of the NC-th roots of unity, NC = N << e (position u <-> w_NC^u): data block i at
     // i << e (blocks k..N-1 of a zero-extended code are known zero blocks), parity at the positions fastecc_create
@@ -398,7 +409,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     d->erased_data = erased_data;
     d->erased_total = erased.size();
     d->positions = NC;
-    d->standard = ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
+    d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
+    d->mixed = mixed;
     {
         std::vector<uint32_t> plost(ci.user_m);
         d->erased_parity = 0;
@@ -419,12 +431,14 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while (T < NC - N) T <<= 1;
     int lgT = 0;
     while ((1ull << lgT) < T) lgT++;
+    if (lgT > 20) return FASTECC_E_UNSUPPORTED;  // the top of the product tree is a cyclic product of length T: w_T must exist
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
     if (!d->pattern_ntt) {
         const std::vector<uint32_t> ones(NC, 1u);
-        const int rc = create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
+        const int rc = mixed ? create_mixed_transform_ctx(&d->pattern_ntt, ci.q, lgc, 8, ones.data(), ci.device)
+                             : create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
     if (!d->pattern_buf) DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
@@ -432,8 +446,9 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         std::vector<uint32_t> factor(NC);
         const uint32_t inv_nc = gf::h_inv((uint32_t)NC);
         for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mul((uint32_t)m, inv_nc);  // x p'(x): coefficient m times m, and the 1/NC of the inverse transform
-        // fold e: only the data positions (multiples of 2^e) are evaluated
-        const int rc = create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
+        // fold e: only the data positions (multiples of 2^e) are evaluated (mixed radix: all positions, the even ones are used)
+        const int rc = mixed ? create_mixed_transform_ctx(&d->transform, ci.q, lgc, ci.words * 4, factor.data(), ci.device)
+                             : create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
     if (d->tree_T != T) {
@@ -467,7 +482,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));
     if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
-    if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, N * ci.words * 4));
+    // mixed radix: the work stripe of all NC positions, transformed in place; else the N recovered data positions
+    if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, (mixed ? NC : N) * ci.words * 4));
     if (d->standard && !d->tile_order_valid) {
         std::vector<uint32_t> order;
         if (gather_tile_order(d->transform, order)) {
@@ -518,11 +534,12 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     hipLaunchKernelGGL(locator_columns_kernel, grid(NC), dim3(256), 0, st, x, d->pattern_buf, (uint32_t)T, (uint32_t)NC);
     DEC_TRY(hipGetLastError());
     {
-        const int rc = fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, st);
+        const int rc = mixed ? mixed_dif(d->pattern_ntt, d->pattern_buf, d->pattern_buf, st)
+                             : fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, st);
         if (rc != FASTECC_OK) return rc;
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
-                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k);
+                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc);
     DEC_TRY(hipGetLastError());
     if (d->fin_first_pass != d->fin) {
         hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);
@@ -584,7 +601,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         if (rc0 != FASTECC_OK) return rc0;
     }
     Marker marker{call, st};
-    const uint64_t N = ci.k;
+    const uint64_t N = d->mixed ? (uint64_t)ci.q * ci.k : ci.k;
     const size_t block = ci.words * 4, data_bytes = ci.user_k * block, parity_bytes = ci.user_m * block;
 
     uint32_t* ddata = (uint32_t*)data;
@@ -605,10 +622,13 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     int rc = d->standard ? run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st) : FASTECC_E_UNSUPPORTED;
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
-    uint32_t* work = nullptr;
-    rc = scratch_of(d->transform, &work);
-    if (rc != FASTECC_OK) return rc;
+    uint32_t* work = d->recovered;
+    if (!d->mixed) {
+        rc = scratch_of(d->transform, &work);
+        if (rc != FASTECC_OK) return rc;
+    }
     const uint32_t S = (uint32_t)ci.words;
+    const uint32_t ld_rec = d->mixed ? 2u * S : S;  // mixed radix: data position i is row 2i of the transformed work stripe
     const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)work | (uintptr_t)d->recovered) & 15u) == 0);
     const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
     if (!fused) {
@@ -617,14 +637,14 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         if (v4) hipLaunchKernelGGL(decode_gather_kernel<4>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, d->srcmap, S, S, S, col_chunks, items);
         else    hipLaunchKernelGGL(decode_gather_kernel<1>, grid, dim3(256), 0, st, ddata, dparity, work, d->fin, d->srcmap, S, S, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
-        rc = fastecc_encode(d->transform, work, d->recovered, FASTECC_MEM_DEVICE, st);
+        rc = fastecc_encode(d->transform, work, d->mixed ? work : d->recovered, FASTECC_MEM_DEVICE, st);
         if (rc != FASTECC_OK) return rc;
     }
     {
         const uint64_t items = N * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
-        if (v4) hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, S, S, col_chunks, items);
-        else    hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, S, S, col_chunks, items);
+        if (v4) hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, ld_rec, S, col_chunks, items);
+        else    hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, ld_rec, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
     }
     }

@@ -53,6 +53,12 @@ void set_error_detail(const char* what, hipError_t e);
 // output block.  fastecc_encode(ctx, in, out, FASTECC_MEM_DEVICE, stream) runs it; k may be 2^20 (no root of order 2k
 // is needed).  The encoder of RS.cpp:40-63 is the case factor[m] = w_2k^m / k.
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device);
+// The same for a transform of order q * 2^log2m (q an odd radix of mixed_kernels.hip): factor has q << log2m entries by
+// coefficient index; fastecc_encode(ctx, in, out, DEVICE, stream) maps all q << log2m blocks, in place if in == out.
+int create_mixed_transform_ctx(fastecc_ctx** out, int q, int log2m, uint64_t block_bytes, const uint32_t* factor, int device);
+// The way down of such a context alone (inverse roots, unscaled): block j1 * 2^log2m + r of `out` holds
+// Y[q * bitrev(r) + j1],  Y[v] = sum_i in[i] w^(-i v),  w of order q << log2m.
+int mixed_dif(fastecc_ctx* c, const uint32_t* in, uint32_t* out, hipStream_t st);
 // Decoder: when the transform's first pass is a register DIF pass it can read the codeword straight from its two
 // halves (PassArgs::in_odd / row_factor) and the separate gather pass disappears.  run_gathered does that and returns
 // FASTECC_E_UNSUPPORTED (nothing enqueued) when the plan starts with another kind of pass.

@@ -112,8 +112,7 @@ def test_every_plan_and_block_pointers(torch_cuda, fe, oracle):
         enc.encode_blocks([b.ctypes.data for b in blocks])
         assert np.array_equal(np.stack(blocks), want)
         assert enc.check_range(to_dev(torch, x)) == 0
-        for call in (lambda: enc.ntt(to_dev(torch, x)), lambda: enc.encode_columns(d, d, 0, 32),
-                     lambda: enc.decode_prepare([1] * k, [1] * k)):
+        for call in (lambda: enc.ntt(to_dev(torch, x)), lambda: enc.encode_columns(d, d, 0, 32)):
             with pytest.raises(fe.FastEccError) as ei:
                 call()
             assert ei.value.code == fe.E_UNSUPPORTED
@@ -159,3 +158,121 @@ def test_large_orders_linearity_and_sampled_columns(torch_cuda, fe, oracle):
         assert np.array_equal(to_host(pa.view(k, S)[:, cols].contiguous()).reshape(k, len(cols)), want), (q, m)
         del a, pa
         torch.cuda.empty_cache()
+
+
+def erase_and_check(torch, fe, enc, x, par, lost_data, lost_parity, repair):
+    """Overwrite the lost blocks with garbage, decode (or repair) on the device, compare with the originals."""
+    k, S = x.shape
+    m = par.shape[0]
+    dp = np.ones(k, dtype=np.uint8)
+    pp = np.ones(m, dtype=np.uint8)
+    dp[lost_data] = 0
+    pp[lost_parity] = 0
+    bad_x, bad_p = x.copy(), par.copy()
+    bad_x[lost_data] = 0xEEEEEEEE
+    bad_p[lost_parity] = 0xDDDDDDDD
+    d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+    enc.decode_prepare(dp, pp)
+    if repair:
+        enc.repair(d, q)
+    else:
+        enc.decode(d, q)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_host(d).reshape(k, S), x)
+    if repair:
+        assert np.array_equal(to_host(q).reshape(m, S), par)
+    else:
+        assert np.array_equal(to_host(q).reshape(m, S), bad_p)  # decode leaves the parity stripe alone
+
+
+@pytest.mark.parametrize("q", [3, 5, 7, 9, 13, 15])
+@pytest.mark.parametrize("m,S", [(1, 3), (3, 64), (6, 40), (10, 32)])
+def test_decoder_of_mixed_radix_codes(torch_cuda, fe, oracle, q, m, S):
+    """Round trip through the encoder that test_full_codes_match_the_oracle pins: encode, lose blocks, decode = original.
+    Patterns: one block, every data block (the most the code tolerates), random halves of data and parity."""
+    torch = torch_cuda
+    k = q << m
+    rng = np.random.default_rng(q * 1000 + m)
+    x = rand_stripe(q * 10 + m, k, S)
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        out = torch.empty(k * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        torch.cuda.synchronize()
+        par = to_host(out).reshape(k, S).copy()
+        if k <= 96:
+            assert np.array_equal(par, oracle.encode_mixed(x))
+        none = np.array([], dtype=np.int64)
+        erase_and_check(torch, fe, enc, x, par, np.array([k - 1]), none, False)
+        erase_and_check(torch, fe, enc, x, par, np.arange(k), none, False)
+        for repair in (False, True):
+            lost = rng.permutation(2 * k)[:k]  # exactly n - k losses over the whole codeword
+            erase_and_check(torch, fe, enc, x, par, lost[lost < k], lost[lost >= k] - k, repair)
+        few = rng.permutation(2 * k)[: max(1, k // 7)]
+        erase_and_check(torch, fe, enc, x, par, few[few < k], few[few >= k] - k, True)
+        # one loss too many is refused
+        dp = np.zeros(k, dtype=np.uint8)
+        pp = np.ones(k, dtype=np.uint8)
+        pp[0] = 0
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.decode_prepare(dp, pp)
+        assert ei.value.code == fe.E_INVAL
+
+
+@pytest.mark.parametrize("k,m", [(5, 3), (11, 12), (100, 37), (1000, 900), (1500, 1536), (3000, 100)])
+def test_decoder_of_zero_extended_mixed_codes(torch_cuda, fe, k, m):
+    """Any k with a mixed-radix order: data blocks k..order-1 are known zeros, parity blocks m..order-1 do not exist (they count
+    as lost), so exactly m losses among the k + m blocks are repaired."""
+    torch = torch_cuda
+    S = 24
+    order = fe.mixed_radix_order(k)
+    if not order & (order - 1):
+        pytest.skip("a power of two: the ordinary code, tests/test_gpu_decode.py")
+    rng = np.random.default_rng(k * 7 + m)
+    x = rand_stripe(k + m, k, S)
+    with fe.Encoder(k + m, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        out = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        torch.cuda.synchronize()
+        par = to_host(out).reshape(m, S).copy()
+        for repair in (False, True):
+            lost = rng.permutation(k + m)[:m]
+            erase_and_check(torch, fe, enc, x, par, lost[lost < k], lost[lost >= k] - k, repair)
+        erase_and_check(torch, fe, enc, x, par, np.arange(min(k, m)), np.array([], dtype=np.int64), False)
+        # host stripes
+        dp = np.ones(k, dtype=np.uint8)
+        pp = np.ones(m, dtype=np.uint8)
+        dp[0] = 0
+        pp[m - 1] = 0
+        hx, hp = x.copy(), par.copy()
+        hx[0] = 1
+        hp[m - 1] = 2
+        enc.decode_prepare(dp, pp)
+        enc.repair(hx, hp, mem=fe.MEM_HOST)
+        assert np.array_equal(hx, x) and np.array_equal(hp, par)
+
+
+def test_decoder_at_a_large_mixed_order(torch_cuda, fe):
+    """k = 3 * 2^17 x 4 KB blocks (1.5 GiB of data): 30 % of the codeword lost, repaired, compared on the device."""
+    torch = torch_cuda
+    S, q, m = 1024, 3, 17
+    k = q << m
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(99)
+    x = torch.randint(0, P, (k * S,), generator=g, device="cuda:0", dtype=torch.int64).to(torch.int32)
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        par = torch.empty_like(x)
+        enc.encode(x, par)
+        rng = np.random.default_rng(3)
+        lost = rng.permutation(2 * k)[: int(0.3 * 2 * k)]
+        ld, lp = lost[lost < k], lost[lost >= k] - k
+        dp = np.ones(k, dtype=np.uint8)
+        pp = np.ones(k, dtype=np.uint8)
+        dp[ld] = 0
+        pp[lp] = 0
+        bx, bp = x.clone(), par.clone()
+        bx.view(k, S)[torch.from_numpy(ld).to("cuda:0")] = -1
+        bp.view(k, S)[torch.from_numpy(lp).to("cuda:0")] = -2
+        enc.decode_prepare(dp, pp)
+        enc.repair(bx, bp)
+        torch.cuda.synchronize()
+        assert torch.equal(bx, x) and torch.equal(bp, par)
