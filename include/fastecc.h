@@ -113,7 +113,8 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * RS.cpp:40-63 with N1 for N (k < N1: zero extension as in RS.md:23-33; the first n - k <= N1 of the N1 parity blocks
  * are the parity).  With q = 1 this IS fastecc_create; otherwise it is a different code than the zero-extended power-of-
  * two one fastecc_create builds for the same (n,k) — a stripe must be decoded with the flags it was encoded with.
- * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile (no decoder yet).  The odd-radix
+ * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile, and decode_prepare / decode / repair for
+ * orders up to 2^20 (the locator's product tree needs w_T, T the power of two >= the order).  The odd-radix
  * level costs two more trips through HBM than the power-of-two pipeline; measured against zero extension in
  * profiles/r02/mixed_radix_bench.json.
  */
@@ -237,7 +238,8 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity
  * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
- * as known, so exactly n - k losses are tolerated.
+ * as known, so exactly n - k losses are tolerated.  Mixed-radix codes (fastecc_create_ex) are decoded the same way on the
+ * (2 q 2^m)-th roots of unity with mixed-radix transforms, for orders q 2^m <= 2^20.
  *   fastecc_decode_prepare : set the erasure pattern, k data flags and n - k parity flags (non-zero = block survives).
  *                            The host classifies the positions; the locator's product tree, its two size-NC transforms
  *                            and the inversions run on the device (2-8 ms at (2^20,2^19); the first call also builds the
