@@ -1295,7 +1295,7 @@ int fastecc_encode_columns(fastecc_ctx* c, const void* data, void* parity, uint6
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (c->sharded) return FASTECC_E_UNSUPPORTED;
-    if (width == 0 || col0 + width > c->S) return FASTECC_E_INVAL;
+    if (width == 0 || col0 > c->S || width > c->S - col0) return FASTECC_E_INVAL;
     if (!columns_supported(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;

@@ -268,6 +268,7 @@ struct Decoder {
     uint64_t* work = nullptr;          // 2k blocks (lazy)
     uint64_t* again = nullptr;         // k parity blocks of the re-encode (lazy, repair only)
     uint64_t erased_data = 0, erased_parity = 0;
+    bool built = false;  // contexts, buffers and the w^u table exist
     bool ready = false;
 };
 
@@ -317,8 +318,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     int lgT = log2k;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
 
-    // ---- built once ----
-    if (!d->transform) {
+    // ---- built once; a failure half way leaves no decoder behind (the next call starts from scratch) ----
+    auto build_once = [&]() -> int {
         std::vector<uint64_t> factor(2 * NC);
         const gf61::Elem inv_nc = gf61::h_inv(gf61::Elem{NC % P, 0});
         for (uint64_t m = 0; m < NC; m++) {
@@ -348,6 +349,16 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         const gf61::Elem w = gf61::h_root(NC);
         hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, nullptr, d->wpow, w.re, w.im, (uint32_t)NC);
         D61_TRY(hipGetLastError());
+        d->built = true;
+        return FASTECC_OK;
+    };
+    if (!d->built) {
+        const int rc = build_once();
+        if (rc != FASTECC_OK) {
+            destroy_decoder(d);
+            *slot = nullptr;
+            return rc;
+        }
     }
     hipStream_t s0 = nullptr;
     // (the caller has waited for the last decode that used the previous pattern)
