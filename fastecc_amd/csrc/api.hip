@@ -128,9 +128,10 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
+    int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
-    static constexpr int MAX_SLABS = 8;
+    static constexpr int MAX_SLABS = 32;
     hipStream_t slab_stream[MAX_SLABS] = {};
     hipEvent_t slab_fork = nullptr, slab_first_done[MAX_SLABS] = {}, slab_done[MAX_SLABS] = {};
     bool slab_ready = false;
@@ -581,9 +582,18 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
     // Column slabs are independent transforms.  Slab h runs on its own stream and starts when slab h-1 has
     // finished its first pass, so that at any time the GPU holds one slab in each kind of pass: the
     // VALU-bound MID tiles and the HBM-bound outer tiles then share the CUs (both are 64 KiB / 16 waves).
+    const uint32_t width = (uint32_t)(c->S / H);
+    if (c->slab_mode == 1) {
+        // one slab after the other on the caller's stream: a slab's three passes follow each other closely enough for the
+        // second and third to find it in the memory-side cache (256 MB) when the slab is small enough
+        for (int h = 0; h < H; h++) {
+            const int rc1 = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st, h * width, width, nullptr, 1, cb);
+            if (rc1 != FASTECC_OK) return rc1;
+        }
+        return FASTECC_OK;
+    }
     int rc = ensure_slab_streams(c);
     if (rc != FASTECC_OK) return rc;
-    const uint32_t width = (uint32_t)(c->S / H);
     HIP_TRY(hipEventRecord(c->slab_fork, st));
     for (int h = 0; h < H; h++) {
         hipStream_t sh = c->slab_stream[h];
@@ -1653,6 +1663,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
     if (!strcmp(name, "host_slabs")) {
         if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
         c->host_slabs = value;
+        return FASTECC_OK;
+    }
+    if (!strcmp(name, "slab_mode")) {  // 0: slabs staggered on internal streams, 1: one after the other on the caller's stream
+        if (value < 0 || value > 1) return FASTECC_E_INVAL;
+        c->slab_mode = value;
         return FASTECC_OK;
     }
     if (!strcmp(name, "slabs")) {
