@@ -793,7 +793,7 @@ static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user, 
     const uint64_t M = c->N, N1 = (uint64_t)q * M;
     const uint32_t wN1 = gf::h_root((uint32_t)N1), wN1i = gf::h_inv(wN1);
     const uint32_t inv = gf::h_inv((uint32_t)N1);
-    std::vector<uint32_t> dsc(N1), twd((size_t)M * (q - 1)), twu((size_t)M * (q - 1)), dfi((size_t)q * q), dff((size_t)q * q);
+    std::vector<uint32_t> dsc(N1), twd((size_t)M * (q - 1)), twu((size_t)M * (q - 1)), dfi, dff;
     {
         std::vector<uint32_t> pw(N1);  // w_(2 N1)^j / N1 by coefficient index, or the caller's factors (a transform context)
         if (custom_factor) {
@@ -819,12 +819,9 @@ static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user, 
             twd[i2 * (q - 1) + j - 1] = gf::h_to_mont(y);
         }
     }
-    const uint32_t wq = gf::h_pow(wN1, M), wqi = gf::h_inv(wq);
-    for (int i = 0; i < q; i++)
-        for (int j = 0; j < q; j++) {
-            dff[(size_t)i * q + j] = gf::h_to_mont(gf::h_pow(wq, (uint64_t)(i * j) % q));
-            dfi[(size_t)i * q + j] = gf::h_to_mont(gf::h_pow(wqi, (uint64_t)(i * j) % q));
-        }
+    const uint32_t wq = gf::h_pow(wN1, M);
+    dff = radix_dft_table(q, wq);
+    dfi = radix_dft_table(q, gf::h_inv(wq));
     (void)hipFree(c->dscale);  // sized for one stripe by create_impl
     c->dscale = nullptr;
     int rc = upload_table(&c->dscale, dsc);

@@ -1,5 +1,6 @@
 // kernels.hpp — launcher interface between the C-ABI host code (api.hip) and the gfx950 kernels.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,7 +66,7 @@ struct TileArgs {
 struct RadixArgs {
     const uint32_t* in;   // stripe of q * M blocks read by this pass
     uint32_t* out;        // stripe written (may equal `in`: a wave reads and writes the same q rows)
-    const uint32_t* dft;  // q x q: w_q^(+-i*j), Montgomery form
+    const uint32_t* dft;  // constants of the q-point transform (radix_dft_table), Montgomery form
     const uint32_t* tw;   // M x (q-1): w_(q*M)^(+-i2*j), j = 1..q-1, Montgomery form
     uint32_t S;           // words per block
     uint32_t ld;          // words between consecutive blocks
@@ -76,6 +77,7 @@ struct RadixArgs {
     uint64_t items;       // filled by the launcher
 };
 bool radix_supported(int q);
+std::vector<uint32_t> radix_dft_table(int q, uint32_t wq);  // host: wq = the primitive q-th root of the direction
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st);
 
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
