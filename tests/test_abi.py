@@ -100,3 +100,32 @@ def test_p61_field_host_helpers_and_validation(hip_lib):
     assert create(ctypes.byref(h), 256, 128, 4100, fe.FIELD_GF_P61_SQUARED, 0) == fe.E_INVAL      # block_bytes % 16
     assert create(ctypes.byref(h), 1 << 26, 1 << 25, 64, fe.FIELD_GF_P61_SQUARED, 0) == fe.E_UNSUPPORTED
     assert not h.value
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path, hip_lib):
+    """include/fastecc.h must be consumable by the bindings INTEGRATION.md shows (cgo, JNI, ctypes are all C): compile a C99
+    translation unit that takes the address of every entry point, link it against the library, and run it without a GPU
+    (argument validation and the host-side field helpers only)."""
+    import subprocess
+    from fastecc_amd import _build
+    names = declared_symbols()
+    src = tmp_path / "host.c"
+    src.write_text(
+        '#include "fastecc.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "    typedef void (*entry_point)(void);\n"
+        "    entry_point entry[] = {" + ", ".join("(entry_point)%s" % n for n in names) + "};\n"
+        "    fastecc_ctx *ctx = 0;\n"
+        "    if (fastecc_create(&ctx, 8, 8, 64, FASTECC_FIELD_GF_FFF00001, 0) != FASTECC_E_INVAL) return 2;  /* n <= k */\n"
+        "    if (fastecc_encode(0, 0, 0, FASTECC_MEM_DEVICE, 0) != FASTECC_E_INVAL) return 3;\n"
+        "    if (fastecc_gf_mul(2, 3) != 6u || fastecc_version() != FASTECC_VERSION) return 4;\n"
+        '    printf("%d entry points\\n", (int)(sizeof entry / sizeof entry[0]));\n'
+        "    return 0;\n}\n")
+    exe = tmp_path / "host"
+    lib_dir = os.path.dirname(_build.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-lfastecc_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip() == "%d entry points" % len(names) and len(names) >= 30
