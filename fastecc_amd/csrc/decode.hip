@@ -571,14 +571,15 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     CallScope call(c);
     if (info_of(c).field == FASTECC_FIELD_GF_P61_SQUARED) {
         if ((((uintptr_t)data | (uintptr_t)parity) & 15u)) return FASTECC_E_INVAL;
-        if (mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_UNSUPPORTED;  // this field's decoder works on device stripes
         p61::Decoder* d61 = decoder61_of(c);
         if (!p61::decoder_ready(d61)) return FASTECC_E_INVAL;
         DeviceScope ds61(info_of(c).device);
         if (!ds61.ok) return FASTECC_E_DEVICE;
         int rc61 = call.begin((hipStream_t)stream);  // the decoder's work stripe and tables are internal buffers
         if (rc61 != FASTECC_OK) return rc61;
-        rc61 = p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
+        rc61 = mem_kind == FASTECC_MEM_DEVICE
+                   ? p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr)
+                   : p61::decode_host(d61, data, const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
         const int rc_end = call.end((hipStream_t)stream);
         return rc61 != FASTECC_OK ? rc61 : rc_end;
     }

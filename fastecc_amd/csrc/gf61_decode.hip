@@ -267,6 +267,7 @@ struct Decoder {
     uint8_t* state = nullptr;
     uint64_t* work = nullptr;          // 2k blocks (lazy)
     uint64_t* again = nullptr;         // k parity blocks of the re-encode (lazy, repair only)
+    uint64_t* stage = nullptr;         // data + parity stripes of a host-memory call (lazy)
     uint64_t erased_data = 0, erased_parity = 0;
     bool built = false;  // contexts, buffers and the w^u table exist
     bool ready = false;
@@ -281,7 +282,7 @@ void destroy_decoder(Decoder* d)
     destroy(d->pattern);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
-                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again})
+                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again, (void*)d->stage})
         if (b) (void)hipFree(b);
     delete d;
 }
@@ -437,6 +438,28 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         hipLaunchKernelGGL(k_restore, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->state, elems, col_chunks, items);
         D61_TRY(hipGetLastError());
     }
+    return FASTECC_OK;
+}
+
+// The same for stripes in (pageable) host memory: staged through HBM, synchronous.
+int decode_host(Decoder* d, void* data, void* parity, Path* rebuild_with, hipStream_t s0, const LaunchHooks* hooks)
+{
+    if (!d || !d->ready) return FASTECC_E_INVAL;
+    char* detail = nullptr;
+    const size_t cap = 0;
+    const bool rebuild = rebuild_with != nullptr && d->erased_parity != 0;
+    if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
+    const size_t stripe = d->N * d->elems * 16;
+    if (!d->stage) D61_TRY(hipMalloc((void**)&d->stage, 2 * stripe));
+    uint64_t* ddata = d->stage;
+    uint64_t* dpar = d->stage + stripe / 8;
+    D61_TRY(hipMemcpyAsync(ddata, data, stripe, hipMemcpyHostToDevice, s0));
+    D61_TRY(hipMemcpyAsync(dpar, parity, stripe, hipMemcpyHostToDevice, s0));
+    const int rc = decode(d, ddata, dpar, rebuild_with, s0, hooks);
+    if (rc != FASTECC_OK) return rc;
+    if (d->erased_data != 0) D61_TRY(hipMemcpyAsync(data, ddata, stripe, hipMemcpyDeviceToHost, s0));
+    if (rebuild) D61_TRY(hipMemcpyAsync(parity, dpar, stripe, hipMemcpyDeviceToHost, s0));
+    D61_TRY(hipStreamSynchronize(s0));
     return FASTECC_OK;
 }
 

@@ -49,6 +49,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
 // Recover the erased data blocks in place (device pointers, enqueued on st); rebuild_with != null: also re-encode with that
 // path (the context's encoder) and write the lost parity blocks into `parity`.
 int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hipStream_t st, const LaunchHooks* hooks);
+// host-memory stripes: staged through device buffers of the decoder, synchronous
+int decode_host(Decoder* d, void* data, void* parity, Path* rebuild_with, hipStream_t st, const LaunchHooks* hooks);
 bool decoder_ready(const Decoder* d);
 
 }  // namespace p61

@@ -233,7 +233,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
 /*
  * Erasure decoding: recover the erased DATA blocks from any k or more surviving blocks of the codeword.  Both fields:
  * GF(0xFFF00001) as described below; GF((2^61-1)^2) for its (2k,k) codes with the same scheme on 16-byte elements
- * (gf61_decode.hip; FASTECC_MEM_DEVICE stripes only).  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
+ * (gf61_decode.hip).  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity

@@ -110,10 +110,11 @@ def test_patterns_can_change_and_errors(torch_cuda, fe, oracle):
         d = to_dev(torch, x)
         enc.decode(d, to_dev(torch, par))
         assert (to_host(d, (N, S)) == x).all()
-    with fe.Encoder(2 * 96, 96, 64, flags=fe.CODE_MIXED_RADIX) as enc:   # no decoder for the mixed-radix codes yet
-        with pytest.raises(fe.FastEccError) as ei:
-            enc.decode_prepare(np.ones(96, np.uint8), np.ones(96, np.uint8))
-        assert ei.value.code == fe.E_UNSUPPORTED
+    with fe.Encoder(2 * 96, 96, 64, flags=fe.CODE_MIXED_RADIX) as enc:   # the mixed-radix codes decode too (tests/test_gpu_mixed.py)
+        enc.decode_prepare(np.ones(96, np.uint8), np.ones(96, np.uint8))
+        with pytest.raises(fe.FastEccError) as ei:                        # and refuse what no code can repair
+            enc.decode_prepare(np.zeros(96, np.uint8), np.r_[np.zeros(1, np.uint8), np.ones(95, np.uint8)])
+        assert ei.value.code == fe.E_INVAL
 
 
 @pytest.mark.parametrize("lost_fraction", [0.02, 0.5])

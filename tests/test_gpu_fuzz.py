@@ -161,9 +161,13 @@ def test_random_p61_configuration(torch_cuda, fe, seed):
         bx, bp = x.copy(), want.copy()
         bx[dp == 0] = 7
         bp[pp == 0] = 9
+        enc.decode_prepare(dp, pp)
+        if seed % 2:
+            enc.repair(bx, bp, mem=fe.MEM_HOST)  # stripes in host memory
+            assert np.array_equal(bx, x) and np.array_equal(bp, want), what
+            return
         dd = torch.from_numpy(bx.view(np.int64).reshape(-1)).to("cuda:0")
         dq = torch.from_numpy(bp.view(np.int64).reshape(-1)).to("cuda:0")
-        enc.decode_prepare(dp, pp)
         enc.repair(dd, dq)
         torch.cuda.synchronize()
         assert np.array_equal(dd.cpu().numpy().view(np.uint64).reshape(k, 2 * E), x), what

@@ -276,9 +276,10 @@ def test_decode_patterns_change_and_errors(torch_cuda, fe, orc61):
         with pytest.raises(fe.FastEccError) as ei:  # N + 1 losses
             enc.decode_prepare(dp, pp)
         assert ei.value.code == fe.E_INVAL
-        with pytest.raises(fe.FastEccError) as ei:
-            enc.decode(x, par, mem=fe.MEM_HOST)
-        assert ei.value.code in (fe.E_UNSUPPORTED, fe.E_INVAL)
+        # the refused pattern changed nothing: the last accepted one still decodes — here from stripes in host memory
+        host = damaged.copy()
+        enc.decode(host, par, mem=fe.MEM_HOST)
+        assert (host == x).all()
 
 
 def test_decode_at_2_16_blocks(torch_cuda, fe):
