@@ -36,6 +36,8 @@ struct Pass {
     bool pair;  // tile only: 32-word rows with the cross-lane top level
     int rlog;   // tile only: log2 of the words a lane keeps in registers (5, or 4 for the slim outer tiles)
     int wide = 0;  // tile only: the tile's blocks span >= 2^32 bytes and are addressed through this many windows (2, 4, 8)
+    int fused = 0;  // > 0: this outer tile also does the odd-radix level of a mixed-radix context (mixed_kernels.hip: fused_radix_kernel,
+                    // launched by encode_mixed; run_passes skips it).  rlog = its register run, pair = false.
 };
 
 struct ProfileRec {
@@ -135,6 +137,7 @@ struct fastecc_ctx {
     hipStream_t slab_stream[MAX_SLABS] = {};
     hipEvent_t slab_fork = nullptr, slab_first_done[MAX_SLABS] = {}, slab_done[MAX_SLABS] = {};
     bool slab_ready = false;
+    int fuse_radix = 1;      // mixed-radix contexts: fuse the odd-radix level into the outermost tile where a shape exists (option "fuse_radix")
     bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
     bool prefetch = false;   // ... that request the next tile before computing the current one
@@ -250,15 +253,19 @@ void build_plans(fastecc_ctx* c)
     if (!mid_tile && mid < c->fold) mid = std::min(n, c->fold);  // a register MID pass drops blocks within its own 2^mid
     const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
     const std::vector<int> outer = split_levels(n - mid, max_chunk);
+    // mixed radix: one outer chunk and a fused shape for it -> the odd-radix level rides on that pass (3 trips instead of 5)
+    const int fused_run = (c->q > 1 && c->fuse_radix && outer.size() == 1) ? fused_rlog(c->q, outer[0]) : 0;
     int s = n;
     for (int r : outer) {
         s -= r;
-        push_chunk(c->encode_plan, MODE_DIF, r, s, c);
+        if (fused_run) c->encode_plan.push_back({MODE_DIF, r, s, true, false, fused_run, 0, c->q});
+        else push_chunk(c->encode_plan, MODE_DIF, r, s, c);
     }
     c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair, 5});
     s = mid;
     for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
-        push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
+        if (fused_run) c->encode_plan.push_back({MODE_DIT, *it, s, true, false, fused_run, 0, c->q});
+        else push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
         s += *it;
     }
     // stand-alone transform: DIF over all levels, then the block bit-reversal
@@ -270,11 +277,16 @@ void build_plans(fastecc_ctx* c)
     char buf[64];
     c->plan_text.clear();
     for (const Pass& p : c->encode_plan) {
+        if (p.fused) {  // R<q>+: the odd-radix level and these levels in one pass
+            snprintf(buf, sizeof buf, "%sR%d+%s%d@%d", c->plan_text.empty() ? "" : ",", p.fused, p.mode == MODE_DIF ? "dif" : "dit", p.logr, p.s);
+            c->plan_text += buf;
+            continue;
+        }
         snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : p.wide == 8 ? "SW8x32:" : "SW16x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
                  p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
         c->plan_text += buf;
     }
-    if (c->q > 1) {  // the odd-radix level around the power-of-two pipeline (mixed_kernels.hip)
+    if (c->q > 1 && !fused_run) {  // the odd-radix level around the power-of-two pipeline (mixed_kernels.hip)
         snprintf(buf, sizeof buf, "R%d:dif1@%d,", c->q, c->n);
         c->plan_text = std::string(buf) + c->plan_text;
         snprintf(buf, sizeof buf, ",R%d:dit1@%d", c->q, c->n);
@@ -430,6 +442,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
     if (!staged) {
         bool first = true;
         for (const Pass& p : plan) {
+            if (p.fused) continue;  // encode_mixed launches it
             const int rc = run_one(p, src, out, c->dscale, &p == &plan.back());
             if (rc != FASTECC_OK) return rc;
             src = out;  // after the first pass everything is in place on `out`
@@ -514,6 +527,45 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
     const uintptr_t bits = (uintptr_t)data | (uintptr_t)work | (uintptr_t)parity;
     while (vec > 1 && ((c->S % vec) != 0 || (c->ld % vec) != 0 || (bits % (4u * vec)) != 0)) vec >>= 1;
     char name[32];
+    if (!c->encode_plan.empty() && c->encode_plan.front().fused) {
+        // [odd radix + outer DIF tile][MID on q stripes][outer DIT tile + odd radix]: three trips through HBM
+        const Pass& pd = c->encode_plan.front();
+        const Pass& pu = c->encode_plan.back();
+        FusedArgs f{};
+        f.S = (uint32_t)c->S;
+        f.ld = (uint32_t)c->ld;
+        f.M = (uint32_t)c->N;
+        {
+            f.in = data;
+            f.out = work;
+            f.dft = c->q_dft_inv;
+            f.tw = c->q_tw_dif;
+            f.twl = c->tw_enc_dif;
+            f.s = pd.s;
+            f.in_rows = c->K != N1 ? (uint32_t)c->K : 0;
+            snprintf(name, sizeof name, "fused%d_dif%d", c->q, pd.logr);
+            ProfScope ps(c, st, name, (c->K + N1) * c->S * 4ull);
+            HIP_TRY(launch_fused(c->q, pd.logr, false, f, st));
+        }
+        CallBounds cbm;
+        cbm.dscale_whole = true;
+        const int rcm = run_passes(c, c->encode_plan, work, work, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, (uint32_t)c->q, cbm);
+        if (rcm != FASTECC_OK) return rcm;
+        {
+            f.in = work;
+            f.out = parity;
+            f.dft = c->q_dft_fwd;
+            f.tw = c->q_tw_dit;
+            f.twl = c->tw_enc_dit;
+            f.s = pu.s;
+            f.in_rows = 0;
+            f.out_rows = c->Mu != N1 ? (uint32_t)c->Mu : 0;
+            snprintf(name, sizeof name, "fused%d_dit%d", c->q, pu.logr);
+            ProfScope ps(c, st, name, (N1 + c->Mu) * c->S * 4ull);
+            HIP_TRY(launch_fused(c->q, pu.logr, true, f, st));
+        }
+        return FASTECC_OK;
+    }
     RadixArgs a{};
     a.S = (uint32_t)c->S;
     a.ld = (uint32_t)c->ld;
@@ -835,8 +887,8 @@ static int setup_mixed(fastecc_ctx* c, int q, uint64_t k_user, uint64_t m_user, 
     c->Mu = m_user;
     c->stripe_bytes = (size_t)N1 * c->S * 4;  // the staging stripe of the host-memory calls holds all q * N blocks
     c->parity_bytes = (size_t)m_user * c->S * 4;
-    build_plans(c);  // the same passes; the plan text now names the two odd-radix passes
-    return FASTECC_OK;
+    build_plans(c);  // the odd-radix level joins the plan: its own two passes, or fused into the outer tiles (other run lengths)
+    return upload_twiddles(c);
 }
 
 extern "C" {
@@ -1661,6 +1713,14 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
         c->host_slabs = value;
         return FASTECC_OK;
+    }
+    if (!strcmp(name, "fuse_radix")) {  // mixed-radix contexts: 1 = odd-radix level fused into the outer tiles (default), 0 = its own passes
+        if (value < 0 || value > 1) return FASTECC_E_INVAL;
+        if (c->fuse_radix == value) return FASTECC_OK;
+        c->fuse_radix = value;
+        HIP_TRY(hipDeviceSynchronize());
+        build_plans(c);
+        return upload_twiddles(c);
     }
     if (!strcmp(name, "slab_mode")) {  // 0: slabs staggered on internal streams, 1: one after the other on the caller's stream
         if (value < 0 || value > 1) return FASTECC_E_INVAL;

@@ -76,6 +76,21 @@ struct RadixArgs {
     uint32_t col_chunks;  // filled by the launcher
     uint64_t items;       // filled by the launcher
 };
+// Arguments of the odd-radix level fused with the outermost power-of-two tile (mixed_kernels.hip: fused_radix_kernel).
+struct FusedArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    const uint32_t* dft;  // radix_dft_table of the direction
+    const uint32_t* tw;   // M x (q-1) twiddles of the odd-radix level (as in RadixArgs)
+    const uint32_t* twl;  // level-packed twiddles of the power-of-two levels (DIF or DIT table of the plan)
+    uint32_t S, ld, M;
+    uint32_t in_rows, out_rows;
+    int s;                // the tile covers levels [s, s + A) of the size-M transforms
+    uint32_t col_chunks;  // filled by the launcher
+};
+// the register run length the fused kernel uses for (q, A levels), 0 if that shape is not instantiated
+int fused_rlog(int q, int levels);
+hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st);
 bool radix_supported(int q);
 std::vector<uint32_t> radix_dft_table(int q, uint32_t wq);  // host: wq = the primitive q-th root of the direction
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st);

@@ -87,43 +87,52 @@ template <int Q> constexpr int out_slot(int j)
     return j;
 }
 
-template <int Q, int V>
-__device__ __forceinline__ void small_dft(uint32_t (&x)[Q][V], const_u32_ptr tab)
+// In-place Q-point transform of the values *p[0..Q-1] (p: anything indexable that yields pointers to uint32_t[V] registers);
+// X[j] ends up in *p[out_slot<Q>(j)].
+template <int Q, int V, typename Slots>
+__device__ __forceinline__ void small_dft_at(const Slots& p, const_u32_ptr tab)
 {
+    using Reg = uint32_t(*)[V];
     if constexpr (Q == 9) {
         // tab: C3, S3 (root w^3), then w^(i2*j1) for (i2, j1) = (1,1), (1,2), (2,1), (2,2)
 #pragma unroll
         for (int i2 = 0; i2 < 3; ++i2) {
-            uint32_t(*const p[3])[V] = {&x[i2], &x[3 + i2], &x[6 + i2]};
-            sym_dft<3, V>(p, tab);
+            const Reg t[3] = {p[i2], p[3 + i2], p[6 + i2]};
+            sym_dft<3, V>(t, tab);
         }
-        vmul<V>(x[3 + 1], x[3 + 1], tab[2]);
-        vmul<V>(x[6 + 1], x[6 + 1], tab[3]);
-        vmul<V>(x[3 + 2], x[3 + 2], tab[4]);
-        vmul<V>(x[6 + 2], x[6 + 2], tab[5]);
+        vmul<V>(*p[3 + 1], *p[3 + 1], tab[2]);
+        vmul<V>(*p[6 + 1], *p[6 + 1], tab[3]);
+        vmul<V>(*p[3 + 2], *p[3 + 2], tab[4]);
+        vmul<V>(*p[6 + 2], *p[6 + 2], tab[5]);
 #pragma unroll
         for (int j1 = 0; j1 < 3; ++j1) {
-            uint32_t(*const p[3])[V] = {&x[3 * j1], &x[3 * j1 + 1], &x[3 * j1 + 2]};
-            sym_dft<3, V>(p, tab);
+            const Reg t[3] = {p[3 * j1], p[3 * j1 + 1], p[3 * j1 + 2]};
+            sym_dft<3, V>(t, tab);
         }
     } else if constexpr (Q == 15) {
         // tab: C3, S3 (root w^5), then the 2 x 2 C and S tables of the 5-point transform (root w^3)
 #pragma unroll
         for (int i2 = 0; i2 < 5; ++i2) {
-            uint32_t(*const p[3])[V] = {&x[(3 * i2) % 15], &x[(5 + 3 * i2) % 15], &x[(10 + 3 * i2) % 15]};
-            sym_dft<3, V>(p, tab);
+            const Reg t[3] = {p[(3 * i2) % 15], p[(5 + 3 * i2) % 15], p[(10 + 3 * i2) % 15]};
+            sym_dft<3, V>(t, tab);
         }
 #pragma unroll
         for (int j1 = 0; j1 < 3; ++j1) {
-            uint32_t(*const p[5])[V] = {&x[(5 * j1) % 15], &x[(5 * j1 + 3) % 15], &x[(5 * j1 + 6) % 15], &x[(5 * j1 + 9) % 15], &x[(5 * j1 + 12) % 15]};
-            sym_dft<5, V>(p, tab + 2);
+            const Reg t[5] = {p[(5 * j1) % 15], p[(5 * j1 + 3) % 15], p[(5 * j1 + 6) % 15], p[(5 * j1 + 9) % 15], p[(5 * j1 + 12) % 15]};
+            sym_dft<5, V>(t, tab + 2);
         }
     } else {
-        uint32_t(*p[Q])[V];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) p[i] = &x[i];
         sym_dft<Q, V>(p, tab);
     }
+}
+
+template <int Q, int V>
+__device__ __forceinline__ void small_dft(uint32_t (&x)[Q][V], const_u32_ptr tab)
+{
+    uint32_t(*p[Q])[V];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) p[i] = &x[i];
+    small_dft_at<Q, V>(p, tab);
 }
 
 }  // namespace
@@ -166,6 +175,181 @@ __global__ __launch_bounds__(256) void radix_kernel(const RadixArgs a)
         }
         const uint32_t row = (uint32_t)j * a.M + i2;
         if (a.out_rows == 0 || row < a.out_rows) store_vec<V>(a.out + (size_t)row * a.ld + col, y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The odd-radix level fused with the A outermost power-of-two levels: one trip through HBM instead of two.
+//
+// A workgroup owns, for one (hi, lo) and one 64-word column chunk, the 2^A rows i2 = (hi << (s+A)) + (r << s) + lo of ALL q
+// stripes.  A lane is one word column; the G = 2^(A-RLOG) waves hold
+//     layout A  rows r = j*G + g  (j < R = 2^RLOG): the q-point transforms (each needs the q blocks i1*M + i2 of one r) and the
+//               high RLOG levels are in-thread, all twiddles wave-uniform scalars;
+//     layout B  rows r = g*R + k: the low A - RLOG levels are in-thread,
+// and LDS is touched only to turn A into B, one stripe at a time (2^A rows of 256 bytes, conflict-free).  Way down:
+// load A -> q-point transforms + twiddles -> per stripe: high levels, A=>B, low levels -> store B.  Way up: the mirror image.
+// Reads happen before the first barrier and writes after it, so the pass may run in place.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int A, int RLOG, bool DIT>
+__global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const FusedArgs a)
+{
+    constexpr int R = 1 << RLOG, L2 = A - RLOG, G = 1 << L2;
+    static_assert(L2 >= 0 && L2 <= RLOG, "fused tile shape");
+    extern __shared__ uint32_t lds[];  // 2^A rows of 64 words (unused when L2 == 0)
+    const uint32_t g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t cc = tile % a.col_chunks;
+    const uint32_t grp = tile / a.col_chunks;
+    const uint32_t col = cc * 64u + lane;
+    const bool live = col < a.S;
+    const int s = a.s;
+    const uint32_t lo = grp & ((1u << s) - 1u);
+    const uint32_t hi = grp >> s;
+    const uint32_t row0 = (hi << (s + A)) + lo;  // row of the tile's r = 0 inside a stripe
+    const_u32_ptr dft = as_constant(a.dft);
+    uint32_t* my_lds = lds + lane;
+
+    auto row_a = [&](int j) { return (uint32_t)j * G + g; };
+    auto row_b = [&](int k) { return g * R + (uint32_t)k; };
+    uint32_t x[Q][R][1];
+
+    // one stripe's registers from layout `from` to layout `to`
+    auto exchange = [&](uint32_t (&y)[R][1], auto from, auto to) {
+        if constexpr (L2 > 0) {
+            __syncthreads();  // the previous stripe's reads are done
+#pragma unroll
+            for (int j = 0; j < R; ++j) my_lds[from(j) * 64u] = y[j][0];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < R; ++j) y[j][0] = my_lds[to(j) * 64u];
+        }
+    };
+    // the q-point transforms of register row j (tile row r): twiddles w_N^(+-i2*j1) before (way up) or after (way down)
+    auto radix = [&](int j, uint32_t r) {
+        const uint32_t i2 = row0 + (r << s);
+        const_u32_ptr tw = as_constant(a.tw) + (size_t)i2 * (Q - 1);
+        uint32_t(*p[Q])[1];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) p[i] = &x[i][j];
+        if constexpr (DIT) {
+#pragma unroll
+            for (int i = 1; i < Q; ++i) x[i][j][0] = gf::mul_mont(x[i][j][0], tw[i - 1]);
+        }
+        small_dft_at<Q, 1>(p, dft);
+        if constexpr (!DIT) {
+#pragma unroll
+            for (int i = 1; i < Q; ++i) x[out_slot<Q>(i)][j][0] = gf::mul_mont(x[out_slot<Q>(i)][j][0], tw[i - 1]);
+        }
+    };
+
+    if constexpr (!DIT) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint32_t row = (uint32_t)i * a.M + row0 + (row_a(j) << s);
+                x[i][j][0] = (live && (a.in_rows == 0 || row < a.in_rows)) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
+            }
+#pragma unroll
+        for (int j = 0; j < R; ++j) radix(j, row_a(j));
+#pragma unroll
+        for (int j1 = 0; j1 < Q; ++j1) {
+            uint32_t(&y)[R][1] = x[out_slot<Q>(j1)];  // stripe j1
+            dif_levels<RLOG, 1, false, RLOG>(y, a.twl, (g << s) + lo, s + L2);
+            exchange(y, row_a, row_b);
+            if constexpr (L2 > 0) dif_levels<RLOG, 1, false, L2>(y, a.twl, lo, s);
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const uint32_t row = (uint32_t)j1 * a.M + row0 + ((L2 > 0 ? row_b(k) : row_a(k)) << s);
+                    __builtin_nontemporal_store(y[k][0], a.out + (size_t)row * a.ld + col);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j1 = 0; j1 < Q; ++j1)  // every load of the tile is in flight before the first barrier
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const uint32_t row = (uint32_t)j1 * a.M + row0 + ((L2 > 0 ? row_b(k) : row_a(k)) << s);
+                x[j1][k][0] = live ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
+            }
+#pragma unroll
+        for (int j1 = 0; j1 < Q; ++j1) {
+            uint32_t(&y)[R][1] = x[j1];
+            if constexpr (L2 > 0) dit_levels<RLOG, 1, false, L2>(y, a.twl, lo, s);
+            exchange(y, row_b, row_a);
+            dit_levels<RLOG, 1, false, RLOG>(y, a.twl, (g << s) + lo, s + L2);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) radix(j, row_a(j));
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < Q; ++t)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const uint32_t row = (uint32_t)t * a.M + row0 + (row_a(j) << s);
+                    if (a.out_rows == 0 || row < a.out_rows) __builtin_nontemporal_store(x[out_slot<Q>(t)][j][0], a.out + (size_t)row * a.ld + col);
+                }
+        }
+    }
+}
+
+// register run length per radix: q * 2^RLOG values per lane must fit the register file at a useful occupancy
+constexpr int fused_rmax(int q) { return q <= 5 ? 4 : q <= 9 ? 3 : 0; }
+int fused_rlog(int q, int levels)
+{
+    const int rmax = fused_rmax(q);
+    if (rmax == 0 || levels < 1 || levels > 8) return 0;
+    if (q == 5 && levels == 8) return 0;  // 80 values per lane in a 1024-lane workgroup: spills
+    const int rlog = levels < rmax ? levels : rmax;
+    return levels - rlog <= rlog ? rlog : 0;
+}
+
+template <int Q, int A, bool DIT>
+static hipError_t launch_fused_shape(const FusedArgs& a, unsigned tiles, hipStream_t st)
+{
+    constexpr int RLOG = A < fused_rmax(Q) ? A : fused_rmax(Q);
+    if constexpr (A - RLOG > RLOG) {
+        return hipErrorInvalidValue;
+    } else {
+        constexpr int lds_bytes = A > RLOG ? (1 << A) * 256 : 0;
+        hipLaunchKernelGGL((fused_radix_kernel<Q, A, RLOG, DIT>), dim3(tiles), dim3(64 << (A - RLOG)), lds_bytes, st, a);
+        return hipGetLastError();
+    }
+}
+
+template <int Q, bool DIT>
+static hipError_t launch_fused_q(int levels, const FusedArgs& a, unsigned tiles, hipStream_t st)
+{
+    switch (levels) {
+        case 1: return launch_fused_shape<Q, 1, DIT>(a, tiles, st);
+        case 2: return launch_fused_shape<Q, 2, DIT>(a, tiles, st);
+        case 3: return launch_fused_shape<Q, 3, DIT>(a, tiles, st);
+        case 4: return launch_fused_shape<Q, 4, DIT>(a, tiles, st);
+        case 5: return launch_fused_shape<Q, 5, DIT>(a, tiles, st);
+        case 6: return launch_fused_shape<Q, 6, DIT>(a, tiles, st);
+        case 7: return launch_fused_shape<Q, 7, DIT>(a, tiles, st);
+        case 8:
+            if constexpr (Q == 3) return launch_fused_shape<Q, 8, DIT>(a, tiles, st);
+            else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st)
+{
+    if (fused_rlog(q, levels) == 0 || a.M == 0 || (a.M >> levels) == 0) return hipErrorInvalidValue;
+    a.col_chunks = (a.S + 63u) / 64u;
+    const uint64_t tiles = (uint64_t)(a.M >> levels) * a.col_chunks;
+    if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    switch (q) {
+        case 3: return dit ? launch_fused_q<3, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<3, false>(levels, a, (unsigned)tiles, st);
+        case 5: return dit ? launch_fused_q<5, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<5, false>(levels, a, (unsigned)tiles, st);
+        case 7: return dit ? launch_fused_q<7, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<7, false>(levels, a, (unsigned)tiles, st);
+        case 9: return dit ? launch_fused_q<9, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<9, false>(levels, a, (unsigned)tiles, st);
+        default: return hipErrorInvalidValue;
     }
 }
 

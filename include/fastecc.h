@@ -115,8 +115,9 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * two one fastecc_create builds for the same (n,k) — a stripe must be decoded with the flags it was encoded with.
  * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile, and decode_prepare / decode / repair for
  * orders up to 2^20 (the locator's product tree needs w_T, T the power of two >= the order).  The odd-radix
- * level costs two more trips through HBM than the power-of-two pipeline; measured against zero extension in
- * profiles/r02/mixed_radix_bench.json.
+ * level is fused into the outermost tile passes for q <= 9 (three trips through HBM, like the power-of-two orders; option
+ * "fuse_radix" = 0 gives it its own two passes, which is what q = 13, 15 always use); measured against zero extension in
+ * profiles/r02/mixed_radix_bench.jsonl: faster than zero extension for q <= 9.
  */
 #define FASTECC_CODE_MIXED_RADIX 1u
 int fastecc_create_ex(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device, unsigned flags);
@@ -316,11 +317,12 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  HBM layout pad odd block sizes (2052, 4100 bytes) to a multiple of 128 bytes: +50 % throughput.
  *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
  *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
- *   "host_slabs" = 1, 2, 4 or 8 (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
- *   "slabs" = H (1..8): encode H column slabs of the stripe on internal streams, each one pass
- * behind the previous, so that different kinds of passes overlap on the GPU.  The call still
- * behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream`
- * waits for it.
+ *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
+ *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;
+ *   "slabs" = H (1..32): encode H column slabs of the stripe on internal streams, each one pass
+ * behind the previous, so that different kinds of passes overlap on the GPU, or with "slab_mode" = 1 one
+ * after the other on `stream` (a memory-side-cache experiment: profiles/r02/slab_cache_sweep.md — neither pays).  The call
+ * still behaves as one operation on `stream`: it starts after prior work on `stream` and later work on `stream` waits for it.
  */
 int fastecc_set_option(fastecc_ctx *ctx, const char *name, int value);
 

@@ -53,7 +53,7 @@ def test_full_codes_match_the_oracle(torch_cuda, fe, oracle, q, m, S):
     x = rand_stripe(q * 100 + m, k, S)
     want = oracle.encode_mixed(x)
     with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
-        assert ("R%d:" % q) in enc.plan()
+        assert ("R%d:" % q) in enc.plan() or ("R%d+" % q) in enc.plan()
         d = to_dev(torch, x)
         out = torch.empty_like(d)
         enc.encode(d, out)
@@ -276,3 +276,39 @@ def test_decoder_at_a_large_mixed_order(torch_cuda, fe):
         enc.repair(bx, bp)
         torch.cuda.synchronize()
         assert torch.equal(bx, x) and torch.equal(bp, par)
+
+
+@pytest.mark.parametrize("q", [3, 5, 7, 9, 13])
+@pytest.mark.parametrize("m", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_fused_odd_radix_level(torch_cuda, fe, oracle, q, m):
+    """Orders with an outer tile above MID: the odd-radix level fused into that tile (3 trips) against its own two passes
+    (5 trips, option fuse_radix = 0) and, where the oracle finishes quickly, against the oracle; full and zero-extended codes."""
+    torch = torch_cuda
+    order = q << m
+    S = 4 if m >= 16 else 20
+    for k, par in ((order, order), (order - 7, order // 2 + 3)):
+        x = rand_stripe(q * 100 + m, k, S)
+        with fe.Encoder(k + par, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+            fused_plan = enc.plan()
+            d = to_dev(torch, x)
+            out = torch.empty(par * S, dtype=torch.int32, device="cuda:0")
+            enc.encode(d, out)
+            torch.cuda.synchronize()
+            got = to_host(out).reshape(par, S).copy()
+            enc.set_option("fuse_radix", 0)
+            assert ("R%d:dif1" % q) in enc.plan()
+            out.zero_()
+            enc.encode(d, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(out).reshape(par, S), got), (fused_plan, enc.plan())
+            enc.set_option("fuse_radix", 1)
+            assert enc.plan() == fused_plan
+            if k == order:
+                work = to_dev(torch, x)
+                enc.encode(work)  # in place
+                torch.cuda.synchronize()
+                assert np.array_equal(to_host(work).reshape(k, S), got), fused_plan
+            if m <= 13:
+                assert np.array_equal(got, oracle.encode_mixed_code(x, k + par, order)), fused_plan
+        supported = (q <= 5 and m - 10 <= (7 if q == 5 else 8)) or (q in (7, 9) and m - 10 <= 6)
+        assert (("R%d+dif" % q) in fused_plan) == supported, fused_plan
