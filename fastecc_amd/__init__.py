@@ -20,6 +20,7 @@ FIELD_GF_FFF00001 = 0
 FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 CODE_MIXED_RADIX = 1  # fastecc_create_ex flag: transform order q * 2^m, q in {1, 3, 5, 7, 9, 13, 15}
+CODE_TOP_RADIX2 = 2  # fastecc_create_ex flag (A/B experiment): the top level of a power-of-two transform through the fused odd-radix kernel
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 

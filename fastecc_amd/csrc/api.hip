@@ -992,7 +992,22 @@ int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_
 {
     if (!out) return FASTECC_E_INVAL;
     *out = nullptr;
-    if (flags & ~(unsigned)FASTECC_CODE_MIXED_RADIX) return FASTECC_E_INVAL;
+    if (flags & ~(unsigned)(FASTECC_CODE_MIXED_RADIX | FASTECC_CODE_TOP_RADIX2)) return FASTECC_E_INVAL;
+    if (flags & FASTECC_CODE_TOP_RADIX2) {
+        if (flags != FASTECC_CODE_TOP_RADIX2 || field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
+        int lg = 0;
+        while ((1ull << lg) < k) lg++;
+        if (n != 2 * k || (1ull << lg) != k || lg < 12 || lg > 19 || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_UNSUPPORTED;
+        const uint64_t M = k / 2;
+        int rc = create_impl(out, 2 * M, M, lg - 1, block_bytes, field, device, 0, 1, nullptr);
+        if (rc != FASTECC_OK) return rc;
+        rc = setup_mixed(*out, 2, k, k);
+        if (rc != FASTECC_OK) {
+            fastecc_destroy(*out);
+            *out = nullptr;
+        }
+        return rc;
+    }
     if (!(flags & FASTECC_CODE_MIXED_RADIX)) return fastecc_create(out, n, k, block_bytes, field, device);
     if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;

@@ -93,7 +93,13 @@ template <int Q, int V, typename Slots>
 __device__ __forceinline__ void small_dft_at(const Slots& p, const_u32_ptr tab)
 {
     using Reg = uint32_t(*)[V];
-    if constexpr (Q == 9) {
+    if constexpr (Q == 2) {  // the ordinary butterfly (ntt.cpp:16-22): a power-of-two top level treated like an odd one
+        uint32_t t[V];
+        vsub<V>(t, *p[0], *p[1]);
+        vadd<V>(*p[0], *p[0], *p[1]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) (*p[1])[v] = t[v];
+    } else if constexpr (Q == 9) {
         // tab: C3, S3 (root w^3), then w^(i2*j1) for (i2, j1) = (1,1), (1,2), (2,1), (2,2)
 #pragma unroll
         for (int i2 = 0; i2 < 3; ++i2) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
 }
 
 // register run length per radix: q * 2^RLOG values per lane must fit the register file at a useful occupancy
-constexpr int fused_rmax(int q) { return q <= 5 ? 4 : q <= 9 ? 3 : 0; }
+constexpr int fused_rmax(int q) { return q <= 5 ? 4 : q <= 9 ? 3 : 0; }  // q = 2: an experiment, see FASTECC_CODE_TOP_RADIX2
 int fused_rlog(int q, int levels)
 {
     const int rmax = fused_rmax(q);
@@ -332,7 +338,7 @@ static hipError_t launch_fused_q(int levels, const FusedArgs& a, unsigned tiles,
         case 6: return launch_fused_shape<Q, 6, DIT>(a, tiles, st);
         case 7: return launch_fused_shape<Q, 7, DIT>(a, tiles, st);
         case 8:
-            if constexpr (Q == 3) return launch_fused_shape<Q, 8, DIT>(a, tiles, st);
+            if constexpr (Q <= 3) return launch_fused_shape<Q, 8, DIT>(a, tiles, st);
             else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
@@ -345,6 +351,7 @@ hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st
     const uint64_t tiles = (uint64_t)(a.M >> levels) * a.col_chunks;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     switch (q) {
+        case 2: return dit ? launch_fused_q<2, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<2, false>(levels, a, (unsigned)tiles, st);
         case 3: return dit ? launch_fused_q<3, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<3, false>(levels, a, (unsigned)tiles, st);
         case 5: return dit ? launch_fused_q<5, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<5, false>(levels, a, (unsigned)tiles, st);
         case 7: return dit ? launch_fused_q<7, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<7, false>(levels, a, (unsigned)tiles, st);
@@ -371,7 +378,9 @@ std::vector<uint32_t> radix_dft_table(int q, uint32_t wq)
             }
     };
     std::vector<uint32_t> t;
-    if (q == 9) {
+    if (q == 2) {
+        t.push_back(0);  // the two-point transform has no constants
+    } else if (q == 9) {
         sym(t, 3, gf::h_pow(wq, 3));
         for (int i2 = 1; i2 <= 2; i2++)
             for (int j1 = 1; j1 <= 2; j1++) t.push_back(gf::h_to_mont(gf::h_pow(wq, (uint64_t)i2 * j1)));
@@ -397,6 +406,7 @@ template <int V>
 static hipError_t launch_v(int q, bool dit, const RadixArgs& a, dim3 grid, hipStream_t st)
 {
     switch (q) {
+        case 2: return launch_q<2, V>(dit, a, grid, st);
         case 3: return launch_q<3, V>(dit, a, grid, st);
         case 5: return launch_q<5, V>(dit, a, grid, st);
         case 7: return launch_q<7, V>(dit, a, grid, st);
@@ -411,7 +421,7 @@ static hipError_t launch_v(int q, bool dit, const RadixArgs& a, dim3 grid, hipSt
     }
 }
 
-bool radix_supported(int q) { return q == 3 || q == 5 || q == 7 || q == 9 || q == 13 || q == 15; }
+bool radix_supported(int q) { return q == 2 || q == 3 || q == 5 || q == 7 || q == 9 || q == 13 || q == 15; }
 
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st)
 {

@@ -120,6 +120,9 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * profiles/r02/mixed_radix_bench.jsonl: faster than zero extension for q <= 9.
  */
 #define FASTECC_CODE_MIXED_RADIX 1u
+/* A/B experiment (same code, same results as fastecc_create): for n = 2k, k = 2^m >= 2^12 the top level of the transform is handled
+ * like an odd radix with q = 2 — fused with the next levels in mixed_kernels.hip's kernel instead of tile_kernels.hip's outer tile. */
+#define FASTECC_CODE_TOP_RADIX2 2u
 int fastecc_create_ex(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device, unsigned flags);
 void fastecc_destroy(fastecc_ctx *ctx);
 
