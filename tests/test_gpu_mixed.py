@@ -120,7 +120,7 @@ def test_every_plan_and_block_pointers(torch_cuda, fe, oracle):
 
 def test_flags_validation(torch_cuda, fe):
     with pytest.raises(fe.FastEccError) as ei:
-        fe.Encoder(8, 4, 64, flags=2)
+        fe.Encoder(8, 4, 64, flags=4)
     assert ei.value.code == fe.E_INVAL
     with pytest.raises(fe.FastEccError) as ei:
         fe.Encoder(2 * 96, 96, 64, field=fe.FIELD_GF_P61_SQUARED, flags=fe.CODE_MIXED_RADIX)
@@ -312,3 +312,34 @@ def test_fused_odd_radix_level(torch_cuda, fe, oracle, q, m):
                 assert np.array_equal(got, oracle.encode_mixed_code(x, k + par, order)), fused_plan
         supported = (q <= 5 and m - 10 <= (7 if q == 5 else 8)) or (q in (7, 9) and m - 10 <= 6)
         assert (("R%d+dif" % q) in fused_plan) == supported, fused_plan
+
+
+@pytest.mark.parametrize("m", [12, 13, 15, 17])
+def test_power_of_two_top_level_as_a_radix(torch_cuda, fe, oracle, m):
+    """FASTECC_CODE_TOP_RADIX2 (an A/B experiment): the same (2k,k) code, its top level through the odd-radix machinery with q = 2,
+    fused and unfused; bit-identical to fastecc_create's path and to the oracle."""
+    torch = torch_cuda
+    k, S = 1 << m, 12
+    x = rand_stripe(m, k, S)
+    d = to_dev(torch, x)
+    with fe.Encoder(2 * k, k, 4 * S) as ref:
+        want = torch.empty_like(d)
+        ref.encode(d, want)
+    if m <= 13:
+        assert np.array_equal(to_host(want).reshape(k, S), oracle.encode_fast(x))
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_TOP_RADIX2) as enc:
+        assert "R2+dif" in enc.plan()
+        out = torch.empty_like(d)
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), enc.plan()
+        enc.set_option("fuse_radix", 0)
+        assert "R2:dif1" in enc.plan()
+        out.zero_()
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), enc.plan()
+    for bad in ((2 * k + 2, k + 1), (3 * k, k), (64, 32)):
+        with pytest.raises(fe.FastEccError) as ei:
+            fe.Encoder(bad[0], bad[1], 4 * S, flags=fe.CODE_TOP_RADIX2)
+        assert ei.value.code == fe.E_UNSUPPORTED
