@@ -130,6 +130,7 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
+    int decode_direct_max = 16;  // (2k,k) codes: up to this many lost blocks are recomputed directly (decode.hip), 0 = always the transform
     int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
@@ -1128,7 +1129,7 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
@@ -1727,6 +1728,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
     if (!strcmp(name, "host_slabs")) {
         if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
         c->host_slabs = value;
+        return FASTECC_OK;
+    }
+    if (!strcmp(name, "decode_direct_max")) {  // takes effect at the next fastecc_decode_prepare
+        if (value < 0 || value > 16) return FASTECC_E_INVAL;
+        c->decode_direct_max = value;
         return FASTECC_OK;
     }
     if (!strcmp(name, "fuse_radix")) {  // mixed-radix contexts: 1 = odd-radix level fused into the outer tiles (default), 0 = its own passes

@@ -64,6 +64,13 @@ struct DecodeState {
     uint32_t* parity_again = nullptr;
     uint64_t erased_parity = 0;
     uint64_t erased_data = 0, erased_total = 0;
+    // few losses in the (2k,k) layout: every lost block is a fixed linear combination of the surviving ones (direct path)
+    int direct = 0;                    // > 0: number of lost blocks handled directly (padded to direct_pad accumulators)
+    int direct_pad = 0;
+    uint32_t* direct_coef = nullptr;   // [positions][direct_pad]: coefficient of the block at position u in lost block j (Montgomery), 0 = unused
+    uint32_t* direct_pos = nullptr;    // [direct_pad]: codeword position of lost block j (0xFFFFFFFF = padding)
+    uint32_t* direct_partial = nullptr;  // [row chunks][direct_pad][words]: partial sums
+    uint64_t direct_partial_words = 0;
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
     bool mixed = false;                // mixed-radix code: `recovered` is the whole work stripe (all positions), transformed in place
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
@@ -84,7 +91,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->parity_dev) (void)hipFree(d->parity_dev);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
-    for (uint32_t* b : {d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
+    for (uint32_t* b : {d->direct_coef, d->direct_pos, d->direct_partial, d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
         if (b) (void)hipFree(b);
     delete d;
 }
@@ -301,6 +308,125 @@ __global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __r
     store_vec<V>(parity + (size_t)q * S + col, x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Few losses, (2k,k) layout.  With E the lost positions, e0 one of them and l0(x) = prod_{e in E, e != e0} (x - w^e), the
+// polynomial g = x f l0 has degree <= k + |E| - 1 < 2k and no constant term, so sum_u g(w^u) = 0 over the 2k-th roots of unity;
+// g vanishes on E \ {e0}, hence
+//     c[e0] = f(w^e0) = - sum_{u not in E} c[u] * w^(u - e0) * l0(w^u) / l0(w^e0)
+// — every lost block (data or parity) is a linear combination of ALL surviving blocks with coefficients that cost |E| - 1
+// products each: no locator tree, no transform, one read of the codeword.  (|E| = 1: c[e0] w^e0 = - sum_{u != e0} c[u] w^u.)
+// ------------------------------------------------------------------------------------------------
+constexpr int DIRECT_MAX = 16;        // lost blocks per pattern on this path
+constexpr uint32_t DIRECT_ROWS = 512; // codeword positions per partial sum
+
+// coef[u][j] for all positions u; inv[j] = -1 / l0_j(w^e_j) (plain), epos[j] = e_j
+__global__ __launch_bounds__(256) void direct_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ state,
+                                                          const uint32_t* __restrict__ epos, const uint32_t* __restrict__ inv, uint32_t NC, int e, int pad)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= NC) return;
+    const bool held = ((state[u >> 2] >> (8 * (u & 3u))) & 0xFFu) == ST_HELD;
+    const uint32_t wu = wpow[u];
+    for (int j = 0; j < pad; ++j) {
+        uint32_t v = 0;
+        if (held && j < e) {
+            v = inv[j];
+            for (int i = 0; i < e; ++i)
+                if (i != j) v = gf::mul(v, gf::sub(wu, wpow[epos[i]]));
+            const uint32_t ej = epos[j];
+            v = gf::mul(v, wpow[u >= ej ? u - ej : u + NC - ej]);  // w^(u - e_j)
+            v = gf::mul(v, gf::MONT_ONE);
+        }
+        coef[(size_t)u * pad + j] = v;
+    }
+}
+
+// partial[chunk][j][col] = sum over the chunk's positions u of block(u)[col] * coef[u][j]; a wave owns (chunk, 64*V-word column
+// chunk) and keeps four rows in flight
+template <int EB, int V>
+__global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
+                                                                const uint32_t* __restrict__ coef, uint32_t* __restrict__ partial, uint32_t S,
+                                                                uint32_t NC, uint32_t col_chunks, uint64_t items)
+{
+    constexpr int U = V == 4 ? 4 : 8;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t chunk = (uint32_t)(item / col_chunks);
+    const uint32_t col = (cc * 64u + lane) * V;
+    const bool live = col < S;
+    uint32_t acc[EB][V];
+#pragma unroll
+    for (int j = 0; j < EB; ++j)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[j][v] = 0;
+    const uint32_t u0 = chunk * DIRECT_ROWS, u1 = min(u0 + DIRECT_ROWS, NC);
+    for (uint32_t ub = u0; ub < u1; ub += U) {
+        uint32_t w[U][EB], x[U][V];
+        bool use[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t u = ub + i;
+            uint32_t any = 0;
+            if (u < u1) {
+                const_u32_ptr cf = as_constant(coef) + (size_t)u * EB;
+#pragma unroll
+                for (int j = 0; j < EB; ++j) any |= (w[i][j] = cf[j]);
+            }
+            use[i] = any != 0;  // a lost block has no coefficients: whatever is stored in its place is not used (wave-uniform)
+#pragma unroll
+            for (int v = 0; v < V; ++v) x[i][v] = 0;
+            // the load does not wait for the coefficients: all U rows are in flight at once
+            if (u < u1 && live) load_vec<V>(x[i], ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S + col);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if (!use[i]) continue;
+#pragma unroll
+            for (int j = 0; j < EB; ++j)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[j][v] = gf::add(acc[j][v], gf::mul_mont(x[i][v], w[i][j]));
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < EB; ++j) store_vec<V>(partial + ((size_t)chunk * EB + j) * S + col, acc[j]);
+    }
+}
+
+// Sum of the partial sums in two steps.  Step 1 (to == nullptr ... see args): segment `seg` of the chunks -> stage[seg][j][col];
+// step 2: the DIRECT_SEGS stage rows -> lost block j, written where it belongs: data (even positions) or — only for repair — parity.
+constexpr uint32_t DIRECT_SEGS = 32;
+__global__ __launch_bounds__(256) void direct_reduce1_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ stage, uint32_t S, uint32_t chunks,
+                                                             int pad, int e)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const uint32_t seg = blockIdx.z;
+    if (col >= S || j >= e) return;
+    const uint32_t per = (chunks + DIRECT_SEGS - 1) / DIRECT_SEGS;
+    const uint32_t c0 = seg * per, c1 = min(c0 + per, chunks);
+    uint32_t v = 0;
+#pragma unroll 8
+    for (uint32_t c = c0; c < c1; ++c) v = gf::add(v, partial[((size_t)c * pad + j) * S + col]);
+    stage[((size_t)seg * pad + j) * S + col] = v;
+}
+__global__ __launch_bounds__(256) void direct_reduce2_kernel(const uint32_t* __restrict__ stage, const uint32_t* __restrict__ epos, uint32_t* __restrict__ data,
+                                                             uint32_t* __restrict__ parity, uint32_t S, int pad, int e, bool with_parity)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (col >= S || j >= e) return;
+    const uint32_t pos = epos[j];
+    if ((pos & 1u) && !with_parity) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf::add(v, stage[((size_t)g * pad + j) * S + col]);
+    ((pos & 1u) ? parity : data)[(size_t)(pos >> 1) * S + col] = v;
+}
+
 int hip_code(const char* what, hipError_t e)
 {
     set_error_detail(what, e);
@@ -419,6 +545,55 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         const int rc = call.wait_idle();  // a repair still reading the previous pattern
         if (rc != FASTECC_OK) return rc;
         DEC_TRY(hipMemcpy(d->parity_lost, plost.data(), ci.user_m * 4, hipMemcpyHostToDevice));
+    }
+    d->direct = 0;
+    if (d->standard && !erased.empty() && (int)erased.size() <= std::min(ci.direct_max, DIRECT_MAX) && erased.size() < N) {
+        // few losses: a table of coefficients instead of the locator machinery (direct_coef_kernel)
+        const int e = (int)erased.size();
+        int pad = 1;
+        while (pad < e) pad <<= 1;
+        const uint32_t w = gf::h_root((uint32_t)NC);
+        std::vector<uint32_t> we(e), inv(e), epos(pad, 0xFFFFFFFFu);
+        for (int j = 0; j < e; j++) we[j] = gf::h_pow(w, erased[j]), epos[j] = erased[j];
+        for (int j = 0; j < e; j++) {
+            uint32_t l0 = 1;
+            for (int i = 0; i < e; i++)
+                if (i != j) l0 = gf::h_mul(l0, (uint32_t)(((uint64_t)we[j] + gf::P - we[i]) % gf::P));
+            inv[j] = (gf::P - gf::h_inv(l0)) % gf::P;  // -1 / l0(w^e_j)
+        }
+        hipStream_t st = nullptr;
+        if (!d->wpow) {
+            DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
+            hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
+            DEC_TRY(hipGetLastError());
+        }
+        if (!d->dev_state) DEC_TRY(hipMalloc((void**)&d->dev_state, NC));
+        if (!d->direct_coef) DEC_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 4));
+        if (!d->direct_pos) DEC_TRY(hipMalloc((void**)&d->direct_pos, 2 * DIRECT_MAX * 4));
+        const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const uint64_t need = (chunks + 32 /* DIRECT_SEGS: the second step's staging rows */) * pad * ci.words;
+        if (d->direct_partial_words < need) {
+            if (d->direct_partial) (void)hipFree(d->direct_partial);
+            d->direct_partial = nullptr;
+            d->direct_partial_words = 0;
+            DEC_TRY(hipMalloc((void**)&d->direct_partial, need * 4));
+            d->direct_partial_words = need;
+        }
+        {
+            const int rc = call.wait_idle();  // a decode still using the previous pattern
+            if (rc != FASTECC_OK) return rc;
+        }
+        DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
+        DEC_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), pad * 4, hipMemcpyHostToDevice, st));
+        DEC_TRY(hipMemcpyAsync(d->direct_pos + DIRECT_MAX, inv.data(), e * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(direct_coef_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->direct_coef, d->wpow, d->dev_state, d->direct_pos,
+                           d->direct_pos + DIRECT_MAX, (uint32_t)NC, e, pad);
+        DEC_TRY(hipGetLastError());
+        DEC_TRY(hipStreamSynchronize(st));
+        d->direct = e;
+        d->direct_pad = pad;
+        d->ready = true;
+        return FASTECC_OK;
     }
     if (erased_data == 0) {  // no data block to recover
         d->ready = true;
@@ -616,6 +791,31 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         ddata = d->parity_dev + ci.user_m * ci.words;
     }
 
+    if (d->direct > 0) {
+        // every lost block straight from the surviving ones: one read of the codeword, |E| products per word
+        const uint32_t S = (uint32_t)ci.words, NC = (uint32_t)d->positions;
+        const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)d->direct_partial) & 15u) == 0) && d->direct_pad <= 8;
+        const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const uint64_t items = (uint64_t)chunks * col_chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+        uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
+#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, ddata, dparity, d->direct_coef, d->direct_partial, S, NC, col_chunks, items)
+        switch (d->direct_pad) {
+            case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
+            case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
+            case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
+            case 8: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
+            default: FASTECC_DIRECT(16, 1); break;
+        }
+#undef FASTECC_DIRECT
+        DEC_TRY(hipGetLastError());
+        uint32_t* stage = d->direct_partial + (size_t)chunks * d->direct_pad * S;  // behind the partial sums
+        hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)d->direct, DIRECT_SEGS), dim3(256), 0, st, d->direct_partial, stage, S, chunks,
+                           d->direct_pad, d->direct);
+        hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)d->direct), dim3(256), 0, st, stage, d->direct_pos, ddata, dpar_out, S,
+                           d->direct_pad, d->direct, rebuild);
+        DEC_TRY(hipGetLastError());
+    } else {
     if (d->erased_data != 0) {
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).
     // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
@@ -665,6 +865,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         else    hipLaunchKernelGGL(restore_parity_kernel<1>, grid, dim3(256), 0, st, d->parity_again, dpar_out, d->parity_lost, S, col_chunks, items);
         DEC_TRY(hipGetLastError());
     }
+    }  // transform path
     if (mem_kind == FASTECC_MEM_HOST) {
         if (d->erased_data != 0) DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
         if (rebuild) DEC_TRY(hipMemcpyAsync(parity_out, d->parity_dev, parity_bytes, hipMemcpyDeviceToHost, st));

@@ -31,6 +31,7 @@ struct CtxInfo {
     bool zero_extended;        // k or n - k is not the power of two the transform works on
     uint64_t user_k, user_m;   // data / parity blocks of the caller's stripes (== k, k >> fold unless zero_extended)
     int q;                     // > 1: the transform order is q * k (mixed radix); k is its power-of-two part
+    int direct_max;            // decoder: patterns with at most this many lost blocks take the direct path (option "decode_direct_max")
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);

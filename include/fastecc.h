@@ -253,6 +253,10 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
  *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
+ * (2k,k) codes of GF(0xFFF00001) with at most 16 lost blocks (option "decode_direct_max", 0..16, default 16) take a direct path:
+ * every lost block is a fixed linear combination of the surviving ones, so prepare builds a coefficient table (~1 ms, no
+ * transform contexts) and decode / repair are one read of the codeword — 0.8 ms for one or two lost blocks of the (2^20,2^19)
+ * x 4 KB code against 7.7 / 11.3 ms on the transform path; identical results.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
 int fastecc_decode(fastecc_ctx *ctx, void *data, const void *parity, int mem_kind, void *stream);
@@ -321,6 +325,7 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
  *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
  *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
+ *   "decode_direct_max" = 0..16 (default 16): lost blocks up to which the decoder's direct path is used (next decode_prepare);
  *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;
  *   "slabs" = H (1..32): encode H column slabs of the stripe on internal streams, each one pass
  * behind the previous, so that different kinds of passes overlap on the GPU, or with "slab_mode" = 1 one

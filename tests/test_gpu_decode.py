@@ -272,3 +272,47 @@ def test_repair_restores_data_and_parity(torch_cuda, fe, oracle, n_over_k, k, S)
         enc.decode(to_dev(torch, damaged), dq3)
         torch.cuda.synchronize()
         assert (to_host(dq3, (m, S)) == dpar).all()
+
+
+@pytest.mark.parametrize("N,S", [(2, 5), (16, 64), (2048, 37), (1 << 15, 8)])
+def test_few_losses_take_the_direct_path(torch_cuda, fe, oracle, N, S):
+    """Up to 16 lost blocks of a (2k,k) codeword are recomputed straight from the survivors (no locator tree, no transform):
+    same results as the transform path (option decode_direct_max = 0), as the original data and parity, and — small N — as the
+    oracle's Lagrange decoder; data only (decode) and data + parity (repair), device and host stripes."""
+    torch = torch_cuda
+    rng = np.random.default_rng(N + S)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    par = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        for e in (1, 2, 3, 5, 8, 16, 17):
+            if e > N:
+                continue
+            lost = rng.permutation(2 * N)[:e]
+            lost[0] = 2 * int(rng.integers(0, N)) // 2  # a data block for sure
+            lost = np.unique(np.r_[lost[0] % N, lost[1:]])
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            bad_x, bad_p = x.copy(), par.copy()
+            bad_x[dp == 0] = 0xA5A5A5A5
+            bad_p[pp == 0] = 0x5A5A5A5A
+            results = []
+            for direct_max in (16, 0):
+                enc.set_option("decode_direct_max", direct_max)
+                enc.decode_prepare(dp, pp)
+                d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+                enc.decode(d, q)
+                assert (to_host(d, (N, S)) == x).all(), (e, direct_max)
+                assert (to_host(q, (N, S)) == bad_p).all(), (e, direct_max)  # decode leaves the parity alone
+                enc.repair(d, q)
+                assert (to_host(q, (N, S)) == par).all(), (e, direct_max)
+                hx, hp = bad_x.copy(), bad_p.copy()
+                enc.repair(hx, hp, mem=fe.MEM_HOST)
+                assert (hx == x).all() and (hp == par).all(), (e, direct_max)
+                results.append(to_host(d, (N, S)).copy())
+            assert (results[0] == results[1]).all()
+            if N <= 256:
+                assert (oracle.decode(bad_x, bad_p, dp, pp) == x).all()
+        enc.set_option("decode_direct_max", 16)
+        with pytest.raises(fe.FastEccError):
+            enc.set_option("decode_direct_max", 17)

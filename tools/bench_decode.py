@@ -34,9 +34,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     with fastecc_amd.Encoder(2 * N, N, 4096, field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001) as enc:
         enc.encode(data, parity, stream=stream)
-        for frac in (0.001, 0.02, 0.25, 0.5):
+        # a few lost blocks (the direct path of the 32-bit field's (2k,k) codes), then loss rates (locator tree + transform)
+        for frac in ((1, 2, 4, 8, 16) if not p61 else ()) + (0.001, 0.02, 0.25, 0.5):
             rng = np.random.default_rng(int(frac * 1000))
-            lost = rng.permutation(2 * N)[: max(1, int(2 * N * frac))]
+            lost = rng.permutation(2 * N)[: (frac if isinstance(frac, int) else max(1, int(2 * N * frac)))]
+            if isinstance(frac, int):
+                lost[0] = 5 * 2  # at least one data block among them
             dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
             dp[lost[lost < N]] = 0
             pp[lost[lost >= N] - N] = 0
@@ -48,8 +51,10 @@ def main():
             prep_ms = (time.perf_counter() - t0) * 1e3
             work = data.clone()
             work.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
-            enc.decode(work, parity, stream=stream)  # warm-up (allocations)
-            assert bool((work == data).all())
+            wpar = parity.clone()
+            wpar.view(N, S)[torch.from_numpy(pp == 0).to("cuda:0")] = -2
+            enc.repair(work, wpar, stream=stream)  # warm-up (allocations), and the check of what is timed below
+            assert bool((work == data).all()) and bool((wpar == parity).all())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
@@ -58,7 +63,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / steps
-            out["cases"].append({"lost_fraction": frac, "erased_blocks": int(lost.size), "erased_data_blocks": int((dp == 0).sum()),
+            e0.record()
+            for _ in range(steps):
+                enc.repair(work, wpar, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            repair_ms = e0.elapsed_time(e1) / steps
+            out["cases"].append({"lost": frac, "erased_blocks": int(np.unique(lost).size), "repair_ms": round(repair_ms, 3), "erased_data_blocks": int((dp == 0).sum()),
                                  "prepare_ms": round(prep_ms, 2), "prepare_first_call_ms": round(first_ms, 1), "decode_ms": round(ms, 3),
                                  "codeword_GBps": round(2.0 * N * 4096 / (ms * 1e-3) / 1e9, 1)})
     print(json.dumps(out))
