@@ -475,7 +475,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             if (rc0 != FASTECC_OK) return rc0;
         }
         char detail[160] = "";
-        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, detail, sizeof detail);
+        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail);
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
         return rc;
     }

@@ -240,6 +240,110 @@ __global__ __launch_bounds__(256) void k_restore(const uint64_t* __restrict__ ag
     st(parity + ((uint64_t)j * elems + col) * 2, ld(again + ((uint64_t)j * elems + col) * 2));
 }
 
+// ---- few losses: every lost block is a fixed linear combination of the surviving ones (see decode.hip, "Few losses") ----
+constexpr int DIRECT_MAX = 16;
+constexpr uint32_t DIRECT_ROWS = 512, DIRECT_SEGS = 32;
+
+// coef[u][j] = -w^(u - e_j) * prod_{i != j} (w^u - w^e_i) / prod_{i != j} (w^e_j - w^e_i) on surviving positions, 0 on lost ones
+__global__ __launch_bounds__(256) void k_direct_coef(uint64_t* __restrict__ coef, const uint64_t* __restrict__ wpow, const uint8_t* __restrict__ state,
+                                                     const uint32_t* __restrict__ epos, const uint64_t* __restrict__ inv, uint32_t NC, int e, int pad)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= NC) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const bool held = state[u] == ST_HELD;
+    const Elem wu = ld(wpow + 2ull * u);
+    for (int j = 0; j < pad; ++j) {
+        Elem v{0, 0};
+        if (held && j < e) {
+            v = ld(inv + 2ull * j);
+            for (int i = 0; i < e; ++i) {
+                if (i == j) continue;
+                const Elem wi = ld(wpow + 2ull * epos[i]);
+                v = mulc(v, Elem{subc(wu.re, wi.re), subc(wu.im, wi.im)}, k);
+            }
+            const uint32_t ej = epos[j];
+            v = mulc(v, ld(wpow + 2ull * (u >= ej ? u - ej : u + NC - ej)), k);
+        }
+        st(coef + 2ull * ((uint64_t)u * pad + j), v);
+    }
+}
+
+// partial[chunk][j][col] = sum over the chunk's positions of block(u)[col] * coef[u][j] (lazy values); a wave owns (chunk, 64 element columns)
+template <int EB>
+__global__ __launch_bounds__(256) void k_direct_accumulate(const uint64_t* __restrict__ data, const uint64_t* __restrict__ parity,
+                                                           const uint64_t* __restrict__ coef, uint64_t* __restrict__ partial, uint32_t elems, uint32_t NC,
+                                                           uint32_t col_chunks, uint64_t items)
+{
+    constexpr int U = 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t chunk = (uint32_t)(item / col_chunks);
+    const uint32_t col = cc * 64u + lane;
+    const bool live = col < elems;
+    const gf61::Opaque k = gf61::make_opaque();
+    Elem acc[EB];
+#pragma unroll
+    for (int j = 0; j < EB; ++j) acc[j] = Elem{0, 0};
+    const uint32_t u0 = chunk * DIRECT_ROWS, u1 = min(u0 + DIRECT_ROWS, NC);
+    for (uint32_t ub = u0; ub < u1; ub += U) {
+        Elem x[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {  // all U rows in flight; what stands in a lost block's place meets zero coefficients
+            const uint32_t u = ub + i;
+            x[i] = (u < u1 && live) ? ld(((u & 1u) ? parity : data) + ((uint64_t)(u >> 1) * elems + col) * 2) : Elem{0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t u = ub + i;
+            if (u >= u1) continue;
+            const_u64_ptr cf = as_constant(coef) + 2ull * ((uint64_t)u * EB);
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const uint64_t cre = cf[2 * j], cim = cf[2 * j + 1];
+                if ((cre | cim) == 0) continue;  // wave-uniform
+                acc[j] = gf61::add(acc[j], gf61::mul(x[i], gf61::make_twiddle(cre, cim), k), k);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < EB; ++j) st(partial + 2ull * (((uint64_t)chunk * EB + j) * elems + col), acc[j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_direct_reduce1(const uint64_t* __restrict__ partial, uint64_t* __restrict__ stage, uint32_t elems, uint32_t chunks,
+                                                        int pad, int e)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const uint32_t seg = blockIdx.z;
+    if (col >= elems || j >= e) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint32_t per = (chunks + DIRECT_SEGS - 1) / DIRECT_SEGS;
+    const uint32_t c0 = seg * per, c1 = min(c0 + per, chunks);
+    Elem v{0, 0};
+#pragma unroll 4
+    for (uint32_t c = c0; c < c1; ++c) v = gf61::add(v, ld(partial + 2ull * (((uint64_t)c * pad + j) * elems + col)), k);
+    st(stage + 2ull * (((uint64_t)seg * pad + j) * elems + col), v);
+}
+__global__ __launch_bounds__(256) void k_direct_reduce2(const uint64_t* __restrict__ stage, const uint32_t* __restrict__ epos, uint64_t* __restrict__ data,
+                                                        uint64_t* __restrict__ parity, uint32_t elems, int pad, int e, bool with_parity)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (col >= elems || j >= e) return;
+    const uint32_t pos = epos[j];
+    if ((pos & 1u) && !with_parity) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    Elem v{0, 0};
+    for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf61::add(v, ld(stage + 2ull * (((uint64_t)g * pad + j) * elems + col)), k);
+    st(((pos & 1u) ? parity : data) + ((uint64_t)(pos >> 1) * elems + col) * 2, gf61::canon(v));
+}
+
 int fail(char* detail, size_t cap, hipError_t e, const char* what)
 {
     if (detail && cap) snprintf(detail, cap, "%s: %s", what, hipGetErrorString(e));
@@ -270,6 +374,15 @@ struct Decoder {
     uint64_t* stage = nullptr;         // data + parity stripes of a host-memory call (lazy)
     uint64_t erased_data = 0, erased_parity = 0;
     bool built = false;  // contexts, buffers and the w^u table exist
+    // few losses: the direct path
+    int direct = 0, direct_pad = 0;
+    uint64_t* direct_coef = nullptr;     // [NC][pad] elements
+    uint64_t* direct_inv = nullptr;      // [DIRECT_MAX] elements
+    uint32_t* direct_pos = nullptr;      // [DIRECT_MAX]
+    uint64_t* direct_partial = nullptr;  // [chunks + DIRECT_SEGS][pad][elems] elements
+    uint64_t direct_partial_elems = 0;
+    uint64_t* direct_wpow = nullptr;     // the w^u table when only this path has been used (else d->wpow)
+    uint8_t* direct_state = nullptr;
     bool ready = false;
 };
 
@@ -282,12 +395,14 @@ void destroy_decoder(Decoder* d)
     destroy(d->pattern);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
-                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again, (void*)d->stage})
+                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
+                    (void*)d->direct_inv, (void*)d->direct_pos, (void*)d->direct_partial, (void*)d->direct_wpow, (void*)d->direct_state})
         if (b) (void)hipFree(b);
     delete d;
 }
 
-int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, char* detail, size_t cap)
+int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
+                   size_t cap)
 {
     const uint64_t N = 1ull << log2k, NC = 2 * N;
     std::vector<uint8_t> state(NC);
@@ -319,6 +434,58 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     int lgT = log2k;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
 
+    d->direct = 0;
+    if (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX)) {
+        // few losses: a coefficient table, no locator tree and no transform contexts
+        const int e = (int)erased.size();
+        int pad = 1;
+        while (pad < e) pad <<= 1;
+        const gf61::Elem w = gf61::h_root(NC);
+        std::vector<gf61::Elem> we(e);
+        std::vector<uint64_t> inv(2 * e);
+        std::vector<uint32_t> epos(DIRECT_MAX, 0xFFFFFFFFu);
+        for (int j = 0; j < e; j++) we[j] = gf61::h_pow(w, erased[j]), epos[j] = erased[j];
+        for (int j = 0; j < e; j++) {
+            gf61::Elem l0{1, 0};
+            for (int i = 0; i < e; i++)
+                if (i != j) l0 = gf61::h_mul(l0, gf61::Elem{gf61::h_subp(we[j].re, we[i].re), gf61::h_subp(we[j].im, we[i].im)});
+            const gf61::Elem r = gf61::h_inv(l0);
+            inv[2 * j] = gf61::h_subp(0, r.re);  // -1 / l0(w^e_j)
+            inv[2 * j + 1] = gf61::h_subp(0, r.im);
+        }
+        hipStream_t s0 = nullptr;
+        uint64_t* wp = d->built ? d->wpow : d->direct_wpow;
+        if (!wp) {
+            D61_TRY(hipMalloc((void**)&d->direct_wpow, NC * 16));
+            wp = d->direct_wpow;
+            hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, wp, w.re, w.im, (uint32_t)NC);
+            D61_TRY(hipGetLastError());
+        }
+        if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC));
+        if (!d->direct_coef) D61_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 16));
+        if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, DIRECT_MAX * 16));
+        if (!d->direct_pos) D61_TRY(hipMalloc((void**)&d->direct_pos, DIRECT_MAX * 4));
+        const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const uint64_t need = (chunks + DIRECT_SEGS) * pad * elems;
+        if (d->direct_partial_elems < need) {
+            if (d->direct_partial) (void)hipFree(d->direct_partial);
+            d->direct_partial = nullptr;
+            d->direct_partial_elems = 0;
+            D61_TRY(hipMalloc((void**)&d->direct_partial, need * 16));
+            d->direct_partial_elems = need;
+        }
+        D61_TRY(hipMemcpyAsync(d->direct_state, state.data(), NC, hipMemcpyHostToDevice, s0));
+        D61_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), DIRECT_MAX * 4, hipMemcpyHostToDevice, s0));
+        D61_TRY(hipMemcpyAsync(d->direct_inv, inv.data(), e * 16, hipMemcpyHostToDevice, s0));
+        hipLaunchKernelGGL(k_direct_coef, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, d->direct_coef, wp, d->direct_state, d->direct_pos,
+                           d->direct_inv, (uint32_t)NC, e, pad);
+        D61_TRY(hipGetLastError());
+        D61_TRY(hipStreamSynchronize(s0));
+        d->direct = e;
+        d->direct_pad = pad;
+        d->ready = true;
+        return FASTECC_OK;
+    }
     // ---- built once; a failure half way leaves no decoder behind (the next call starts from scratch) ----
     auto build_once = [&]() -> int {
         std::vector<uint64_t> factor(2 * NC);
@@ -415,6 +582,29 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
     const size_t cap = 0;
     const uint32_t elems = (uint32_t)d->elems, col_chunks = (elems + 63) / 64;
     const bool rebuild = rebuild_with != nullptr && d->erased_parity != 0;
+    if (d->direct > 0) {
+        if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
+        const uint32_t NC = (uint32_t)d->NC, chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const uint64_t items = (uint64_t)chunks * col_chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+#define FASTECC_DIRECT61(EB) hipLaunchKernelGGL(k_direct_accumulate<EB>, grid, dim3(256), 0, s0, data, parity, d->direct_coef, d->direct_partial, elems, NC, col_chunks, items)
+        switch (d->direct_pad) {
+            case 1: FASTECC_DIRECT61(1); break;
+            case 2: FASTECC_DIRECT61(2); break;
+            case 4: FASTECC_DIRECT61(4); break;
+            case 8: FASTECC_DIRECT61(8); break;
+            default: FASTECC_DIRECT61(16); break;
+        }
+#undef FASTECC_DIRECT61
+        D61_TRY(hipGetLastError());
+        uint64_t* stage = d->direct_partial + 2ull * (uint64_t)chunks * d->direct_pad * elems;
+        hipLaunchKernelGGL(k_direct_reduce1, dim3((elems + 255) / 256, (unsigned)d->direct, DIRECT_SEGS), dim3(256), 0, s0, d->direct_partial, stage, elems, chunks,
+                           d->direct_pad, d->direct);
+        hipLaunchKernelGGL(k_direct_reduce2, dim3((elems + 255) / 256, (unsigned)d->direct), dim3(256), 0, s0, stage, d->direct_pos, data, parity, elems,
+                           d->direct_pad, d->direct, rebuild);
+        D61_TRY(hipGetLastError());
+        return FASTECC_OK;
+    }
     if (d->erased_data != 0) {
         if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
         {

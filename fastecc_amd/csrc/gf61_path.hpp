@@ -44,7 +44,8 @@ struct Decoder;
 void destroy_decoder(Decoder* d);
 // data_present / parity_present: k flags each (non-zero = the block survives).  Synchronous.  The current device must be
 // the target device.  *slot is created on first use and reused.
-int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, char* detail,
+// direct_max: patterns with at most that many lost blocks (<= 16) get the direct one-pass path instead of locator + transform.
+int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
                    size_t detail_cap);
 // Recover the erased data blocks in place (device pointers, enqueued on st); rebuild_with != null: also re-encode with that
 // path (the context's encoder) and write the lost parity blocks into `parity`.

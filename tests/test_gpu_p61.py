@@ -304,3 +304,41 @@ def test_decode_at_2_16_blocks(torch_cuda, fe):
         enc.repair(d, q)
         torch.cuda.synchronize()
         assert torch.equal(d, x) and torch.equal(q, par)
+
+
+@pytest.mark.parametrize("N,elems", [(2, 3), (16, 70), (1024, 9), (1 << 14, 4)])
+def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
+    """Up to 16 lost blocks: recomputed straight from the survivors (no locator tree, no transform); same bits as the transform
+    path (decode_direct_max = 0), the original stripes and — small N — the oracle's Lagrange decoder; decode and repair."""
+    torch = torch_cuda
+    rng = np.random.default_rng(N * 3 + elems)
+    x = rand_stripe(rng, N, elems)
+    par = orc61.encode(x)
+    with encoder(fe, N, elems) as enc:
+        for e in (1, 2, 3, 7, 16, 17):
+            if e > N:
+                continue
+            lost = np.unique(np.r_[int(rng.integers(0, N)), rng.permutation(2 * N)[: e - 1]])
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            bad_x, bad_p = x.copy(), par.copy()
+            bad_x[dp == 0] = 11
+            bad_p[pp == 0] = 13
+            for direct_max in (16, 0):
+                enc.set_option("decode_direct_max", direct_max)
+                enc.decode_prepare(dp, pp)
+                d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+                enc.decode(d, q)
+                torch.cuda.synchronize()
+                assert (to_host(d).reshape(x.shape) == x).all(), (e, direct_max)
+                assert (to_host(q).reshape(x.shape) == bad_p).all(), (e, direct_max)
+                enc.repair(d, q)
+                torch.cuda.synchronize()
+                assert (to_host(q).reshape(x.shape) == par).all(), (e, direct_max)
+                hx, hp = bad_x.copy(), bad_p.copy()
+                enc.repair(hx, hp, mem=fe.MEM_HOST)
+                assert (hx == x).all() and (hp == par).all(), (e, direct_max)
+            if N <= 64:
+                assert (orc61.decode(bad_x, bad_p, dp, pp) == x).all()
+        enc.set_option("decode_direct_max", 16)

@@ -35,7 +35,7 @@ def main():
     with fastecc_amd.Encoder(2 * N, N, 4096, field=fastecc_amd.FIELD_GF_P61_SQUARED if p61 else fastecc_amd.FIELD_GF_FFF00001) as enc:
         enc.encode(data, parity, stream=stream)
         # a few lost blocks (the direct path of the 32-bit field's (2k,k) codes), then loss rates (locator tree + transform)
-        for frac in ((1, 2, 4, 8, 16) if not p61 else ()) + (0.001, 0.02, 0.25, 0.5):
+        for frac in (1, 2, 4, 8, 16, 0.001, 0.02, 0.25, 0.5):
             rng = np.random.default_rng(int(frac * 1000))
             lost = rng.permutation(2 * N)[: (frac if isinstance(frac, int) else max(1, int(2 * N * frac)))]
             if isinstance(frac, int):
