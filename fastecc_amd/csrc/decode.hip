@@ -320,12 +320,13 @@ constexpr int DIRECT_MAX = 16;        // lost blocks per pattern on this path
 constexpr uint32_t DIRECT_ROWS = 512; // codeword positions per partial sum
 
 // coef[u][j] for all positions u; inv[j] = -1 / l0_j(w^e_j) (plain), epos[j] = e_j
-__global__ __launch_bounds__(256) void direct_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ state,
-                                                          const uint32_t* __restrict__ epos, const uint32_t* __restrict__ inv, uint32_t NC, int e, int pad)
+__global__ __launch_bounds__(256) void direct_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ epos,
+                                                          const uint32_t* __restrict__ inv, uint32_t NC, int e, int pad)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
-    const bool held = ((state[u >> 2] >> (8 * (u & 3u))) & 0xFFu) == ST_HELD;
+    bool held = true;  // in this layout every position holds a block: it survives unless it is on the list
+    for (int i = 0; i < e; ++i) held = held && epos[i] != u;
     const uint32_t wu = wpow[u];
     for (int j = 0; j < pad; ++j) {
         uint32_t v = 0;
@@ -494,6 +495,82 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while ((1 << e) < ci.cosets + 1) e++;
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
+    // ---- few losses in the reference's (2k,k) layout: decided before any per-position table is built ----
+    const bool standard_layout = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
+    const int direct_limit = std::min(ci.direct_max, (int)DIRECT_MAX);
+    if (standard_layout && direct_limit > 0) {
+        std::vector<uint32_t> few;
+        uint64_t lost_data = 0, lost_parity = 0;
+        bool over = false;
+        for (uint64_t i = 0; i < N && !over; i++)
+            if (!data_present[i]) lost_data++, few.push_back((uint32_t)(2 * i)), over = (int)few.size() > direct_limit;
+        for (uint64_t q = 0; q < N && !over; q++)
+            if (!parity_present[q]) lost_parity++, few.push_back((uint32_t)(2 * q + 1)), over = (int)few.size() > direct_limit;
+        if (!over && !few.empty() && few.size() < N) {
+            std::sort(few.begin(), few.end());
+            DeviceScope ds(ci.device);
+            if (!ds.ok) return FASTECC_E_DEVICE;
+            CallScope call(c);
+            DecodeState*& slot = decoder_of(c);
+            if (!slot) {
+                slot = new (std::nothrow) DecodeState();
+                if (!slot) return FASTECC_E_NOMEM;
+            }
+            DecodeState* d = slot;
+            d->ready = false;
+            d->direct = 0;
+            d->erased_data = lost_data;
+            d->erased_parity = lost_parity;
+            d->erased_total = few.size();
+            d->positions = NC;
+            d->standard = true;
+            d->mixed = false;
+            // a table of coefficients instead of the locator machinery (direct_coef_kernel)
+            const int e = (int)few.size();
+            int pad = 1;
+            while (pad < e) pad <<= 1;
+            const uint32_t w = gf::h_root((uint32_t)NC);
+            std::vector<uint32_t> we(e), inv(e), epos(pad, 0xFFFFFFFFu);
+            for (int j = 0; j < e; j++) we[j] = gf::h_pow(w, few[j]), epos[j] = few[j];
+            for (int j = 0; j < e; j++) {
+                uint32_t l0 = 1;
+                for (int i = 0; i < e; i++)
+                    if (i != j) l0 = gf::h_mul(l0, (uint32_t)(((uint64_t)we[j] + gf::P - we[i]) % gf::P));
+                inv[j] = (gf::P - gf::h_inv(l0)) % gf::P;  // -1 / l0(w^e_j)
+            }
+            hipStream_t st = nullptr;
+            if (!d->wpow) {
+                DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
+                hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
+                DEC_TRY(hipGetLastError());
+            }
+            if (!d->direct_coef) DEC_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 4));
+            if (!d->direct_pos) DEC_TRY(hipMalloc((void**)&d->direct_pos, 2 * DIRECT_MAX * 4));
+            const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+            const uint64_t need = (chunks + 32 /* DIRECT_SEGS: the second step's staging rows */) * pad * ci.words;
+            if (d->direct_partial_words < need) {
+                if (d->direct_partial) (void)hipFree(d->direct_partial);
+                d->direct_partial = nullptr;
+                d->direct_partial_words = 0;
+                DEC_TRY(hipMalloc((void**)&d->direct_partial, need * 4));
+                d->direct_partial_words = need;
+            }
+            {
+                const int rc = call.wait_idle();  // a decode still using the previous pattern
+                if (rc != FASTECC_OK) return rc;
+            }
+            DEC_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), pad * 4, hipMemcpyHostToDevice, st));
+            DEC_TRY(hipMemcpyAsync(d->direct_pos + DIRECT_MAX, inv.data(), e * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(direct_coef_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->direct_coef, d->wpow, d->direct_pos,
+                               d->direct_pos + DIRECT_MAX, (uint32_t)NC, e, pad);
+            DEC_TRY(hipGetLastError());
+            DEC_TRY(hipStreamSynchronize(st));
+            d->direct = e;
+            d->direct_pad = pad;
+            d->ready = true;
+            return FASTECC_OK;
+        }
+    }
     enum : uint8_t { LOST = ST_LOST, HELD = ST_HELD, ZERO = ST_ZERO };
     std::vector<uint8_t> state(NC, LOST);
     std::vector<uint32_t> srcmap(NC, 0);
@@ -547,54 +624,6 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipMemcpy(d->parity_lost, plost.data(), ci.user_m * 4, hipMemcpyHostToDevice));
     }
     d->direct = 0;
-    if (d->standard && !erased.empty() && (int)erased.size() <= std::min(ci.direct_max, DIRECT_MAX) && erased.size() < N) {
-        // few losses: a table of coefficients instead of the locator machinery (direct_coef_kernel)
-        const int e = (int)erased.size();
-        int pad = 1;
-        while (pad < e) pad <<= 1;
-        const uint32_t w = gf::h_root((uint32_t)NC);
-        std::vector<uint32_t> we(e), inv(e), epos(pad, 0xFFFFFFFFu);
-        for (int j = 0; j < e; j++) we[j] = gf::h_pow(w, erased[j]), epos[j] = erased[j];
-        for (int j = 0; j < e; j++) {
-            uint32_t l0 = 1;
-            for (int i = 0; i < e; i++)
-                if (i != j) l0 = gf::h_mul(l0, (uint32_t)(((uint64_t)we[j] + gf::P - we[i]) % gf::P));
-            inv[j] = (gf::P - gf::h_inv(l0)) % gf::P;  // -1 / l0(w^e_j)
-        }
-        hipStream_t st = nullptr;
-        if (!d->wpow) {
-            DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
-            hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
-            DEC_TRY(hipGetLastError());
-        }
-        if (!d->dev_state) DEC_TRY(hipMalloc((void**)&d->dev_state, NC));
-        if (!d->direct_coef) DEC_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 4));
-        if (!d->direct_pos) DEC_TRY(hipMalloc((void**)&d->direct_pos, 2 * DIRECT_MAX * 4));
-        const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
-        const uint64_t need = (chunks + 32 /* DIRECT_SEGS: the second step's staging rows */) * pad * ci.words;
-        if (d->direct_partial_words < need) {
-            if (d->direct_partial) (void)hipFree(d->direct_partial);
-            d->direct_partial = nullptr;
-            d->direct_partial_words = 0;
-            DEC_TRY(hipMalloc((void**)&d->direct_partial, need * 4));
-            d->direct_partial_words = need;
-        }
-        {
-            const int rc = call.wait_idle();  // a decode still using the previous pattern
-            if (rc != FASTECC_OK) return rc;
-        }
-        DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
-        DEC_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), pad * 4, hipMemcpyHostToDevice, st));
-        DEC_TRY(hipMemcpyAsync(d->direct_pos + DIRECT_MAX, inv.data(), e * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(direct_coef_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->direct_coef, d->wpow, d->dev_state, d->direct_pos,
-                           d->direct_pos + DIRECT_MAX, (uint32_t)NC, e, pad);
-        DEC_TRY(hipGetLastError());
-        DEC_TRY(hipStreamSynchronize(st));
-        d->direct = e;
-        d->direct_pad = pad;
-        d->ready = true;
-        return FASTECC_OK;
-    }
     if (erased_data == 0) {  // no data block to recover
         d->ready = true;
         return FASTECC_OK;
