@@ -130,6 +130,8 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
+    DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (decode.hip), built on first use
+    int encode_direct_max = 8;
     int decode_direct_max = 16;  // (2k,k) codes: up to this many lost blocks are recomputed directly (decode.hip), 0 = always the transform
     int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
@@ -600,8 +602,22 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
     return FASTECC_OK;
 }
 
+// codes with few parity blocks skip the transform pipeline: one read of the data (decode.hip: direct_encode_run)
+static bool direct_encode_applies(const fastecc_ctx* c)
+{
+    return c->q == 1 && !c->p61 && c->cosets == 1 && c->ld == c->S && c->Mu >= 1 && (int)std::min<uint64_t>(c->Mu, 1000) <= std::min(c->encode_direct_max, direct_encode_max());
+}
+
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
+    if (direct_encode_applies(c)) {
+        if (!c->direct_enc) {
+            const int rc = direct_encode_build(&c->direct_enc, c->n, c->K, c->Mu, c->fold, c->S);
+            if (rc != FASTECC_OK) return rc;
+        }
+        ProfScope ps(c, st, "direct_encode", (c->K + c->Mu) * c->S * 4ull);
+        return direct_encode_run(c->direct_enc, data, parity, st);
+    }
     if (c->q > 1) return encode_mixed(c, data, parity, st);
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
     // any (n,k): the first pass reads the K existing data blocks and takes the rest of the stripe as zero, the last pass
@@ -1096,6 +1112,7 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
     const uint64_t N = k;
     std::vector<uint32_t> dsc(N * cosets);
     const uint32_t invN = gf::h_inv((uint32_t)N);
+    if (custom_factor) c->encode_direct_max = 0;  // a transform context is not the encoder's polynomial evaluation: always the pipeline
     for (int t = 0; t < cosets && custom_factor; t++) {
         for (uint64_t i = 0; i < N; i++) dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(custom_factor[i] % gf::P);
     }
@@ -1290,6 +1307,8 @@ void fastecc_destroy(fastecc_ctx* c)
     destroy_decode_state(c->decoder);
     c->decoder = nullptr;
     DeviceGuard dg(c->device);
+    direct_encode_destroy(c->direct_enc);
+    c->direct_enc = nullptr;
     p61::destroy_decoder(c->decoder61);
     c->decoder61 = nullptr;
     for (ProfileRec& r : c->prof) {
@@ -1338,7 +1357,7 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     if (mem_kind == FASTECC_MEM_DEVICE) {
         // the reference's configuration touches nothing but the caller's buffers and the read-only tables: calls on
         // different streams may overlap on the device.  The other codes work through scratch stripes of the context.
-        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1 || c->q > 1;
+        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1 || c->q > 1 || direct_encode_applies(c);
         if (!internal) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
         return with_internal_buffers(c, st, [&] { return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st); });
     }
@@ -1728,6 +1747,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
     if (!strcmp(name, "host_slabs")) {
         if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
         c->host_slabs = value;
+        return FASTECC_OK;
+    }
+    if (!strcmp(name, "encode_direct_max")) {  // codes with at most this many parity blocks are encoded without the transform (0 = never)
+        if (value < 0 || value > direct_encode_max()) return FASTECC_E_INVAL;
+        c->encode_direct_max = value;
         return FASTECC_OK;
     }
     if (!strcmp(name, "decode_direct_max")) {  // takes effect at the next fastecc_decode_prepare

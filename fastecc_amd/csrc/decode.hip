@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ coef, uint32_t* __restrict__ partial, uint32_t S,
                                                                 uint32_t NC, uint32_t col_chunks, uint64_t items)
 {
+    // parity == nullptr: the NC "positions" are the rows of `data` (the encoder for few parity blocks, below)
     constexpr int U = V == 4 ? 4 : 8;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* 
 #pragma unroll
             for (int v = 0; v < V; ++v) x[i][v] = 0;
             // the load does not wait for the coefficients: all U rows are in flight at once
-            if (u < u1 && live) load_vec<V>(x[i], ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S + col);
+            if (u < u1 && live) load_vec<V>(x[i], parity ? ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S + col : data + (size_t)u * S + col);
         }
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -420,12 +421,35 @@ __global__ __launch_bounds__(256) void direct_reduce2_kernel(const uint32_t* __r
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (col >= S || j >= e) return;
-    const uint32_t pos = epos[j];
+    const uint32_t pos = epos ? epos[j] : 2u * (uint32_t)j + 1u;  // no list: output j is row j of `parity` (the encoder below)
     if ((pos & 1u) && !with_parity) return;
     uint32_t v = 0;
 #pragma unroll
     for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf::add(v, stage[((size_t)g * pad + j) * S + col]);
     ((pos & 1u) ? parity : data)[(size_t)(pos >> 1) * S + col] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same idea for ENCODING when a code has few parity blocks (n - k <= 8): with the data points x_i = w_N^i and
+// L_i(x) = (x^N - 1) x_i / (N (x - x_i)) the Lagrange basis, parity block j = f(y_j) = sum_i data_i * L_i(y_j), y_j = w_2N^(odd): y_j^N = -1,
+// so coef[i][j] = -2 x_i / (N (y_j - x_i)) — one read of the data instead of three trips of the transform pipeline.  Exactly the
+// polynomial evaluation the transform computes (RS.cpp:40-63), hence the same parity bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int DIRECT_ENC_MAX = 8;
+__global__ __launch_bounds__(256) void encode_coef_kernel(uint32_t* __restrict__ coef, uint32_t w2n, uint32_t minus_two_over_n, uint32_t K, int m, int pad, int fold)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const uint32_t xi = dev_pow(w2n, 2u * i);
+    for (int j = 0; j < pad; ++j) {
+        uint32_t v = 0;
+        if (j < m) {
+            const uint32_t yj = dev_pow(w2n, (((uint32_t)j << fold) << 1) + 1u);
+            v = gf::mul(gf::mul(minus_two_over_n, xi), dev_pow(gf::sub(yj, xi), gf::P - 2u));
+            v = gf::mul(v, gf::MONT_ONE);
+        }
+        coef[(size_t)i * pad + j] = v;
+    }
 }
 
 int hip_code(const char* what, hipError_t e)
@@ -455,6 +479,80 @@ struct DeviceScope {
 };
 
 }  // namespace
+
+struct DirectEncode {
+    uint32_t* coef = nullptr;     // [K][pad], Montgomery form
+    uint32_t* partial = nullptr;  // [chunks + DIRECT_SEGS][pad][S]
+    uint32_t K = 0, S = 0;
+    int m = 0, pad = 0;
+};
+
+void direct_encode_destroy(DirectEncode* de)
+{
+    if (!de) return;
+    if (de->coef) (void)hipFree(de->coef);
+    if (de->partial) (void)hipFree(de->partial);
+    delete de;
+}
+
+int direct_encode_max() { return DIRECT_ENC_MAX; }
+
+// N = 2^log2n data points, K <= N existing data blocks, m <= 8 parity blocks at the odd positions ((j << fold) << 1) + 1 of the
+// 2N-th roots of unity (fastecc_create's layout).  The current device is the context's.
+int direct_encode_build(DirectEncode** out, int log2n, uint64_t K, uint64_t m, int fold, uint64_t words)
+{
+    *out = nullptr;
+    if (m < 1 || m > DIRECT_ENC_MAX || K < 1 || log2n < 1 || log2n > 19) return FASTECC_E_UNSUPPORTED;
+    DirectEncode* de = new (std::nothrow) DirectEncode();
+    if (!de) return FASTECC_E_NOMEM;
+    de->K = (uint32_t)K;
+    de->S = (uint32_t)words;
+    de->m = (int)m;
+    de->pad = 1;
+    while (de->pad < de->m) de->pad <<= 1;
+    const uint64_t N = 1ull << log2n, chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
+    auto bail = [&](int rc) {
+        direct_encode_destroy(de);
+        return rc;
+    };
+    hipError_t e = hipMalloc((void**)&de->coef, K * de->pad * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&de->partial, (chunks + DIRECT_SEGS) * de->pad * words * 4);
+    if (e != hipSuccess) return bail(hip_code("hipMalloc(direct encode)", e));
+    const uint32_t w2n = gf::h_root((uint32_t)(2 * N));
+    const uint32_t c0 = gf::h_mul(gf::P - 2u, gf::h_inv((uint32_t)(N % gf::P)));  // -2 / N
+    hipLaunchKernelGGL(encode_coef_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, nullptr, de->coef, w2n, c0, (uint32_t)K, de->m, de->pad, fold);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return bail(hip_code("encode_coef_kernel", e));
+    *out = de;
+    return FASTECC_OK;
+}
+
+// parity[j] = sum_i data[i] * coef[i][j]; data: K rows of S words, parity: m rows (may be the first m rows of data)
+int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    const uint32_t S = de->S, K = de->K;
+    const bool v4 = (S % 4) == 0 && ((((uintptr_t)data | (uintptr_t)de->partial) & 15u) == 0);
+    const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
+    const uint64_t items = (uint64_t)chunks * col_chunks;
+    const dim3 grid((unsigned)((items + 3) / 4));
+#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, data, (const uint32_t*)nullptr, de->coef, de->partial, S, K, col_chunks, items)
+    switch (de->pad) {
+        case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
+        case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
+        case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
+        default: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
+    }
+#undef FASTECC_DIRECT
+    DEC_TRY(hipGetLastError());
+    uint32_t* stage = de->partial + (size_t)chunks * de->pad * S;
+    hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)de->m, DIRECT_SEGS), dim3(256), 0, st, de->partial, stage, S, chunks, de->pad, de->m);
+    hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)de->m), dim3(256), 0, st, stage, (const uint32_t*)nullptr, (uint32_t*)nullptr, parity, S,
+                       de->pad, de->m, true);
+    DEC_TRY(hipGetLastError());
+    return FASTECC_OK;
+}
+
 }  // namespace fastecc
 
 using namespace fastecc;

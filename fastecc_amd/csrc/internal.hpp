@@ -24,6 +24,13 @@ int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, cons
 int sharded_decode_stripe(fastecc_ctx* shell, void* data, void* parity, int mem_kind, bool repair, hipStream_t st);
 fastecc_ctx* sharded_child(fastecc_ctx* shell, int g);
 
+// ---- decode.hip: encoding straight from the Lagrange basis for codes with few parity blocks (n - k <= direct_encode_max()) ----
+struct DirectEncode;
+int direct_encode_max();
+int direct_encode_build(DirectEncode** out, int log2n, uint64_t K, uint64_t m, int fold, uint64_t words);  // current device = the context's
+int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, hipStream_t st);
+void direct_encode_destroy(DirectEncode* de);
+
 // ---- api.hip ----
 struct CtxInfo {
     int device, field, fold, cosets, log2k;

@@ -140,3 +140,34 @@ def test_random_codes_round_trip(torch_cuda, fe, oracle):
             dd = to_dev(torch, damaged)
             enc.decode(dd, out)
             assert (to_host(dd, (k, S)) == x).all(), (case, k, m, S, nlost)
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 64, 1000, 4096, 100000])
+def test_few_parity_blocks_are_encoded_directly(torch_cuda, fe, oracle, k):
+    """n - k <= 8: the parity comes straight from the Lagrange basis (one read of the data) — same bits as the transform pipeline
+    (option encode_direct_max = 0) and as the oracle; out of place, in place, host memory."""
+    torch = torch_cuda
+    S = 24 if k < 50000 else 8
+    x = np.random.default_rng(k).integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    N = 1 << max(1, int(np.ceil(np.log2(k))))
+    for m in (1, 2, 3, 5, 8, 9):
+        if m > N:
+            continue
+        want = expected(oracle, x, m)
+        with fe.Encoder(k + m, k, 4 * S) as enc:
+            for direct_max in (8, 0):
+                enc.set_option("encode_direct_max", direct_max)
+                out = torch_cuda.full((m * S,), 0x66666666, dtype=torch_cuda.int32, device="cuda:0")
+                dx = to_dev(torch, x)
+                enc.encode(dx, out)
+                assert (to_host(out, (m, S)) == want).all(), (k, m, direct_max, enc.plan())
+                assert (to_host(dx, (k, S)) == x).all()
+                if m <= k:
+                    enc.encode(dx)  # in place
+                    got = to_host(dx, (k, S))
+                    assert (got[:m] == want).all() and (got[m:] == x[m:]).all(), (k, m, direct_max)
+                host_out = np.empty((m, S), dtype=np.uint32)
+                enc.encode_host(x, host_out)
+                assert (host_out == want).all(), (k, m, direct_max)
+            with pytest.raises(fe.FastEccError):
+                enc.set_option("encode_direct_max", 9)
