@@ -64,13 +64,18 @@ struct DecodeState {
     uint32_t* parity_again = nullptr;
     uint64_t erased_parity = 0;
     uint64_t erased_data = 0, erased_total = 0;
-    // few losses in the (2k,k) layout: every lost block is a fixed linear combination of the surviving ones (direct path)
-    int direct = 0;                    // > 0: number of lost blocks handled directly (padded to direct_pad accumulators)
-    int direct_pad = 0;
-    uint32_t* direct_coef = nullptr;   // [positions][direct_pad]: coefficient of the block at position u in lost block j (Montgomery), 0 = unused
-    uint32_t* direct_pos = nullptr;    // [direct_pad]: codeword position of lost block j (0xFFFFFFFF = padding)
-    uint32_t* direct_partial = nullptr;  // [row chunks][direct_pad][words]: partial sums
+    // few losses: every lost block is a fixed linear combination of surviving ones (the direct path)
+    uint32_t* direct_coef = nullptr;   // [K + lost data][pad]: weight of data block i (then of the parity blocks used as nodes) in lost data block r, Montgomery
+    uint32_t* direct_partial = nullptr;  // [row chunks + 32][pad][words]: partial sums, and the staging rows of the second summation step
     uint64_t direct_partial_words = 0;
+    // any layout (the reference's, zero extension, sub-/extra cosets, mixed radix): interpolation on N nodes — the surviving data
+    // points plus as many surviving parity points as data blocks are lost — then, for repair, the lost parity from the complete data
+    int sub_lost_data = 0, sub_lost_parity = 0, sub_pad_data = 0, sub_pad_parity = 0;
+    bool sub = false;
+    uint32_t* sub_coef_parity = nullptr;  // [K][sub_pad_parity]: lost parity block t from data block i
+    uint32_t* sub_lists = nullptr;        // 4 x 16 words: parity rows used as nodes | data output positions | parity output positions | spare
+    uint32_t* sub_params = nullptr;       // 8 x 16 words of field elements for the coefficient kernels
+    uint64_t direct_coef_words = 0;
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
     bool mixed = false;                // mixed-radix code: `recovered` is the whole work stripe (all positions), transformed in place
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
@@ -91,7 +96,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->parity_dev) (void)hipFree(d->parity_dev);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
-    for (uint32_t* b : {d->direct_coef, d->direct_pos, d->direct_partial, d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
+    for (uint32_t* b : {d->sub_coef_parity, d->sub_lists, d->sub_params, d->direct_coef, d->direct_partial, d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
         if (b) (void)hipFree(b);
     delete d;
 }
@@ -309,47 +314,22 @@ __global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Few losses, (2k,k) layout.  With E the lost positions, e0 one of them and l0(x) = prod_{e in E, e != e0} (x - w^e), the
-// polynomial g = x f l0 has degree <= k + |E| - 1 < 2k and no constant term, so sum_u g(w^u) = 0 over the 2k-th roots of unity;
-// g vanishes on E \ {e0}, hence
-//     c[e0] = f(w^e0) = - sum_{u not in E} c[u] * w^(u - e0) * l0(w^u) / l0(w^e0)
-// — every lost block (data or parity) is a linear combination of ALL surviving blocks with coefficients that cost |E| - 1
-// products each: no locator tree, no transform, one read of the codeword.  (|E| = 1: c[e0] w^e0 = - sum_{u != e0} c[u] w^u.)
+// Few losses: the lost blocks are fixed linear combinations of surviving ones — no locator tree, no transform, one read of N + |lost data|
+// blocks (sub_coef_*_kernel below state the weights).  Partial sums over 512 rows per wave, then a two-step sum.
 // ------------------------------------------------------------------------------------------------
 constexpr int DIRECT_MAX = 16;        // lost blocks per pattern on this path
 constexpr uint32_t DIRECT_ROWS = 512; // codeword positions per partial sum
-
-// coef[u][j] for all positions u; inv[j] = -1 / l0_j(w^e_j) (plain), epos[j] = e_j
-__global__ __launch_bounds__(256) void direct_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ epos,
-                                                          const uint32_t* __restrict__ inv, uint32_t NC, int e, int pad)
-{
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= NC) return;
-    bool held = true;  // in this layout every position holds a block: it survives unless it is on the list
-    for (int i = 0; i < e; ++i) held = held && epos[i] != u;
-    const uint32_t wu = wpow[u];
-    for (int j = 0; j < pad; ++j) {
-        uint32_t v = 0;
-        if (held && j < e) {
-            v = inv[j];
-            for (int i = 0; i < e; ++i)
-                if (i != j) v = gf::mul(v, gf::sub(wu, wpow[epos[i]]));
-            const uint32_t ej = epos[j];
-            v = gf::mul(v, wpow[u >= ej ? u - ej : u + NC - ej]);  // w^(u - e_j)
-            v = gf::mul(v, gf::MONT_ONE);
-        }
-        coef[(size_t)u * pad + j] = v;
-    }
-}
 
 // partial[chunk][j][col] = sum over the chunk's positions u of block(u)[col] * coef[u][j]; a wave owns (chunk, 64*V-word column
 // chunk) and keeps four rows in flight
 template <int EB, int V>
 __global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
                                                                 const uint32_t* __restrict__ coef, uint32_t* __restrict__ partial, uint32_t S,
-                                                                uint32_t NC, uint32_t col_chunks, uint64_t items)
+                                                                uint32_t NC, uint32_t col_chunks, uint64_t items, const uint32_t* __restrict__ extra = nullptr,
+                                                                uint32_t data_rows = 0)
 {
-    // parity == nullptr: the NC "positions" are the rows of `data` (the encoder for few parity blocks, below)
+    // parity == nullptr: the NC "positions" are the rows of `data` (the encoder for few parity blocks, below); extra != nullptr:
+    // rows [0, data_rows) of `data`, then the rows extra[0..] of `parity` (the decoder for any layout)
     constexpr int U = V == 4 ? 4 : 8;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -381,7 +361,13 @@ __global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* 
 #pragma unroll
             for (int v = 0; v < V; ++v) x[i][v] = 0;
             // the load does not wait for the coefficients: all U rows are in flight at once
-            if (u < u1 && live) load_vec<V>(x[i], parity ? ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S + col : data + (size_t)u * S + col);
+            if (u < u1 && live) {
+                const uint32_t* row;
+                if (extra) row = u < data_rows ? data + (size_t)u * S : parity + (size_t)as_constant(extra)[u - data_rows] * S;
+                else if (parity) row = ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S;
+                else row = data + (size_t)u * S;
+                load_vec<V>(x[i], row + col);
+            }
         }
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -427,6 +413,51 @@ __global__ __launch_bounds__(256) void direct_reduce2_kernel(const uint32_t* __r
 #pragma unroll
     for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf::add(v, stage[((size_t)g * pad + j) * S + col]);
     ((pos & 1u) ? parity : data)[(size_t)(pos >> 1) * S + col] = v;
+}
+
+// Any layout with the data at the N-th roots of unity x_i = w^(i << e) (N a power of two or q 2^m), R the lost data blocks and A as many
+// surviving parity points y_a: the N nodes {x_i : i not in R} + {y_a} interpolate f, and with l(x) = (x^N - 1) A(x) / R(x),
+// A(x) = prod_a (x - y_a), R(x) = prod_r (x - x_r), R_r = R / (x - x_r):
+//     weight of data block i in lost block r   = -(x_i / x_r) * A(x_r) / R_r(x_r) * R_r(x_i) / A(x_i)
+//     weight of parity block a in lost block r = N x_r^-1 A_a(x_r) R(y_a) / (R_r(x_r) (y_a^N - 1) A_a(y_a))     (host: sub-table rows K..)
+// params: [0..16) x_r, [16..32) y_a, [32..48) C_r = -A(x_r) / (x_r R_r(x_r)), [48] = number of lost data blocks; all plain
+__global__ __launch_bounds__(256) void sub_coef_data_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ params,
+                                                            const uint32_t* __restrict__ lost_rows, uint32_t K, int shift, int ed, int pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    bool lost = false;
+    for (int r = 0; r < ed; ++r) lost = lost || lost_rows[r] == i;
+    const uint32_t xi = wpow[(size_t)i << shift];
+    uint32_t base = 0;
+    if (!lost) {
+        uint32_t a = 1;
+        for (int t = 0; t < ed; ++t) a = gf::mul(a, gf::sub(xi, params[16 + t]));
+        base = gf::mul(xi, dev_pow(a, gf::P - 2u));  // x_i / A(x_i)
+    }
+    for (int r = 0; r < pad; ++r) {
+        uint32_t v = 0;
+        if (!lost && r < ed) {
+            v = gf::mul(params[32 + r], base);
+            for (int t = 0; t < ed; ++t)
+                if (t != r) v = gf::mul(v, gf::sub(xi, params[t]));
+            v = gf::mul(v, gf::MONT_ONE);
+        }
+        coef[(size_t)i * pad + r] = v;
+    }
+}
+// lost parity block t (point y_t) from the complete data: L_i(y_t) = (y_t^N - 1) x_i / (N (y_t - x_i)); params: [0..16) y_t, [16..32) (y_t^N - 1) / N
+__global__ __launch_bounds__(256) void sub_coef_parity_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ params,
+                                                              uint32_t K, int shift, int ep, int pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const uint32_t xi = wpow[(size_t)i << shift];
+    for (int t = 0; t < pad; ++t) {
+        uint32_t v = 0;
+        if (t < ep) v = gf::mul(gf::mul(gf::mul(params[16 + t], xi), dev_pow(gf::sub(params[t], xi), gf::P - 2u)), gf::MONT_ONE);
+        coef[(size_t)i * pad + t] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,19 +624,29 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while ((1 << e) < ci.cosets + 1) e++;
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
-    // ---- few losses in the reference's (2k,k) layout: decided before any per-position table is built ----
-    const bool standard_layout = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
     const int direct_limit = std::min(ci.direct_max, (int)DIRECT_MAX);
-    if (standard_layout && direct_limit > 0) {
-        std::vector<uint32_t> few;
-        uint64_t lost_data = 0, lost_parity = 0;
+    auto parity_position = [&](uint64_t q) -> uint64_t {
+        if (ci.cosets > 1) {
+            const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
+            int jj = 1;
+            while ((1ull << jj) - 1 <= t) jj++;
+            const uint64_t odd = 2 * (t + 1 - (1ull << (jj - 1))) + 1;
+            return (odd << (e - jj)) + (j << e);
+        }
+        return ((q << ci.fold) << 1) + 1;
+    };
+    // ---- few losses (decided before any per-position table is built): interpolation on the surviving data points + a few parity points ----
+    if (direct_limit > 0 && ci.user_k < 0xFFFFFFF0ull) {
+        std::vector<uint32_t> R, Pl, A;
         bool over = false;
-        for (uint64_t i = 0; i < N && !over; i++)
-            if (!data_present[i]) lost_data++, few.push_back((uint32_t)(2 * i)), over = (int)few.size() > direct_limit;
-        for (uint64_t q = 0; q < N && !over; q++)
-            if (!parity_present[q]) lost_parity++, few.push_back((uint32_t)(2 * q + 1)), over = (int)few.size() > direct_limit;
-        if (!over && !few.empty() && few.size() < N) {
-            std::sort(few.begin(), few.end());
+        for (uint64_t i = 0; i < ci.user_k && !over; i++)
+            if (!data_present[i]) R.push_back((uint32_t)i), over = (int)R.size() > direct_limit;
+        for (uint64_t q = 0; q < ci.user_m && !over; q++)
+            if (!parity_present[q]) Pl.push_back((uint32_t)q), over = (int)(R.size() + Pl.size()) > direct_limit;
+        for (uint64_t q = 0; q < ci.user_m && !over && A.size() < R.size(); q++)
+            if (parity_present[q]) A.push_back((uint32_t)q);
+        if (!over && R.size() + Pl.size() >= 1 && A.size() == R.size()) {
+            const int ed = (int)R.size(), ep = (int)Pl.size();
             DeviceScope ds(ci.device);
             if (!ds.ok) return FASTECC_E_DEVICE;
             CallScope call(c);
@@ -616,25 +657,55 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             }
             DecodeState* d = slot;
             d->ready = false;
-            d->direct = 0;
-            d->erased_data = lost_data;
-            d->erased_parity = lost_parity;
-            d->erased_total = few.size();
+            d->sub = false;
+            d->erased_data = ed;
+            d->erased_parity = ep;
+            d->erased_total = ed + ep;
             d->positions = NC;
-            d->standard = true;
-            d->mixed = false;
-            // a table of coefficients instead of the locator machinery (direct_coef_kernel)
-            const int e = (int)few.size();
-            int pad = 1;
-            while (pad < e) pad <<= 1;
+            d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
+            d->mixed = mixed;
+            const uint32_t K = (uint32_t)ci.user_k;
+            int padd = 1, padp = 1;
+            while (padd < ed) padd <<= 1;
+            while (padp < ep) padp <<= 1;
             const uint32_t w = gf::h_root((uint32_t)NC);
-            std::vector<uint32_t> we(e), inv(e), epos(pad, 0xFFFFFFFFu);
-            for (int j = 0; j < e; j++) we[j] = gf::h_pow(w, few[j]), epos[j] = few[j];
-            for (int j = 0; j < e; j++) {
-                uint32_t l0 = 1;
-                for (int i = 0; i < e; i++)
-                    if (i != j) l0 = gf::h_mul(l0, (uint32_t)(((uint64_t)we[j] + gf::P - we[i]) % gf::P));
-                inv[j] = (gf::P - gf::h_inv(l0)) % gf::P;  // -1 / l0(w^e_j)
+            auto fsub = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + gf::P - b) % gf::P); };
+            const uint32_t Nf = (uint32_t)(N % gf::P);
+            std::vector<uint32_t> xr(ed), ya(ed), yaN1(ed), params(8 * 16, 0), lists(4 * 16, 0);
+            for (int r = 0; r < ed; r++) xr[r] = gf::h_pow(w, (uint64_t)R[r] << e);
+            for (int a = 0; a < ed; a++) {
+                ya[a] = gf::h_pow(w, parity_position(A[a]));
+                yaN1[a] = fsub(gf::h_pow(ya[a], N), 1u);
+            }
+            // per lost data block: C_r, and the weights of the parity nodes
+            std::vector<uint32_t> node_rows((size_t)ed * padd, 0);
+            for (int r = 0; r < ed; r++) {
+                uint32_t Ar = 1, Rr = 1;
+                for (int a = 0; a < ed; a++) Ar = gf::h_mul(Ar, fsub(xr[r], ya[a]));
+                for (int t = 0; t < ed; t++)
+                    if (t != r) Rr = gf::h_mul(Rr, fsub(xr[r], xr[t]));
+                const uint32_t inv_xr_Rr = gf::h_inv(gf::h_mul(xr[r], Rr));
+                params[r] = xr[r];
+                params[32 + r] = fsub(0u, gf::h_mul(Ar, inv_xr_Rr));  // -A(x_r) / (x_r R_r(x_r))
+                for (int a = 0; a < ed; a++) {
+                    uint32_t Aa_xr = 1, Aa_ya = 1, R_ya = 1;
+                    for (int t = 0; t < ed; t++) {
+                        if (t != a) Aa_xr = gf::h_mul(Aa_xr, fsub(xr[r], ya[t])), Aa_ya = gf::h_mul(Aa_ya, fsub(ya[a], ya[t]));
+                        R_ya = gf::h_mul(R_ya, fsub(ya[a], xr[t]));
+                    }
+                    const uint32_t num = gf::h_mul(gf::h_mul(Nf, Aa_xr), R_ya);
+                    const uint32_t den = gf::h_mul(gf::h_mul(gf::h_mul(xr[r], Rr), yaN1[a]), Aa_ya);
+                    node_rows[(size_t)a * padd + r] = gf::h_to_mont(gf::h_mul(num, gf::h_inv(den)));
+                }
+            }
+            for (int a = 0; a < ed; a++) params[16 + a] = ya[a], lists[a] = A[a];
+            for (int r = 0; r < ed; r++) lists[16 + r] = 2u * R[r];           // reduce: even "position" 2r -> data row r
+            for (int t = 0; t < ep; t++) lists[32 + t] = 2u * Pl[t] + 1u;     // odd -> parity row
+            const uint32_t inv_N = gf::h_inv(Nf);
+            for (int t = 0; t < ep; t++) {
+                const uint32_t yt = gf::h_pow(w, parity_position(Pl[t]));
+                params[64 + t] = yt;
+                params[80 + t] = gf::h_mul(fsub(gf::h_pow(yt, N), 1u), inv_N);  // (y_t^N - 1) / N
             }
             hipStream_t st = nullptr;
             if (!d->wpow) {
@@ -642,10 +713,19 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                 hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
                 DEC_TRY(hipGetLastError());
             }
-            if (!d->direct_coef) DEC_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 4));
-            if (!d->direct_pos) DEC_TRY(hipMalloc((void**)&d->direct_pos, 2 * DIRECT_MAX * 4));
-            const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
-            const uint64_t need = (chunks + 32 /* DIRECT_SEGS: the second step's staging rows */) * pad * ci.words;
+            const uint64_t coef_words = ((uint64_t)K + DIRECT_MAX) * DIRECT_MAX;
+            if (d->direct_coef_words < coef_words) {
+                if (d->direct_coef) (void)hipFree(d->direct_coef);
+                d->direct_coef = nullptr;
+                d->direct_coef_words = 0;
+                DEC_TRY(hipMalloc((void**)&d->direct_coef, coef_words * 4));
+                d->direct_coef_words = coef_words;
+            }
+            if (!d->sub_coef_parity) DEC_TRY(hipMalloc((void**)&d->sub_coef_parity, (uint64_t)K * DIRECT_MAX * 4));
+            if (!d->sub_lists) DEC_TRY(hipMalloc((void**)&d->sub_lists, 4 * 16 * 4));
+            if (!d->sub_params) DEC_TRY(hipMalloc((void**)&d->sub_params, 8 * 16 * 4));
+            const uint64_t chunks = ((uint64_t)K + DIRECT_MAX + DIRECT_ROWS - 1) / DIRECT_ROWS;
+            const uint64_t need = (chunks + 32 /* DIRECT_SEGS */) * std::max(padd, padp) * ci.words;
             if (d->direct_partial_words < need) {
                 if (d->direct_partial) (void)hipFree(d->direct_partial);
                 d->direct_partial = nullptr;
@@ -657,14 +737,28 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                 const int rc = call.wait_idle();  // a decode still using the previous pattern
                 if (rc != FASTECC_OK) return rc;
             }
-            DEC_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), pad * 4, hipMemcpyHostToDevice, st));
-            DEC_TRY(hipMemcpyAsync(d->direct_pos + DIRECT_MAX, inv.data(), e * 4, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(direct_coef_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->direct_coef, d->wpow, d->direct_pos,
-                               d->direct_pos + DIRECT_MAX, (uint32_t)NC, e, pad);
-            DEC_TRY(hipGetLastError());
-            DEC_TRY(hipStreamSynchronize(st));
-            d->direct = e;
-            d->direct_pad = pad;
+            DEC_TRY(hipMemcpyAsync(d->sub_params, params.data(), params.size() * 4, hipMemcpyHostToDevice, st));
+            DEC_TRY(hipMemcpyAsync(d->sub_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
+            if (ed > 0) {
+                // lost data rows as a list for the kernel: reuse the spare quarter of the lists
+                std::vector<uint32_t> lost_rows(16, 0xFFFFFFFFu);
+                for (int r = 0; r < ed; r++) lost_rows[r] = R[r];
+                DEC_TRY(hipMemcpyAsync(d->sub_lists + 48, lost_rows.data(), 16 * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(sub_coef_data_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d->direct_coef, d->wpow, d->sub_params, d->sub_lists + 48, K, e, ed,
+                                   padd);
+                DEC_TRY(hipGetLastError());
+                DEC_TRY(hipMemcpyAsync(d->direct_coef + (size_t)K * padd, node_rows.data(), node_rows.size() * 4, hipMemcpyHostToDevice, st));
+            }
+            if (ep > 0) {
+                hipLaunchKernelGGL(sub_coef_parity_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d->sub_coef_parity, d->wpow, d->sub_params + 64, K, e, ep, padp);
+                DEC_TRY(hipGetLastError());
+            }
+            DEC_TRY(hipStreamSynchronize(st));  // the host vectors above go out of scope
+            d->sub = true;
+            d->sub_lost_data = ed;
+            d->sub_lost_parity = ep;
+            d->sub_pad_data = padd;
+            d->sub_pad_parity = padp;
             d->ready = true;
             return FASTECC_OK;
         }
@@ -680,16 +774,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         else erased_data++;
     }
     for (uint64_t q = 0; q < ci.user_m; q++) {
-        uint64_t u;
-        if (ci.cosets > 1) {
-            const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
-            int jj = 1;
-            while ((1ull << jj) - 1 <= t) jj++;
-            const uint64_t odd = 2 * (t + 1 - (1ull << (jj - 1))) + 1;
-            u = (odd << (e - jj)) + (j << e);
-        } else {
-            u = ((q << ci.fold) << 1) + 1;
-        }
+        const uint64_t u = parity_position(q);
         if (parity_present[q]) state[u] = HELD, srcmap[u] = (uint32_t)q | 0x80000000u;
     }
     std::vector<uint32_t> erased;
@@ -721,7 +806,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK) return rc;
         DEC_TRY(hipMemcpy(d->parity_lost, plost.data(), ci.user_m * 4, hipMemcpyHostToDevice));
     }
-    d->direct = 0;
+    d->sub = false;
     if (erased_data == 0) {  // no data block to recover
         d->ready = true;
         return FASTECC_OK;
@@ -918,30 +1003,40 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         ddata = d->parity_dev + ci.user_m * ci.words;
     }
 
-    if (d->direct > 0) {
-        // every lost block straight from the surviving ones: one read of the codeword, |E| products per word
-        const uint32_t S = (uint32_t)ci.words, NC = (uint32_t)d->positions;
-        const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)d->direct_partial) & 15u) == 0) && d->direct_pad <= 8;
-        const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
-        const uint64_t items = (uint64_t)chunks * col_chunks;
-        const dim3 grid((unsigned)((items + 3) / 4));
+    if (d->sub) {
+        // any layout, few losses: the lost data from the surviving data + a few parity blocks, then (repair) the lost parity from the data
+        const uint32_t S = (uint32_t)ci.words, K = (uint32_t)ci.user_k;
         uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
-#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, ddata, dparity, d->direct_coef, d->direct_partial, S, NC, col_chunks, items)
-        switch (d->direct_pad) {
-            case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
-            case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
-            case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
-            case 8: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
-            default: FASTECC_DIRECT(16, 1); break;
-        }
+        auto pass = [&](const uint32_t* coef, int pad, int outputs, uint32_t rows, const uint32_t* extra, const uint32_t* epos, bool to_parity) -> int {
+            const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)d->direct_partial) & 15u) == 0) && pad <= 8;
+            const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (rows + DIRECT_ROWS - 1) / DIRECT_ROWS;
+            const uint64_t items = (uint64_t)chunks * col_chunks;
+            const dim3 grid((unsigned)((items + 3) / 4));
+            const uint32_t* par = extra ? dparity : nullptr;
+#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, ddata, par, coef, d->direct_partial, S, rows, col_chunks, items, extra, K)
+            switch (pad) {
+                case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
+                case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
+                case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
+                case 8: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
+                default: FASTECC_DIRECT(16, 1); break;
+            }
 #undef FASTECC_DIRECT
-        DEC_TRY(hipGetLastError());
-        uint32_t* stage = d->direct_partial + (size_t)chunks * d->direct_pad * S;  // behind the partial sums
-        hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)d->direct, DIRECT_SEGS), dim3(256), 0, st, d->direct_partial, stage, S, chunks,
-                           d->direct_pad, d->direct);
-        hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)d->direct), dim3(256), 0, st, stage, d->direct_pos, ddata, dpar_out, S,
-                           d->direct_pad, d->direct, rebuild);
-        DEC_TRY(hipGetLastError());
+            DEC_TRY(hipGetLastError());
+            uint32_t* stage = d->direct_partial + (size_t)chunks * pad * S;
+            hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)outputs, DIRECT_SEGS), dim3(256), 0, st, d->direct_partial, stage, S, chunks, pad, outputs);
+            hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)outputs), dim3(256), 0, st, stage, epos, ddata, dpar_out, S, pad, outputs, to_parity);
+            DEC_TRY(hipGetLastError());
+            return FASTECC_OK;
+        };
+        if (d->sub_lost_data > 0) {
+            const int rc = pass(d->direct_coef, d->sub_pad_data, d->sub_lost_data, K + (uint32_t)d->sub_lost_data, d->sub_lists, d->sub_lists + 16, false);
+            if (rc != FASTECC_OK) return rc;
+        }
+        if (rebuild) {
+            const int rc = pass(d->sub_coef_parity, d->sub_pad_parity, d->sub_lost_parity, K, nullptr, d->sub_lists + 32, true);
+            if (rc != FASTECC_OK) return rc;
+        }
     } else {
     if (d->erased_data != 0) {
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).

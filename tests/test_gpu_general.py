@@ -171,3 +171,71 @@ def test_few_parity_blocks_are_encoded_directly(torch_cuda, fe, oracle, k):
                 assert (host_out == want).all(), (k, m, direct_max)
             with pytest.raises(fe.FastEccError):
                 enc.set_option("encode_direct_max", 9)
+
+
+def _few_loss_round_trips(torch, fe, enc, x, par, rng, counts):
+    """Lose `e` blocks (at least one data block when possible), decode / repair on both decoder paths, compare with the originals."""
+    k, S = x.shape
+    m = par.shape[0]
+    for e in counts:
+        if e > m:
+            continue
+        lost = np.unique(np.r_[int(rng.integers(0, k)), rng.permutation(k + m)[: e - 1]])
+        dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+        dp[lost[lost < k]] = 0
+        pp[lost[lost >= k] - k] = 0
+        bad_x, bad_p = x.copy(), par.copy()
+        bad_x[dp == 0] = 0xA5A5A5A5
+        bad_p[pp == 0] = 0x5A5A5A5A
+        for direct_max in (16, 0):
+            enc.set_option("decode_direct_max", direct_max)
+            enc.decode_prepare(dp, pp)
+            d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+            enc.decode(d, q)
+            assert (to_host(d, (k, S)) == x).all(), (e, direct_max)
+            assert (to_host(q, (m, S)) == bad_p).all(), (e, direct_max)
+            enc.repair(d, q)
+            assert (to_host(d, (k, S)) == x).all() and (to_host(q, (m, S)) == par).all(), (e, direct_max)
+            hx, hp = bad_x.copy(), bad_p.copy()
+            enc.repair(hx, hp, mem=fe.MEM_HOST)
+            assert (hx == x).all() and (hp == par).all(), (e, direct_max)
+        # parity only
+        if m >= 2:
+            dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+            pp[[0, m - 1]] = 0
+            bad_p = par.copy()
+            bad_p[pp == 0] = 7
+            enc.set_option("decode_direct_max", 16)
+            enc.decode_prepare(dp, pp)
+            d, q = to_dev(torch, x), to_dev(torch, bad_p)
+            enc.repair(d, q)
+            assert (to_host(d, (k, S)) == x).all() and (to_host(q, (m, S)) == par).all()
+    enc.set_option("decode_direct_max", 16)
+
+
+@pytest.mark.parametrize("k,m", [(3, 2), (100, 30), (1000, 1000), (1024, 64), (3000, 700), (4096, 512), (5000, 5000), (20000, 3000)])
+def test_few_losses_in_any_layout(torch_cuda, fe, oracle, k, m):
+    """Zero-extended codes and codes with fewer parity blocks: up to 16 lost blocks are interpolated from the surviving data blocks
+    plus as many parity blocks (no locator, no transform), the lost parity then re-evaluated from the data; same results as the
+    transform path."""
+    S = 24 if k < 10000 else 8
+    rng = np.random.default_rng(k * 31 + m)
+    x = rng.integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    par = expected(oracle, x, m)
+    with fe.Encoder(k + m, k, 4 * S) as enc:
+        _few_loss_round_trips(torch_cuda, fe, enc, x, par, rng, (1, 2, 3, 7, 16, 17))
+
+
+@pytest.mark.parametrize("k,ratio", [(64, 4), (1024, 4), (512, 8)])
+def test_few_losses_with_extra_cosets(torch_cuda, fe, k, ratio):
+    """n = 4k, 8k: the parity sits on other cosets of the data points; the same interpolation."""
+    torch = torch_cuda
+    S = 16
+    rng = np.random.default_rng(k + ratio)
+    x = rng.integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    m = (ratio - 1) * k
+    with fe.Encoder(ratio * k, k, 4 * S) as enc:
+        out = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        par = to_host(out, (m, S)).copy()
+        _few_loss_round_trips(torch, fe, enc, x, par, rng, (1, 4, 16))

@@ -343,3 +343,28 @@ def test_power_of_two_top_level_as_a_radix(torch_cuda, fe, oracle, m):
         with pytest.raises(fe.FastEccError) as ei:
             fe.Encoder(bad[0], bad[1], 4 * S, flags=fe.CODE_TOP_RADIX2)
         assert ei.value.code == fe.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("k,m", [(96, 96), (100, 37), (3 << 11, 3 << 11), (5000, 1200), (7 << 9, 100)])
+def test_few_losses_of_mixed_radix_codes(torch_cuda, fe, k, m):
+    """Up to 16 lost blocks: interpolated from the surviving data blocks and a few parity blocks (the data points are the (q 2^m)-th roots of
+    unity, the formulas do not care about the radix); both decoder paths agree."""
+    torch = torch_cuda
+    S = 12
+    rng = np.random.default_rng(k + m)
+    x = rand_stripe(k + m, k, S)
+    with fe.Encoder(k + m, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        out = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        torch.cuda.synchronize()
+        par = to_host(out).reshape(m, S).copy()
+        none = np.array([], dtype=np.int64)
+        for e in (1, 3, 16, 17):
+            if e > m:
+                continue
+            lost = np.unique(np.r_[int(rng.integers(0, k)), rng.permutation(k + m)[: e - 1]])
+            for direct_max in (16, 0):
+                enc.set_option("decode_direct_max", direct_max)
+                erase_and_check(torch, fe, enc, x, par, lost[lost < k], lost[lost >= k] - k, True)
+                erase_and_check(torch, fe, enc, x, par, lost[lost < k], none, False)
+        enc.set_option("decode_direct_max", 16)
