@@ -605,14 +605,14 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
 // codes with few parity blocks skip the transform pipeline: one read of the data (decode.hip: direct_encode_run)
 static bool direct_encode_applies(const fastecc_ctx* c)
 {
-    return c->q == 1 && !c->p61 && c->cosets == 1 && c->ld == c->S && c->Mu >= 1 && (int)std::min<uint64_t>(c->Mu, 1000) <= std::min(c->encode_direct_max, direct_encode_max());
+    return !c->p61 && c->cosets == 1 && c->ld == c->S && c->Mu >= 1 && (int)std::min<uint64_t>(c->Mu, 1000) <= std::min(c->encode_direct_max, direct_encode_max());
 }
 
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     if (direct_encode_applies(c)) {
         if (!c->direct_enc) {
-            const int rc = direct_encode_build(&c->direct_enc, c->n, c->K, c->Mu, c->fold, c->S);
+            const int rc = direct_encode_build(&c->direct_enc, (uint64_t)c->q * c->N, c->K, c->Mu, c->fold, c->S);  // q > 1: the mixed-radix order
             if (rc != FASTECC_OK) return rc;
         }
         ProfScope ps(c, st, "direct_encode", (c->K + c->Mu) * c->S * 4ull);

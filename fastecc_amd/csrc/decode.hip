@@ -528,12 +528,12 @@ void direct_encode_destroy(DirectEncode* de)
 
 int direct_encode_max() { return DIRECT_ENC_MAX; }
 
-// N = 2^log2n data points, K <= N existing data blocks, m <= 8 parity blocks at the odd positions ((j << fold) << 1) + 1 of the
+// N data points (a power of two, or q 2^m for the mixed-radix codes), K <= N existing data blocks, m <= 8 parity blocks at the odd positions ((j << fold) << 1) + 1 of the
 // 2N-th roots of unity (fastecc_create's layout).  The current device is the context's.
-int direct_encode_build(DirectEncode** out, int log2n, uint64_t K, uint64_t m, int fold, uint64_t words)
+int direct_encode_build(DirectEncode** out, uint64_t N, uint64_t K, uint64_t m, int fold, uint64_t words)
 {
     *out = nullptr;
-    if (m < 1 || m > DIRECT_ENC_MAX || K < 1 || log2n < 1 || log2n > 19) return FASTECC_E_UNSUPPORTED;
+    if (m < 1 || m > DIRECT_ENC_MAX || K < 1 || K > N || N < 2 || ((gf::P - 1ull) % (2 * N)) != 0) return FASTECC_E_UNSUPPORTED;
     DirectEncode* de = new (std::nothrow) DirectEncode();
     if (!de) return FASTECC_E_NOMEM;
     de->K = (uint32_t)K;
@@ -541,7 +541,7 @@ int direct_encode_build(DirectEncode** out, int log2n, uint64_t K, uint64_t m, i
     de->m = (int)m;
     de->pad = 1;
     while (de->pad < de->m) de->pad <<= 1;
-    const uint64_t N = 1ull << log2n, chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
+    const uint64_t chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
     auto bail = [&](int rc) {
         direct_encode_destroy(de);
         return rc;

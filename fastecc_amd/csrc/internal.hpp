@@ -27,7 +27,7 @@ fastecc_ctx* sharded_child(fastecc_ctx* shell, int g);
 // ---- decode.hip: encoding straight from the Lagrange basis for codes with few parity blocks (n - k <= direct_encode_max()) ----
 struct DirectEncode;
 int direct_encode_max();
-int direct_encode_build(DirectEncode** out, int log2n, uint64_t K, uint64_t m, int fold, uint64_t words);  // current device = the context's
+int direct_encode_build(DirectEncode** out, uint64_t N, uint64_t K, uint64_t m, int fold, uint64_t words);  // current device = the context's
 int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, hipStream_t st);
 void direct_encode_destroy(DirectEncode* de);
 

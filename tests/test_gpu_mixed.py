@@ -368,3 +368,26 @@ def test_few_losses_of_mixed_radix_codes(torch_cuda, fe, k, m):
                 erase_and_check(torch, fe, enc, x, par, lost[lost < k], lost[lost >= k] - k, True)
                 erase_and_check(torch, fe, enc, x, par, lost[lost < k], none, False)
         enc.set_option("decode_direct_max", 16)
+
+
+@pytest.mark.parametrize("k", [5, 96, 1000, 3 << 11, 9 << 10])
+def test_few_parity_blocks_of_mixed_radix_codes(torch_cuda, fe, oracle, k):
+    """n - k <= 8 on a mixed-radix order: the parity straight from the Lagrange basis of the (q 2^m)-th roots of unity; same bits as the
+    pipeline (encode_direct_max = 0) and the oracle."""
+    torch = torch_cuda
+    S = 12
+    order = fe.mixed_radix_order(k)
+    if not order & (order - 1):
+        pytest.skip("a power of two: tests/test_gpu_general.py")
+    x = rand_stripe(k, k, S)
+    for m in (1, 3, 8):
+        if m > order:
+            continue
+        want = oracle.encode_mixed_code(x, k + m, order)
+        with fe.Encoder(k + m, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+            for direct_max in (8, 0):
+                enc.set_option("encode_direct_max", direct_max)
+                out = torch.zeros(m * S, dtype=torch.int32, device="cuda:0")
+                enc.encode(to_dev(torch, x), out)
+                torch.cuda.synchronize()
+                assert np.array_equal(to_host(out).reshape(m, S), want), (k, m, direct_max, enc.plan())
