@@ -739,9 +739,9 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             }
             DEC_TRY(hipMemcpyAsync(d->sub_params, params.data(), params.size() * 4, hipMemcpyHostToDevice, st));
             DEC_TRY(hipMemcpyAsync(d->sub_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
+            std::vector<uint32_t> lost_rows(16, 0xFFFFFFFFu);  // (outlives the asynchronous copy below)
             if (ed > 0) {
-                // lost data rows as a list for the kernel: reuse the spare quarter of the lists
-                std::vector<uint32_t> lost_rows(16, 0xFFFFFFFFu);
+                // lost data rows as a list for the kernel: the spare quarter of the lists
                 for (int r = 0; r < ed; r++) lost_rows[r] = R[r];
                 DEC_TRY(hipMemcpyAsync(d->sub_lists + 48, lost_rows.data(), 16 * 4, hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL(sub_coef_data_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d->direct_coef, d->wpow, d->sub_params, d->sub_lists + 48, K, e, ed,
