@@ -60,7 +60,7 @@ enum {
      * Supported by create/destroy/encode/encode_blocks/ntt/check_range/decode_prepare/decode/repair/profile/plan_string and
      * fastecc_set_plan (0 = default: LDS tiles; 1..4 = register passes with that many radix-2 levels; 10+L / 20+L = tiles with a
      * 64 / 128 KiB exchange buffer); the 32-bit-word entry points
-     * (scale_blocks, gf_binary, set_option) return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
+     * (scale_blocks, gf_binary, set_option other than "decode_direct_max") return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
 };
@@ -102,7 +102,8 @@ int fastecc_version(void);
  *                          copies: the first and last kernels bound their reads / writes to the existing blocks).
  *                          GF(0xFFF00001) only; encode, encode_blocks, check_range and decode (no ntt / scale_blocks /
  *                          pack / encode_batch).
- * `parity` buffers hold n - k blocks.
+ * `parity` buffers hold n - k blocks.  Codes with n - k <= 8 are encoded without the transform (one read of the data, option
+ * "encode_direct_max"); the parity is the same.
  */
 int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);
 /*
