@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""More seeds for tests/test_gpu_fuzz.py than the suite runs (2000 + 400 + 400 random configurations, about 100 s on an MI355X).
+Last run at the end of round 2: 0 failures."""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch, fastecc_amd as fe
+from oracle import Oracle
+import test_gpu_fuzz as t
+orc = Oracle()
+import __graft_entry__ as ge
+bad = 0
+for seed in range(1000, 3000):
+    try:
+        t.test_random_u32_configuration.__wrapped__(torch, fe, orc, seed) if hasattr(t.test_random_u32_configuration, "__wrapped__") else t.test_random_u32_configuration(torch, fe, orc, seed)
+    except Exception as e:
+        bad += 1; print("u32 seed", seed, repr(e)[:300]); 
+        if bad > 5: break
+for seed in range(1000, 1400):
+    try:
+        t.test_random_p61_configuration(torch, fe, seed)
+        t.test_random_sharded_batched_and_column_calls(torch, fe, orc, seed)
+    except Exception as e:
+        bad += 1; print("p61/sharded seed", seed, repr(e)[:300])
+        if bad > 5: break
+print("done, failures:", bad)
