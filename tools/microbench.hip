@@ -8,6 +8,7 @@
 // Prints one JSON object per line.  Usage: microbench [valu] [bfly] [copy]   (default: all)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -284,6 +285,55 @@ static void run_bfly(uint32_t* d_out, int blocks, std::vector<uint32_t>* first)
     fflush(stdout);
 }
 
+// The same butterfly loops run for seconds instead of milliseconds: the board's power cap (1400 W) then sets the clock, and variants
+// that issue the same number of instructions may differ in what they sustain.  Power and clock are read with rocm-smi while a queue
+// of launches keeps the GPU busy.
+template <int VAR>
+static void run_bfly_sustained(uint32_t* d_out, int blocks, double seconds)
+{
+    const int iters = 2048;
+    hipStream_t st = nullptr;
+    auto launch = [&](int n) {
+        for (int i = 0; i < n; i++) hipLaunchKernelGGL(bfly_kernel<VAR>, dim3(blocks), dim3(256), 0, st, d_out, iters, 12345u);
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    while (elapsed() < seconds / 2) {  // heat up
+        launch(50);
+        CK(hipStreamSynchronize(st));
+    }
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    long launches = 0;
+    CK(hipEventRecord(a, st));
+    char smi[256] = "";
+    bool sampled = false;
+    while (elapsed() < seconds) {
+        launch(200);
+        launches += 200;
+        if (!sampled) {  // the queue above keeps the GPU busy for ~0.5 s while rocm-smi runs
+            FILE* f = popen("rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'Package Power|sclk' | sed -e 's/.*: //' | tr '\\n' ' '", "r");
+            if (f) {
+                if (!fgets(smi, sizeof smi, f)) smi[0] = 0;
+                pclose(f);
+            }
+            sampled = true;
+        }
+        CK(hipStreamSynchronize(st));
+    }
+    CK(hipEventRecord(b, st));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    for (char* c = smi; *c; ++c)
+        if (*c == '"' || *c == '\n') *c = ' ';
+    const double bf = (double)blocks * 256 * iters * 8 * launches;
+    printf("{\"probe\":\"bfly_sustained\",\"variant\":\"%s\",\"seconds\":%.1f,\"Gbfly_per_s\":%.1f,\"rocm_smi\":\"%s\"}\n", BFLY_NAME[VAR], ms / 1e3,
+           bf / ms / 1e6, smi);
+    fflush(stdout);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Access-pattern probes: a wave copies ROWS row segments of 64*V/RPL... see below.
 //   V    words per lane (1,2,4)
@@ -352,7 +402,9 @@ static void run_copy(const uint32_t* in, uint32_t* out, uint32_t S, int n, int s
 int main(int argc, char** argv)
 {
     bool do_valu = argc == 1, do_bfly = argc == 1, do_copy = argc == 1;
+    double sustain = 0;
     for (int i = 1; i < argc; i++) {
+        if (!strncmp(argv[i], "sustain=", 8)) sustain = atof(argv[i] + 8);
         if (!strcmp(argv[i], "valu")) do_valu = true;
         if (!strcmp(argv[i], "bfly")) do_bfly = true;
         if (!strcmp(argv[i], "copy")) do_copy = true;
@@ -375,6 +427,17 @@ int main(int argc, char** argv)
         run_valu<OP_LSHL_ADD>(d_out, blocks);
         run_valu<OP_SUBCO_CND>(d_out, blocks);
         run_valu<OP_CNDMASK_ONLY>(d_out, blocks);
+    }
+    if (sustain > 0) {
+        run_bfly_sustained<0>(d_out, blocks, sustain);
+        run_bfly_sustained<1>(d_out, blocks, sustain);
+        run_bfly_sustained<3>(d_out, blocks, sustain);
+        run_bfly_sustained<5>(d_out, blocks, sustain);
+        run_bfly_sustained<6>(d_out, blocks, sustain);
+        run_bfly_sustained<7>(d_out, blocks, sustain);
+        run_bfly_sustained<8>(d_out, blocks, sustain);
+        run_bfly_sustained<10>(d_out, blocks, sustain);
+        run_bfly_sustained<11>(d_out, blocks, sustain);
     }
     if (do_bfly) {
         std::vector<uint32_t> first;
