@@ -744,6 +744,13 @@ std::vector<int> level_strides(const std::vector<Pass>& plan, int n, bool up = f
         if (p.mode == (up ? MODE_DIF : MODE_DIT)) continue;
         if (!p.tile) {
             for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
+        } else if (p.fused) {
+            // fused_radix_kernel: runs of p.rlog levels counted from the top of the pass, the rest in the last one
+            const int runs = (p.logr + p.rlog - 1) / p.rlog;
+            for (int l = p.s; l < p.s + p.logr; l++) {
+                const int run = (p.s + p.logr - 1 - l) / p.rlog;
+                sl[l] = run == runs - 1 ? p.s : p.s + p.logr - (run + 1) * p.rlog;
+            }
         } else {
             const int l2 = p.logr - p.rlog - (p.pair ? 1 : 0);  // TileCfg::L2
             for (int l = p.s; l < p.s + l2; l++) sl[l] = p.s;

@@ -199,9 +199,12 @@ __global__ __launch_bounds__(256) void radix_kernel(const RadixArgs a)
 template <int Q, int A, int RLOG, bool DIT>
 __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const FusedArgs a)
 {
-    constexpr int R = 1 << RLOG, L2 = A - RLOG, G = 1 << L2;
-    static_assert(L2 >= 0 && L2 <= RLOG, "fused tile shape");
-    extern __shared__ uint32_t lds[];  // 2^A rows of 64 words (unused when L2 == 0)
+    // The A levels run in NRUNS register runs, counted from the top: run p < NRUNS-1 covers the RLOG levels [A - (p+1) RLOG, A - p RLOG),
+    // the last one the remaining LAST levels [0, LAST).  In the layout of run p a lane's register j is bits [B, B + RLOG) of the tile row
+    // (B = the run's lowest level; 0 for the last run) and the wave number fills the other A - RLOG bits.
+    constexpr int R = 1 << RLOG, NRUNS = (A + RLOG - 1) / RLOG, LAST = A - (NRUNS - 1) * RLOG;
+    static_assert(A >= RLOG && A - RLOG <= 4, "at most 16 waves per workgroup");
+    extern __shared__ uint32_t lds[];  // 2^A rows of 64 words (unused with a single run)
     const uint32_t g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tile = blockIdx.x;
@@ -216,20 +219,24 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
     const_u32_ptr dft = as_constant(a.dft);
     uint32_t* my_lds = lds + lane;
 
-    auto row_a = [&](int j) { return (uint32_t)j * G + g; };
-    auto row_b = [&](int k) { return g * R + (uint32_t)k; };
+    auto run_base = [](int p) { return p == NRUNS - 1 ? 0 : A - (p + 1) * RLOG; };
+    // tile row of register j in the layout of run p
+    auto row_of = [&](int p, int j) -> uint32_t {
+        const int B = run_base(p);
+        return ((g >> B) << (B + RLOG)) | ((uint32_t)j << B) | (g & ((1u << B) - 1u));
+    };
+    // block offset below the run's lowest level: what its twiddles depend on
+    auto off_of = [&](int p) -> uint32_t { return ((g & ((1u << run_base(p)) - 1u)) << s) + lo; };
     uint32_t x[Q][R][1];
 
-    // one stripe's registers from layout `from` to layout `to`
-    auto exchange = [&](uint32_t (&y)[R][1], auto from, auto to) {
-        if constexpr (L2 > 0) {
-            __syncthreads();  // the previous stripe's reads are done
+    // one stripe's registers from the layout of run `from` to that of run `to`
+    auto exchange = [&](uint32_t (&y)[R][1], int from, int to) {
+        __syncthreads();  // the previous exchange's reads are done
 #pragma unroll
-            for (int j = 0; j < R; ++j) my_lds[from(j) * 64u] = y[j][0];
-            __syncthreads();
+        for (int j = 0; j < R; ++j) my_lds[row_of(from, j) * 64u] = y[j][0];
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < R; ++j) y[j][0] = my_lds[to(j) * 64u];
-        }
+        for (int j = 0; j < R; ++j) y[j][0] = my_lds[row_of(to, j) * 64u];
     };
     // the q-point transforms of register row j (tile row r): twiddles w_N^(+-i2*j1) before (way up) or after (way down)
     auto radix = [&](int j, uint32_t r) {
@@ -248,27 +255,40 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
             for (int i = 1; i < Q; ++i) x[out_slot<Q>(i)][j][0] = gf::mul_mont(x[out_slot<Q>(i)][j][0], tw[i - 1]);
         }
     };
+    // the levels of run p on one stripe
+    auto levels = [&](uint32_t (&y)[R][1], int p) {
+        const int B = run_base(p);
+        if (p == NRUNS - 1) {
+            if constexpr (DIT) dit_levels<RLOG, 1, false, LAST>(y, a.twl, off_of(p), s + B);
+            else               dif_levels<RLOG, 1, false, LAST>(y, a.twl, off_of(p), s + B);
+        } else {
+            if constexpr (DIT) dit_levels<RLOG, 1, false, RLOG>(y, a.twl, off_of(p), s + B);
+            else               dif_levels<RLOG, 1, false, RLOG>(y, a.twl, off_of(p), s + B);
+        }
+    };
 
     if constexpr (!DIT) {
 #pragma unroll
         for (int i = 0; i < Q; ++i)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const uint32_t row = (uint32_t)i * a.M + row0 + (row_a(j) << s);
+                const uint32_t row = (uint32_t)i * a.M + row0 + (row_of(0, j) << s);
                 x[i][j][0] = (live && (a.in_rows == 0 || row < a.in_rows)) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
             }
 #pragma unroll
-        for (int j = 0; j < R; ++j) radix(j, row_a(j));
+        for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
 #pragma unroll
         for (int j1 = 0; j1 < Q; ++j1) {
             uint32_t(&y)[R][1] = x[out_slot<Q>(j1)];  // stripe j1
-            dif_levels<RLOG, 1, false, RLOG>(y, a.twl, (g << s) + lo, s + L2);
-            exchange(y, row_a, row_b);
-            if constexpr (L2 > 0) dif_levels<RLOG, 1, false, L2>(y, a.twl, lo, s);
+#pragma unroll
+            for (int p = 0; p < NRUNS; ++p) {
+                if (p > 0) exchange(y, p - 1, p);
+                levels(y, p);
+            }
             if (live) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const uint32_t row = (uint32_t)j1 * a.M + row0 + ((L2 > 0 ? row_b(k) : row_a(k)) << s);
+                    const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
                     __builtin_nontemporal_store(y[k][0], a.out + (size_t)row * a.ld + col);
                 }
             }
@@ -278,46 +298,48 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
         for (int j1 = 0; j1 < Q; ++j1)  // every load of the tile is in flight before the first barrier
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const uint32_t row = (uint32_t)j1 * a.M + row0 + ((L2 > 0 ? row_b(k) : row_a(k)) << s);
+                const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
                 x[j1][k][0] = live ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
             }
 #pragma unroll
         for (int j1 = 0; j1 < Q; ++j1) {
             uint32_t(&y)[R][1] = x[j1];
-            if constexpr (L2 > 0) dit_levels<RLOG, 1, false, L2>(y, a.twl, lo, s);
-            exchange(y, row_b, row_a);
-            dit_levels<RLOG, 1, false, RLOG>(y, a.twl, (g << s) + lo, s + L2);
+#pragma unroll
+            for (int p = NRUNS - 1; p >= 0; --p) {
+                levels(y, p);
+                if (p > 0) exchange(y, p, p - 1);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) radix(j, row_a(j));
+        for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
         if (live) {
 #pragma unroll
             for (int t = 0; t < Q; ++t)
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    const uint32_t row = (uint32_t)t * a.M + row0 + (row_a(j) << s);
+                    const uint32_t row = (uint32_t)t * a.M + row0 + (row_of(0, j) << s);
                     if (a.out_rows == 0 || row < a.out_rows) __builtin_nontemporal_store(x[out_slot<Q>(t)][j][0], a.out + (size_t)row * a.ld + col);
                 }
         }
     }
 }
 
-// register run length per radix: q * 2^RLOG values per lane must fit the register file at a useful occupancy
-constexpr int fused_rmax(int q) { return q <= 5 ? 4 : q <= 9 ? 3 : 0; }  // q = 2: an experiment, see FASTECC_CODE_TOP_RADIX2
-int fused_rlog(int q, int levels)
+// Values per lane (q * 2^RLOG) against workgroup size (64 * 2^(A - RLOG) lanes, at most 1024): the register run per radix and level count.
+constexpr int fused_shape_rlog(int q, int levels)
 {
-    const int rmax = fused_rmax(q);
-    if (rmax == 0 || levels < 1 || levels > 8) return 0;
-    if (q == 5 && levels == 8) return 0;  // 80 values per lane in a 1024-lane workgroup: spills
-    const int rlog = levels < rmax ? levels : rmax;
-    return levels - rlog <= rlog ? rlog : 0;
+    if (levels < 1 || levels > 8) return 0;
+    int rlog = q <= 3 ? 4 : q <= 5 ? (levels == 8 ? 0 : 4) : q <= 9 ? 3 : q <= 15 ? 2 : 0;  // 48 / 80 / 56-72 / 52-60 values per lane
+    if (rlog == 0 || (q == 9 && levels == 7)) return 0;  // (9, 7): 72 values per lane in a 1024-lane workgroup spill
+    if (rlog > levels) rlog = levels;
+    return levels - rlog <= 4 ? rlog : 0;
 }
+int fused_rlog(int q, int levels) { return radix_supported(q) ? fused_shape_rlog(q, levels) : 0; }
 
 template <int Q, int A, bool DIT>
 static hipError_t launch_fused_shape(const FusedArgs& a, unsigned tiles, hipStream_t st)
 {
-    constexpr int RLOG = A < fused_rmax(Q) ? A : fused_rmax(Q);
-    if constexpr (A - RLOG > RLOG) {
+    constexpr int RLOG = fused_shape_rlog(Q, A);
+    if constexpr (RLOG == 0) {
         return hipErrorInvalidValue;
     } else {
         constexpr int lds_bytes = A > RLOG ? (1 << A) * 256 : 0;
@@ -337,9 +359,7 @@ static hipError_t launch_fused_q(int levels, const FusedArgs& a, unsigned tiles,
         case 5: return launch_fused_shape<Q, 5, DIT>(a, tiles, st);
         case 6: return launch_fused_shape<Q, 6, DIT>(a, tiles, st);
         case 7: return launch_fused_shape<Q, 7, DIT>(a, tiles, st);
-        case 8:
-            if constexpr (Q <= 3) return launch_fused_shape<Q, 8, DIT>(a, tiles, st);
-            else return hipErrorInvalidValue;
+        case 8: return launch_fused_shape<Q, 8, DIT>(a, tiles, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -356,6 +376,8 @@ hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st
         case 5: return dit ? launch_fused_q<5, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<5, false>(levels, a, (unsigned)tiles, st);
         case 7: return dit ? launch_fused_q<7, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<7, false>(levels, a, (unsigned)tiles, st);
         case 9: return dit ? launch_fused_q<9, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<9, false>(levels, a, (unsigned)tiles, st);
+        case 13: return dit ? launch_fused_q<13, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<13, false>(levels, a, (unsigned)tiles, st);
+        case 15: return dit ? launch_fused_q<15, true>(levels, a, (unsigned)tiles, st) : launch_fused_q<15, false>(levels, a, (unsigned)tiles, st);
         default: return hipErrorInvalidValue;
     }
 }

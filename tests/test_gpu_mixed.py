@@ -278,7 +278,7 @@ def test_decoder_at_a_large_mixed_order(torch_cuda, fe):
         assert torch.equal(bx, x) and torch.equal(bp, par)
 
 
-@pytest.mark.parametrize("q", [3, 5, 7, 9, 13])
+@pytest.mark.parametrize("q", [3, 5, 7, 9, 13, 15])
 @pytest.mark.parametrize("m", [11, 12, 13, 14, 15, 16, 17, 18])
 def test_fused_odd_radix_level(torch_cuda, fe, oracle, q, m):
     """Orders with an outer tile above MID: the odd-radix level fused into that tile (3 trips) against its own two passes
@@ -310,7 +310,7 @@ def test_fused_odd_radix_level(torch_cuda, fe, oracle, q, m):
                 assert np.array_equal(to_host(work).reshape(k, S), got), fused_plan
             if m <= 13:
                 assert np.array_equal(got, oracle.encode_mixed_code(x, k + par, order)), fused_plan
-        supported = (q <= 5 and m - 10 <= (7 if q == 5 else 8)) or (q in (7, 9) and m - 10 <= 6)
+        supported = m - 10 <= {3: 8, 5: 7, 7: 7, 9: 6, 13: 6, 15: 6}[q]
         assert (("R%d+dif" % q) in fused_plan) == supported, fused_plan
 
 
