@@ -237,3 +237,45 @@ def test_random_sharded_batched_and_column_calls(torch_cuda, fe, oracle, seed):
         got = om.cpu().numpy().view(np.uint32).reshape(count, k, S)
         for i in range(count):
             assert np.array_equal(got[i], oracle.encode_fast(many[i])), (k, S, count, i, one.plan())
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_large_mixed_radix_configuration(torch_cuda, fe, oracle, seed):
+    """Mixed-radix orders large enough for the fused odd-radix tiles (2^m with m >= 11), random k (zero extension) and parity counts
+    (truncation), narrow blocks; encode against the oracle, then lose up to 20 blocks and repair (both decoder paths occur)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(3 << 11, 120000))
+    order = fe.mixed_radix_order(k)
+    if not order & (order - 1):
+        pytest.skip("a power of two")
+    m = int(rng.integers(1, order + 1)) if seed % 3 else int(rng.integers(1, 20))
+    S = int(rng.choice([1, 2, 3, 4]))
+    x = rng.integers(0, P, size=(k, S), dtype=np.uint64).astype(np.uint32)
+    want = oracle.encode_mixed_code(x, k + m, order)
+    with fe.Encoder(k + m, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        if seed % 5 == 0:
+            enc.set_option("fuse_radix", 0)
+        what = (k, m, S, order, enc.plan())
+        d = offset_view(torch, x, int(rng.integers(0, 4)))
+        out = offset_view(torch, np.zeros((m, S), dtype=np.uint32), int(rng.integers(0, 4)))
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(m, S), want), what
+        lost = rng.permutation(k + m)[: int(rng.integers(1, min(m, 20) + 1))]
+        dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+        dp[lost[lost < k]] = 0
+        pp[lost[lost >= k] - k] = 0
+        bad_x, bad_p = x.copy(), want.copy()
+        bad_x[dp == 0] = 0x11111111
+        bad_p[pp == 0] = 0x22222222
+        try:
+            enc.decode_prepare(dp, pp)
+        except fe.FastEccError as e:
+            assert e.code == fe.E_UNSUPPORTED and order > (1 << 20), what  # the transform path stops at order 2^20
+            return
+        dd, dq = offset_view(torch, bad_x, 0), offset_view(torch, bad_p, 0)
+        enc.repair(dd, dq)
+        torch.cuda.synchronize()
+        assert np.array_equal(dd.cpu().numpy().view(np.uint32).reshape(k, S), x), what
+        assert np.array_equal(dq.cpu().numpy().view(np.uint32).reshape(m, S), want), what
