@@ -13,6 +13,10 @@ in column slabs over the ranks (strong scaling), timed compute-only and with the
 blocks on rank 0 (fastecc_amd/sharding.py).  A single-process run that sees several GPUs additionally times the
 C-ABI form of that mode (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
 
+At N = 1 the line additionally carries `other_paths`: short, checked timings of the rows around the headline path (few-loss repair
+and a 2 % loss pattern on the context that was just timed, a code with 4 parity blocks, a mixed-radix order) and BASELINE configs[4]
+(the 64-bit field, 32 + 32 GiB) — so that the driver's record holds them too; none of it enters `value` (--no-other-paths skips it).
+
 Throughput convention = the reference's (RS.cpp:38): bytes = data + parity = 2*k*block_bytes per encode,
 reported in GB/s (1e9).  Prints ONE JSON line on rank 0.
 """
@@ -79,6 +83,7 @@ def parse():
                     help="N > 1: seconds the sharded_one_stripe measurement may take before the line is printed without it (0 = wait forever)")
     ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the gather pipeline (sharded_one_stripe)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the short timings of the widened rows (other_paths)")
     ap.add_argument("--cabi-sharded-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--slabs", type=int, default=0, help="column slabs on internal streams (0 = library default)")
     ap.add_argument("--option", action="append", default=[], help="library tuning option name=value (fastecc_set_option)")
@@ -207,6 +212,103 @@ def parity_check_p61(data, parity, k, block_bytes):
     want = OracleP61().encode(np.ascontiguousarray(x))
     return {"status": "ok" if np.array_equal(got, want) else "FAILED",
             "what": "element columns %s of the timed stripe re-encoded by oracle/fastecc_oracle_p61.c (no upstream output exists for this field)" % cols}
+
+
+def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stream):
+    """Short, checked timings of the rows around the headline path, so that the driver's record carries them too —
+    they are NOT the metric.  `data` / `parity` are the codeword the timed context just produced.  Every entry verifies what it timed."""
+    import numpy as np
+    k, S = 1 << log2k, block_bytes // 4
+    out = {"what": "HIP-event timings of other paths at this size, each checked; not part of `value`"}
+
+    def event_ms(fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # --- erasure decoding on the context that was timed: lost blocks are overwritten, repaired in place and compared with saved copies
+    try:
+        rng = np.random.default_rng(7)
+        dv, pv = data.view(k, S), parity.view(k, S)
+        for name, lost in (("repair_1_data_1_parity_lost", np.array([k // 3, k + k // 7])),
+                           ("repair_8_data_8_parity_lost", np.r_[rng.permutation(k)[:8], k + rng.permutation(k)[:8]]),
+                           ("repair_2_percent_of_the_codeword_lost", rng.permutation(2 * k)[: (2 * k) // 50])):
+            dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
+            dp[lost[lost < k]] = 0
+            pp[lost[lost >= k] - k] = 0
+            di = torch.from_numpy(np.flatnonzero(dp == 0)).to(device)
+            pi = torch.from_numpy(np.flatnonzero(pp == 0)).to(device)
+            saved_d, saved_p = dv[di].clone(), pv[pi].clone()
+            t0 = time.perf_counter()
+            enc.decode_prepare(dp, pp)
+            prep = (time.perf_counter() - t0) * 1e3
+
+            def once():
+                dv[di] = -1
+                pv[pi] = -2
+                enc.repair(data, parity, stream=stream)
+
+            once()
+            ok = bool(torch.equal(dv[di], saved_d)) and bool(torch.equal(pv[pi], saved_p))
+            ms = event_ms(lambda: enc.repair(data, parity, stream=stream), 5)
+            out[name] = {"prepare_ms": round(prep, 2), "repair_ms": round(ms, 3), "restored": ok}
+    except Exception as e:  # noqa: BLE001
+        out["decode_error"] = repr(e)
+    # --- a code with 4 parity blocks: direct evaluation against the transform pipeline of the same context
+    try:
+        with fastecc_amd.Encoder(k + 4, k, block_bytes, device=device.index or 0) as small:
+            p_direct = torch.empty(4 * S, dtype=torch.int32, device=device)
+            p_pipe = torch.empty_like(p_direct)
+            ms = event_ms(lambda: small.encode(data, p_direct, stream=stream), 10)
+            small.set_option("encode_direct_max", 0)
+            small.encode(data, p_pipe, stream=stream)
+            out["encode_k_plus_4_parity"] = {"ms": round(ms, 3), "data_GBps": round(k * block_bytes / ms / 1e6, 1),
+                                             "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe))}
+    except Exception as e:  # noqa: BLE001
+        out["small_m_error"] = repr(e)
+    # --- a mixed-radix order (3 * 2^(log2k - 2) data blocks), fused odd-radix tiles against the unfused plan of the same context
+    try:
+        km = 3 << max(log2k - 2, 1)
+        with fastecc_amd.Encoder(2 * km, km, block_bytes, device=device.index or 0, flags=fastecc_amd.CODE_MIXED_RADIX) as mixed:
+            src = data[: km * S]
+            p_fused, p_plain = torch.empty(km * S, dtype=torch.int32, device=device), torch.empty(km * S, dtype=torch.int32, device=device)
+            plan = mixed.plan()
+            ms = event_ms(lambda: mixed.encode(src, p_fused, stream=stream), 10)
+            mixed.set_option("fuse_radix", 0)
+            mixed.encode(src, p_plain, stream=stream)
+            out["encode_mixed_radix_3x2^%d" % max(log2k - 2, 1)] = {"ms": round(ms, 3), "GBps": round(2.0 * km * block_bytes / ms / 1e6, 1), "plan": plan,
+                                                                     "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain))}
+    except Exception as e:  # noqa: BLE001
+        out["mixed_radix_error"] = repr(e)
+    return out
+
+
+def other_field_p61(fastecc_amd, device, stream, steps=3):
+    """BASELINE.json configs[4] in the same run: (2^20, 2^19) x 64 KB over GF((2^61-1)^2), 32 + 32 GiB, HBM-resident."""
+    k, bb = 1 << 19, 65536
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 70 * 2**30:
+        return {"skipped": "needs 64 GiB of free HBM, %.0f GiB free" % (free / 2**30)}
+    data = random_stripe_p61(k * (bb // 8), device, seed=0x61)
+    parity = torch.empty_like(data)
+    with fastecc_amd.Encoder(2 * k, k, bb, device=device.index or 0, field=fastecc_amd.FIELD_GF_P61_SQUARED) as enc:
+        enc.encode(data, parity, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            enc.encode(data, parity, stream=stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        check = parity_check_p61(data, parity, k, bb)
+        return {"workload": "RS encode k=2^19 -> 2^19 parity blocks, 65536 B blocks, GF((2^61-1)^2), 32 GiB stripe", "ms_per_step": round(ms, 3),
+                "GBps": round(2.0 * k * bb / ms / 1e6, 1), "steps": steps, "plan": enc.plan(), "parity_check": check,
+                "parity_pin": "no upstream code exists for this field: pinned to this repository's oracle and Python big-integer goldens"}
 
 
 def time_steps(step, steps, barrier):
@@ -427,6 +529,7 @@ def main():
                 check = {"status": "error", "why": repr(e)}
 
     emitted = threading.Event()
+    other_paths_result = {}
 
     def emit(sharded, cabi=None, cpu=None):
         if rank != 0 or emitted.is_set():
@@ -449,6 +552,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "sharded_one_stripe": sharded,
         }
+        if other_paths_result:
+            line["other_paths"] = other_paths_result
         if p61:
             line["parity_pin"] = ("no upstream code exists for this field: the HIP path is pinned to this repository's own oracle and "
                                   "Python big-integer goldens (tests/test_gpu_p61.py), not to the reference")
@@ -564,6 +669,17 @@ def main():
                 cpu = (cpu_baseline_p61 if p61 else cpu_baseline)(args.cpu_log2k or args.log2k, args.block_bytes)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cpu = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_other_paths and not p61 and args.batch == 1 and m_blocks == k and not args.plan and not args.option:
+        try:
+            extras = other_paths(fastecc_amd, enc, data, parity, args.log2k, args.block_bytes, device, stream)
+        except Exception as e:  # noqa: BLE001
+            extras = {"error": repr(e)}
+        try:
+            if args.log2k == 19:
+                extras["configs4_64bit_field"] = other_field_p61(fastecc_amd, device, stream)
+        except Exception as e:  # noqa: BLE001
+            extras["configs4_64bit_field"] = {"error": repr(e)}
+        other_paths_result.update(extras)
     emit(sharded, cabi, cpu)
     enc.close()
     if world > 1:
