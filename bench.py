@@ -14,8 +14,8 @@ blocks on rank 0 (fastecc_amd/sharding.py).  A single-process run that sees seve
 C-ABI form of that mode (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
 
 At N = 1 the line additionally carries `other_paths`: short, checked timings of the rows around the headline path (few-loss repair
-and a 2 % loss pattern on the context that was just timed, a code with 4 parity blocks, a mixed-radix order) and BASELINE configs[4]
-(the 64-bit field, 32 + 32 GiB) — so that the driver's record holds them too; none of it enters `value` (--no-other-paths skips it).
+and a 2 % loss pattern, a code with 4 parity blocks, a mixed-radix order) and BASELINE configs[4] (the 64-bit field, 32 + 32 GiB),
+measured in a child process — so that the driver's record holds them too; none of it enters `value` (--no-other-paths skips it).
 
 Throughput convention = the reference's (RS.cpp:38): bytes = data + parity = 2*k*block_bytes per encode,
 reported in GB/s (1e9).  Prints ONE JSON line on rank 0.
@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the short timings of the widened rows (other_paths)")
     ap.add_argument("--cabi-sharded-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--other-paths-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--slabs", type=int, default=0, help="column slabs on internal streams (0 = library default)")
     ap.add_argument("--option", action="append", default=[], help="library tuning option name=value (fastecc_set_option)")
     return ap.parse_args()
@@ -311,6 +312,34 @@ def other_field_p61(fastecc_amd, device, stream, steps=3):
                 "parity_pin": "no upstream code exists for this field: pinned to this repository's oracle and Python big-integer goldens"}
 
 
+def other_paths_child(args):
+    """The widened rows in a process of their own (one JSON object, progressively: the parent keeps the last complete line)."""
+    import fastecc_amd
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    k, bb = 1 << args.log2k, args.block_bytes or 4096
+    stream = torch.cuda.current_stream().cuda_stream
+    data = random_stripe(k * (bb // 4), device, seed=0x1234)
+    parity = torch.empty_like(data)
+    out = {}
+    with fastecc_amd.Encoder(2 * k, k, bb, device=0) as enc:
+        enc.encode(data, parity, stream=stream)
+        torch.cuda.synchronize()
+        try:
+            out = other_paths(fastecc_amd, enc, data, parity, args.log2k, bb, device, stream)
+        except Exception as e:  # noqa: BLE001
+            out = {"error": repr(e)}
+    print(json.dumps(out), flush=True)
+    del data, parity
+    torch.cuda.empty_cache()
+    if args.log2k == 19:
+        try:
+            out["configs4_64bit_field"] = other_field_p61(fastecc_amd, device, stream)
+        except Exception as e:  # noqa: BLE001
+            out["configs4_64bit_field"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+
+
 def time_steps(step, steps, barrier):
     barrier()
     t0 = time.perf_counter()
@@ -403,6 +432,8 @@ def main():
     args = parse()
     if args.cabi_sharded_child:
         return cabi_sharded_child(args)
+    if args.other_paths_child:
+        return other_paths_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -670,16 +701,15 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cpu = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_other_paths and not p61 and args.batch == 1 and m_blocks == k and not args.plan and not args.option:
+        # in a child process: a fault in one of these paths must not cost the line its headline number
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--other-paths-child", "--log2k", str(args.log2k), "--block-bytes", str(args.block_bytes)]
         try:
-            extras = other_paths(fastecc_amd, enc, data, parity, args.log2k, args.block_bytes, device, stream)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            other_paths_result.update(json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]})
         except Exception as e:  # noqa: BLE001
-            extras = {"error": repr(e)}
-        try:
-            if args.log2k == 19:
-                extras["configs4_64bit_field"] = other_field_p61(fastecc_amd, device, stream)
-        except Exception as e:  # noqa: BLE001
-            extras["configs4_64bit_field"] = {"error": repr(e)}
-        other_paths_result.update(extras)
+            other_paths_result.update({"error": repr(e)})
     emit(sharded, cabi, cpu)
     enc.close()
     if world > 1:
