@@ -115,7 +115,8 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * are the parity).  With q = 1 this IS fastecc_create; otherwise it is a different code than the zero-extended power-of-
  * two one fastecc_create builds for the same (n,k) — a stripe must be decoded with the flags it was encoded with.
  * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile, and decode_prepare / decode / repair for
- * orders up to 2^20 (the locator's product tree needs w_T, T the power of two >= the order).  The odd-radix
+ * orders up to 2^20 (the locator's product tree needs w_T, T the power of two >= the order; patterns of at most 16 lost blocks
+ * do not use it and are repaired at every order).  The odd-radix
  * level is fused into the outermost tile passes where a shape exists (2^m with m <= 16..18 depending on q: three trips through
  * HBM, like the power-of-two orders; option "fuse_radix" = 0 gives it its own two passes); measured against zero extension in
  * profiles/r02/mixed_radix_bench.jsonl: faster than zero extension for q <= 9.

@@ -391,3 +391,34 @@ def test_few_parity_blocks_of_mixed_radix_codes(torch_cuda, fe, oracle, k):
                 enc.encode(to_dev(torch, x), out)
                 torch.cuda.synchronize()
                 assert np.array_equal(to_host(out).reshape(m, S), want), (k, m, direct_max, enc.plan())
+
+
+def test_orders_above_2_20_repair_few_losses_only(torch_cuda, fe):
+    """k = 3 * 2^19 (transform order 1.5 M > 2^20): the locator tree does not exist there, the few-loss interpolation does."""
+    torch = torch_cuda
+    k, S = 3 << 19, 2
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    x = torch.randint(0, P, (k * S,), generator=g, device="cuda:0", dtype=torch.int64).to(torch.int32)
+    with fe.Encoder(2 * k, k, 4 * S, flags=fe.CODE_MIXED_RADIX) as enc:
+        par = torch.empty_like(x)
+        enc.encode(x, par)
+        rng = np.random.default_rng(8)
+        for count in (1, 16, 17):
+            lost = rng.permutation(2 * k)[:count]
+            lost[0] = int(rng.integers(0, k))
+            dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
+            dp[lost[lost < k]] = 0
+            pp[lost[lost >= k] - k] = 0
+            if count > 16:
+                with pytest.raises(fe.FastEccError) as ei:
+                    enc.decode_prepare(dp, pp)
+                assert ei.value.code == fe.E_UNSUPPORTED
+                continue
+            bx, bp = x.clone(), par.clone()
+            bx.view(k, S)[torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0")] = -1
+            bp.view(k, S)[torch.from_numpy(np.flatnonzero(pp == 0)).to("cuda:0")] = -2
+            enc.decode_prepare(dp, pp)
+            enc.repair(bx, bp)
+            torch.cuda.synchronize()
+            assert torch.equal(bx, x) and torch.equal(bp, par), count
