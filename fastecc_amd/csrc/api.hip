@@ -130,9 +130,10 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
-    DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (decode.hip), built on first use
-    int encode_direct_max = 8;
-    int decode_direct_max = 16;  // (2k,k) codes: up to this many lost blocks are recomputed directly (decode.hip), 0 = always the transform
+    DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
+    int encode_direct_max = 128;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 16
+    int decode_direct_max = 128;  // up to this many lost blocks are recomputed directly (direct.hip), 0 = always the transform
+    int direct_kernel = 0;        // 0 choose, 1 VALU, 2 MFMA
     int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
                              // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
@@ -602,21 +603,25 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
     return FASTECC_OK;
 }
 
-// codes with few parity blocks skip the transform pipeline: one read of the data (decode.hip: direct_encode_run)
-static bool direct_encode_applies(const fastecc_ctx* c)
+// codes with few parity blocks skip the transform pipeline: one read of the data (direct.hip: direct_encode_run).  The pipeline costs the
+// same for any n - k <= N/16; the direct pass grows with n - k: on the matrix cores it wins up to ~128 parity blocks, on the VALU up to 16.
+static bool direct_encode_applies(const fastecc_ctx* c, const void* data = nullptr, const void* parity = nullptr)
 {
-    return !c->p61 && c->cosets == 1 && c->ld == c->S && c->Mu >= 1 && (int)std::min<uint64_t>(c->Mu, 1000) <= std::min(c->encode_direct_max, direct_encode_max());
+    if (c->p61 || c->cosets != 1 || c->ld != c->S || c->Mu < 1) return false;
+    int limit = std::min(c->encode_direct_max, direct_encode_max());
+    if (c->direct_kernel == 1 || !direct_mfma_applies(data, parity, c->S)) limit = std::min(limit, 16);
+    return (int)std::min<uint64_t>(c->Mu, 100000) <= limit;
 }
 
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
-    if (direct_encode_applies(c)) {
+    if (direct_encode_applies(c, data, parity)) {
         if (!c->direct_enc) {
             const int rc = direct_encode_build(&c->direct_enc, (uint64_t)c->q * c->N, c->K, c->Mu, c->fold, c->S);  // q > 1: the mixed-radix order
             if (rc != FASTECC_OK) return rc;
         }
         ProfScope ps(c, st, "direct_encode", (c->K + c->Mu) * c->S * 4ull);
-        return direct_encode_run(c->direct_enc, data, parity, st);
+        return direct_encode_run(c->direct_enc, data, parity, c->direct_kernel, st);
     }
     if (c->q > 1) return encode_mixed(c, data, parity, st);
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
@@ -1153,7 +1158,7 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max, c->direct_kernel};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
@@ -1762,8 +1767,13 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         return FASTECC_OK;
     }
     if (!strcmp(name, "decode_direct_max")) {  // takes effect at the next fastecc_decode_prepare
-        if (value < 0 || value > 16) return FASTECC_E_INVAL;
+        if (value < 0 || value > (c->p61 ? 16 : direct_cap())) return FASTECC_E_INVAL;
         c->decode_direct_max = value;
+        return FASTECC_OK;
+    }
+    if (!strcmp(name, "direct_kernel")) {  // 0 = choose, 1 = VALU, 2 = MFMA where the stripes allow it; decoder: from the next decode_prepare
+        if (value < 0 || value > 2) return FASTECC_E_INVAL;
+        c->direct_kernel = value;
         return FASTECC_OK;
     }
     if (!strcmp(name, "fuse_radix")) {  // mixed-radix contexts: 1 = odd-radix level fused into the outer tiles (default), 0 = its own passes

@@ -64,18 +64,14 @@ struct DecodeState {
     uint32_t* parity_again = nullptr;
     uint64_t erased_parity = 0;
     uint64_t erased_data = 0, erased_total = 0;
-    // few losses: every lost block is a fixed linear combination of surviving ones (the direct path)
-    uint32_t* direct_coef = nullptr;   // [K + lost data][pad]: weight of data block i (then of the parity blocks used as nodes) in lost data block r, Montgomery
-    uint32_t* direct_partial = nullptr;  // [row chunks + 32][pad][words]: partial sums, and the staging rows of the second summation step
-    uint64_t direct_partial_words = 0;
-    // any layout (the reference's, zero extension, sub-/extra cosets, mixed radix): interpolation on N nodes — the surviving data
-    // points plus as many surviving parity points as data blocks are lost — then, for repair, the lost parity from the complete data
-    int sub_lost_data = 0, sub_lost_parity = 0, sub_pad_data = 0, sub_pad_parity = 0;
+    // few losses (any layout: the reference's, zero extension, sub-/extra cosets, mixed radix): every lost data block is a fixed linear
+    // combination of the surviving data blocks and as many surviving parity blocks (interpolation on N nodes); for repair the lost parity
+    // blocks follow from the complete data (direct.hip)
+    DirectPass* direct_data = nullptr;
+    DirectPass* direct_parity = nullptr;
+    int sub_lost_data = 0, sub_lost_parity = 0;
     bool sub = false;
-    uint32_t* sub_coef_parity = nullptr;  // [K][sub_pad_parity]: lost parity block t from data block i
-    uint32_t* sub_lists = nullptr;        // 4 x 16 words: parity rows used as nodes | data output positions | parity output positions | spare
-    uint32_t* sub_params = nullptr;       // 8 x 16 words of field elements for the coefficient kernels
-    uint64_t direct_coef_words = 0;
+    int direct_kernel = 0;             // 0 choose, 1 VALU, 2 MFMA (option "direct_kernel")
     uint64_t positions = 0;            // code length on the roots of unity: k << log2(n / k) rounded up to powers of two
     bool mixed = false;                // mixed-radix code: `recovered` is the whole work stripe (all positions), transformed in place
     bool standard = false;             // the reference's (2k,k) layout: position u = data u/2 or parity u/2, every block in memory
@@ -96,7 +92,9 @@ void destroy_decode_state(DecodeState* d)
     if (d->parity_dev) (void)hipFree(d->parity_dev);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
-    for (uint32_t* b : {d->sub_coef_parity, d->sub_lists, d->sub_params, d->direct_coef, d->direct_partial, d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
+    direct_pass_free(d->direct_data);
+    direct_pass_free(d->direct_parity);
+    for (uint32_t* b : {d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
         if (b) (void)hipFree(b);
     delete d;
 }
@@ -313,176 +311,6 @@ __global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __r
     store_vec<V>(parity + (size_t)q * S + col, x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Few losses: the lost blocks are fixed linear combinations of surviving ones — no locator tree, no transform, one read of N + |lost data|
-// blocks (sub_coef_*_kernel below state the weights).  Partial sums over 512 rows per wave, then a two-step sum.
-// ------------------------------------------------------------------------------------------------
-constexpr int DIRECT_MAX = 16;        // lost blocks per pattern on this path
-constexpr uint32_t DIRECT_ROWS = 512; // codeword positions per partial sum
-
-// partial[chunk][j][col] = sum over the chunk's positions u of block(u)[col] * coef[u][j]; a wave owns (chunk, 64*V-word column
-// chunk) and keeps four rows in flight
-template <int EB, int V>
-__global__ __launch_bounds__(256) void direct_accumulate_kernel(const uint32_t* __restrict__ data, const uint32_t* __restrict__ parity,
-                                                                const uint32_t* __restrict__ coef, uint32_t* __restrict__ partial, uint32_t S,
-                                                                uint32_t NC, uint32_t col_chunks, uint64_t items, const uint32_t* __restrict__ extra = nullptr,
-                                                                uint32_t data_rows = 0)
-{
-    // parity == nullptr: the NC "positions" are the rows of `data` (the encoder for few parity blocks, below); extra != nullptr:
-    // rows [0, data_rows) of `data`, then the rows extra[0..] of `parity` (the decoder for any layout)
-    constexpr int U = V == 4 ? 4 : 8;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
-    if (item >= items) return;
-    const uint32_t cc = (uint32_t)(item % col_chunks);
-    const uint32_t chunk = (uint32_t)(item / col_chunks);
-    const uint32_t col = (cc * 64u + lane) * V;
-    const bool live = col < S;
-    uint32_t acc[EB][V];
-#pragma unroll
-    for (int j = 0; j < EB; ++j)
-#pragma unroll
-        for (int v = 0; v < V; ++v) acc[j][v] = 0;
-    const uint32_t u0 = chunk * DIRECT_ROWS, u1 = min(u0 + DIRECT_ROWS, NC);
-    for (uint32_t ub = u0; ub < u1; ub += U) {
-        uint32_t w[U][EB], x[U][V];
-        bool use[U];
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const uint32_t u = ub + i;
-            uint32_t any = 0;
-            if (u < u1) {
-                const_u32_ptr cf = as_constant(coef) + (size_t)u * EB;
-#pragma unroll
-                for (int j = 0; j < EB; ++j) any |= (w[i][j] = cf[j]);
-            }
-            use[i] = any != 0;  // a lost block has no coefficients: whatever is stored in its place is not used (wave-uniform)
-#pragma unroll
-            for (int v = 0; v < V; ++v) x[i][v] = 0;
-            // the load does not wait for the coefficients: all U rows are in flight at once
-            if (u < u1 && live) {
-                const uint32_t* row;
-                if (extra) row = u < data_rows ? data + (size_t)u * S : parity + (size_t)as_constant(extra)[u - data_rows] * S;
-                else if (parity) row = ((u & 1u) ? parity : data) + (size_t)(u >> 1) * S;
-                else row = data + (size_t)u * S;
-                load_vec<V>(x[i], row + col);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            if (!use[i]) continue;
-#pragma unroll
-            for (int j = 0; j < EB; ++j)
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[j][v] = gf::add(acc[j][v], gf::mul_mont(x[i][v], w[i][j]));
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < EB; ++j) store_vec<V>(partial + ((size_t)chunk * EB + j) * S + col, acc[j]);
-    }
-}
-
-// Sum of the partial sums in two steps.  Step 1 (to == nullptr ... see args): segment `seg` of the chunks -> stage[seg][j][col];
-// step 2: the DIRECT_SEGS stage rows -> lost block j, written where it belongs: data (even positions) or — only for repair — parity.
-constexpr uint32_t DIRECT_SEGS = 32;
-__global__ __launch_bounds__(256) void direct_reduce1_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ stage, uint32_t S, uint32_t chunks,
-                                                             int pad, int e)
-{
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const uint32_t seg = blockIdx.z;
-    if (col >= S || j >= e) return;
-    const uint32_t per = (chunks + DIRECT_SEGS - 1) / DIRECT_SEGS;
-    const uint32_t c0 = seg * per, c1 = min(c0 + per, chunks);
-    uint32_t v = 0;
-#pragma unroll 8
-    for (uint32_t c = c0; c < c1; ++c) v = gf::add(v, partial[((size_t)c * pad + j) * S + col]);
-    stage[((size_t)seg * pad + j) * S + col] = v;
-}
-__global__ __launch_bounds__(256) void direct_reduce2_kernel(const uint32_t* __restrict__ stage, const uint32_t* __restrict__ epos, uint32_t* __restrict__ data,
-                                                             uint32_t* __restrict__ parity, uint32_t S, int pad, int e, bool with_parity)
-{
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (col >= S || j >= e) return;
-    const uint32_t pos = epos ? epos[j] : 2u * (uint32_t)j + 1u;  // no list: output j is row j of `parity` (the encoder below)
-    if ((pos & 1u) && !with_parity) return;
-    uint32_t v = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf::add(v, stage[((size_t)g * pad + j) * S + col]);
-    ((pos & 1u) ? parity : data)[(size_t)(pos >> 1) * S + col] = v;
-}
-
-// Any layout with the data at the N-th roots of unity x_i = w^(i << e) (N a power of two or q 2^m), R the lost data blocks and A as many
-// surviving parity points y_a: the N nodes {x_i : i not in R} + {y_a} interpolate f, and with l(x) = (x^N - 1) A(x) / R(x),
-// A(x) = prod_a (x - y_a), R(x) = prod_r (x - x_r), R_r = R / (x - x_r):
-//     weight of data block i in lost block r   = -(x_i / x_r) * A(x_r) / R_r(x_r) * R_r(x_i) / A(x_i)
-//     weight of parity block a in lost block r = N x_r^-1 A_a(x_r) R(y_a) / (R_r(x_r) (y_a^N - 1) A_a(y_a))     (host: sub-table rows K..)
-// params: [0..16) x_r, [16..32) y_a, [32..48) C_r = -A(x_r) / (x_r R_r(x_r)), [48] = number of lost data blocks; all plain
-__global__ __launch_bounds__(256) void sub_coef_data_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ params,
-                                                            const uint32_t* __restrict__ lost_rows, uint32_t K, int shift, int ed, int pad)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    bool lost = false;
-    for (int r = 0; r < ed; ++r) lost = lost || lost_rows[r] == i;
-    const uint32_t xi = wpow[(size_t)i << shift];
-    uint32_t base = 0;
-    if (!lost) {
-        uint32_t a = 1;
-        for (int t = 0; t < ed; ++t) a = gf::mul(a, gf::sub(xi, params[16 + t]));
-        base = gf::mul(xi, dev_pow(a, gf::P - 2u));  // x_i / A(x_i)
-    }
-    for (int r = 0; r < pad; ++r) {
-        uint32_t v = 0;
-        if (!lost && r < ed) {
-            v = gf::mul(params[32 + r], base);
-            for (int t = 0; t < ed; ++t)
-                if (t != r) v = gf::mul(v, gf::sub(xi, params[t]));
-            v = gf::mul(v, gf::MONT_ONE);
-        }
-        coef[(size_t)i * pad + r] = v;
-    }
-}
-// lost parity block t (point y_t) from the complete data: L_i(y_t) = (y_t^N - 1) x_i / (N (y_t - x_i)); params: [0..16) y_t, [16..32) (y_t^N - 1) / N
-__global__ __launch_bounds__(256) void sub_coef_parity_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ wpow, const uint32_t* __restrict__ params,
-                                                              uint32_t K, int shift, int ep, int pad)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    const uint32_t xi = wpow[(size_t)i << shift];
-    for (int t = 0; t < pad; ++t) {
-        uint32_t v = 0;
-        if (t < ep) v = gf::mul(gf::mul(gf::mul(params[16 + t], xi), dev_pow(gf::sub(params[t], xi), gf::P - 2u)), gf::MONT_ONE);
-        coef[(size_t)i * pad + t] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same idea for ENCODING when a code has few parity blocks (n - k <= 8): with the data points x_i = w_N^i and
-// L_i(x) = (x^N - 1) x_i / (N (x - x_i)) the Lagrange basis, parity block j = f(y_j) = sum_i data_i * L_i(y_j), y_j = w_2N^(odd): y_j^N = -1,
-// so coef[i][j] = -2 x_i / (N (y_j - x_i)) — one read of the data instead of three trips of the transform pipeline.  Exactly the
-// polynomial evaluation the transform computes (RS.cpp:40-63), hence the same parity bits.
-// ------------------------------------------------------------------------------------------------
-constexpr int DIRECT_ENC_MAX = 8;
-__global__ __launch_bounds__(256) void encode_coef_kernel(uint32_t* __restrict__ coef, uint32_t w2n, uint32_t minus_two_over_n, uint32_t K, int m, int pad, int fold)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    const uint32_t xi = dev_pow(w2n, 2u * i);
-    for (int j = 0; j < pad; ++j) {
-        uint32_t v = 0;
-        if (j < m) {
-            const uint32_t yj = dev_pow(w2n, (((uint32_t)j << fold) << 1) + 1u);
-            v = gf::mul(gf::mul(minus_two_over_n, xi), dev_pow(gf::sub(yj, xi), gf::P - 2u));
-            v = gf::mul(v, gf::MONT_ONE);
-        }
-        coef[(size_t)i * pad + j] = v;
-    }
-}
-
 int hip_code(const char* what, hipError_t e)
 {
     set_error_detail(what, e);
@@ -510,79 +338,6 @@ struct DeviceScope {
 };
 
 }  // namespace
-
-struct DirectEncode {
-    uint32_t* coef = nullptr;     // [K][pad], Montgomery form
-    uint32_t* partial = nullptr;  // [chunks + DIRECT_SEGS][pad][S]
-    uint32_t K = 0, S = 0;
-    int m = 0, pad = 0;
-};
-
-void direct_encode_destroy(DirectEncode* de)
-{
-    if (!de) return;
-    if (de->coef) (void)hipFree(de->coef);
-    if (de->partial) (void)hipFree(de->partial);
-    delete de;
-}
-
-int direct_encode_max() { return DIRECT_ENC_MAX; }
-
-// N data points (a power of two, or q 2^m for the mixed-radix codes), K <= N existing data blocks, m <= 8 parity blocks at the odd positions ((j << fold) << 1) + 1 of the
-// 2N-th roots of unity (fastecc_create's layout).  The current device is the context's.
-int direct_encode_build(DirectEncode** out, uint64_t N, uint64_t K, uint64_t m, int fold, uint64_t words)
-{
-    *out = nullptr;
-    if (m < 1 || m > DIRECT_ENC_MAX || K < 1 || K > N || N < 2 || ((gf::P - 1ull) % (2 * N)) != 0) return FASTECC_E_UNSUPPORTED;
-    DirectEncode* de = new (std::nothrow) DirectEncode();
-    if (!de) return FASTECC_E_NOMEM;
-    de->K = (uint32_t)K;
-    de->S = (uint32_t)words;
-    de->m = (int)m;
-    de->pad = 1;
-    while (de->pad < de->m) de->pad <<= 1;
-    const uint64_t chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
-    auto bail = [&](int rc) {
-        direct_encode_destroy(de);
-        return rc;
-    };
-    hipError_t e = hipMalloc((void**)&de->coef, K * de->pad * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&de->partial, (chunks + DIRECT_SEGS) * de->pad * words * 4);
-    if (e != hipSuccess) return bail(hip_code("hipMalloc(direct encode)", e));
-    const uint32_t w2n = gf::h_root((uint32_t)(2 * N));
-    const uint32_t c0 = gf::h_mul(gf::P - 2u, gf::h_inv((uint32_t)(N % gf::P)));  // -2 / N
-    hipLaunchKernelGGL(encode_coef_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, nullptr, de->coef, w2n, c0, (uint32_t)K, de->m, de->pad, fold);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    if (e != hipSuccess) return bail(hip_code("encode_coef_kernel", e));
-    *out = de;
-    return FASTECC_OK;
-}
-
-// parity[j] = sum_i data[i] * coef[i][j]; data: K rows of S words, parity: m rows (may be the first m rows of data)
-int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, hipStream_t st)
-{
-    const uint32_t S = de->S, K = de->K;
-    const bool v4 = (S % 4) == 0 && ((((uintptr_t)data | (uintptr_t)de->partial) & 15u) == 0);
-    const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (K + DIRECT_ROWS - 1) / DIRECT_ROWS;
-    const uint64_t items = (uint64_t)chunks * col_chunks;
-    const dim3 grid((unsigned)((items + 3) / 4));
-#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, data, (const uint32_t*)nullptr, de->coef, de->partial, S, K, col_chunks, items)
-    switch (de->pad) {
-        case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
-        case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
-        case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
-        default: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
-    }
-#undef FASTECC_DIRECT
-    DEC_TRY(hipGetLastError());
-    uint32_t* stage = de->partial + (size_t)chunks * de->pad * S;
-    hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)de->m, DIRECT_SEGS), dim3(256), 0, st, de->partial, stage, S, chunks, de->pad, de->m);
-    hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)de->m), dim3(256), 0, st, stage, (const uint32_t*)nullptr, (uint32_t*)nullptr, parity, S,
-                       de->pad, de->m, true);
-    DEC_TRY(hipGetLastError());
-    return FASTECC_OK;
-}
 
 }  // namespace fastecc
 
@@ -624,7 +379,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while ((1 << e) < ci.cosets + 1) e++;
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
-    const int direct_limit = std::min(ci.direct_max, (int)DIRECT_MAX);
+    const int direct_limit = std::min(ci.direct_max, direct_cap());
     auto parity_position = [&](uint64_t q) -> uint64_t {
         if (ci.cosets > 1) {
             const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
@@ -664,103 +419,42 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             d->positions = NC;
             d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
             d->mixed = mixed;
+            d->direct_kernel = ci.direct_kernel;
             const uint32_t K = (uint32_t)ci.user_k;
-            int padd = 1, padp = 1;
-            while (padd < ed) padd <<= 1;
-            while (padp < ep) padp <<= 1;
-            const uint32_t w = gf::h_root((uint32_t)NC);
+            const uint32_t w = gf::h_root((uint32_t)NC), wd = gf::h_pow(w, 1ull << e);  // data row i sits at wd^i
             auto fsub = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + gf::P - b) % gf::P); };
-            const uint32_t Nf = (uint32_t)(N % gf::P);
-            std::vector<uint32_t> xr(ed), ya(ed), yaN1(ed), params(8 * 16, 0), lists(4 * 16, 0);
-            for (int r = 0; r < ed; r++) xr[r] = gf::h_pow(w, (uint64_t)R[r] << e);
-            for (int a = 0; a < ed; a++) {
-                ya[a] = gf::h_pow(w, parity_position(A[a]));
-                yaN1[a] = fsub(gf::h_pow(ya[a], N), 1u);
-            }
-            // per lost data block: C_r, and the weights of the parity nodes
-            std::vector<uint32_t> node_rows((size_t)ed * padd, 0);
-            for (int r = 0; r < ed; r++) {
-                uint32_t Ar = 1, Rr = 1;
-                for (int a = 0; a < ed; a++) Ar = gf::h_mul(Ar, fsub(xr[r], ya[a]));
-                for (int t = 0; t < ed; t++)
-                    if (t != r) Rr = gf::h_mul(Rr, fsub(xr[r], xr[t]));
-                const uint32_t inv_xr_Rr = gf::h_inv(gf::h_mul(xr[r], Rr));
-                params[r] = xr[r];
-                params[32 + r] = fsub(0u, gf::h_mul(Ar, inv_xr_Rr));  // -A(x_r) / (x_r R_r(x_r))
-                for (int a = 0; a < ed; a++) {
-                    uint32_t Aa_xr = 1, Aa_ya = 1, R_ya = 1;
-                    for (int t = 0; t < ed; t++) {
-                        if (t != a) Aa_xr = gf::h_mul(Aa_xr, fsub(xr[r], ya[t])), Aa_ya = gf::h_mul(Aa_ya, fsub(ya[a], ya[t]));
-                        R_ya = gf::h_mul(R_ya, fsub(ya[a], xr[t]));
-                    }
-                    const uint32_t num = gf::h_mul(gf::h_mul(Nf, Aa_xr), R_ya);
-                    const uint32_t den = gf::h_mul(gf::h_mul(gf::h_mul(xr[r], Rr), yaN1[a]), Aa_ya);
-                    node_rows[(size_t)a * padd + r] = gf::h_to_mont(gf::h_mul(num, gf::h_inv(den)));
-                }
-            }
-            for (int a = 0; a < ed; a++) params[16 + a] = ya[a], lists[a] = A[a];
-            for (int r = 0; r < ed; r++) lists[16 + r] = 2u * R[r];           // reduce: even "position" 2r -> data row r
-            for (int t = 0; t < ep; t++) lists[32 + t] = 2u * Pl[t] + 1u;     // odd -> parity row
-            const uint32_t inv_N = gf::h_inv(Nf);
-            for (int t = 0; t < ep; t++) {
-                const uint32_t yt = gf::h_pow(w, parity_position(Pl[t]));
-                params[64 + t] = yt;
-                params[80 + t] = gf::h_mul(fsub(gf::h_pow(yt, N), 1u), inv_N);  // (y_t^N - 1) / N
-            }
-            hipStream_t st = nullptr;
-            if (!d->wpow) {
-                DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
-                hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
-                DEC_TRY(hipGetLastError());
-            }
-            const uint64_t coef_words = ((uint64_t)K + DIRECT_MAX) * DIRECT_MAX;
-            if (d->direct_coef_words < coef_words) {
-                if (d->direct_coef) (void)hipFree(d->direct_coef);
-                d->direct_coef = nullptr;
-                d->direct_coef_words = 0;
-                DEC_TRY(hipMalloc((void**)&d->direct_coef, coef_words * 4));
-                d->direct_coef_words = coef_words;
-            }
-            if (!d->sub_coef_parity) DEC_TRY(hipMalloc((void**)&d->sub_coef_parity, (uint64_t)K * DIRECT_MAX * 4));
-            if (!d->sub_lists) DEC_TRY(hipMalloc((void**)&d->sub_lists, 4 * 16 * 4));
-            if (!d->sub_params) DEC_TRY(hipMalloc((void**)&d->sub_params, 8 * 16 * 4));
-            const uint64_t chunks = ((uint64_t)K + DIRECT_MAX + DIRECT_ROWS - 1) / DIRECT_ROWS;
-            const uint64_t need = (chunks + 32 /* DIRECT_SEGS */) * std::max(padd, padp) * ci.words;
-            if (d->direct_partial_words < need) {
-                if (d->direct_partial) (void)hipFree(d->direct_partial);
-                d->direct_partial = nullptr;
-                d->direct_partial_words = 0;
-                DEC_TRY(hipMalloc((void**)&d->direct_partial, need * 4));
-                d->direct_partial_words = need;
-            }
             {
                 const int rc = call.wait_idle();  // a decode still using the previous pattern
                 if (rc != FASTECC_OK) return rc;
             }
-            DEC_TRY(hipMemcpyAsync(d->sub_params, params.data(), params.size() * 4, hipMemcpyHostToDevice, st));
-            DEC_TRY(hipMemcpyAsync(d->sub_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
-            std::vector<uint32_t> lost_rows(16, 0xFFFFFFFFu);  // (outlives the asynchronous copy below)
+            int rc = FASTECC_OK;
             if (ed > 0) {
-                // lost data rows as a list for the kernel: the spare quarter of the lists
-                for (int r = 0; r < ed; r++) lost_rows[r] = R[r];
-                DEC_TRY(hipMemcpyAsync(d->sub_lists + 48, lost_rows.data(), 16 * 4, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(sub_coef_data_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d->direct_coef, d->wpow, d->sub_params, d->sub_lists + 48, K, e, ed,
-                                   padd);
-                DEC_TRY(hipGetLastError());
-                DEC_TRY(hipMemcpyAsync(d->direct_coef + (size_t)K * padd, node_rows.data(), node_rows.size() * 4, hipMemcpyHostToDevice, st));
+                std::vector<uint32_t> xr(ed), ya(ed);
+                for (int r = 0; r < ed; r++) xr[r] = gf::h_pow(w, (uint64_t)R[r] << e);
+                for (int a = 0; a < ed; a++) ya[a] = gf::h_pow(w, parity_position(A[a]));
+                if (!d->direct_data && !(d->direct_data = direct_pass_new())) return FASTECC_E_NOMEM;
+                rc = direct_build_interp(d->direct_data, wd, N, K, R, xr, A, ya, nullptr);
             }
-            if (ep > 0) {
-                hipLaunchKernelGGL(sub_coef_parity_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d->sub_coef_parity, d->wpow, d->sub_params + 64, K, e, ep, padp);
-                DEC_TRY(hipGetLastError());
+            if (rc == FASTECC_OK && ep > 0) {
+                std::vector<uint32_t> yt(ep), ct(ep), pos(ep);
+                const uint32_t inv_N = gf::h_inv((uint32_t)(N % gf::P));
+                for (int t = 0; t < ep; t++) {
+                    yt[t] = gf::h_pow(w, parity_position(Pl[t]));
+                    ct[t] = gf::h_mul(fsub(gf::h_pow(yt[t], N), 1u), inv_N);  // (y_t^N - 1) / N
+                    pos[t] = 2u * Pl[t] + 1u;
+                }
+                if (!d->direct_parity && !(d->direct_parity = direct_pass_new())) return FASTECC_E_NOMEM;
+                rc = direct_build_lagrange(d->direct_parity, wd, K, yt, ct, pos, nullptr);
             }
-            DEC_TRY(hipStreamSynchronize(st));  // the host vectors above go out of scope
-            d->sub = true;
-            d->sub_lost_data = ed;
-            d->sub_lost_parity = ep;
-            d->sub_pad_data = padd;
-            d->sub_pad_parity = padp;
-            d->ready = true;
-            return FASTECC_OK;
+            if (rc == FASTECC_OK) {
+                d->sub = true;
+                d->sub_lost_data = ed;
+                d->sub_lost_parity = ep;
+                d->ready = true;
+                return FASTECC_OK;
+            }
+            if (rc != FASTECC_E_NOMEM) return rc;
+            // no memory for the weight tables: the transform path below needs none of them
         }
     }
     enum : uint8_t { LOST = ST_LOST, HELD = ST_HELD, ZERO = ST_ZERO };
@@ -1005,36 +699,14 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
 
     if (d->sub) {
         // any layout, few losses: the lost data from the surviving data + a few parity blocks, then (repair) the lost parity from the data
-        const uint32_t S = (uint32_t)ci.words, K = (uint32_t)ci.user_k;
+        const uint32_t S = (uint32_t)ci.words;
         uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
-        auto pass = [&](const uint32_t* coef, int pad, int outputs, uint32_t rows, const uint32_t* extra, const uint32_t* epos, bool to_parity) -> int {
-            const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dparity | (uintptr_t)d->direct_partial) & 15u) == 0) && pad <= 8;
-            const uint32_t col_chunks = (S + (v4 ? 255u : 63u)) / (v4 ? 256u : 64u), chunks = (rows + DIRECT_ROWS - 1) / DIRECT_ROWS;
-            const uint64_t items = (uint64_t)chunks * col_chunks;
-            const dim3 grid((unsigned)((items + 3) / 4));
-            const uint32_t* par = extra ? dparity : nullptr;
-#define FASTECC_DIRECT(EB, V) hipLaunchKernelGGL((direct_accumulate_kernel<EB, V>), grid, dim3(256), 0, st, ddata, par, coef, d->direct_partial, S, rows, col_chunks, items, extra, K)
-            switch (pad) {
-                case 1: if (v4) FASTECC_DIRECT(1, 4); else FASTECC_DIRECT(1, 1); break;
-                case 2: if (v4) FASTECC_DIRECT(2, 4); else FASTECC_DIRECT(2, 1); break;
-                case 4: if (v4) FASTECC_DIRECT(4, 4); else FASTECC_DIRECT(4, 1); break;
-                case 8: if (v4) FASTECC_DIRECT(8, 4); else FASTECC_DIRECT(8, 1); break;
-                default: FASTECC_DIRECT(16, 1); break;
-            }
-#undef FASTECC_DIRECT
-            DEC_TRY(hipGetLastError());
-            uint32_t* stage = d->direct_partial + (size_t)chunks * pad * S;
-            hipLaunchKernelGGL(direct_reduce1_kernel, dim3((S + 255) / 256, (unsigned)outputs, DIRECT_SEGS), dim3(256), 0, st, d->direct_partial, stage, S, chunks, pad, outputs);
-            hipLaunchKernelGGL(direct_reduce2_kernel, dim3((S + 255) / 256, (unsigned)outputs), dim3(256), 0, st, stage, epos, ddata, dpar_out, S, pad, outputs, to_parity);
-            DEC_TRY(hipGetLastError());
-            return FASTECC_OK;
-        };
         if (d->sub_lost_data > 0) {
-            const int rc = pass(d->direct_coef, d->sub_pad_data, d->sub_lost_data, K + (uint32_t)d->sub_lost_data, d->sub_lists, d->sub_lists + 16, false);
+            const int rc = direct_run(d->direct_data, ddata, dparity, ddata, nullptr, S, d->direct_kernel, st);
             if (rc != FASTECC_OK) return rc;
         }
         if (rebuild) {
-            const int rc = pass(d->sub_coef_parity, d->sub_pad_parity, d->sub_lost_parity, K, nullptr, d->sub_lists + 32, true);
+            const int rc = direct_run(d->direct_parity, ddata, nullptr, nullptr, dpar_out, S, d->direct_kernel, st);
             if (rc != FASTECC_OK) return rc;
         }
     } else {

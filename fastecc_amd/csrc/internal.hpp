@@ -24,11 +24,26 @@ int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, cons
 int sharded_decode_stripe(fastecc_ctx* shell, void* data, void* parity, int mem_kind, bool repair, hipStream_t st);
 fastecc_ctx* sharded_child(fastecc_ctx* shell, int g);
 
-// ---- decode.hip: encoding straight from the Lagrange basis for codes with few parity blocks (n - k <= direct_encode_max()) ----
+// ---- direct.hip: blocks as fixed linear combinations of other blocks (few lost blocks / few parity blocks) ----
+struct DirectPass;                 // the weights of one pattern (or code) and the work buffers of its pass
+DirectPass* direct_pass_new();
+void direct_pass_free(DirectPass*);
+int direct_cap();                  // most outputs (lost or parity blocks) of one pass
+// Output t = f(y[t]) from ALL K data rows (row i at the point wd^i, wd of order N): weight c[t] x_i / (y[t] - x_i), c[t] = (y[t]^N - 1) / N;
+// written to data row pos >> 1 (pos even) or parity row pos >> 1 (pos odd).  Synchronises `st`.
+int direct_build_lagrange(DirectPass* p, uint32_t wd, uint32_t K, const std::vector<uint32_t>& y, const std::vector<uint32_t>& c, const std::vector<uint32_t>& out_pos,
+                          hipStream_t st);
+// The lost data rows (points lost_points) from the surviving data rows and as many surviving parity rows (node_rows at node_points).
+int direct_build_interp(DirectPass* p, uint32_t wd, uint64_t N, uint32_t K, const std::vector<uint32_t>& lost_rows, const std::vector<uint32_t>& lost_points,
+                        const std::vector<uint32_t>& node_rows, const std::vector<uint32_t>& node_points, hipStream_t st);
+// kernel: 0 = choose, 1 = VALU (96-bit lazy accumulation), 2 = MFMA (i8 digits) when the stripes allow it
+int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint32_t* data_out, uint32_t* parity_out, uint32_t S, int kernel, hipStream_t st);
+bool direct_mfma_applies(const void* data, const void* parity, uint64_t words);
+// encoding straight from the Lagrange basis for codes with few parity blocks (n - k <= direct_encode_max())
 struct DirectEncode;
 int direct_encode_max();
 int direct_encode_build(DirectEncode** out, uint64_t N, uint64_t K, uint64_t m, int fold, uint64_t words);  // current device = the context's
-int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, hipStream_t st);
+int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, int kernel, hipStream_t st);
 void direct_encode_destroy(DirectEncode* de);
 
 // ---- api.hip ----
@@ -39,6 +54,7 @@ struct CtxInfo {
     uint64_t user_k, user_m;   // data / parity blocks of the caller's stripes (== k, k >> fold unless zero_extended)
     int q;                     // > 1: the transform order is q * k (mixed radix); k is its power-of-two part
     int direct_max;            // decoder: patterns with at most this many lost blocks take the direct path (option "decode_direct_max")
+    int direct_kernel;         // 0 choose, 1 VALU, 2 MFMA (option "direct_kernel")
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);

@@ -315,4 +315,4 @@ def test_few_losses_take_the_direct_path(torch_cuda, fe, oracle, N, S):
                 assert (oracle.decode(bad_x, bad_p, dp, pp) == x).all()
         enc.set_option("decode_direct_max", 16)
         with pytest.raises(fe.FastEccError):
-            enc.set_option("decode_direct_max", 17)
+            enc.set_option("decode_direct_max", 257)

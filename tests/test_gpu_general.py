@@ -170,7 +170,7 @@ def test_few_parity_blocks_are_encoded_directly(torch_cuda, fe, oracle, k):
                 enc.encode_host(x, host_out)
                 assert (host_out == want).all(), (k, m, direct_max)
             with pytest.raises(fe.FastEccError):
-                enc.set_option("encode_direct_max", 9)
+                enc.set_option("encode_direct_max", 257)
 
 
 def _few_loss_round_trips(torch, fe, enc, x, par, rng, counts):

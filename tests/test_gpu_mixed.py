@@ -404,13 +404,13 @@ def test_orders_above_2_20_repair_few_losses_only(torch_cuda, fe):
         par = torch.empty_like(x)
         enc.encode(x, par)
         rng = np.random.default_rng(8)
-        for count in (1, 16, 17):
+        for count in (1, 16, 17, 200, 257):
             lost = rng.permutation(2 * k)[:count]
             lost[0] = int(rng.integers(0, k))
             dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
             dp[lost[lost < k]] = 0
             pp[lost[lost >= k] - k] = 0
-            if count > 16:
+            if count > 256:
                 with pytest.raises(fe.FastEccError) as ei:
                     enc.decode_prepare(dp, pp)
                 assert ei.value.code == fe.E_UNSUPPORTED
