@@ -171,6 +171,30 @@ def pmc_traffic(kernel):
         return None
 
 
+ROCPROF_STATS = os.path.join("profiles", "r03", "rocprofv3_kernel_stats_bench_default.csv")
+
+
+def rocprof_avg_ms(kernel):
+    """Average duration of `kernel` (the library's profile name, e.g. tile_mid10_w32) in the committed rocprofv3 --kernel-trace --stats
+    summary of this command (captured in the same GPU session as profiles/r03/bench_n1_default.json), or None.
+    tile_<mode><levels>_w32[_r16] <-> ntt_tile_kernel<levels, 5 or 4, true, 0/1/2, ...>."""
+    import csv
+    import re
+    m = re.match(r"tile_(dif|dit|mid)(\d+)_w(32|64)(_r16)?$", kernel)
+    if not m:
+        return None
+    want = (int(m.group(2)), 4 if m.group(4) else 5, "true" if m.group(3) == "32" else "false", {"dif": 0, "dit": 1, "mid": 2}[m.group(1)])
+    try:
+        with open(os.path.join(ROOT, ROCPROF_STATS)) as f:
+            for row in csv.DictReader(f):
+                t = re.search(r"ntt_tile_kernel<(\d+), (\d+), (true|false), (\d+)", row.get("Name", ""))
+                if t and (int(t.group(1)), int(t.group(2)), t.group(3), int(t.group(4))) == want:
+                    return float(row["AverageNs"]) / 1e6
+    except Exception:
+        return None
+    return None
+
+
 def parity_check(enc, log2k, block_bytes, device):
     """The gate BASELINE.md §3.4 specifies: encode the splitmix(0x1234) stripe with the context that was just timed and
     compare the parity hash (main.cpp:202-212) with the value recorded from the unmodified reference.  The oracle
@@ -239,6 +263,9 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
         dv, pv = data.view(k, S), parity.view(k, S)
         for name, lost in (("repair_1_data_1_parity_lost", np.array([k // 3, k + k // 7])),
                            ("repair_8_data_8_parity_lost", np.r_[rng.permutation(k)[:8], k + rng.permutation(k)[:8]]),
+                           ("repair_16_data_lost", rng.permutation(k)[:16]),
+                           ("repair_64_data_lost", rng.permutation(k)[:64]),
+                           ("repair_128_data_128_parity_lost", np.r_[rng.permutation(k)[:128], k + rng.permutation(k)[:128]]),
                            ("repair_2_percent_of_the_codeword_lost", rng.permutation(2 * k)[: (2 * k) // 50])):
             dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
             dp[lost[lost < k]] = 0
@@ -273,6 +300,44 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
                                              "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe))}
     except Exception as e:  # noqa: BLE001
         out["small_m_error"] = repr(e)
+    # --- more parity blocks, still one read of the data (matrix cores)
+    try:
+        with fastecc_amd.Encoder(k + 64, k, block_bytes, device=device.index or 0) as small:
+            p_direct = torch.empty(64 * S, dtype=torch.int32, device=device)
+            p_pipe = torch.empty_like(p_direct)
+            ms = event_ms(lambda: small.encode(data, p_direct, stream=stream), 10)
+            small.set_option("encode_direct_max", 0)
+            small.encode(data, p_pipe, stream=stream)
+            ms_pipe = event_ms(lambda: small.encode(data, p_pipe, stream=stream), 5)
+            out["encode_k_plus_64_parity"] = {"ms": round(ms, 3), "data_GBps": round(k * block_bytes / ms / 1e6, 1), "transform_pipeline_ms": round(ms_pipe, 3),
+                                              "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe))}
+    except Exception as e:  # noqa: BLE001
+        out["k_plus_64_error"] = repr(e)
+    # --- the stripe in HOST memory (what RS.cpp times, RS.cpp:25-38): pinned buffers in and out over the host link, column slabs
+    #     uploaded, encoded and downloaded in a pipeline (FASTECC_MEM_HOST_PINNED); GB/s counts data + parity bytes like `value`
+    try:
+        hx = torch.empty(k * S, dtype=torch.int32).pin_memory()
+        hp = torch.empty(k * S, dtype=torch.int32).pin_memory()
+        hx.copy_(data.cpu())
+        ref = parity.clone()
+        enc.encode(data, ref, stream=stream)
+
+        def host_once():
+            enc.encode(hx, hp, stream=stream, mem=fastecc_amd.MEM_HOST_PINNED)
+            torch.cuda.synchronize()
+
+        host_once()
+        ok = bool(torch.equal(hp, ref.cpu()))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            host_once()
+        hms = (time.perf_counter() - t0) / 3 * 1e3
+        out["host_pinned_end_to_end"] = {"ms": round(hms, 2), "GBps": round(2.0 * k * block_bytes / hms / 1e6, 1), "same_parity_as_the_device_encode": ok,
+                                         "what": "fastecc_encode(FASTECC_MEM_HOST_PINNED): 2 GiB of data up and 2 GiB of parity down over the host link "
+                                                 "inside the timed region (wall clock, 3 calls); the regime RS.cpp:25-38 measures"}
+        del hx, hp, ref
+    except Exception as e:  # noqa: BLE001
+        out["host_pinned_error"] = repr(e)
     # --- a mixed-radix order (3 * 2^(log2k - 2) data blocks), fused odd-radix tiles against the unfused plan of the same context
     try:
         km = 3 << max(log2k - 2, 1)
@@ -538,11 +603,19 @@ def main():
             log2m = args.log2k if args.log2m is None or m_blocks > k else args.log2m
             bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block * args.batch / (ms_per_step * 1e-3) / 1e9
             traffic = pmc_traffic(name)
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            headline = args.log2k == 19 and args.block_bytes == 4096 and not p61 and m_blocks == k and args.batch == 1 and not args.plan and not args.option
+            prof_ms = rocprof_avg_ms(name) if headline else None
+            # The fused MID tile is bound by integer VALU issue (SQ_INSTS_VALU / duration: profiles/r01/pmc_default_plan_summary.json,
+            # profiles/r02/mid_valu_analysis.md), the outer passes by HBM: `bound` says which; achieved / peak / frac stay the HBM
+            # figures the contract asks for, the VALU figures are in `valu`.
+            roof = {"bound": "valu" if "_mid" in name else "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
                                                                    "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)",
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
+                    "frac_rocprof": None if not prof_ms else round(per_launch / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "rocprof_avg_kernel_ms": None if not prof_ms else round(prof_ms, 4),
+                    "rocprof_source": None if not prof_ms else ROCPROF_STATS + " (rocprofv3 --kernel-trace --stats of this command, committed; not measured in this run)",
                     "encode": {"ms_per_step": round(ms_per_step, 4), "sum_of_kernel_ms_per_step": round(kernel_ms_per_step, 4),
                                "achieved": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -558,6 +631,38 @@ def main():
                 check = parity_check_p61(data, parity, k, args.block_bytes) if p61 else parity_check(enc, args.log2k, args.block_bytes, device)
             except Exception as e:  # noqa: BLE001
                 check = {"status": "error", "why": repr(e)}
+
+    # ---- who measured: one record per rank (the driver's scaling line must be able to show N distinct GPUs) ----
+    def identity():
+        rec = {"rank": rank, "local_rank": local, "device_index": torch.cuda.current_device()}
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            rec["name"] = pr.name
+            rec["uuid"] = str(getattr(pr, "uuid", ""))
+            rec["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+            rec["compute_units"] = pr.multi_processor_count
+            rec["hbm_GiB"] = round(pr.total_memory / 2**30, 1)
+            rec["gcn_arch"] = getattr(pr, "gcnArchName", "")
+            rec["can_access_peer"] = [bool(j == local or torch.cuda.can_device_access_peer(local, j)) for j in range(torch.cuda.device_count())]
+        except Exception as e:  # noqa: BLE001
+            rec["error"] = repr(e)
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            if os.environ.get(var) is not None:
+                rec[var] = os.environ[var]
+        return rec
+
+    devices = [identity()]
+    dist_info = {"world_size": 1, "backend": None}
+    if world > 1:
+        try:
+            every_rec = [None] * world
+            dist.all_gather_object(every_rec, devices[0])
+            devices = every_rec
+            dist_info = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()),
+                         "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                         "distinct_gpus": len({(d or {}).get("uuid") or (d or {}).get("pci_bus_id") for d in devices})}
+        except Exception as e:  # noqa: BLE001
+            dist_info = {"world_size": world, "backend": backend, "error": repr(e)}
 
     emitted = threading.Event()
     other_paths_result = {}
@@ -582,6 +687,7 @@ def main():
             "parity_check": check,
             "roofline": roof, "cpu_baseline": cpu,
             "sharded_one_stripe": sharded,
+            "devices": devices, "distributed": dist_info,
         }
         if other_paths_result:
             line["other_paths"] = other_paths_result
@@ -620,29 +726,37 @@ def main():
             if os.environ.get("FASTECC_BENCH_TEST_STALL") and rank == world - 1:
                 time.sleep(1e6)  # test hook for the watchdog above: one rank never reaches the collectives
             w = words // world
-            senc = fastecc_amd.Encoder(n, k, args.block_bytes // world, device=local, field=field)
-            tune(senc)
-            # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM
-            slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(k, w)
-            pslab = torch.empty_like(slab)
+            # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM as `sub` contiguous
+            # column sub-slabs [sub][k][w/sub] (what a scatter delivers); each sub-slab is an ordinary stripe of narrower blocks
             sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
-            columns = sharding.hip_columns_encoder(senc, unit // 4)
+            wsub = w // sub
+            senc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
+            tune(senc)
+            slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
+            pslab = torch.empty_like(slab)
             wsp = {}
-            modes = {"compute_only": lambda: senc.encode(slab, pslab, stream=stream),
-                     "with_gather": lambda: sharding.encode_slab_and_gather(slab, columns, k, dst=0, sub_slabs=sub, workspace=wsp,
-                                                                           collective_on_host=backend != "nccl")}
-            sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank; "
-                               "with_gather adds the RCCL gather of the parity slabs into full blocks on rank 0, "
-                               "pipelined in %d sub-slab(s)" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+
+            def encode_all():
+                for h in range(sub):
+                    senc.encode(slab[h], pslab[h], stream=stream)
+
+            modes = {"compute_only": encode_all,
+                     "with_gather": lambda: sharding.encode_sub_slabs_and_gather(
+                         slab, lambda d, o: senc.encode(d, o, stream=torch.cuda.current_stream().cuda_stream), k, dst=0, workspace=wsp,
+                         collective_on_host=backend != "nccl")}
+            sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d "
+                               "contiguous sub-slab(s); with_gather adds the RCCL gather of the parity into full blocks on rank 0: no pack, "
+                               "the root's own part is encoded where it is gathered, transfers and one re-interleaving kernel per sub-slab "
+                               "run on a side stream under the next sub-slab's encode" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
                        "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
             for name, fn in modes.items():
                 for _ in range(max(1, args.warmup)):
                     fn()
                 ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
                 sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
-            # what was timed is also right: the gathered blocks on rank 0 hold this rank's slab where it belongs
+            # what was timed is also right: the gathered blocks on rank 0 hold every rank's slab where it belongs
             full = wsp.get("parity_full")
-            mine = wsp["parity_slab"].to(torch.int64)
+            mine = (wsp["recv"][:, rank] if rank == 0 else wsp["send"]).permute(1, 0, 2).reshape(k, w).to(torch.int64)
             sums = torch.stack([mine.sum(), (mine * torch.arange(1, w + 1, device=device)).sum()])  # wraps mod 2^64: fine for a checksum
             if world > 1:
                 sums = sums.to(device if backend == "nccl" else "cpu")
@@ -651,7 +765,9 @@ def main():
             else:
                 every = [sums]
             if rank == 0 and full is not None:
-                ok = torch.equal(full[:, :w], wsp["parity_slab"])
+                encode_all()  # the same slab through the plain calls: compute_only's result
+                torch.cuda.synchronize()
+                ok = torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w))
                 for g in range(world):  # every rank's slab arrived in its columns of the full blocks
                     part = full[:, g * w:(g + 1) * w].to(torch.int64)
                     want = every[g].to(part.device)

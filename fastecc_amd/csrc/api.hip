@@ -131,8 +131,8 @@ struct fastecc_ctx {
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
     DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
-    int encode_direct_max = 128;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 16
-    int decode_direct_max = 128;  // up to this many lost blocks are recomputed directly (direct.hip), 0 = always the transform
+    int encode_direct_max = 160;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 32
+    int decode_direct_max = 256;  // up to this many lost blocks are recomputed directly (direct.hip), 0 = always the transform; 96 without the MFMA kernel
     int direct_kernel = 0;        // 0 choose, 1 VALU, 2 MFMA
     int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
     int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
@@ -144,7 +144,6 @@ struct fastecc_ctx {
     int fuse_radix = 1;      // mixed-radix contexts: fuse the odd-radix level into the outermost tile where a shape exists (option "fuse_radix")
     bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
     bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
-    bool prefetch = false;   // ... that request the next tile before computing the current one
     int cus = 256;           // compute units of the device (sizes the persistent grids)
     std::vector<Pass> encode_plan, ntt_plan;
     std::string plan_text;
@@ -408,7 +407,6 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.row_factor = cb.gather_factor;
             }
             a.persistent_cus = c->persistent ? c->cus : 0;
-            a.prefetch = c->prefetch;
             a.split2 = c->split2;
             a.xcd_swizzle = c->xcd_swizzle;
             // Non-temporal streaming only pays when block rows are cache-line aligned: with e.g. 2052- or 4100-byte
@@ -608,8 +606,10 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
 static bool direct_encode_applies(const fastecc_ctx* c, const void* data = nullptr, const void* parity = nullptr)
 {
     if (c->p61 || c->cosets != 1 || c->ld != c->S || c->Mu < 1) return false;
+    // measured at k = 2^19 x 4 KB (profiles/r03/direct_bench.jsonl): pipeline 2.4 ms; MFMA kernel 0.40 (n - k <= 16) ... 1.4 (128) ... 2.7 ms (256);
+    // VALU kernel 0.9 ms per sweep of 16 outputs
     int limit = std::min(c->encode_direct_max, direct_encode_max());
-    if (c->direct_kernel == 1 || !direct_mfma_applies(data, parity, c->S)) limit = std::min(limit, 16);
+    if (c->direct_kernel == 0 && !direct_mfma_applies(data, parity, c->S)) limit = std::min(limit, 32);
     return (int)std::min<uint64_t>(c->Mu, 100000) <= limit;
 }
 
@@ -1548,7 +1548,7 @@ int fastecc_gf_binary(fastecc_ctx* c, int op, const uint32_t* x, const uint32_t*
 
 int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* stream, uint64_t* bad_words)
 {
-    if (!c || !data || !bad_words || ((uintptr_t)data & (c->p61 ? 7u : 3u))) return FASTECC_E_INVAL;
+    if (!c || !data || !bad_words || ((uintptr_t)data & (c->p61 ? 15u : 3u))) return FASTECC_E_INVAL;  // as fastecc_encode
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
     if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // scans k * block_bytes contiguous bytes
@@ -1779,6 +1779,8 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
     if (!strcmp(name, "fuse_radix")) {  // mixed-radix contexts: 1 = odd-radix level fused into the outer tiles (default), 0 = its own passes
         if (value < 0 || value > 1) return FASTECC_E_INVAL;
         if (c->fuse_radix == value) return FASTECC_OK;
+        DeviceGuard dg(c->device);  // the tables of THIS context's device are rebuilt: wait for its work, not the caller's current device's
+        if (!dg.ok) return FASTECC_E_DEVICE;
         c->fuse_radix = value;
         HIP_TRY(hipDeviceSynchronize());
         build_plans(c);
@@ -1840,11 +1842,11 @@ const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str(
 //   0            default
 //   rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
 //   1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
-//                f&2: next-tile prefetch in persistent DIF/DIT tiles; f&4: never use persistent workgroups
+//                f&4: never use persistent workgroups (f&2, the next-tile prefetch of rounds 1-2, is gone: such ids are rejected)
 static int apply_plan(fastecc_ctx* c, int plan)
 {
     int rmax = 5, vec = 1, tile_mid = 10;
-    bool wide = false, prefetch = false, persistent = true, slim = true;  // plan 0 == 2100
+    bool wide = false, persistent = true, slim = true;  // plan 0 == 2100
     bool split2 = true;  // plan 0 == 3100
     if (plan >= 1000) {
         slim = plan >= 2000;  // 2000+10*a+f: as 1000+10*a+f with 16-word-per-lane outer tiles (8/9 levels)
@@ -1853,9 +1855,8 @@ static int apply_plan(fastecc_ctx* c, int plan)
         tile_mid = (plan % 1000) / 10;
         const int f = (plan % 1000) % 10;
         wide = f & 1;
-        prefetch = (f & 2) != 0;
         persistent = !(f & 4);
-        if (f > 7) return FASTECC_E_INVAL;
+        if (f > 7 || (f & 2)) return FASTECC_E_INVAL;
         if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
     } else if (plan != 0) {
         rmax = plan / 10;
@@ -1867,7 +1868,6 @@ static int apply_plan(fastecc_ctx* c, int plan)
     c->vec = vec;
     c->tile_mid = tile_mid;
     c->tile_mid_wide = wide;
-    c->prefetch = prefetch;
     c->persistent = persistent;
     c->slim_outer = slim;
     c->split2 = split2;

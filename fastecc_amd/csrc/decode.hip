@@ -379,7 +379,10 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while ((1 << e) < ci.cosets + 1) e++;
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
-    const int direct_limit = std::min(ci.direct_max, direct_cap());
+    // the matrix-core kernel recomputes 256 blocks in a third of the transform path's time, the VALU kernel breaks even near 128
+    // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for
+    int direct_limit = std::min(ci.direct_max, direct_cap());
+    if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, 96);
     auto parity_position = [&](uint64_t q) -> uint64_t {
         if (ci.cosets > 1) {
             const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
@@ -555,9 +558,17 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         d->tree_T = T;
     }
     if (!d->wpow) {
-        DEC_TRY(hipMalloc((void**)&d->wpow, NC * 4));
-        hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, d->wpow, w, (uint32_t)NC);
-        DEC_TRY(hipGetLastError());
+        // the table becomes visible to later calls only once the kernel that fills it has been launched without error
+        // (an unfilled table behind a non-null pointer would give silently wrong weights on the next prepare)
+        uint32_t* fresh = nullptr;
+        DEC_TRY(hipMalloc((void**)&fresh, NC * 4));
+        hipLaunchKernelGGL(wpow_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, fresh, w, (uint32_t)NC);
+        const hipError_t e_fill = hipGetLastError();
+        if (e_fill != hipSuccess) {
+            (void)hipFree(fresh);
+            return hip_code("wpow_kernel", e_fill);
+        }
+        d->wpow = fresh;
     }
     if (!d->dev_state) DEC_TRY(hipMalloc((void**)&d->dev_state, NC));
     if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));

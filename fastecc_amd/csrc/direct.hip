@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -37,7 +38,8 @@ namespace {
 constexpr int DIRECT_CAP = 256;          // outputs per pass: bound of the small parameter tables
 constexpr uint32_t DIRECT_ROWS = 512;    // rows per partial sum (times the number of sweeps, up to 8)
 constexpr uint32_t DIRECT_SEGS = 32;     // first summation step: the partial sums in this many segments
-constexpr uint32_t MFMA_ROWS = 2048;     // rows per partial sum of the MFMA kernel (i32 digit sums: < 2^19 per 8 rows)
+constexpr uint32_t MFMA_ROWS = 4096;     // most rows per partial sum of the MFMA kernel (i32 digit sums: < 2^19 per 8 rows, so < 2^28)
+constexpr uint32_t TAIL_ROWS = 16;       // rows per partial sum for the few rows the MFMA kernel leaves to the VALU kernel
 constexpr int MFMA_G = 4;                // 8-row steps per LDS stage of weight fragments
 
 __device__ __forceinline__ uint32_t dev_pow(uint32_t x, uint32_t e)
@@ -222,6 +224,7 @@ struct MfmaArgs {
     const uint4* frag;       // [rows / 8 + MFMA_G][mt_total][64], the last MFMA_G steps zero
     uint32_t* partial;       // [chunks (+ the VALU kernel's)][pad][S]
     uint32_t S, rows, pad, mt_total, chunks, col_groups, sweeps;
+    uint32_t chunk_rows;     // rows per chunk: a multiple of 8 * MFMA_G, at most MFMA_ROWS
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t direct_desc(const void* p, uint32_t bytes)
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
     const bool live = col < a.S;
     const uint32_t row_bytes = a.S * 4u;
     const uint32_t voff = 4u * half * row_bytes + 4u * (live ? col : 0u);  // dead lanes read column 0: their D columns are never stored
-    const uint32_t per_chunk = MFMA_ROWS / 8u;
+    const uint32_t per_chunk = a.chunk_rows / 8u;
     const uint32_t ks0 = chunk * per_chunk, ks1 = min(ks0 + per_chunk, a.rows / 8u);
     const uint32_t stages = (ks1 - ks0) / G;
     const uint32_t step_bytes = a.mt_total * 1024u;  // fragments of one step, all M-tiles
@@ -277,54 +280,66 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0;
 
-    v2u x[G][4];
+    // NB row buffers: stage s lives in buffer s % NB and, once its steps have been turned into B fragments, the buffer is refilled with
+    // stage s + NB — that many stages of rows (NB * G * 4 KB per wave) are in flight, which is what hides the HBM latency when only one or
+    // two waves fit a SIMD.  Stages past the end re-read the chunk's first stages (never used), so no bound has to be checked.
+    constexpr int NB = MT >= 4 ? 2 : 1;
+    v2u x[NB][G][4];
     v4u wreg[WN];
 #pragma unroll
     for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], 0, 0);
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t st0 = (uint32_t)nb < stages ? nb : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * g + i) * row_bytes, 0);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[nb][g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (st0 * G + g) + i) * row_bytes, 0);
+    }
 #pragma unroll
     for (int q = 0; q < WN; ++q) wl[0][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
     __syncthreads();
-    for (uint32_t s = 0; s < stages; ++s) {
-        // what is fetched during the last stage is not used: it re-reads the chunk's first stage, so that no bound has to be checked
-        const uint32_t sn = s + 1 < stages ? s + 1 : 0;
+    for (uint32_t s0 = 0; s0 < stages; s0 += NB) {
 #pragma unroll
-        for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], sn * G * step_bytes, 0);
-        const uint4* wcur = wl[s & 1u];
-        uint4 af[2];
-        af[0] = wcur[lane];
+        for (int nb = 0; nb < NB; ++nb) {
+            const uint32_t s = s0 + nb;
+            if (s < stages) {  // workgroup-uniform
+                const uint32_t sw = s + 1 < stages ? s + 1 : 0, sx = s + NB < stages ? s + NB : 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            v4i bf[2];
+                for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], sw * G * step_bytes, 0);
+                const uint4* wcur = wl[s & 1u];
+                uint4 af[2];
+                af[0] = wcur[lane];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf[0][i] = (int)balanced_digits(x[g][i][0]);
-                bf[1][i] = (int)balanced_digits(x[g][i][1]);
-            }
-            // the registers of this step are free again: the same step of the next stage is requested into them, a whole stage ahead
+                for (int g = 0; g < G; ++g) {
+                    v4i bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (sn * G + g) + i) * row_bytes, 0);
-            __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the arithmetic
+                    for (int i = 0; i < 4; ++i) {
+                        bf[0][i] = (int)balanced_digits(x[nb][g][i][0]);
+                        bf[1][i] = (int)balanced_digits(x[nb][g][i][1]);
+                    }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int t = g * MT + mt;
-                if (t + 1 < G * MT) af[(t + 1) & 1] = wcur[(t + 1) * 64 + lane];  // one fragment ahead of the MFMAs that use it
-                v4i av;
-                av[0] = (int)af[t & 1].x; av[1] = (int)af[t & 1].y; av[2] = (int)af[t & 1].z; av[3] = (int)af[t & 1].w;
-                acc[mt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[0], acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[1], acc[mt][1], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) x[nb][g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (sx * G + g) + i) * row_bytes, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the arithmetic
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int t = g * MT + mt;
+                        if (t + 1 < G * MT) af[(t + 1) & 1] = wcur[(t + 1) * 64 + lane];  // one fragment ahead of the MFMAs that use it
+                        v4i av;
+                        av[0] = (int)af[t & 1].x; av[1] = (int)af[t & 1].y; av[2] = (int)af[t & 1].z; av[3] = (int)af[t & 1].w;
+                        acc[mt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[0], acc[mt][0], 0, 0, 0);
+                        acc[mt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[1], acc[mt][1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
+                __syncthreads();
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
-        __syncthreads();
     }
     // D: column n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = 4 j' + b: registers 4 q .. 4 q + 3 of a lane are the
-    // four digit sums of output j' = 2 q + half.  value = sum_b d_b 256^b, |d_b| < 2^27 here; + p * 2^24 makes it positive.
+    // four digit sums of output j' = 2 q + half.  value = sum_b d_b 256^b, |d_b| < 2^28 here; + p * 2^24 makes it positive.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -592,12 +607,16 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
     if (!p || !p->built) return FASTECC_E_INVAL;
     const uint32_t rows = p->rows;
     const uint32_t bulk = p->data_rows / (8u * MFMA_G) * (8u * MFMA_G);  // the MFMA kernel's share: whole stages of the data stripe
-    const bool mfma_ok = (S % 2) == 0 && (((uintptr_t)data) & 7u) == 0 && S >= 32 && bulk > 0 && (uint64_t)S * 4u * MFMA_ROWS < (1ull << 32);
-    const bool use_mfma = kernel == 2 ? mfma_ok : kernel == 1 ? false : (mfma_ok && p->outputs >= 16 && S >= 64 && bulk >= 4096);
+    const bool mfma_ok = (S % 2) == 0 && (((uintptr_t)data) & 7u) == 0 && S >= 32 && bulk > 0 && (uint64_t)S * 4u * MFMA_ROWS < (1ull << 32);  // a chunk's rows within one buffer descriptor
+    const bool use_mfma = kernel == 2 ? mfma_ok : kernel == 1 ? false : (mfma_ok && p->outputs >= 5 && S >= 64 && bulk >= 4096);
     uint32_t chunks;
     int pad;
     if (use_mfma) {
-        const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
+        int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
+        if (const char* ev = getenv("FASTECC_DIRECT_MT")) {  // experiments only
+            const int v = atoi(ev);
+            if (v == 2 || v == 4 || v == 8) mt = v;
+        }
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
         const uint32_t steps_alloc = bulk / 8u + MFMA_G;  // zero steps at the end: the prefetch of a stage never leaves the table
@@ -610,12 +629,16 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
             p->frag_valid = true;
             p->mfma_pad = pad;
         }
-        const uint32_t mchunks = (bulk + MFMA_ROWS - 1) / MFMA_ROWS;
-        const uint32_t tail_chunks = rows > bulk ? (rows - bulk + DIRECT_ROWS - 1) / DIRECT_ROWS : 0;
+        // rows per chunk: about a thousand workgroups (four per CU) when the stripe is large enough for that
+        const uint32_t col_groups = (S + 255u) / 256u, sweeps = (uint32_t)(pad / (8 * mt));
+        uint32_t chunk_rows = 8u * MFMA_G * 8u;
+        while (chunk_rows < MFMA_ROWS && (uint64_t)(bulk / (2u * chunk_rows)) * col_groups * sweeps >= 1024u) chunk_rows *= 2u;
+        const uint32_t mchunks = (bulk + chunk_rows - 1) / chunk_rows;
+        const uint32_t tail_chunks = rows > bulk ? (rows - bulk + TAIL_ROWS - 1) / TAIL_ROWS : 0;
         chunks = mchunks + tail_chunks;
         int rc = ensure(p->partial, p->partial_words, ((uint64_t)chunks + DIRECT_SEGS) * pad * S);
         if (rc != FASTECC_OK) return rc;
-        MfmaArgs a{data, p->frag, p->partial, S, bulk, (uint32_t)pad, mt_total, mchunks, (S + 255u) / 256u, (uint32_t)(pad / (8 * mt))};
+        MfmaArgs a{data, p->frag, p->partial, S, bulk, (uint32_t)pad, mt_total, mchunks, col_groups, sweeps, chunk_rows};
         const dim3 grid((mchunks + 7u) / 8u * 8u * a.col_groups * a.sweeps);
         switch (mt) {
             case 2: hipLaunchKernelGGL(direct_mfma_kernel<2>, grid, dim3(256), 0, st, a); break;
@@ -624,7 +647,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
         }
         DIR_TRY(hipGetLastError());
         if (tail_chunks) {  // the last data rows and the parity rows used as nodes
-            rc = launch_accumulate(p, data, parity, S, bulk, mchunks, (uint32_t)pad, DIRECT_ROWS, st);
+            rc = launch_accumulate(p, data, parity, S, bulk, mchunks, (uint32_t)pad, TAIL_ROWS, st);
             if (rc != FASTECC_OK) return rc;
         }
     } else {

@@ -8,7 +8,7 @@
 // Device arithmetic, built for a VALU whose widest multiply is v_mad_u64_u32 (32 x 32 + 64 -> 64):
 //
 //   * A data component x is kept LAZY in [0, 2^61 + 2^33): congruent to the value, not necessarily canonical.
-//     It is split x = x1 * 2^31 + x0 with x0 < 2^31 and x1 <= 2^30.
+//     It is split x = x1 * 2^31 + x0 with x0 < 2^31 and x1 <= 2^30 + 4 (x >> 31 of a value below 2^61 + 2^33).
 //   * A twiddle (c, d) is canonical and wave-uniform: its limbs c0 < 2^31, c1 < 2^30 and the doubled high
 //     limb 2*c1 live in SGPRs, as do those of e = p - d.
 //   * re = a*c + b*e and im = a*d + b*c are each accumulated as TWO 64-bit sums of four v_mad_u64_u32:
@@ -16,7 +16,8 @@
 //         mid = a0*c1 + a1*c0 + b0*e1 + b1*e0              < 2^63           (weight 2^31)
 //     and  value = acc + mid * 2^31  (mod p), with mid = mh * 2^30 + ml  =>  mid * 2^31 = mh + ml * 2^31 (mod p),
 //     so   t = acc + ml * 2^31 + mh < 2^64 needs one more v_mad_u64_u32 and one 64-bit add, and
-//          fold(t) = (t mod 2^61) + (t >> 61) < 2^61 + 8 is lazy again.  No division, no conditional.
+//          fold(t) = (t mod 2^61) + (t >> 61) < 2^61 + 8 is lazy again (rot30 results reach 2^61 + 2^32: the bound of the lazy range).
+//          No division, no conditional.
 //   * add/sub fold the same way; only the last pass of a transform makes values canonical (one conditional
 //     subtract) so that the stripe in HBM is bit-identical to what exact arithmetic gives.
 #pragma once
@@ -108,7 +109,7 @@ GF61_D uint64_t fold(uint64_t t, const Opaque& k)
 
 // lazy + lazy -> lazy
 GF61_D uint64_t add(uint64_t x, uint64_t y, const Opaque& k) { return fold(x + y, k); }
-// lazy - lazy, NOT folded: < 2^63.  y < 2^61 + 16 <= 2p, so 2p - y does not wrap.  Feeds mul() directly.
+// lazy - lazy, NOT folded: < 2^63.  y < 2^61 + 2^33 < 2p, so 2p - y does not wrap.  Feeds mul() directly.
 GF61_D uint64_t sub_raw(uint64_t x, uint64_t y) { return x + (2 * P - y); }
 // lazy - lazy -> lazy
 GF61_D uint64_t sub(uint64_t x, uint64_t y, const Opaque& k) { return fold(sub_raw(x, y), k); }
@@ -158,7 +159,7 @@ GF61_D void split_raw(uint64_t x, uint32_t& x0, uint32_t& x1)
     x1 = __builtin_amdgcn_alignbit(hi, lo, 31) & 0x3FFFFFFFu;
     x0 = (lo & 0x7FFFFFFFu) + (hi >> 29);
 }
-// the same for a lazy x (< 2^61 + 16): x1 <= 2^30 needs no mask
+// the same for a lazy x (< 2^61 + 2^33): x1 <= 2^30 + 4 needs no mask (the products below keep their bounds with 2^30 + 4)
 GF61_D void split_lazy(uint64_t x, uint32_t& x0, uint32_t& x1)
 {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
@@ -175,7 +176,7 @@ GF61_D uint64_t combine(uint64_t acc, uint64_t mid, const Opaque& k)
     return fold(t, k);
 }
 
-// (a + b i)(c + d i) = (a c + b e) + (a d + b c) i,  e = -d; limbs a0, b0 < 2^31 + 4 and a1, b1 <= 2^30
+// (a + b i)(c + d i) = (a c + b e) + (a d + b c) i,  e = -d; limbs a0, b0 < 2^31 + 4 and a1, b1 <= 2^30 + 4
 GF61_D Elem mul_limbs(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const Twiddle& w, const Opaque& k)
 {
     const uint64_t re_acc = mad64(b1, w.e1d, mad64(a1, w.c1d, mad64(b0, w.e0, mad64(a0, w.c0, 0))));

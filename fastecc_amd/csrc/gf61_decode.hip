@@ -377,6 +377,7 @@ struct Decoder {
     // few losses: the direct path
     int direct = 0, direct_pad = 0;
     uint64_t* direct_coef = nullptr;     // [NC][pad] elements
+    uint64_t direct_coef_elems = 0;
     uint64_t* direct_inv = nullptr;      // [DIRECT_MAX] elements
     uint32_t* direct_pos = nullptr;      // [DIRECT_MAX]
     uint64_t* direct_partial = nullptr;  // [chunks + DIRECT_SEGS][pad][elems] elements
@@ -436,55 +437,79 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
 
     d->direct = 0;
     if (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX)) {
-        // few losses: a coefficient table, no locator tree and no transform contexts
-        const int e = (int)erased.size();
-        int pad = 1;
-        while (pad < e) pad <<= 1;
-        const gf61::Elem w = gf61::h_root(NC);
-        std::vector<gf61::Elem> we(e);
-        std::vector<uint64_t> inv(2 * e);
-        std::vector<uint32_t> epos(DIRECT_MAX, 0xFFFFFFFFu);
-        for (int j = 0; j < e; j++) we[j] = gf61::h_pow(w, erased[j]), epos[j] = erased[j];
-        for (int j = 0; j < e; j++) {
-            gf61::Elem l0{1, 0};
-            for (int i = 0; i < e; i++)
-                if (i != j) l0 = gf61::h_mul(l0, gf61::Elem{gf61::h_subp(we[j].re, we[i].re), gf61::h_subp(we[j].im, we[i].im)});
-            const gf61::Elem r = gf61::h_inv(l0);
-            inv[2 * j] = gf61::h_subp(0, r.re);  // -1 / l0(w^e_j)
-            inv[2 * j + 1] = gf61::h_subp(0, r.im);
-        }
-        hipStream_t s0 = nullptr;
-        uint64_t* wp = d->built ? d->wpow : d->direct_wpow;
-        if (!wp) {
-            D61_TRY(hipMalloc((void**)&d->direct_wpow, NC * 16));
-            wp = d->direct_wpow;
-            hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, wp, w.re, w.im, (uint32_t)NC);
+        // few losses: a coefficient table, no locator tree and no transform contexts.  Out of memory for its tables is not an
+        // error: the transform path below needs none of them.
+        const int rc_direct = [&]() -> int {
+            const int e = (int)erased.size();
+            int pad = 1;
+            while (pad < e) pad <<= 1;
+            const gf61::Elem w = gf61::h_root(NC);
+            std::vector<gf61::Elem> we(e);
+            std::vector<uint64_t> inv(2 * e);
+            std::vector<uint32_t> epos(DIRECT_MAX, 0xFFFFFFFFu);
+            for (int j = 0; j < e; j++) we[j] = gf61::h_pow(w, erased[j]), epos[j] = erased[j];
+            for (int j = 0; j < e; j++) {
+                gf61::Elem l0{1, 0};
+                for (int i = 0; i < e; i++)
+                    if (i != j) l0 = gf61::h_mul(l0, gf61::Elem{gf61::h_subp(we[j].re, we[i].re), gf61::h_subp(we[j].im, we[i].im)});
+                const gf61::Elem r = gf61::h_inv(l0);
+                inv[2 * j] = gf61::h_subp(0, r.re);  // -1 / l0(w^e_j)
+                inv[2 * j + 1] = gf61::h_subp(0, r.im);
+            }
+            hipStream_t s0 = nullptr;
+            uint64_t* wp = d->built ? d->wpow : d->direct_wpow;
+            if (!wp) {
+                // the table becomes visible to later calls only once it has been filled
+                uint64_t* fresh = nullptr;
+                D61_TRY(hipMalloc((void**)&fresh, NC * 16));
+                hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, fresh, w.re, w.im, (uint32_t)NC);
+                hipError_t e1 = hipGetLastError();
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(s0);
+                if (e1 != hipSuccess) {
+                    (void)hipFree(fresh);
+                    D61_TRY(e1);
+                }
+                d->direct_wpow = wp = fresh;
+            }
+            if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC));
+            // [NC][pad] weights: sized for this pattern's pad (1 GiB instead of 8 GiB at NC = 2^25 for one lost block), grown on demand
+            const uint64_t coef_elems = NC * (uint64_t)pad;
+            if (d->direct_coef_elems < coef_elems) {
+                if (d->direct_coef) (void)hipFree(d->direct_coef);
+                d->direct_coef = nullptr;
+                d->direct_coef_elems = 0;
+                D61_TRY(hipMalloc((void**)&d->direct_coef, coef_elems * 16));
+                d->direct_coef_elems = coef_elems;
+            }
+            if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, DIRECT_MAX * 16));
+            if (!d->direct_pos) D61_TRY(hipMalloc((void**)&d->direct_pos, DIRECT_MAX * 4));
+            const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+            const uint64_t need = (chunks + DIRECT_SEGS) * pad * elems;
+            if (d->direct_partial_elems < need) {
+                if (d->direct_partial) (void)hipFree(d->direct_partial);
+                d->direct_partial = nullptr;
+                d->direct_partial_elems = 0;
+                D61_TRY(hipMalloc((void**)&d->direct_partial, need * 16));
+                d->direct_partial_elems = need;
+            }
+            D61_TRY(hipMemcpyAsync(d->direct_state, state.data(), NC, hipMemcpyHostToDevice, s0));
+            D61_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), DIRECT_MAX * 4, hipMemcpyHostToDevice, s0));
+            D61_TRY(hipMemcpyAsync(d->direct_inv, inv.data(), e * 16, hipMemcpyHostToDevice, s0));
+            hipLaunchKernelGGL(k_direct_coef, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, d->direct_coef, wp, d->direct_state, d->direct_pos,
+                               d->direct_inv, (uint32_t)NC, e, pad);
             D61_TRY(hipGetLastError());
+            D61_TRY(hipStreamSynchronize(s0));
+            d->direct = e;
+            d->direct_pad = pad;
+            return FASTECC_OK;
+        }();
+        if (rc_direct == FASTECC_OK) {
+            d->ready = true;
+            return FASTECC_OK;
         }
-        if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC));
-        if (!d->direct_coef) D61_TRY(hipMalloc((void**)&d->direct_coef, NC * DIRECT_MAX * 16));
-        if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, DIRECT_MAX * 16));
-        if (!d->direct_pos) D61_TRY(hipMalloc((void**)&d->direct_pos, DIRECT_MAX * 4));
-        const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
-        const uint64_t need = (chunks + DIRECT_SEGS) * pad * elems;
-        if (d->direct_partial_elems < need) {
-            if (d->direct_partial) (void)hipFree(d->direct_partial);
-            d->direct_partial = nullptr;
-            d->direct_partial_elems = 0;
-            D61_TRY(hipMalloc((void**)&d->direct_partial, need * 16));
-            d->direct_partial_elems = need;
-        }
-        D61_TRY(hipMemcpyAsync(d->direct_state, state.data(), NC, hipMemcpyHostToDevice, s0));
-        D61_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), DIRECT_MAX * 4, hipMemcpyHostToDevice, s0));
-        D61_TRY(hipMemcpyAsync(d->direct_inv, inv.data(), e * 16, hipMemcpyHostToDevice, s0));
-        hipLaunchKernelGGL(k_direct_coef, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, d->direct_coef, wp, d->direct_state, d->direct_pos,
-                           d->direct_inv, (uint32_t)NC, e, pad);
-        D61_TRY(hipGetLastError());
-        D61_TRY(hipStreamSynchronize(s0));
-        d->direct = e;
-        d->direct_pad = pad;
-        d->ready = true;
-        return FASTECC_OK;
+        if (rc_direct != FASTECC_E_NOMEM) return rc_direct;
+        (void)hipGetLastError();
+        d->direct = 0;
     }
     // ---- built once; a failure half way leaves no decoder behind (the next call starts from scratch) ----
     auto build_once = [&]() -> int {

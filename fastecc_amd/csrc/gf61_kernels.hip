@@ -216,16 +216,44 @@ __device__ __forceinline__ void small_level(Elem (&x)[1 << LOGR], const gf61::Op
 }
 
 // x[j] *= (root of order 2^(sl+LEVELS))^(off * bitrev(j mod 2^LEVELS)) for the registers with j mod 2^LEVELS != 0
+// A twiddle in use is ~12 SGPRs of limbs.  Left alone, the scheduler fetches and splits all 2^LEVELS - 1 of them before the first
+// product (while the tile's rows are still arriving), which for 4 levels is > 150 SGPRs: 91-117 SGPR spills and, with them, VGPR spills
+// to scratch in the 7-level DIT / MID tiles of round 2.  So the raw words travel in groups of four, the next group requested before the
+// current one is split and used, and scheduling barriers keep the groups apart.
 template <int LOGR, int LEVELS>
 __device__ __forceinline__ void collected_twiddles(Elem (&x)[1 << LOGR], const uint64_t* tw, uint32_t off, int sl, const gf61::Opaque& k)
 {
     constexpr int R = 1 << LOGR, W = 1 << LEVELS;
     const_u64_ptr p = as_constant(tw) + 2 * (((size_t)1 << (sl + LEVELS)) + ((size_t)off << LEVELS));
+    if constexpr (W <= 8) {
 #pragma unroll
-    for (int jl = 1; jl < W; ++jl) {
-        const gf61::Twiddle w = gf61::make_twiddle(p[2 * jl], p[2 * jl + 1]);
+        for (int jl = 1; jl < W; ++jl) {
+            const gf61::Twiddle w = gf61::make_twiddle(p[2 * jl], p[2 * jl + 1]);
 #pragma unroll
-        for (int j0 = 0; j0 < R; j0 += W) x[j0 + jl] = gf61::mul(x[j0 + jl], w, k);
+            for (int j0 = 0; j0 < R; j0 += W) x[j0 + jl] = gf61::mul(x[j0 + jl], w, k);
+        }
+    } else {
+        constexpr int GS = 4, NG = W / GS;
+        uint64_t raw[2][GS][2];
+#pragma unroll
+        for (int i = 0; i < GS; ++i) raw[0][i][0] = p[2 * i], raw[0][i][1] = p[2 * i + 1];
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            if (grp + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < GS; ++i) raw[(grp + 1) & 1][i][0] = p[2 * ((grp + 1) * GS + i)], raw[(grp + 1) & 1][i][1] = p[2 * ((grp + 1) * GS + i) + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {
+                const int jl = grp * GS + i;
+                if (jl == 0) continue;
+                const gf61::Twiddle w = gf61::make_twiddle(raw[grp & 1][i][0], raw[grp & 1][i][1]);
+#pragma unroll
+                for (int j0 = 0; j0 < R; j0 += W) x[j0 + jl] = gf61::mul(x[j0 + jl], w, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -343,8 +371,10 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     const uint32_t tile = blockIdx.x;
     const uint32_t cc = tile % a.col_chunks;
     const uint32_t grp = tile / a.col_chunks;
-    const uint32_t col = cc * 64u + lane;
-    const bool live = col < a.elems;
+    // Lanes beyond a ragged block end work on the block's LAST element column as well: same loads, same arithmetic, and stores of the same
+    // value to the same address from the same wave — so the kernel has no divergent region at all.  (With an "if (live)" around the stores
+    // the compiler sinks the whole second half of the tile into that branch, where its scheduling barriers no longer apply.)
+    const uint32_t col = min(cc * 64u + lane, a.elems - 1u);
     const int s = MODE == MODE_MID ? 0 : a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
@@ -360,10 +390,9 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     auto load = [&](auto row_of) {
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            x[j] = live ? load_elem(a.in + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col) : Elem{0, 0};
+            x[j] = load_elem(a.in + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col);
     };
     auto store = [&](auto row_of) {
-        if (!live) return;
 #pragma unroll
         for (int j = 0; j < R; ++j)
             store_elem(a.out + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);

@@ -48,7 +48,6 @@ struct TileArgs {
     uint32_t tiles;       // filled by the launcher: tiles in this pass (persistent workgroups loop over them)
     uint32_t debug;       // ablation switches (profiles/r01/ablation_dif_tiles.md); always 0 in the product
     int persistent_cus;   // > 0: 128-KiB tiles run as persistent workgroups sized for that many CUs
-    bool prefetch;        // persistent DIF/DIT tiles request the next tile before computing the current one
     bool split2;          // 1024-block pair tiles exchange 16 columns at a time (64 KiB LDS, 2 workgroups per CU)
     int cache_policy;     // bit 0: non-temporal stripe loads, bit 1: non-temporal stripe stores
     const uint32_t* in_odd;      // wide DIF tiles, optional: as PassArgs::in_odd / row_factor (the decoder's first pass)

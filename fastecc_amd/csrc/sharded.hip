@@ -93,6 +93,8 @@ struct Sharded {
     int gather_mode = 1;  // 1 = hipMemcpy2DAsync (copy engines), 2 = copy kernel on the slab's GPU
     bool copy_engine_refused = false;  // mode 2 was forced by an error return of hipMemcpy2DAsync
     hipEvent_t fork = nullptr;
+    int fault_at = 0;    // tests only (option "inject_fault"): the fault_at-th slab step of the next call fails after its work has been enqueued
+    int fault_step = 0;
     std::string text;
 };
 
@@ -136,10 +138,34 @@ int copy_window(Sharded* s, void* dst, size_t dpitch, const void* src, size_t sp
     return FASTECC_OK;
 }
 
+// An entry point that fails half way has already forked work onto some slabs' streams.  Before the error is returned that work is waited
+// for (host side), so that neither the caller's buffers nor the slab buffers are still being read or written when the caller reacts, and
+// the next call does not race with orphaned kernels and copies.  Errors of the wait itself are ignored: the first error is reported.
+void settle_after_failure(Sharded* s)
+{
+    for (Shard& sh : s->shards) {
+        if (hipSetDevice(sh.device) != hipSuccess) continue;
+        for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down})
+            if (q) (void)hipStreamSynchronize(q);
+        sh.used = false;  // nothing of this shard is in flight any more
+    }
+    (void)hipGetLastError();
+}
+// tests only: the "inject_fault"-th slab step of a call reports a device error AFTER its copies / kernels have been enqueued
+bool injected_fault(Sharded* s)
+{
+    if (s->fault_at <= 0) return false;
+    if (++s->fault_step != s->fault_at) return false;
+    s->fault_at = 0;
+    s->fault_step = 0;
+    set_error_detail("injected fault (option inject_fault)", hipErrorUnknown);
+    return true;
+}
+
 // The whole data path.  Exactly one of (data_slabs, data_stripe) and at least one of (parity_slabs, parity_stripe).
 // stripe_on_host: the stripes are host memory (each GPU uses its own host link), else the root device's memory.
-int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stripe, void* const* parity_slabs, void* parity_stripe,
-        bool stripe_on_host, hipStream_t st)
+int run_body(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stripe, void* const* parity_slabs, void* parity_stripe,
+             bool stripe_on_host, hipStream_t st)
 {
     Sharded* s = sharded_of(shell);
     const int G = (int)s->shards.size();
@@ -185,6 +211,7 @@ int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stri
             const int rc = H > 1 ? fastecc_encode_columns(sh.ctx, din, pout, col / 4, wbytes / 4, sh.s_comp)
                                  : fastecc_encode(sh.ctx, din, pout, FASTECC_MEM_DEVICE, sh.s_comp);
             if (rc != FASTECC_OK) return rc;
+            if (injected_fault(s)) return FASTECC_E_DEVICE;
             SH_TRY(hipSetDevice(sh.device));  // the entry points restore the caller's device; keep ours explicit
             SH_TRY(hipEventRecord(sh.ev_comp[h], sh.s_comp));
             SH_TRY(hipStreamWaitEvent(sh.s_down, sh.ev_comp[h], 0));
@@ -203,12 +230,21 @@ int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stri
     return FASTECC_OK;
 }
 
+int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stripe, void* const* parity_slabs, void* parity_stripe, bool stripe_on_host,
+        hipStream_t st)
+{
+    DeviceSwitch restore;
+    const int rc = run_body(shell, data_slabs, data_stripe, parity_slabs, parity_stripe, stripe_on_host, st);
+    if (rc != FASTECC_OK) settle_after_failure(sharded_of(shell));
+    return rc;
+}
+
 // Decoding on a sharded context: erasures hit whole blocks, so every slab sees the same pattern and repairs its own columns
 // with its device context's decoder.  Full stripes (root memory or host): slab g of data and parity is pulled to GPU g,
 // repaired in place, and the data slab (with `repair`: the parity slab too) pushed back; only the columns move, no exchange
 // between slabs.  data_slabs / parity_slabs given: the slabs are repaired where they live.
-int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void* const* data_slabs, void* const* parity_slabs, bool stripe_on_host,
-               bool repair, hipStream_t st)
+int run_decode_body(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void* const* data_slabs, void* const* parity_slabs, bool stripe_on_host,
+                    bool repair, hipStream_t st)
 {
     Sharded* s = sharded_of(shell);
     const int G = (int)s->shards.size();
@@ -237,6 +273,7 @@ int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void*
         }
         const int rc = repair ? fastecc_repair(sh.ctx, d, p, FASTECC_MEM_DEVICE, q) : fastecc_decode(sh.ctx, d, p, FASTECC_MEM_DEVICE, q);
         if (rc != FASTECC_OK) return rc;
+        if (injected_fault(s)) return FASTECC_E_DEVICE;
         SH_TRY(hipSetDevice(sh.device));
         if (!data_slabs) {
             int rc2 = copy_window(s, (char*)data_stripe + (size_t)g * slab, full, d, slab, slab, s->K, !stripe_on_host, q);
@@ -250,6 +287,15 @@ int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void*
     for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
     if (s->copy_engine_refused) describe(shell);
     return FASTECC_OK;
+}
+
+int run_decode(fastecc_ctx* shell, void* data_stripe, void* parity_stripe, void* const* data_slabs, void* const* parity_slabs, bool stripe_on_host, bool repair,
+               hipStream_t st)
+{
+    DeviceSwitch restore;
+    const int rc = run_decode_body(shell, data_stripe, parity_stripe, data_slabs, parity_slabs, stripe_on_host, repair, st);
+    if (rc != FASTECC_OK) settle_after_failure(sharded_of(shell));
+    return rc;
 }
 
 }  // namespace
@@ -303,6 +349,7 @@ void destroy_sharded(Sharded* s)
 int sharded_encode_stripe(fastecc_ctx* shell, const void* data, void* parity, int mem_kind, hipStream_t st)
 {
     if (mem_kind != FASTECC_MEM_DEVICE && mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_HOST_PINNED) return FASTECC_E_INVAL;
+    if (parity == data && sharded_of(shell)->M > sharded_of(shell)->K) return FASTECC_E_INVAL;  // in place: the parity must fit the data stripe (as fastecc_encode on one device)
     std::lock_guard<std::mutex> lk(mutex_of(shell));
     const int rc = run(shell, nullptr, data, nullptr, parity, mem_kind != FASTECC_MEM_DEVICE, st);
     if (rc != FASTECC_OK || mem_kind != FASTECC_MEM_HOST) return rc;
@@ -327,6 +374,12 @@ int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value)
         if (value < 1 || value > MAX_SUB || (value & (value - 1))) return FASTECC_E_INVAL;
         s->sub_slabs = value;
         describe(shell);
+        return FASTECC_OK;
+    }
+    if (what == SH_SET_OPTION && !strcmp(name, "inject_fault")) {  // tests only: see injected_fault
+        if (value < 0) return FASTECC_E_INVAL;
+        s->fault_at = value;
+        s->fault_step = 0;
         return FASTECC_OK;
     }
     if (what == SH_SET_OPTION && !strcmp(name, "row_pitch_words")) return FASTECC_E_UNSUPPORTED;  // slabs are contiguous [k][block_bytes / G]

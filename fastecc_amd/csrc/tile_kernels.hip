@@ -134,7 +134,7 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
 // The host only selects a tile pass when a tile spans < 2^32 - 2^16 bytes (tile_fits, api.hip), so live lane
 // offset + block offset stay below num_records = 2^32-1 and "offset | dead_mask" = 2^32-1 is always out of range.
 // Workgroup barrier for the LDS exchanges.  __syncthreads() also fences global memory (s_waitcnt
-// vmcnt(0)), which would drain the next tile's prefetch and the previous tile's stores at every exchange;
+// vmcnt(0)), which would drain the previous tile's stores at every exchange;
 // the exchange only needs this wave's LDS traffic to have completed.
 __device__ __forceinline__ void lds_barrier()
 {
@@ -164,13 +164,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, u
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(num_records), 0x00020000);
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, int NWIN = 1>
+template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1>
 __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
     // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
-    static_assert(NWIN == 1 || (PAIR && MODE != MODE_MID && !PREFETCH), "windows: outer pair tiles only");
+    static_assert(NWIN == 1 || (PAIR && MODE != MODE_MID), "windows: outer pair tiles only");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
     static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
@@ -209,8 +209,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     auto view_of = [&](uint32_t tile) {
         View v;
         // `tile` is wave-uniform by construction; readfirstlane makes it provably so, which keeps every
-        // twiddle fetch below a SCALAR load.  (A vector load there would sit behind the prefetch in the
-        // in-order vmcnt queue and force it to drain.)
+        // twiddle fetch below a SCALAR load.
         tile = __builtin_amdgcn_readfirstlane(tile);
         uint32_t cc = tile % a.col_chunks;
         uint32_t grp = tile / a.col_chunks;
@@ -419,34 +418,20 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         else                          load_rows(r, v, lane_b, qb_u, 1);
     };
 
-    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With PREFETCH the next tile's
-    // blocks are requested before the current tile is computed, so HBM latency and the store drain of the
-    // previous tile hide behind the butterflies even with a single resident workgroup per CU.
+    // Persistent workgroup (128-KiB tiles only): tiles blockIdx.x, blockIdx.x + gridDim.x, ...  (A next-tile register prefetch
+    // existed in rounds 1-2; it measured neutral once the kernels turned out VALU-bound and its variants spilled to scratch.)
+    // Only those tiles loop: for the others PERSIST = false makes the body straight-line code, which keeps the compiler from
+    // hoisting every level's table address out of a "loop" that runs once (55 SGPR spills in the 1024-block MID tile, round 2).
+    constexpr bool PERSIST = C::LDS_BYTES > 80 * 1024;
     uint32_t tile = blockIdx.x;
     if (tile >= a.tiles) return;
     View v = view_of(tile);
     uint32_t x[R][1];
     load_tile(x, v);
-    if constexpr (PREFETCH) {
-        // Consume the first tile's loads before the loop.  Otherwise the compiler's wait-count pass merges
-        // "x still in flight" (this path) into the loop header and conservatively drains the NEXT tile's
-        // prefetch at the first use of x in every iteration.
-#pragma unroll
-        for (int j = 0; j < R; ++j) asm volatile("" : "+v"(x[j][0]));
-    }
 
     for (;;) {
         const uint32_t next = tile + gridDim.x;
         const bool has_next = next < a.tiles;  // uniform
-        View vn = v;
-        uint32_t y[PREFETCH ? R : 1][1];
-        if constexpr (PREFETCH) {
-            if (has_next) {
-                vn = view_of(next);
-                load_tile(y, vn);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
-        }
 
         const uint32_t off = (g << s) + v.lo;
         const bool compute = !(a.debug & 1u), stores = !(a.debug & 2u);  // uniform; always true outside experiments
@@ -528,16 +513,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
             }
         }
 
+        if constexpr (!PERSIST) break;
         if (!has_next) break;
         tile = next;
-        if constexpr (PREFETCH) {
-            v = vn;
-#pragma unroll
-            for (int j = 0; j < R; ++j) x[j][0] = y[j][0];
-        } else {
-            v = view_of(tile);
-            load_tile(x, v);
-        }
+        v = view_of(tile);
+        load_tile(x, v);
         lds_barrier();  // the LDS tile is rewritten by the next iteration
     }
 }
@@ -545,11 +525,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE, bool PREFETCH, int SPLIT = 1, int NWIN = 1>
+template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, PREFETCH, SPLIT, NWIN>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, SPLIT, NWIN>;
     // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
     static bool configured[64] = {};
     int dev = 0;
@@ -585,23 +565,23 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     if (a.wide) {
         // several address windows per tile (blocks spanning up to 2^33 / 2^34 / 2^35 bytes): outer passes of the shapes the plans use
         if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
-            if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2, 2>(a, st);
-            if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2, 2>(a, st);
+            if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2>(a, st);
+            if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2>(a, st);
         } else if constexpr (LOGR == 4) {
             if (mode == MODE_DIF) {
-                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 2>(a, st);
-                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 4>(a, st);
-                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 8>(a, st);
+                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 2>(a, st);
+                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 4>(a, st);
+                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 8>(a, st);
                 if constexpr (LOGT == 9) {
-                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 1, 16>(a, st);
+                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 16>(a, st);
                 }
             }
             if (mode == MODE_DIT) {
-                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 2>(a, st);
-                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 4>(a, st);
-                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 8>(a, st);
+                if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 2>(a, st);
+                if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 4>(a, st);
+                if (a.wide == 8) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 8>(a, st);
                 if constexpr (LOGT == 9) {
-                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 1, 16>(a, st);
+                    if (a.wide == 16) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 16>(a, st);
                 }
             }
         }
@@ -610,18 +590,17 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
         if (a.split2) {  // 1024-block tiles through a 64 KiB buffer: two workgroups per CU, never persistent
             switch (mode) {
-                case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, false, 2>(a, st);
-                case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, false, 2>(a, st);
-                default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, false, 2>(a, st);
+                case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2>(a, st);
+                case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
+                default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
             }
         }
     }
-    const bool pf = a.prefetch && a.persistent_cus > 0 && TileCfg<LOGT, LOGR, PAIR>::LDS_BYTES > 80 * 1024;
     switch (mode) {
-        case MODE_DIF: return pf ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, true>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, false>(a, st);
-        case MODE_DIT: return pf ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, true>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, false>(a, st);
+        case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF>(a, st);
+        case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT>(a, st);
         default:
-            if constexpr (LOGR == 5) return launch_one<LOGT, LOGR, PAIR, MODE_MID, false>(a, st);
+            if constexpr (LOGR == 5) return launch_one<LOGT, LOGR, PAIR, MODE_MID>(a, st);
             else return hipErrorInvalidValue;
     }
 }

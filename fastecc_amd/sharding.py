@@ -6,9 +6,10 @@ The encode has no exchange step: the S word columns of a stripe are independent 
   * independent stripes ("replicas") — rank r encodes stripes r, r+G, ...; nothing is communicated;
   * ONE stripe in column slabs (BASELINE.json configs[3]) — rank r owns words [r*S/G, (r+1)*S/G) of every block
     (a [k, S/G] slab resident in its HBM), encodes them with an encoder for block_bytes/G, and the parity slabs are
-    gathered over xGMI into full 4 KB parity blocks on one rank: `encode_slab_and_gather`.  The gather is pipelined in
-    column sub-slabs: while sub-slab h travels (RCCL send/recv on its own stream), sub-slab h+1 is being encoded
-    (fastecc_encode_columns), and the root re-interleaves what has arrived.
+    gathered over xGMI into full 4 KB parity blocks on one rank: `encode_sub_slabs_and_gather` (slab resident as contiguous
+    column sub-slabs: no pack, the root's own part never moves, one re-interleaving kernel per sub-slab, transfers and
+    re-interleave on a side stream under the next sub-slab's encode) or `encode_slab_and_gather` (slab resident as one
+    [k, w] array: fastecc_encode_columns per sub-slab, a pack per sub-slab, a copy per received piece).
 
 The single-process form of the same thing (one host thread driving all GPUs, peer copies instead of RCCL) is
 fastecc_create_sharded / fastecc_encode_sharded in the C ABI (csrc/sharded.hip).
@@ -140,6 +141,84 @@ def _unpack(item, parity_full, rank, dst, w, ws):
         return
     for g, piece in enumerate(recv):
         parity_full[:, g * w + h * ws: g * w + (h + 1) * ws].copy_(piece, non_blocking=True)
+
+
+def split_into_sub_slabs(slab, sub_slabs):
+    """[rows, w] column slab -> [H, rows, w/H] contiguous sub-slabs (the residency encode_sub_slabs_and_gather works on)."""
+    rows, w = slab.shape
+    return slab.view(rows, sub_slabs, w // sub_slabs).permute(1, 0, 2).contiguous()
+
+
+def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=None, dst=0, group=None, collective_on_host=False, workspace=None):
+    """The gather of BASELINE configs[3] without a pack and with ONE re-interleaving kernel per sub-slab on the root.
+
+    A rank's slab is resident as H contiguous SUB-SLABS (data_sub: [H, k, ws], words [rank*w + h*ws, ...) of every block, w = H*ws),
+    which is how a scatter would deliver them anyway.  Each sub-slab is an ordinary contiguous stripe of narrower blocks:
+
+        encode_fn(data_sub[h], out[rows, ws])     every rank, on the current stream; the root's `out` is its own slot of the receive
+                                                  buffer, so its contribution never travels and is never copied
+        gather(out -> recv[h][g])                 RCCL (point-to-point sends over xGMI: every peer uses its own link to the root),
+                                                  on a side stream, so sub-slab h travels while sub-slab h+1 is being encoded
+        parity_full[:, g*w + h*ws ...] <- recv    root: one strided kernel for all `world` pieces of the sub-slab, on the side
+                                                  stream as well (it overlaps the next encode and the next transfer)
+
+    Returns (this rank's parity sub-slabs [H, rows, ws], parity_full [rows, world*w] on the root or None).  workspace: dict keeping
+    the buffers and the side stream between calls.  collective_on_host: the CPU / gloo form of the same control flow (tests).
+    """
+    import torch.distributed as dist
+    ranked = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if ranked else 1
+    rank = dist.get_rank(group) if ranked else 0
+    H, k, ws = data_sub.shape
+    w = H * ws
+    dev = data_sub.device
+    ws_ = workspace if workspace is not None else {}
+    key = ("sub", parity_rows, ws, H, world, str(dev), collective_on_host)
+    if ws_.get("key") != key:
+        ws_.clear()
+        ws_["key"] = key
+    root = rank == dst
+
+    def buf(name, shape, device=dev):
+        t = ws_.get(name)
+        if t is None:
+            t = ws_[name] = torch.empty(shape, dtype=data_sub.dtype, device=device)
+        return t
+
+    # root: [H][world][rows][ws], its own results land in [:, rank]; other ranks: [H][rows][ws]
+    recv = buf("recv", (H, world, parity_rows, ws)) if root else None
+    mine = recv[:, rank] if root else buf("send", (H, parity_rows, ws))
+    if root and parity_full is None:
+        parity_full = buf("parity_full", (parity_rows, world * w))
+    full4 = parity_full.view(parity_rows, world, H, ws) if root else None
+    on_gpu = dev.type == "cuda" and not collective_on_host
+    if on_gpu:
+        side = ws_.get("side_stream")
+        if side is None:
+            side = ws_["side_stream"] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+    for h in range(H):
+        encode_fn(data_sub[h], mine[h])
+        if on_gpu:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if world > 1:
+                    dist.gather(mine[h], gather_list=[recv[h, g] for g in range(world)] if root else None, dst=dst, group=group, async_op=True).wait()
+                if root:
+                    full4[:, :, h, :].copy_(recv[h].permute(1, 0, 2), non_blocking=True)
+        else:
+            if world > 1:
+                piece = mine[h].cpu() if collective_on_host else mine[h]
+                got = [torch.empty_like(piece) for _ in range(world)] if root else None
+                dist.gather(piece, gather_list=got, dst=dst, group=group)
+                if root:
+                    for g in range(world):
+                        recv[h, g].copy_(got[g])
+            if root:
+                full4[:, :, h, :].copy_(recv[h].permute(1, 0, 2))
+    if on_gpu:
+        main.wait_stream(side)  # the call behaves as one operation on the caller's stream
+    return mine, (parity_full if root else None)
 
 
 def encode_column_sharded(stripe, encode_fn, group=None):

@@ -102,8 +102,9 @@ int fastecc_version(void);
  *                          copies: the first and last kernels bound their reads / writes to the existing blocks).
  *                          GF(0xFFF00001) only; encode, encode_blocks, check_range and decode (no ntt / scale_blocks /
  *                          pack / encode_batch).
- * `parity` buffers hold n - k blocks.  Codes with n - k <= 8 are encoded without the transform (one read of the data, option
- * "encode_direct_max"); the parity is the same.
+ * `parity` buffers hold n - k blocks.  Codes with n - k <= 160 (GF(0xFFF00001), option "encode_direct_max") are encoded without the
+ * transform — one read of the data, the parity blocks being a dense product of the data with a weight matrix, on the matrix cores (or, for
+ * rows they cannot take, up to 32 parity blocks on the VALU); the parity is the same.
  */
 int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, int device);
 /*
@@ -132,7 +133,8 @@ void fastecc_destroy(fastecc_ctx *ctx);
  * encode(n,k,block_bytes, data -> parity).  Replaces the timed lambda RS.cpp:39-67:
  *     MFA_NTT(data,N,SIZE,true); block_i *= root(2N)^i / N; MFA_NTT(data,N,SIZE,false);
  * data   : k blocks, block-major, k*block_bytes bytes (read only unless parity == data)
- * parity : k blocks, same layout; parity == data gives the reference's in-place behaviour.
+ * parity : n - k blocks (k for the reference's (2k,k) code), same layout; parity == data gives the reference's in-place behaviour
+ *          and needs n - k <= k.  Codes with few parity blocks are evaluated directly (option "encode_direct_max"), same bits.
  * mem_kind FASTECC_MEM_DEVICE: both pointers are device memory on the context's device; the work is
  *          enqueued on `stream` (a hipStream_t, NULL = default stream) and the call does not
  *          synchronise.  FASTECC_MEM_HOST: pointers are host memory; the call stages through HBM and
@@ -255,10 +257,11 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
  *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
- * Patterns with at most 16 lost blocks (option "decode_direct_max", 0..16, default 16) take a direct path: every lost block is a
- * fixed linear combination of surviving ones, so prepare builds weight tables (0.2-0.5 ms, no transform contexts) and decode is one
- * read of the data plus a few parity blocks — 0.3-0.4 ms for one lost block of a 2 GiB stripe against 7.7-9 ms on the transform
- * path (repair: a second read for the lost parity); every GF(0xFFF00001) code, and the (2k,k) codes of GF((2^61-1)^2); identical results.
+ * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
+ * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.3-3.5 ms, no transform contexts) and decode
+ * is one read of the data plus a few parity blocks — 0.4 ms for up to 16 lost blocks of a 2 GiB stripe, 0.7 ms for 64, 2.6 ms for 256 (matrix
+ * cores; option "direct_kernel") against 7.7-9 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
+ * code, and the (2k,k) codes of GF((2^61-1)^2); identical results.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
 int fastecc_decode(fastecc_ctx *ctx, void *data, const void *parity, int mem_kind, void *stream);
@@ -327,9 +330,14 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
  *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
  *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
- *   "encode_direct_max" = 0..8 (default 8): codes with at most this many parity blocks (n - k) are encoded straight from the Lagrange
- *                  basis — one read of the data (0.4-1.2 ms at k = 2^19 x 4 KB) instead of the transform pipeline (2.2 ms); same parity bits;
- *   "decode_direct_max" = 0..16 (default 16): lost blocks up to which the decoder's direct path is used (next decode_prepare);
+ *   "encode_direct_max" = 0..256 (default 160): codes with at most this many parity blocks (n - k) are encoded straight from the Lagrange
+ *                  basis — one read of the data (0.4 ms up to 16 parity blocks ... 1.4 ms for 128 at k = 2^19 x 4 KB) instead of the transform
+ *                  pipeline (2.4 ms); same parity bits.  Rows the matrix-core kernel cannot take (odd length, < 64 words, not 8-byte aligned)
+ *                  stop at 32;
+ *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
+ *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96;
+ *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),
+ *                  2 = MFMA (i8 digits; falls back to 1 where it cannot run).  Same bits either way;
  *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;
  *   "slabs" = H (1..32): encode H column slabs of the stripe on internal streams, each one pass
  * behind the previous, so that different kinds of passes overlap on the GPU, or with "slab_mode" = 1 one

@@ -55,6 +55,27 @@ def _worker(rank, world, port, N, S, sub_slabs, use_gpu, q):
         ok_slab = np.array_equal(pslab.cpu().numpy().view(np.uint32), want[:, rank * w:(rank + 1) * w])
         ok_cols = (full is None) if rank != 0 else np.array_equal(full.cpu().numpy().view(np.uint32), want)
 
+        # (1a) the slab resident as contiguous sub-slabs: no pack, the root's part encoded in place, one re-interleave per sub-slab
+        H = sharding.sub_slab_count(w, sub_slabs)
+        sub = sharding.split_into_sub_slabs(my_slab, H)
+        if use_gpu:
+            sub_enc = fastecc_amd.Encoder(2 * N, N, 4 * (w // H), device=0)
+            def sub_fn(d, o):
+                sub_enc.encode(d, o)
+        else:
+            def sub_fn(d, o):
+                o.copy_(torch.from_numpy(orc.encode_fast(np.ascontiguousarray(d.numpy().view(np.uint32))).view(np.int32)))
+        for _ in range(2):  # twice: the second call reuses the workspace
+            wsp = {}
+            mine, full2 = sharding.encode_sub_slabs_and_gather(sub, sub_fn, N, dst=0, collective_on_host=use_gpu, workspace=wsp)
+            if use_gpu:
+                torch.cuda.synchronize()
+            got_mine = mine.permute(1, 0, 2).reshape(N, w).cpu().numpy().view(np.uint32)
+            ok_slab = ok_slab and np.array_equal(got_mine, want[:, rank * w:(rank + 1) * w])
+            ok_cols = ok_cols and ((full2 is None) if rank != 0 else np.array_equal(full2.cpu().numpy().view(np.uint32), want))
+        if use_gpu:
+            sub_enc.close()
+
         # (1b) the all-gather form: every rank ends with the full parity
         def encode_fn(slab):
             out = torch.empty_like(slab)
@@ -132,6 +153,17 @@ def test_single_rank_pipeline_with_the_hip_encoder(hip_lib, oracle):
             want = oracle.encode_fast(host)
             assert np.array_equal(pslab.cpu().numpy().view(np.uint32), want)
             assert np.array_equal(full.cpu().numpy().view(np.uint32), want)
+    # the sub-slab-resident form: side stream for the re-interleave, device path (no host staging) at world = 1
+    for sub in (1, 2, 4):
+        with fastecc_amd.Encoder(2 * N, N, 4 * (w // sub), device=0) as enc:
+            wsp = {}
+            data_sub = sharding.split_into_sub_slabs(slab, sub)
+            for _ in range(2):
+                mine, full = sharding.encode_sub_slabs_and_gather(data_sub, lambda d, o: enc.encode(d, o, stream=torch.cuda.current_stream().cuda_stream), N, workspace=wsp)
+            torch.cuda.synchronize()
+            want = oracle.encode_fast(host)
+            assert np.array_equal(full.cpu().numpy().view(np.uint32), want)
+            assert np.array_equal(mine.permute(1, 0, 2).reshape(N, w).cpu().numpy().view(np.uint32), want)
 
 
 def test_slab_helpers_roundtrip():

@@ -316,3 +316,58 @@ def test_sharded_decode_and_repair(torch_cuda, fe, oracle, field):
             hd, hq = damaged.copy(), dpar.copy()
             senc.repair(hd, hq, mem=fe.MEM_HOST)
             assert np.array_equal(hd, x) and np.array_equal(hq, par)
+
+
+@pytest.mark.parametrize("fault_at", [1, 3, 6, 8])
+def test_a_failure_half_way_leaves_the_context_usable(torch_cuda, fe, oracle, fault_at):
+    """Fault injection (option "inject_fault" = i: the i-th slab step of the next call reports a device error after its copies and kernels
+    have been enqueued).  The call must return the error only after the forked work has been waited for — the caller may free or reuse its
+    buffers at once — and the following calls on the same context (encode, decode, repair) must be correct."""
+    torch = torch_cuda
+    N, S, G = 1 << 10, 512, 4
+    x = rand_stripe(fault_at, N, S)
+    want = oracle.encode_fast(x)
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        senc.set_option("sub_slabs", 2)
+        for rounds in range(2):
+            d = to_dev(torch, x)
+            out = torch.full_like(d, 0x11111111)
+            senc.set_option("inject_fault", fault_at)
+            with pytest.raises(fe.FastEccError) as ei:
+                senc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+            assert ei.value.code == fe.E_DEVICE
+            # the buffers may be dropped right away: nothing of the failed call is still in flight
+            del out
+            d.fill_(0)
+            torch.cuda.synchronize()
+            d = to_dev(torch, x)
+            out = torch.empty_like(d)
+            senc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(out).reshape(N, S), want), (fault_at, rounds)
+        # the decoder's entry point
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        dp[[3, 77, 500]] = 0
+        pp[[9]] = 0
+        damaged, dpar = x.copy(), want.copy()
+        damaged[dp == 0] = 0xFFFFFFFF
+        dpar[pp == 0] = 0xFFFFFFFF
+        senc.decode_prepare(dp, pp)
+        senc.set_option("inject_fault", min(fault_at, G))
+        with pytest.raises(fe.FastEccError):
+            senc.repair(to_dev(torch, damaged), to_dev(torch, dpar))
+        dd, dq = to_dev(torch, damaged), to_dev(torch, dpar)
+        senc.repair(dd, dq)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(dd).reshape(N, S), x) and np.array_equal(to_host(dq).reshape(N, S), want)
+
+
+def test_sharded_in_place_needs_room_for_the_parity(torch_cuda, fe):
+    """parity == data with n - k > k would write past the data stripe: rejected like on one device."""
+    torch = torch_cuda
+    k, S, G = 64, 64, 2
+    with fe.ShardedEncoder(4 * k, k, 4 * S, [0] * G) as senc:
+        d = torch.zeros(k * S, dtype=torch.int32, device="cuda:0")
+        with pytest.raises(fe.FastEccError) as ei:
+            senc.encode(d)  # in place
+        assert ei.value.code == fe.E_INVAL

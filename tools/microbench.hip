@@ -285,6 +285,83 @@ static void run_bfly(uint32_t* d_out, int blocks, std::vector<uint32_t>* first)
     fflush(stdout);
 }
 
+// Radix-4 against two radix-2 levels (the reference's NTT4 codelet, ntt.cpp:50-62, is 2 x NTT2, one multiply by
+// GF_Root(4), 2 x NTT2).  Four registers (x0..x3) at distance "1" and "2", DIF, outer twiddle w:
+//   radix 2 x 2:  u0 = x0+x2, u2 = (x0-x2) w,    u1 = x1+x3, u3 = (x1-x3) (w w4);   y0 = u0+u1, y1 = (u0-u1) w^2, y2 = u2+u3, y3 = (u2-u3) w^2
+//   radix 4    :  t0 = x0+x2, t2 = x0-x2, t1 = x1+x3, t3 = (x1-x3) w4;  y0 = t0+t1, y1 = (t0-t1) w^2, y2 = (t2+t3) w, y3 = (t2-t3) w^3
+// Same values (tested), and the same 4 products + 8 additions per 4 words: w4 is a general element of this field (ord(2) = 2^18 * 117:
+// no power of two is a small root of unity), so the radix-4 form saves nothing but one scalar twiddle.
+template <int RADIX>
+__global__ __launch_bounds__(256) void radix_kernel(uint32_t* out, int iters, uint32_t w0, uint32_t w4)
+{
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = (threadIdx.x * 2654435761u + i * 40503u) % gf::P;
+    uint32_t w = w0;
+    for (int it = 0; it < iters; it++) {
+        const uint32_t w2 = w * 5u + 3u, w3 = w * 7u + 1u, ww4 = w * 11u + 5u;  // stand-ins for w^2, w^3, w w4: scalar, changing, < 2^32
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            const uint32_t x0 = x[g], x1 = x[g + 1], x2 = x[g + 2], x3 = x[g + 3];
+            if constexpr (RADIX == 2) {
+                const uint32_t u0 = gf::add(x0, x2), u2 = gf::mul_mont(gf::sub(x0, x2), w);
+                const uint32_t u1 = gf::add(x1, x3), u3 = gf::mul_mont(gf::sub(x1, x3), ww4);
+                x[g] = gf::add(u0, u1);
+                x[g + 1] = gf::mul_mont(gf::sub(u0, u1), w2);
+                x[g + 2] = gf::add(u2, u3);
+                x[g + 3] = gf::mul_mont(gf::sub(u2, u3), w2);
+            } else {
+                const uint32_t t0 = gf::add(x0, x2), t2 = gf::sub(x0, x2);
+                const uint32_t t1 = gf::add(x1, x3), t3 = gf::mul_mont(gf::sub(x1, x3), w4);
+                x[g] = gf::add(t0, t1);
+                x[g + 1] = gf::mul_mont(gf::sub(t0, t1), w2);
+                x[g + 2] = gf::mul_mont(gf::add(t2, t3), w);
+                x[g + 3] = gf::mul_mont(gf::sub(t2, t3), w3);
+            }
+        }
+        w = w * 3u + 1u;
+        w = w >= gf::P ? w - gf::P : w;
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc ^= x[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// exactness of the identity above with true powers (one launch, real twiddles): both forms on the same inputs
+__global__ void radix_check_kernel(uint32_t* out, uint32_t w, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t ww4)
+{
+    const uint32_t x0 = (threadIdx.x * 2654435761u) % gf::P, x1 = (threadIdx.x * 40503u + 1u) % gf::P, x2 = (threadIdx.x * 97u + 5u) % gf::P, x3 = gf::P - 1u - threadIdx.x;
+    const uint32_t u0 = gf::add(x0, x2), u2 = gf::mul_mont(gf::sub(x0, x2), w), u1 = gf::add(x1, x3), u3 = gf::mul_mont(gf::sub(x1, x3), ww4);
+    const uint32_t a0 = gf::add(u0, u1), a1 = gf::mul_mont(gf::sub(u0, u1), w2), a2 = gf::add(u2, u3), a3 = gf::mul_mont(gf::sub(u2, u3), w2);
+    const uint32_t t0 = gf::add(x0, x2), t2 = gf::sub(x0, x2), t1 = gf::add(x1, x3), t3 = gf::mul_mont(gf::sub(x1, x3), w4);
+    const uint32_t b0 = gf::add(t0, t1), b1 = gf::mul_mont(gf::sub(t0, t1), w2), b2 = gf::mul_mont(gf::add(t2, t3), w), b3 = gf::mul_mont(gf::sub(t2, t3), w3);
+    out[threadIdx.x] = (a0 == b0 && a1 == b1 && a2 == b2 && a3 == b3) ? 1u : 0u;
+}
+
+template <int RADIX>
+static void run_radix(uint32_t* d_out, int blocks)
+{
+    const int iters = 2048;
+    hipStream_t st = nullptr;
+    const uint32_t w4m = gf::h_to_mont(gf::h_root(4));
+    float ms = time_ms(st, 5, [&] { hipLaunchKernelGGL(radix_kernel<RADIX>, dim3(blocks), dim3(256), 0, st, d_out, iters, 12345u, w4m); });
+    const double bf = (double)blocks * 256 * iters * 16;  // 4 butterfly-equivalents per 4 words and 2 levels
+    printf("{\"probe\":\"radix\",\"variant\":\"%s\",\"ms\":%.4f,\"Gbfly_per_s\":%.1f}\n", RADIX == 2 ? "two radix-2 levels" : "one radix-4 level (NTT4 form)", ms, bf / ms / 1e6);
+    fflush(stdout);
+}
+static void run_radix_check(uint32_t* d_out)
+{
+    const uint32_t w = gf::h_root(1u << 12), w4 = gf::h_root(4);
+    const uint32_t w2 = gf::h_mul(w, w), w3 = gf::h_mul(w2, w), ww4 = gf::h_mul(w, w4);
+    hipLaunchKernelGGL(radix_check_kernel, dim3(1), dim3(256), 0, nullptr, d_out, gf::h_to_mont(w), gf::h_to_mont(w2), gf::h_to_mont(w3), gf::h_to_mont(w4), gf::h_to_mont(ww4));
+    std::vector<uint32_t> h(256);
+    CK(hipMemcpy(h.data(), d_out, 1024, hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (uint32_t v : h) ok = ok && v == 1u;
+    printf("{\"probe\":\"radix\",\"check\":\"radix-4 (w4 = 0x%08X) == two radix-2 levels on 256 random quadruples\",\"agrees\":%s}\n", w4, ok ? "true" : "false");
+}
+
 // The same butterfly loops run for seconds instead of milliseconds: the board's power cap (1400 W) then sets the clock, and variants
 // that issue the same number of instructions may differ in what they sustain.  Power and clock are read with rocm-smi while a queue
 // of launches keeps the GPU busy.
@@ -401,12 +478,13 @@ static void run_copy(const uint32_t* in, uint32_t* out, uint32_t S, int n, int s
 
 int main(int argc, char** argv)
 {
-    bool do_valu = argc == 1, do_bfly = argc == 1, do_copy = argc == 1;
+    bool do_valu = argc == 1, do_bfly = argc == 1, do_copy = argc == 1, do_radix = argc == 1;
     double sustain = 0;
     for (int i = 1; i < argc; i++) {
         if (!strncmp(argv[i], "sustain=", 8)) sustain = atof(argv[i] + 8);
         if (!strcmp(argv[i], "valu")) do_valu = true;
         if (!strcmp(argv[i], "bfly")) do_bfly = true;
+        if (!strcmp(argv[i], "radix")) do_radix = true;
         if (!strcmp(argv[i], "copy")) do_copy = true;
     }
     hipDeviceProp_t prop;
@@ -438,6 +516,13 @@ int main(int argc, char** argv)
         run_bfly_sustained<8>(d_out, blocks, sustain);
         run_bfly_sustained<10>(d_out, blocks, sustain);
         run_bfly_sustained<11>(d_out, blocks, sustain);
+    }
+    if (do_radix) {
+        run_radix_check(d_out);
+        for (int r = 0; r < 2; r++) {
+            run_radix<2>(d_out, blocks);
+            run_radix<4>(d_out, blocks);
+        }
     }
     if (do_bfly) {
         std::vector<uint32_t> first;

@@ -22,7 +22,7 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "fastecc" not in k: continue
-        k = k.split("(")[0].replace("void fastecc::", "")
+        k = k.replace("void ", "").replace("fastecc::", "").replace("(anonymous namespace)::", "").split("(")[0]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)

@@ -18,7 +18,7 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "fastecc" not in k: continue
-        k = k.split("(")[0].replace("void ", "").replace("fastecc::", "").replace("(anonymous namespace)::", "")
+        k = k.replace("void ", "").replace("fastecc::", "").replace("(anonymous namespace)::", "").split("(")[0]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, cs in agg.items():
