@@ -1,159 +1,14 @@
-// api.hip — the C ABI of libfastecc_hip.so (include/fastecc.h): context, twiddle tables, pass plan.
+// api.hip — the C ABI of libfastecc_hip.so (include/fastecc.h): contexts, the entry points that move data and the drivers behind them.
 //
-// Host side of the encode path.  It replaces the body of EncodeReedSolomon (RS.cpp:22-68) and the
-// drivers MFA_NTT / Rec_NTT (ntt.cpp:349-447): where the reference picks an R x C (x L) split so a
-// sub-transform fits the CPU's L2 (ntt.cpp:385-394), the plan here picks how many radix-2 levels each
-// GPU pass keeps in registers.  No CPU compute fallback exists: every entry point that moves data runs
-// HIP kernels or fails.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/fastecc.h"
-#include "gf.hpp"
-#include "gf61.hpp"
-#include "gf61_path.hpp"
-#include "internal.hpp"
-#include "kernels.hpp"
+// Host side of the encode path.  It replaces the body of EncodeReedSolomon (RS.cpp:22-68) and the drivers MFA_NTT / Rec_NTT
+// (ntt.cpp:349-447).  The pass plans and twiddle tables live in plan.hip, options and profiling in options.hip, the shared context in
+// context.hpp.  No CPU compute fallback exists: every entry point that moves data runs HIP kernels or fails.
+#include "context.hpp"
 
 using namespace fastecc;
 
-namespace {
+namespace fastecc {
 
-struct Pass {
-    int mode;   // MODE_DIF / MODE_DIT / MODE_MID
-    int logr;   // levels covered by the pass (register pass: held in VGPRs; tile pass: log2 of the tile rows)
-    int s;      // log2 of the smallest stride
-    bool tile;  // LDS-tiled kernel (tile_kernels.hip) instead of a register pass (kernels.hip)
-    bool pair;  // tile only: 32-word rows with the cross-lane top level
-    int rlog;   // tile only: log2 of the words a lane keeps in registers (5, or 4 for the slim outer tiles)
-    int wide = 0;  // tile only: the tile's blocks span >= 2^32 bytes and are addressed through this many windows (2, 4, 8)
-    int fused = 0;  // > 0: this outer tile also does the odd-radix level of a mixed-radix context (mixed_kernels.hip: fused_radix_kernel,
-                    // launched by encode_mixed; run_passes skips it).  rlog = its register run, pair = false.
-};
-
-struct ProfileRec {
-    std::string name;
-    hipEvent_t start, stop;
-    uint64_t bytes;  // algorithmic bytes of the launch (stripe or slab read once + written once)
-};
-
-// What one call adds to the plain "read `in`, write `out`" form of run_passes.
-struct CallBounds {
-    // zero-extended codes: the first pass reads a stripe of in_rows blocks (the rest is zero), the last pass writes the
-    // first out_rows blocks of its result to final_out
-    uint32_t in_rows = 0, out_rows = 0;
-    uint32_t* final_out = nullptr;
-    // decoder (run_gathered): see PassArgs::in_odd / row_factor
-    const uint32_t* gather_odd = nullptr;
-    const uint32_t* gather_factor = nullptr;
-    bool dscale_whole = false;  // batch > 1: the per-block factor table covers the whole batch (mixed-radix transforms)
-};
-
-}  // namespace
-
-struct fastecc_ctx {
-    int device = 0;
-    int field = FASTECC_FIELD_GF_FFF00001;
-    // Calls on one context are serialised on the host (every entry point that enqueues work holds `mu`), and nothing
-    // about a call is stored here: what varies per call travels in a CallBounds on the caller's stack.  Work that
-    // uses the context's internal device buffers (scratch, parbuf, dbuf, ...) on a stream other than the previous one
-    // first waits for the previous use (buf_event), so one context may be driven from several streams.
-    std::mutex mu;
-    hipEvent_t buf_event = nullptr;
-    hipStream_t buf_stream = nullptr;
-    bool buf_used = false;
-    DecodeState* decoder = nullptr;  // fastecc_decode_prepare: erasure pattern tables (decode.hip)
-    Sharded* sharded = nullptr;      // fastecc_create_sharded: the per-device contexts of the column slabs (sharded.hip); a
-                                     // context that has it is only a shell around them
-    p61::Decoder* decoder61 = nullptr;  // the same for FASTECC_FIELD_GF_P61_SQUARED (gf61_decode.hip)
-    p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
-    uint64_t N = 0;   // k
-    int n = 0;        // log2 k
-    uint64_t S = 0;   // words per block
-    uint64_t ld = 0;  // words between consecutive blocks in DEVICE stripes (row pitch, >= S; S unless "row_pitch_words" is set)
-    size_t stripe_bytes = 0;
-    // Fewer parity than data blocks: n - k = M = k >> fold.  Parity block j of that code is parity block j << fold of
-    // the (2k, k) code (same polynomial, a sub-coset of the evaluation points), so the DIF half is unchanged, the
-    // MID pass keeps every 2^fold-th output and the DIT passes above it run as a size-M transform on the compact buffer.
-    int fold = 0;
-    // Any (n,k) by zero extension (RS.md:23-33 steps 1-7): K data blocks are the first K of N = 2^ceil(log2 K) (the rest
-    // are zero blocks that never exist in memory), and the Mu requested parity blocks are the first Mu of the M = N >> fold
-    // computed ones.  K == N and Mu == M in the power-of-two configurations.
-    uint64_t K = 0, Mu = 0;
-    // More parity than data blocks: n = 2^e k, e = 2 or 3.  The n - k parity blocks are the values of the same
-    // polynomial on the 2^e - 1 cosets g_t * <w_k> of the data points inside the n-th roots of unity, ordered so that
-    // codes nest: coset 0 is the reference's w_2k (the (2k,k) parity), then w_4k, w_4k^3, then w_8k, w_8k^3, w_8k^5, w_8k^7.
-    int cosets = 1;
-    // Transform order q * N with an odd q (3, 5, 7, 9): the odd-radix level is the outermost one (mixed_kernels.hip) and
-    // N = 2^n is what everything else in this structure describes — q stripes of N blocks back to back.  K <= q*N data
-    // blocks (zero-extended), the first Mu <= q*N parity blocks are handed out.  q = 1: an ordinary context.
-    int q = 1;
-    uint32_t* q_tw_dif = nullptr;   // N x (q-1): w_(qN)^-(i2*j)
-    uint32_t* q_tw_dit = nullptr;   // N x (q-1): w_(qN)^+(i2*j)
-    uint32_t* q_dft_inv = nullptr;  // q x q: w_q^-(i*j)
-    uint32_t* q_dft_fwd = nullptr;  // q x q: w_q^+(i*j)
-    uint32_t* mixbuf = nullptr;     // q*N-block work stripe for callers whose parity buffer is shorter (lazy)
-    uint64_t M = 0;             // parity blocks
-    size_t parity_bytes = 0;    // M * block_bytes
-    uint32_t* scratch = nullptr;      // fold > 0: k-block work stripe for the DIF half (lazy)
-    uint32_t* tw_fold_dit = nullptr;  // fold > 0: forward roots of order M, level-packed for the DIT passes above MID
-
-    // device tables (Montgomery form, see gf.hpp)
-    // level-packed twiddle tables (ntt_device.hpp), N words each, rebuilt whenever the plan changes:
-    uint32_t* tw_enc_dif = nullptr;  // inverse roots, ordered for the encode plan's DIF/MID passes
-    uint32_t* tw_enc_dit = nullptr;  // forward roots, same ordering (the DIT passes mirror the DIF ones)
-    uint32_t* tw_ntt_fwd = nullptr;  // forward roots, ordered for the stand-alone transform's passes
-    uint32_t* tw_ntt_inv = nullptr;  // inverse roots, same ordering
-    uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
-    uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
-    uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
-    uint32_t* parbuf = nullptr;  // Mu < M: the M computed parity blocks, of which the first Mu are handed out (lazy)
-    uint32_t* hostpar = nullptr; // device parity for FASTECC_MEM_HOST encodes with more parity than data blocks (lazy)
-    uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
-    void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
-    size_t pinned_bytes = 0;
-
-    int rmax = 5;            // levels per register pass
-    int vec = 1;             // words per lane in register passes
-    int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
-    bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form
-    bool split2 = true;      // 1024-block tiles exchange through a 64 KiB LDS buffer in two column rounds
-    int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
-    int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
-    int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
-    DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
-    int encode_direct_max = 160;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 32
-    int decode_direct_max = 256;  // up to this many lost blocks are recomputed directly (direct.hip), 0 = always the transform; 96 without the MFMA kernel
-    int direct_kernel = 0;        // 0 choose, 1 VALU, 2 MFMA
-    int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")
-    int slabs = 1;           // > 1: encode in this many column slabs on internal streams, staggered by one pass,
-                             // so the VALU-bound MID of one slab runs beside the HBM-bound outer passes of others
-    static constexpr int MAX_SLABS = 32;
-    hipStream_t slab_stream[MAX_SLABS] = {};
-    hipEvent_t slab_fork = nullptr, slab_first_done[MAX_SLABS] = {}, slab_done[MAX_SLABS] = {};
-    bool slab_ready = false;
-    int fuse_radix = 1;      // mixed-radix contexts: fuse the odd-radix level into the outermost tile where a shape exists (option "fuse_radix")
-    bool slim_outer = true;  // outer 8/9-level tiles keep 16 words per lane instead of 32 (twice the waves per CU)
-    bool persistent = true;  // tile kernels as persistent workgroups (one grid of resident workgroups)
-    int cus = 256;           // compute units of the device (sizes the persistent grids)
-    std::vector<Pass> encode_plan, ntt_plan;
-    std::string plan_text;
-
-    bool profiling = false;
-    std::vector<ProfileRec> prof;
-    size_t prof_used = 0;
-};
-
-namespace {
 
 thread_local char g_detail[256] = "";
 
@@ -164,11 +19,6 @@ int hip_fail(hipError_t e, const char* what)
     return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
 }
 
-#define HIP_TRY(expr)                                   \
-    do {                                                \
-        hipError_t e_ = (expr);                         \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
-    } while (0)
 
 int ilog2_exact(uint64_t v)
 {
@@ -184,120 +34,9 @@ uint32_t bitrev_host(uint32_t v, int bits)
     return r;
 }
 
-// Split `bits` levels into ceil(bits/rmax) passes of near-equal size, largest first.
-std::vector<int> split_levels(int bits, int rmax)
-{
-    std::vector<int> r;
-    if (bits <= 0) return r;
-    const int q = (bits + rmax - 1) / rmax;
-    for (int i = 0; i < q; i++) r.push_back(bits / q + (i < bits % q ? 1 : 0));
-    return r;
-}
+}  // namespace fastecc
 
-// How a run of `bits` consecutive levels is executed: an LDS tile when one exists for that size,
-// register passes otherwise.
-// A tile pass addresses its tile with 32-bit offsets from a per-tile buffer descriptor (tile_kernels.hip).
-bool tile_fits(const fastecc_ctx* c, int logt, int s)
-{
-    // block offsets (SGPR) and lane offsets (VGPR) are 32-bit and their sum must stay below num_records = 2^32-1
-    return (((uint64_t)c->ld * 4) << (logt + s)) <= 0xFFFF0000ull;
-}
-
-void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
-{
-    // with fold > 0 the DIT passes above MID run on the compact parity stripe: their strides are 2^fold smaller
-    const int s_run = mode == MODE_DIT ? s - c->fold : s;
-    const bool fits = tile_fits(c, bits, s_run);
-    // larger spans: 2, 4 or 8 address windows per tile (tile_kernels.hip NWIN), only for the outer pair shapes that have them
-    int windows = 0;
-    for (int lw = 1; lw <= 4 && !fits && windows == 0; lw++)
-        if (bits - lw >= 1 && tile_fits(c, bits - lw, s_run)) windows = 1 << lw;
-    if (c->tile_mid > 0 && windows && c->slim_outer && tile_supported(bits, true, 4) && tile_max_windows(bits, true, 4) >= windows)
-        plan.push_back({mode, bits, s, true, true, 4, windows});
-    else if (c->tile_mid > 0 && windows && tile_supported(bits, true) && tile_max_windows(bits, true) >= windows)
-        plan.push_back({mode, bits, s, true, true, 5, windows});
-    else if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
-    else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
-    else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
-    else if (mode == MODE_DIT) {
-        int ss = s;
-        const std::vector<int> parts = split_levels(bits, c->rmax);
-        for (auto it = parts.rbegin(); it != parts.rend(); ++it) {
-            plan.push_back({mode, *it, ss, false, false, 0});
-            ss += *it;
-        }
-    } else {
-        int ss = s + bits;
-        for (int r : split_levels(bits, c->rmax)) {
-            ss -= r;
-            plan.push_back({mode, r, ss, false, false, 0});
-        }
-    }
-}
-
-void build_plans(fastecc_ctx* c)
-{
-    const int n = c->n;
-    c->encode_plan.clear();
-    c->ntt_plan.clear();
-    // encode: DIF over the high levels, MID over the low levels, DIT back up (kernels.hip header)
-    int mid = std::min(n, c->rmax);
-    bool mid_tile = false, mid_pair = false;
-    if (c->tile_mid > 0) {
-        const int want = std::min(n, c->tile_mid);
-        if (!tile_fits(c, want, 0)) {
-            // blocks too large for 32-bit tile offsets: register passes handle the low levels
-        } else if (tile_supported(want, !c->tile_mid_wide) && tile_max_fold(want, !c->tile_mid_wide) >= c->fold) {
-            mid = want, mid_tile = true, mid_pair = !c->tile_mid_wide;
-        } else if (tile_supported(want, c->tile_mid_wide) && tile_max_fold(want, c->tile_mid_wide) >= c->fold) {
-            mid = want, mid_tile = true, mid_pair = c->tile_mid_wide;
-        }
-    }
-    if (!mid_tile && mid < c->fold) mid = std::min(n, c->fold);  // a register MID pass drops blocks within its own 2^mid
-    const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
-    const std::vector<int> outer = split_levels(n - mid, max_chunk);
-    // mixed radix: one outer chunk and a fused shape for it -> the odd-radix level rides on that pass (3 trips instead of 5)
-    const int fused_run = (c->q > 1 && c->fuse_radix && outer.size() == 1) ? fused_rlog(c->q, outer[0]) : 0;
-    int s = n;
-    for (int r : outer) {
-        s -= r;
-        if (fused_run) c->encode_plan.push_back({MODE_DIF, r, s, true, false, fused_run, 0, c->q});
-        else push_chunk(c->encode_plan, MODE_DIF, r, s, c);
-    }
-    c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair, 5});
-    s = mid;
-    for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
-        if (fused_run) c->encode_plan.push_back({MODE_DIT, *it, s, true, false, fused_run, 0, c->q});
-        else push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
-        s += *it;
-    }
-    // stand-alone transform: DIF over all levels, then the block bit-reversal
-    s = n;
-    for (int r : split_levels(n, max_chunk)) {
-        s -= r;
-        push_chunk(c->ntt_plan, MODE_DIF, r, s, c);
-    }
-    char buf[64];
-    c->plan_text.clear();
-    for (const Pass& p : c->encode_plan) {
-        if (p.fused) {  // R<q>+: the odd-radix level and these levels in one pass
-            snprintf(buf, sizeof buf, "%sR%d+%s%d@%d", c->plan_text.empty() ? "" : ",", p.fused, p.mode == MODE_DIF ? "dif" : "dit", p.logr, p.s);
-            c->plan_text += buf;
-            continue;
-        }
-        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : p.wide == 8 ? "SW8x32:" : "SW16x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
-                 p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
-        c->plan_text += buf;
-    }
-    if (c->q > 1 && !fused_run) {  // the odd-radix level around the power-of-two pipeline (mixed_kernels.hip)
-        snprintf(buf, sizeof buf, "R%d:dif1@%d,", c->q, c->n);
-        c->plan_text = std::string(buf) + c->plan_text;
-        snprintf(buf, sizeof buf, ",R%d:dit1@%d", c->q, c->n);
-        c->plan_text += buf;
-    }
-    snprintf(buf, sizeof buf, " v%d", c->vec);
-    c->plan_text += buf;
-}
+namespace {
 
 // widest lane vector that the block size and the pointers allow
 int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
@@ -306,14 +45,6 @@ int pick_vec(const fastecc_ctx* c, const void* a, const void* b)
     const uintptr_t bits = (uintptr_t)a | (uintptr_t)b;
     while (v > 1 && ((c->S % v) != 0 || (c->ld % v) != 0 || (bits % (4u * v)) != 0)) v >>= 1;
     return v;
-}
-
-const char* pass_name(const Pass& p, int vec, char* buf, size_t cap)
-{
-    const char* m = p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid";
-    if (p.tile) snprintf(buf, cap, "tile_%s%d_w%d%s", m, p.logr, p.pair ? 32 : 64, p.rlog == 4 ? "_r16" : "");
-    else snprintf(buf, cap, "%s%dv%d", m, p.logr, vec);
-    return buf;
 }
 
 struct ProfScope {
@@ -739,79 +470,6 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
     return FASTECC_OK;
 }
 
-// For every level l: the stride 2^sl of the register run that executes it (see ntt_device.hpp).
-// `up` selects the side of an encode plan: false = the way down (DIF passes and MID), true = the way up (MID and DIT
-// passes).  The two sides mirror each other level for level unless fold > 0 made a chunk tile-eligible on one side only.
-std::vector<int> level_strides(const std::vector<Pass>& plan, int n, bool up = false)
-{
-    std::vector<int> sl(n, 0);
-    for (const Pass& p : plan) {
-        if (p.mode == (up ? MODE_DIF : MODE_DIT)) continue;
-        if (!p.tile) {
-            for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
-        } else if (p.fused) {
-            // fused_radix_kernel: runs of p.rlog levels counted from the top of the pass, the rest in the last one
-            const int runs = (p.logr + p.rlog - 1) / p.rlog;
-            for (int l = p.s; l < p.s + p.logr; l++) {
-                const int run = (p.s + p.logr - 1 - l) / p.rlog;
-                sl[l] = run == runs - 1 ? p.s : p.s + p.logr - (run + 1) * p.rlog;
-            }
-        } else {
-            const int l2 = p.logr - p.rlog - (p.pair ? 1 : 0);  // TileCfg::L2
-            for (int l = p.s; l < p.s + l2; l++) sl[l] = p.s;
-            for (int l = p.s + l2; l < p.s + p.logr; l++) sl[l] = p.s + l2;
-        }
-    }
-    return sl;
-}
-
-// Level-packed table: entry 2^l + ((i mod 2^sl) << (l - sl)) + (i >> sl) = (root of order 2^(l+1))^i, i < 2^l,
-// in Montgomery form.  Replaces the roots[] array of ntt.cpp:397-402 and the running root_i *= root of
-// ntt.cpp:270-281: every twiddle of every level is tabulated once per context.
-std::vector<uint32_t> build_level_table(int n, uint32_t root_of_order_N, const std::vector<int>& sl)
-{
-    std::vector<uint32_t> tab(std::max<size_t>((size_t)1 << n, 2), 0);
-    for (int l = 0; l < n; l++) {
-        const uint32_t h = 1u << l;
-        const uint32_t root = gf::h_pow(root_of_order_N, (uint64_t)1 << (n - 1 - l));
-        const int t = l - sl[l];
-        const uint32_t lowmask = (1u << sl[l]) - 1u;
-        uint32_t w = 1;
-        for (uint32_t i = 0; i < h; i++) {
-            tab[h + (((i & lowmask) << t) | (i >> sl[l]))] = gf::h_to_mont(w);
-            w = gf::h_mul(w, root);
-        }
-    }
-    return tab;
-}
-
-int upload_table(uint32_t** dst, const std::vector<uint32_t>& src)
-{
-    if (!*dst) HIP_TRY(hipMalloc((void**)dst, src.size() * 4));
-    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
-    return FASTECC_OK;
-}
-
-// (Re)build the four twiddle tables for the current plans.  The device must be idle w.r.t. this context.
-int upload_twiddles(fastecc_ctx* c)
-{
-    const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
-    const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
-    const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
-    int rc = upload_table(&c->tw_enc_dif, build_level_table(c->n, wNi, enc));  // interpolate: inverse roots (RS.cpp:41)
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc_up));  // evaluate (RS.cpp:63)
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
-    if (rc == FASTECC_OK && c->fold > 0) {
-        // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
-        const int nf = c->n - c->fold;
-        std::vector<int> sl(std::max(nf, 0), 0);
-        for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
-        rc = upload_table(&c->tw_fold_dit, build_level_table(nf, gf::h_root((uint32_t)c->M), sl));
-    }
-    return rc;
-}
-
 int ensure_dbuf(fastecc_ctx* c)
 {
     if (c->dbuf) return FASTECC_OK;
@@ -844,20 +502,6 @@ template <class F> int with_internal_buffers(fastecc_ctx* c, hipStream_t st, F b
     return rc != FASTECC_OK ? rc : rc2;
 }
 using CallLock = std::lock_guard<std::mutex>;
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 }  // namespace
 
@@ -1126,7 +770,10 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
     const uint32_t invN = gf::h_inv((uint32_t)N);
     if (custom_factor) c->encode_direct_max = 0;  // a transform context is not the encoder's polynomial evaluation: always the pipeline
     for (int t = 0; t < cosets && custom_factor; t++) {
-        for (uint64_t i = 0; i < N; i++) dsc[bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(custom_factor[i] % gf::P);
+        for (uint64_t i = 0; i < N; i++) {
+            const uint32_t f = custom_factor[i] >= gf::P ? custom_factor[i] - gf::P : custom_factor[i];
+            dsc[bitrev_host((uint32_t)i, lg)] = gf::h_mont_mul(f, gf::MONT_R2);
+        }
     }
     for (int t = 0; t < cosets && !custom_factor; t++) {
         // coset t: generator w_(2^j k)^c with j = floor(log2(t + 1)) + 1 and c the (t + 2 - 2^(j-1))-th odd number
@@ -1134,10 +781,11 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
         while ((1 << j) - 1 <= t) j++;
         const uint32_t cth_odd = 2u * (uint32_t)(t + 1 - (1 << (j - 1))) + 1u;
         const uint32_t gen = gf::h_pow(gf::h_root((uint32_t)(N << j)), cth_odd);
-        uint32_t d = invN;
+        const uint32_t gen_m = gf::h_to_mont(gen);
+        uint32_t d = gf::h_to_mont(invN);  // Montgomery form throughout
         for (uint64_t i = 0; i < N; i++) {
-            dsc[t * N + bitrev_host((uint32_t)i, lg)] = gf::h_to_mont(d);  // by position: position p holds coefficient bitrev(p)
-            d = gf::h_mul(d, gen);
+            dsc[t * N + bitrev_host((uint32_t)i, lg)] = d;  // by position: position p holds coefficient bitrev(p)
+            d = gf::h_mont_mul(d, gen_m);
         }
     }
     int rc = upload_twiddles(c);
@@ -1686,254 +1334,6 @@ int fastecc_unpack_blocks(fastecc_ctx* c, const void* packed, void* raw, int mem
     if (bad_blocks) *bad_blocks = found;
     return FASTECC_OK;
     });
-}
-
-int fastecc_profile_enable(fastecc_ctx* c, int on)
-{
-    if (!c) return FASTECC_E_INVAL;
-    if (c->sharded) return sharded_forward(c, SH_PROFILE_ENABLE, nullptr, on);
-    CallLock lk(c->mu);
-    c->profiling = on != 0;
-    return FASTECC_OK;
-}
-
-int fastecc_profile_reset(fastecc_ctx* c)
-{
-    if (!c) return FASTECC_E_INVAL;
-    if (c->sharded) return sharded_forward(c, SH_PROFILE_RESET, nullptr, 0);
-    DeviceGuard dg(c->device);
-    CallLock lk(c->mu);
-    (void)hipDeviceSynchronize();
-    c->prof_used = 0;
-    return FASTECC_OK;
-}
-
-int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, uint64_t* bytes, int cap);
-
-int fastecc_profile_read(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, int cap)
-{
-    return fastecc_profile_read_bytes(c, names, ms, launches, nullptr, cap);
-}
-
-int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
-{
-    if (!c || !name) return FASTECC_E_INVAL;
-    if (c->sharded) return sharded_forward(c, SH_SET_OPTION, name, value);
-    if (c->p61 && strcmp(name, "decode_direct_max") != 0) return FASTECC_E_UNSUPPORTED;  // the other options tune the GF(0xFFF00001) tile kernels
-    CallLock lk(c->mu);
-    if (!strcmp(name, "row_pitch_words")) {
-        // DEVICE stripes passed to fastecc_encode are then [k][pitch] words with the first block_bytes/4 of each
-        // row valid: a host that owns its HBM layout can pad e.g. 4100-byte blocks to 4224 bytes so that every
-        // 128-byte row segment is cache-line aligned.  0 restores the contiguous layout.
-        const uint64_t pitch = value == 0 ? c->S : (uint64_t)value;
-        if (value < 0 || pitch < c->S) return FASTECC_E_INVAL;
-        if (pitch != c->ld) {
-            // everything sized or laid out for the old pitch goes: the work stripes, and the decoder's pattern state
-            // (its transform context and tables assume the geometry they were built with)
-            DeviceGuard dgs(c->device);
-            (void)hipDeviceSynchronize();
-            if (c->scratch) (void)hipFree(c->scratch);
-            if (c->parbuf) (void)hipFree(c->parbuf);
-            if (c->mixbuf) (void)hipFree(c->mixbuf);
-            c->scratch = c->parbuf = c->mixbuf = nullptr;
-            destroy_decode_state(c->decoder);
-            c->decoder = nullptr;
-        }
-        c->ld = pitch;
-        build_plans(c);  // tile eligibility depends on the pitch
-        DeviceGuard dg(c->device);
-        if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
-        HIP_TRY(hipDeviceSynchronize());
-        return upload_twiddles(c);
-    }
-    if (!strcmp(name, "cache_policy")) {
-        if (value < 0 || value > 15) return FASTECC_E_INVAL;
-        c->cache_policy = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "xcd_swizzle")) {
-        if (value < 0 || value > 2) return FASTECC_E_INVAL;
-        c->xcd_swizzle = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "host_slabs")) {
-        if (value < 1 || value > fastecc_ctx::MAX_SLABS || (value & (value - 1))) return FASTECC_E_INVAL;
-        c->host_slabs = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "encode_direct_max")) {  // codes with at most this many parity blocks are encoded without the transform (0 = never)
-        if (value < 0 || value > direct_encode_max()) return FASTECC_E_INVAL;
-        c->encode_direct_max = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "decode_direct_max")) {  // takes effect at the next fastecc_decode_prepare
-        if (value < 0 || value > (c->p61 ? 16 : direct_cap())) return FASTECC_E_INVAL;
-        c->decode_direct_max = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "direct_kernel")) {  // 0 = choose, 1 = VALU, 2 = MFMA where the stripes allow it; decoder: from the next decode_prepare
-        if (value < 0 || value > 2) return FASTECC_E_INVAL;
-        c->direct_kernel = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "fuse_radix")) {  // mixed-radix contexts: 1 = odd-radix level fused into the outer tiles (default), 0 = its own passes
-        if (value < 0 || value > 1) return FASTECC_E_INVAL;
-        if (c->fuse_radix == value) return FASTECC_OK;
-        DeviceGuard dg(c->device);  // the tables of THIS context's device are rebuilt: wait for its work, not the caller's current device's
-        if (!dg.ok) return FASTECC_E_DEVICE;
-        c->fuse_radix = value;
-        HIP_TRY(hipDeviceSynchronize());
-        build_plans(c);
-        return upload_twiddles(c);
-    }
-    if (!strcmp(name, "slab_mode")) {  // 0: slabs staggered on internal streams, 1: one after the other on the caller's stream
-        if (value < 0 || value > 1) return FASTECC_E_INVAL;
-        c->slab_mode = value;
-        return FASTECC_OK;
-    }
-    if (!strcmp(name, "slabs")) {
-        if (value < 1 || value > fastecc_ctx::MAX_SLABS) return FASTECC_E_INVAL;
-        c->slabs = value;
-        return FASTECC_OK;
-    }
-    return FASTECC_E_INVAL;
-}
-
-int fastecc_profile_read_bytes(fastecc_ctx* c, const char** names, double* ms, uint64_t* launches, uint64_t* bytes, int cap)
-{
-    if (!c || !names || !ms || !launches || cap <= 0) return FASTECC_E_INVAL;
-    if (c->sharded) return fastecc_profile_read_bytes(sharded_child(c, 0), names, ms, launches, bytes, cap);
-    DeviceGuard dg(c->device);
-    CallLock lk(c->mu);
-    HIP_TRY(hipDeviceSynchronize());
-    // names returned point into the context's records (valid until the next reset/launch)
-    std::map<std::string, int> slot;
-    int used = 0;
-    for (size_t i = 0; i < c->prof_used; i++) {
-        ProfileRec& r = c->prof[i];
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) {
-            (void)hipGetLastError();
-            continue;
-        }
-        auto it = slot.find(r.name);
-        int idx;
-        if (it == slot.end()) {
-            if (used == cap) continue;
-            idx = used++;
-            slot[r.name] = idx;
-            names[idx] = r.name.c_str();
-            ms[idx] = 0.0;
-            launches[idx] = 0;
-            if (bytes) bytes[idx] = 0;
-        } else {
-            idx = it->second;
-        }
-        ms[idx] += t;
-        launches[idx] += 1;
-        if (bytes) bytes[idx] += r.bytes;
-    }
-    return used;
-}
-
-const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str() : ""; }
-
-// Plan ids:
-//   0            default
-//   rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
-//   1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
-//                f&4: never use persistent workgroups (f&2, the next-tile prefetch of rounds 1-2, is gone: such ids are rejected)
-static int apply_plan(fastecc_ctx* c, int plan)
-{
-    int rmax = 5, vec = 1, tile_mid = 10;
-    bool wide = false, persistent = true, slim = true;  // plan 0 == 2100
-    bool split2 = true;  // plan 0 == 3100
-    if (plan >= 1000) {
-        slim = plan >= 2000;  // 2000+10*a+f: as 1000+10*a+f with 16-word-per-lane outer tiles (8/9 levels)
-        split2 = plan >= 3000;  // 3000+10*a+f: as 2000+... with the two-round (64 KiB) exchange in 1024-block tiles
-        if (plan >= 4000) return FASTECC_E_INVAL;
-        tile_mid = (plan % 1000) / 10;
-        const int f = (plan % 1000) % 10;
-        wide = f & 1;
-        persistent = !(f & 4);
-        if (f > 7 || (f & 2)) return FASTECC_E_INVAL;
-        if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
-    } else if (plan != 0) {
-        rmax = plan / 10;
-        vec = plan % 10;
-        tile_mid = 0;
-    }
-    if (plan < 0 || rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
-    c->rmax = rmax;
-    c->vec = vec;
-    c->tile_mid = tile_mid;
-    c->tile_mid_wide = wide;
-    c->persistent = persistent;
-    c->slim_outer = slim;
-    c->split2 = split2;
-    build_plans(c);
-    return FASTECC_OK;
-}
-
-int fastecc_set_plan(fastecc_ctx* c, int plan)
-{
-    if (!c) return FASTECC_E_INVAL;
-    if (c->sharded) return sharded_forward(c, SH_SET_PLAN, nullptr, plan);
-    CallLock lk(c->mu);
-    if (c->p61) {
-        // plan ids of this field: gf61_path.hpp
-        DeviceGuard dg(c->device);
-        if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
-        HIP_TRY(hipDeviceSynchronize());
-        const int rc = p61::set_plan(c->p61, plan, g_detail, sizeof g_detail);
-        c->plan_text = p61::plan_string(c->p61);
-        return rc;
-    }
-    const int rc = apply_plan(c, plan);
-    if (rc != FASTECC_OK) return rc;
-    DeviceGuard dg(c->device);
-    if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
-    HIP_TRY(hipDeviceSynchronize());  // kernels still reading the old tables
-    return upload_twiddles(c);
-}
-
-// ---- host-only introspection: no device is touched, so the planning logic is testable anywhere ----
-static int host_plan(fastecc_ctx* c, uint64_t k, uint64_t block_bytes, int plan)
-{
-    const int lg = ilog2_exact(k);
-    if (k < 2 || lg < 0 || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
-    if (lg > 19) return FASTECC_E_UNSUPPORTED;
-    c->N = k;
-    c->n = lg;
-    c->S = block_bytes / 4;
-    c->ld = c->S;
-    return apply_plan(c, plan);
-}
-
-int fastecc_plan_describe(uint64_t k, uint64_t block_bytes, int plan, char* buf, size_t cap)
-{
-    if (!buf || cap == 0) return FASTECC_E_INVAL;
-    fastecc_ctx c;
-    const int rc = host_plan(&c, k, block_bytes, plan);
-    if (rc != FASTECC_OK) return rc;
-    snprintf(buf, cap, "%s", c.plan_text.c_str());
-    return FASTECC_OK;
-}
-
-int fastecc_plan_twiddles(uint64_t k, uint64_t block_bytes, int plan, int which, uint32_t* out, int32_t* level_stride)
-{
-    if (!out || which < 0 || which > 3) return FASTECC_E_INVAL;
-    fastecc_ctx c;
-    const int rc = host_plan(&c, k, block_bytes, plan);
-    if (rc != FASTECC_OK) return rc;
-    const uint32_t wN = gf::h_root((uint32_t)k), wNi = gf::h_inv(wN);
-    const std::vector<int> sl = level_strides(which < 2 ? c.encode_plan : c.ntt_plan, c.n);
-    const bool inverse_roots = (which == 0 || which == 3);
-    const std::vector<uint32_t> tab = build_level_table(c.n, inverse_roots ? wNi : wN, sl);
-    memcpy(out, tab.data(), (size_t)k * 4);
-    if (level_stride)
-        for (int l = 0; l < c.n; l++) level_stride[l] = sl[l];
-    return FASTECC_OK;
 }
 
 }  // extern "C"

@@ -383,6 +383,12 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for
     int direct_limit = std::min(ci.direct_max, direct_cap());
     if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, 96);
+    {
+        // orders above 2^20 (mixed radix) have no locator tree: whatever the direct path can take, it takes
+        uint64_t T = 1;
+        while (T < NC - N) T <<= 1;
+        if (T > (1ull << 20) && ci.direct_max > 0) direct_limit = direct_cap();
+    }
     auto parity_position = [&](uint64_t q) -> uint64_t {
         if (ci.cosets > 1) {
             const uint64_t t = q / N, j = q % N;  // coset t = generator w_(N << jj)^c, see fastecc_create
@@ -529,7 +535,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->transform) {
         std::vector<uint32_t> factor(NC);
         const uint32_t inv_nc = gf::h_inv((uint32_t)NC);
-        for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mul((uint32_t)m, inv_nc);  // x p'(x): coefficient m times m, and the 1/NC of the inverse transform
+        const uint32_t inv_nc_m = gf::h_to_mont(inv_nc);
+        for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mont_mul((uint32_t)m, inv_nc_m);  // x p'(x): coefficient m times m, and the 1/NC of the inverse transform
         // fold e: only the data positions (multiples of 2^e) are evaluated (mixed radix: all positions, the even ones are used)
         const int rc = mixed ? create_mixed_transform_ctx(&d->transform, ci.q, lgc, ci.words * 4, factor.data(), ci.device)
                              : create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);

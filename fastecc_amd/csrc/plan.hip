@@ -1,0 +1,317 @@
+// plan.hip — how the levels of a transform are cut into GPU passes, and the twiddle tables those passes read.
+//
+// Where the reference picks an R x C (x L) split so that a sub-transform fits the CPU's L2 (ntt.cpp:385-394), the plan here picks how many
+// radix-2 levels each GPU pass keeps in registers or in an LDS tile; the level-packed tables replace the roots[] array of ntt.cpp:397-402 and
+// the running root_i *= root of ntt.cpp:270-281.  Host code only: fastecc_plan_describe / fastecc_plan_twiddles run without a device.
+#include "context.hpp"
+
+using namespace fastecc;
+
+namespace fastecc {
+
+namespace {
+
+// Split `bits` levels into ceil(bits/rmax) passes of near-equal size, largest first.
+std::vector<int> split_levels(int bits, int rmax)
+{
+    std::vector<int> r;
+    if (bits <= 0) return r;
+    const int q = (bits + rmax - 1) / rmax;
+    for (int i = 0; i < q; i++) r.push_back(bits / q + (i < bits % q ? 1 : 0));
+    return r;
+}
+
+// How a run of `bits` consecutive levels is executed: an LDS tile when one exists for that size,
+// register passes otherwise.
+// A tile pass addresses its tile with 32-bit offsets from a per-tile buffer descriptor (tile_kernels.hip).
+bool tile_fits(const fastecc_ctx* c, int logt, int s)
+{
+    // block offsets (SGPR) and lane offsets (VGPR) are 32-bit and their sum must stay below num_records = 2^32-1
+    return (((uint64_t)c->ld * 4) << (logt + s)) <= 0xFFFF0000ull;
+}
+
+void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastecc_ctx* c)
+{
+    // with fold > 0 the DIT passes above MID run on the compact parity stripe: their strides are 2^fold smaller
+    const int s_run = mode == MODE_DIT ? s - c->fold : s;
+    const bool fits = tile_fits(c, bits, s_run);
+    // larger spans: 2, 4 or 8 address windows per tile (tile_kernels.hip NWIN), only for the outer pair shapes that have them
+    int windows = 0;
+    for (int lw = 1; lw <= 4 && !fits && windows == 0; lw++)
+        if (bits - lw >= 1 && tile_fits(c, bits - lw, s_run)) windows = 1 << lw;
+    if (c->tile_mid > 0 && windows && c->slim_outer && tile_supported(bits, true, 4) && tile_max_windows(bits, true, 4) >= windows)
+        plan.push_back({mode, bits, s, true, true, 4, windows});
+    else if (c->tile_mid > 0 && windows && tile_supported(bits, true) && tile_max_windows(bits, true) >= windows)
+        plan.push_back({mode, bits, s, true, true, 5, windows});
+    else if (c->tile_mid > 0 && fits && c->slim_outer && tile_supported(bits, true, 4)) plan.push_back({mode, bits, s, true, true, 4});
+    else if (c->tile_mid > 0 && fits && bits >= 7 && tile_supported(bits, true)) plan.push_back({mode, bits, s, true, true, 5});
+    else if (c->tile_mid > 0 && fits && bits == 6 && tile_supported(bits, false)) plan.push_back({mode, bits, s, true, false, 5});
+    else if (mode == MODE_DIT) {
+        int ss = s;
+        const std::vector<int> parts = split_levels(bits, c->rmax);
+        for (auto it = parts.rbegin(); it != parts.rend(); ++it) {
+            plan.push_back({mode, *it, ss, false, false, 0});
+            ss += *it;
+        }
+    } else {
+        int ss = s + bits;
+        for (int r : split_levels(bits, c->rmax)) {
+            ss -= r;
+            plan.push_back({mode, r, ss, false, false, 0});
+        }
+    }
+}
+
+}  // namespace
+
+void build_plans(fastecc_ctx* c)
+{
+    const int n = c->n;
+    c->encode_plan.clear();
+    c->ntt_plan.clear();
+    // encode: DIF over the high levels, MID over the low levels, DIT back up (kernels.hip header)
+    int mid = std::min(n, c->rmax);
+    bool mid_tile = false, mid_pair = false;
+    if (c->tile_mid > 0) {
+        const int want = std::min(n, c->tile_mid);
+        if (!tile_fits(c, want, 0)) {
+            // blocks too large for 32-bit tile offsets: register passes handle the low levels
+        } else if (tile_supported(want, !c->tile_mid_wide) && tile_max_fold(want, !c->tile_mid_wide) >= c->fold) {
+            mid = want, mid_tile = true, mid_pair = !c->tile_mid_wide;
+        } else if (tile_supported(want, c->tile_mid_wide) && tile_max_fold(want, c->tile_mid_wide) >= c->fold) {
+            mid = want, mid_tile = true, mid_pair = c->tile_mid_wide;
+        }
+    }
+    if (!mid_tile && mid < c->fold) mid = std::min(n, c->fold);  // a register MID pass drops blocks within its own 2^mid
+    const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
+    const std::vector<int> outer = split_levels(n - mid, max_chunk);
+    // mixed radix: one outer chunk and a fused shape for it -> the odd-radix level rides on that pass (3 trips instead of 5)
+    const int fused_run = (c->q > 1 && c->fuse_radix && outer.size() == 1) ? fused_rlog(c->q, outer[0]) : 0;
+    int s = n;
+    for (int r : outer) {
+        s -= r;
+        if (fused_run) c->encode_plan.push_back({MODE_DIF, r, s, true, false, fused_run, 0, c->q});
+        else push_chunk(c->encode_plan, MODE_DIF, r, s, c);
+    }
+    c->encode_plan.push_back({MODE_MID, mid, 0, mid_tile, mid_pair, 5});
+    s = mid;
+    for (auto it = outer.rbegin(); it != outer.rend(); ++it) {
+        if (fused_run) c->encode_plan.push_back({MODE_DIT, *it, s, true, false, fused_run, 0, c->q});
+        else push_chunk(c->encode_plan, MODE_DIT, *it, s, c);
+        s += *it;
+    }
+    // stand-alone transform: DIF over all levels, then the block bit-reversal
+    s = n;
+    for (int r : split_levels(n, max_chunk)) {
+        s -= r;
+        push_chunk(c->ntt_plan, MODE_DIF, r, s, c);
+    }
+    char buf[64];
+    c->plan_text.clear();
+    for (const Pass& p : c->encode_plan) {
+        if (p.fused) {  // R<q>+: the odd-radix level and these levels in one pass
+            snprintf(buf, sizeof buf, "%sR%d+%s%d@%d", c->plan_text.empty() ? "" : ",", p.fused, p.mode == MODE_DIF ? "dif" : "dit", p.logr, p.s);
+            c->plan_text += buf;
+            continue;
+        }
+        snprintf(buf, sizeof buf, "%s%s%s%d@%d", c->plan_text.empty() ? "" : ",", p.tile ? (p.wide ? (p.rlog == 4 ? (p.wide == 2 ? "SW32:" : p.wide == 4 ? "SW4x32:" : p.wide == 8 ? "SW8x32:" : "SW16x32:") : "TW32:") : p.rlog == 4 ? "S32:" : p.pair ? "T32:" : "T64:") : "",
+                 p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid", p.logr, p.s);
+        c->plan_text += buf;
+    }
+    if (c->q > 1 && !fused_run) {  // the odd-radix level around the power-of-two pipeline (mixed_kernels.hip)
+        snprintf(buf, sizeof buf, "R%d:dif1@%d,", c->q, c->n);
+        c->plan_text = std::string(buf) + c->plan_text;
+        snprintf(buf, sizeof buf, ",R%d:dit1@%d", c->q, c->n);
+        c->plan_text += buf;
+    }
+    snprintf(buf, sizeof buf, " v%d", c->vec);
+    c->plan_text += buf;
+}
+
+const char* pass_name(const Pass& p, int vec, char* buf, size_t cap)
+{
+    const char* m = p.mode == MODE_DIF ? "dif" : p.mode == MODE_DIT ? "dit" : "mid";
+    if (p.tile) snprintf(buf, cap, "tile_%s%d_w%d%s", m, p.logr, p.pair ? 32 : 64, p.rlog == 4 ? "_r16" : "");
+    else snprintf(buf, cap, "%s%dv%d", m, p.logr, vec);
+    return buf;
+}
+
+// For every level l: the stride 2^sl of the register run that executes it (see ntt_device.hpp).
+// `up` selects the side of an encode plan: false = the way down (DIF passes and MID), true = the way up (MID and DIT
+// passes).  The two sides mirror each other level for level unless fold > 0 made a chunk tile-eligible on one side only.
+std::vector<int> level_strides(const std::vector<Pass>& plan, int n, bool up)
+{
+    std::vector<int> sl(n, 0);
+    for (const Pass& p : plan) {
+        if (p.mode == (up ? MODE_DIF : MODE_DIT)) continue;
+        if (!p.tile) {
+            for (int l = p.s; l < p.s + p.logr; l++) sl[l] = p.s;
+        } else if (p.fused) {
+            // fused_radix_kernel: runs of p.rlog levels counted from the top of the pass, the rest in the last one
+            const int runs = (p.logr + p.rlog - 1) / p.rlog;
+            for (int l = p.s; l < p.s + p.logr; l++) {
+                const int run = (p.s + p.logr - 1 - l) / p.rlog;
+                sl[l] = run == runs - 1 ? p.s : p.s + p.logr - (run + 1) * p.rlog;
+            }
+        } else {
+            const int l2 = p.logr - p.rlog - (p.pair ? 1 : 0);  // TileCfg::L2
+            for (int l = p.s; l < p.s + l2; l++) sl[l] = p.s;
+            for (int l = p.s + l2; l < p.s + p.logr; l++) sl[l] = p.s + l2;
+        }
+    }
+    return sl;
+}
+
+// Level-packed table: entry 2^l + ((i mod 2^sl) << (l - sl)) + (i >> sl) = (root of order 2^(l+1))^i, i < 2^l,
+// in Montgomery form.  Replaces the roots[] array of ntt.cpp:397-402 and the running root_i *= root of
+// ntt.cpp:270-281: every twiddle of every level is tabulated once per context.
+std::vector<uint32_t> build_level_table(int n, uint32_t root_of_order_N, const std::vector<int>& sl)
+{
+    std::vector<uint32_t> tab(std::max<size_t>((size_t)1 << n, 2), 0);
+    for (int l = 0; l < n; l++) {
+        const uint32_t h = 1u << l;
+        const uint32_t root = gf::h_pow(root_of_order_N, (uint64_t)1 << (n - 1 - l));
+        const int t = l - sl[l];
+        const uint32_t lowmask = (1u << sl[l]) - 1u;
+        const uint32_t root_m = gf::h_to_mont(root);
+        uint32_t w = gf::MONT_ONE;  // running power in Montgomery form: no division per entry
+        for (uint32_t i = 0; i < h; i++) {
+            tab[h + (((i & lowmask) << t) | (i >> sl[l]))] = w;
+            w = gf::h_mont_mul(w, root_m);
+        }
+    }
+    return tab;
+}
+
+int upload_table(uint32_t** dst, const std::vector<uint32_t>& src)
+{
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, src.size() * 4));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    return FASTECC_OK;
+}
+
+// (Re)build the four twiddle tables for the current plans.  The device must be idle w.r.t. this context.
+int upload_twiddles(fastecc_ctx* c)
+{
+    const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
+    const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
+    const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
+    int rc = upload_table(&c->tw_enc_dif, build_level_table(c->n, wNi, enc));  // interpolate: inverse roots (RS.cpp:41)
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc_up));  // evaluate (RS.cpp:63)
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
+    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
+    if (rc == FASTECC_OK && c->fold > 0) {
+        // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
+        const int nf = c->n - c->fold;
+        std::vector<int> sl(std::max(nf, 0), 0);
+        for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
+        rc = upload_table(&c->tw_fold_dit, build_level_table(nf, gf::h_root((uint32_t)c->M), sl));
+    }
+    return rc;
+}
+
+}  // namespace fastecc
+
+extern "C" {
+
+const char* fastecc_plan_string(fastecc_ctx* c) { return c ? c->plan_text.c_str() : ""; }
+
+// Plan ids:
+//   0            default
+//   rv           register passes only: r levels per pass (1..5), v words per lane (1,2,4), e.g. 51
+//   1000+10*a+f  LDS-tiled: MID covers a levels (6..10); f&1: MID tile uses 64-word rows;
+//                f&4: never use persistent workgroups (f&2, the next-tile prefetch of rounds 1-2, is gone: such ids are rejected)
+static int apply_plan(fastecc_ctx* c, int plan)
+{
+    int rmax = 5, vec = 1, tile_mid = 10;
+    bool wide = false, persistent = true, slim = true;  // plan 0 == 2100
+    bool split2 = true;  // plan 0 == 3100
+    if (plan >= 1000) {
+        slim = plan >= 2000;  // 2000+10*a+f: as 1000+10*a+f with 16-word-per-lane outer tiles (8/9 levels)
+        split2 = plan >= 3000;  // 3000+10*a+f: as 2000+... with the two-round (64 KiB) exchange in 1024-block tiles
+        if (plan >= 4000) return FASTECC_E_INVAL;
+        tile_mid = (plan % 1000) / 10;
+        const int f = (plan % 1000) % 10;
+        wide = f & 1;
+        persistent = !(f & 4);
+        if (f > 7 || (f & 2)) return FASTECC_E_INVAL;
+        if (tile_mid < 6 || tile_mid > 10) return FASTECC_E_INVAL;
+    } else if (plan != 0) {
+        rmax = plan / 10;
+        vec = plan % 10;
+        tile_mid = 0;
+    }
+    if (plan < 0 || rmax < 1 || rmax > 5 || (vec != 1 && vec != 2 && vec != 4)) return FASTECC_E_INVAL;
+    c->rmax = rmax;
+    c->vec = vec;
+    c->tile_mid = tile_mid;
+    c->tile_mid_wide = wide;
+    c->persistent = persistent;
+    c->slim_outer = slim;
+    c->split2 = split2;
+    build_plans(c);
+    return FASTECC_OK;
+}
+
+int fastecc_set_plan(fastecc_ctx* c, int plan)
+{
+    if (!c) return FASTECC_E_INVAL;
+    if (c->sharded) return sharded_forward(c, SH_SET_PLAN, nullptr, plan);
+    CallLock lk(c->mu);
+    if (c->p61) {
+        // plan ids of this field: gf61_path.hpp
+        DeviceGuard dg(c->device);
+        if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+        HIP_TRY(hipDeviceSynchronize());
+        const int rc = p61::set_plan(c->p61, plan, g_detail, sizeof g_detail);
+        c->plan_text = p61::plan_string(c->p61);
+        return rc;
+    }
+    const int rc = apply_plan(c, plan);
+    if (rc != FASTECC_OK) return rc;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
+    HIP_TRY(hipDeviceSynchronize());  // kernels still reading the old tables
+    return upload_twiddles(c);
+}
+
+// ---- host-only introspection: no device is touched, so the planning logic is testable anywhere ----
+static int host_plan(fastecc_ctx* c, uint64_t k, uint64_t block_bytes, int plan)
+{
+    const int lg = ilog2_exact(k);
+    if (k < 2 || lg < 0 || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
+    if (lg > 19) return FASTECC_E_UNSUPPORTED;
+    c->N = k;
+    c->n = lg;
+    c->S = block_bytes / 4;
+    c->ld = c->S;
+    return apply_plan(c, plan);
+}
+
+int fastecc_plan_describe(uint64_t k, uint64_t block_bytes, int plan, char* buf, size_t cap)
+{
+    if (!buf || cap == 0) return FASTECC_E_INVAL;
+    fastecc_ctx c;
+    const int rc = host_plan(&c, k, block_bytes, plan);
+    if (rc != FASTECC_OK) return rc;
+    snprintf(buf, cap, "%s", c.plan_text.c_str());
+    return FASTECC_OK;
+}
+
+int fastecc_plan_twiddles(uint64_t k, uint64_t block_bytes, int plan, int which, uint32_t* out, int32_t* level_stride)
+{
+    if (!out || which < 0 || which > 3) return FASTECC_E_INVAL;
+    fastecc_ctx c;
+    const int rc = host_plan(&c, k, block_bytes, plan);
+    if (rc != FASTECC_OK) return rc;
+    const uint32_t wN = gf::h_root((uint32_t)k), wNi = gf::h_inv(wN);
+    const std::vector<int> sl = level_strides(which < 2 ? c.encode_plan : c.ntt_plan, c.n);
+    const bool inverse_roots = (which == 0 || which == 3);
+    const std::vector<uint32_t> tab = build_level_table(c.n, inverse_roots ? wNi : wN, sl);
+    memcpy(out, tab.data(), (size_t)k * 4);
+    if (level_stride)
+        for (int l = 0; l < c.n; l++) level_stride[l] = sl[l];
+    return FASTECC_OK;
+}
+
+}  // extern "C"
