@@ -29,9 +29,7 @@ int ilog2_exact(uint64_t v)
 
 uint32_t bitrev_host(uint32_t v, int bits)
 {
-    uint32_t r = 0;
-    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (bits - 1 - b);
-    return r;
+    return bits <= 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - bits));  // called once per table entry: no bit loop
 }
 
 }  // namespace fastecc
@@ -356,6 +354,23 @@ int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStr
     }
     if (c->q > 1) return encode_mixed(c, data, parity, st);
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);
+    if (c->p61) {
+        // 64-bit field, any (n,k): the K data blocks extended with zero blocks to N (a copy), the (2N,N) encode, and parity block j picked
+        // from block j * stride of its result (a strided copy).  K == N needs no data copy.
+        const size_t row = (size_t)c->S * 4;
+        const uint32_t* src = data;
+        if (c->K != c->N) {
+            if (!c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * row));
+            HIP_TRY(hipMemcpyAsync(c->scratch, data, c->K * row, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemsetAsync((char*)c->scratch + c->K * row, 0, (c->N - c->K) * row, st));
+            src = c->scratch;
+        }
+        if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->N * row));
+        const int rc = encode_pow2(c, src, c->parbuf, st);
+        if (rc != FASTECC_OK) return rc;
+        HIP_TRY(hipMemcpy2DAsync(parity, row, c->parbuf, (size_t)c->p61_stride * row, row, c->Mu, hipMemcpyDeviceToDevice, st));
+        return FASTECC_OK;
+    }
     // any (n,k): the first pass reads the K existing data blocks and takes the rest of the stripe as zero, the last pass
     // writes only the first Mu of the M parity blocks it computes — both through the kernels' bounds handling, no copies.
     // The passes in between need all M blocks somewhere: the caller's parity buffer when it is that large, else parbuf.
@@ -645,7 +660,14 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
         int lgm = 0;
         while ((1ull << lgm) < m) lgm++;
         fold = std::min(lg - lgm, 4);
-        if (f61 && (fold != 0 || !pow2 || m != k)) return FASTECC_E_UNSUPPORTED;
+    }
+    // The 64-bit field always runs the (2 N1, N1) transform; other (n,k) of the rules above (zero extension, fewer parity blocks) work on
+    // padded copies of the stripes, and parity block j is block j * 2^fold of the full parity — the same code definition as for
+    // GF(0xFFF00001), without the kernels' bounds handling (RS.md:23-33 spells out exactly this: extend with zeroes, output some values).
+    int p61_stride = 1;
+    if (f61) {
+        p61_stride = 1 << fold;
+        fold = 0;
     }
     // root(2N) must exist: 2N | 2^20 (GF.md:20, RS.cpp:51); in GF(p61^2) 2N | 2^62, the bound is table memory
     if (lg > (f61 ? p61::MAX_LOG2_K : 19)) return FASTECC_E_UNSUPPORTED;
@@ -656,6 +678,7 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     if (rc == FASTECC_OK) {
         (*out)->K = k;
         (*out)->Mu = m;
+        (*out)->p61_stride = p61_stride;
     }
     return rc;
 
@@ -806,7 +829,7 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max, c->direct_kernel};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max, c->direct_kernel, c->p61_stride};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
@@ -939,6 +962,16 @@ int CallScope::wait_idle()
     return FASTECC_OK;
 }
 
+int p61_work_stripes(fastecc_ctx* c, uint64_t** data_full, uint64_t** parity_full)
+{
+    const size_t row = (size_t)c->S * 4;
+    if (!c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * row));
+    if (!c->parbuf) HIP_TRY(hipMalloc((void**)&c->parbuf, c->N * row));
+    *data_full = (uint64_t*)c->scratch;
+    *parity_full = (uint64_t*)c->parbuf;
+    return FASTECC_OK;
+}
+
 int encode_unlocked(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     DeviceGuard dg(c->device);
@@ -1017,7 +1050,7 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     if (mem_kind == FASTECC_MEM_DEVICE) {
         // the reference's configuration touches nothing but the caller's buffers and the read-only tables: calls on
         // different streams may overlap on the device.  The other codes work through scratch stripes of the context.
-        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1 || c->q > 1 || direct_encode_applies(c);
+        const bool internal = c->fold != 0 || c->cosets != 1 || c->Mu != c->M || c->slabs > 1 || c->q > 1 || (c->p61 && c->K != c->N) || direct_encode_applies(c);
         if (!internal) return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st);
         return with_internal_buffers(c, st, [&] { return encode_device(c, (const uint32_t*)data, (uint32_t*)parity, st); });
     }
@@ -1200,6 +1233,7 @@ int fastecc_check_range(fastecc_ctx* c, const void* data, int mem_kind, void* st
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
     if (c->sharded) return FASTECC_E_UNSUPPORTED;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // scans k * block_bytes contiguous bytes
+    if (c->p61 && c->K != c->N) return FASTECC_E_UNSUPPORTED;  // the 64-bit field's scan covers the whole power-of-two stripe
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     hipStream_t st = (hipStream_t)stream;

@@ -71,6 +71,7 @@ struct fastecc_ctx {
     Sharded* sharded = nullptr;      // fastecc_create_sharded: the per-device contexts of the column slabs (sharded.hip); a
                                      // context that has it is only a shell around them
     p61::Decoder* decoder61 = nullptr;  // the same for FASTECC_FIELD_GF_P61_SQUARED (gf61_decode.hip)
+    int p61_stride = 1;  // 64-bit field, codes other than (2N,N): parity block j of the code is block j * p61_stride of the (2N,N) parity (N = 2^n)
     p61::Path* p61 = nullptr;  // FASTECC_FIELD_GF_P61_SQUARED: tables and plan of gf61_kernels.hip (everything uint32 below is unused)
     uint64_t N = 0;   // k
     int n = 0;        // log2 k

@@ -25,6 +25,9 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -317,6 +320,19 @@ int hip_code(const char* what, hipError_t e)
     return e == hipErrorOutOfMemory ? FASTECC_E_NOMEM : FASTECC_E_DEVICE;
 }
 
+// FASTECC_TRACE_PREPARE=1: wall-clock of the phases of fastecc_decode_prepare on stderr (where does a first call spend its time)
+struct PhaseTimer {
+    bool on = getenv("FASTECC_TRACE_PREPARE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fastecc prepare] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 #define DEC_TRY(expr)                                      \
     do {                                                   \
         hipError_t e_ = (expr);                            \
@@ -360,6 +376,17 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             if (rc0 != FASTECC_OK) return rc0;
         }
         char detail[160] = "";
+        // codes other than (2N,N): the decoder sees the (2N,N) codeword — data blocks beyond the caller's k are surviving zero blocks,
+        // parity positions the code does not use are lost (which is what limits the losses to n - k)
+        std::vector<uint8_t> dfull, pfull;
+        if (ci.zero_extended) {
+            dfull.assign(ci.k, 1);
+            pfull.assign(ci.k, 0);
+            for (uint64_t i = 0; i < ci.user_k; i++) dfull[i] = data_present[i] ? 1 : 0;
+            for (uint64_t q = 0; q < ci.user_m; q++) pfull[q * (uint64_t)ci.p61_stride] = parity_present[q] ? 1 : 0;
+            data_present = dfull.data();
+            parity_present = pfull.data();
+        }
         const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail);
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
         return rc;
@@ -384,10 +411,10 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     int direct_limit = std::min(ci.direct_max, direct_cap());
     if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, 96);
     {
-        // orders above 2^20 (mixed radix) have no locator tree: whatever the direct path can take, it takes
+        // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
         uint64_t T = 1;
         while (T < NC - N) T <<= 1;
-        if (T > (1ull << 20) && ci.direct_max > 0) direct_limit = direct_cap();
+        if (T > (1ull << 20) && ci.direct_max > 0) direct_limit = std::max(direct_limit, 256);  // their tree costs a 2^20-point product: the direct path first
     }
     auto parity_position = [&](uint64_t q) -> uint64_t {
         if (ci.cosets > 1) {
@@ -485,6 +512,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (state[u] == LOST) erased.push_back((uint32_t)u);
     if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
 
+    PhaseTimer pt;
     DeviceScope ds(ci.device);
     if (!ds.ok) return FASTECC_E_DEVICE;
     CallScope call(c);
@@ -500,6 +528,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     d->positions = NC;
     d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
     d->mixed = mixed;
+    pt.mark("lock, state");
     {
         std::vector<uint32_t> plost(ci.user_m);
         d->erased_parity = 0;
@@ -509,6 +538,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK) return rc;
         DEC_TRY(hipMemcpy(d->parity_lost, plost.data(), ci.user_m * 4, hipMemcpyHostToDevice));
     }
+    pt.mark("lost-parity flags");
     d->sub = false;
     if (erased_data == 0) {  // no data block to recover
         d->ready = true;
@@ -517,11 +547,13 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
 
     // ---- device state of the decoder (built once) ----
     // T = padded root count: the smallest power of two that holds the most losses the code tolerates, NC - N
+    // (the top of the product tree is a cyclic product of length T, so w_T must exist: T <= 2^20.  Orders above 2^20 — mixed radix —
+    // tolerate more losses than that; there T = 2^20 and patterns with more erasures than T are refused.)
     uint64_t T = 1;
-    while (T < NC - N) T <<= 1;
+    while (T < NC - N && T < (1ull << 20)) T <<= 1;
     int lgT = 0;
     while ((1ull << lgT) < T) lgT++;
-    if (lgT > 20) return FASTECC_E_UNSUPPORTED;  // the top of the product tree is a cyclic product of length T: w_T must exist
+    if (erased.size() > T) return FASTECC_E_UNSUPPORTED;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
@@ -531,6 +563,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                              : create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
+    pt.mark("pattern_ntt context");
     if (!d->pattern_buf) DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
     if (!d->transform) {
         std::vector<uint32_t> factor(NC);
@@ -542,6 +575,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                              : create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
         if (rc != FASTECC_OK) return rc;
     }
+    pt.mark("transform context");
     if (d->tree_T != T) {
         // level k >= leaf_log multiplies pairs of degree-2^k polynomials: transforms of length 2^(k+1) on T / 2^k columns
         for (fastecc_ctx* t : d->tree_ctx)
@@ -564,6 +598,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipMalloc((void**)&d->dev_erased, T * 4));
         d->tree_T = T;
     }
+    pt.mark("tree contexts + buffers");
     if (!d->wpow) {
         // the table becomes visible to later calls only once the kernel that fills it has been launched without error
         // (an unfilled table behind a non-null pointer would give silently wrong weights on the next prepare)
@@ -600,6 +635,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK) return rc;
     }
 
+    pt.mark("tables, tile order");
     // ---- this pattern ----
     DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
     DEC_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, st));
@@ -645,6 +681,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipGetLastError());
     }
     DEC_TRY(hipStreamSynchronize(st));
+    pt.mark("this pattern (device)");
     d->ready = true;
     return FASTECC_OK;
 }
@@ -676,6 +713,33 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         if (!ds61.ok) return FASTECC_E_DEVICE;
         int rc61 = call.begin((hipStream_t)stream);  // the decoder's work stripe and tables are internal buffers
         if (rc61 != FASTECC_OK) return rc61;
+        const CtxInfo ci61 = info_of(c);
+        if (ci61.zero_extended) {
+            // codes other than (2N,N): decode the padded (2N,N) codeword in the context's two work stripes and copy the caller's blocks back
+            if (mem_kind != FASTECC_MEM_DEVICE) {
+                (void)call.end((hipStream_t)stream);
+                return FASTECC_E_UNSUPPORTED;
+            }
+            hipStream_t st61 = (hipStream_t)stream;
+            const size_t row = ci61.words * 4, prow = row * (size_t)ci61.p61_stride;
+            uint64_t *wd = nullptr, *wp = nullptr;
+            rc61 = p61_work_stripes(c, &wd, &wp);
+            auto step = [&](hipError_t e, const char* what) {
+                if (rc61 == FASTECC_OK && e != hipSuccess) rc61 = hip_code(what, e);
+            };
+            if (rc61 == FASTECC_OK) {
+                step(hipMemcpyAsync(wd, data, ci61.user_k * row, hipMemcpyDeviceToDevice, st61), "hipMemcpyAsync(data)");
+                step(hipMemsetAsync((char*)wd + ci61.user_k * row, 0, (ci61.k - ci61.user_k) * row, st61), "hipMemsetAsync");
+                step(hipMemcpy2DAsync(wp, prow, parity, row, row, ci61.user_m, hipMemcpyDeviceToDevice, st61), "hipMemcpy2DAsync(parity)");
+            }
+            if (rc61 == FASTECC_OK) rc61 = p61::decode(d61, wd, wp, parity_out ? p61_path_of(c) : nullptr, st61, nullptr);
+            if (rc61 == FASTECC_OK) {
+                step(hipMemcpyAsync(data, wd, ci61.user_k * row, hipMemcpyDeviceToDevice, st61), "hipMemcpyAsync(data back)");
+                if (parity_out) step(hipMemcpy2DAsync(parity_out, row, wp, prow, row, ci61.user_m, hipMemcpyDeviceToDevice, st61), "hipMemcpy2DAsync(parity back)");
+            }
+            const int rc_end61 = call.end((hipStream_t)stream);
+            return rc61 != FASTECC_OK ? rc61 : rc_end61;
+        }
         rc61 = mem_kind == FASTECC_MEM_DEVICE
                    ? p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr)
                    : p61::decode_host(d61, data, const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);

@@ -55,6 +55,7 @@ struct CtxInfo {
     int q;                     // > 1: the transform order is q * k (mixed radix); k is its power-of-two part
     int direct_max;            // decoder: patterns with at most this many lost blocks take the direct path (option "decode_direct_max")
     int direct_kernel;         // 0 choose, 1 VALU, 2 MFMA (option "direct_kernel")
+    int p61_stride;            // GF((2^61-1)^2) codes other than (2N,N): parity block j = block j * p61_stride of the (2N,N) parity
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);
@@ -100,6 +101,8 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
 // The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);
+// GF((2^61-1)^2) codes other than (2N,N) work on padded copies of the caller's stripes: the context's two N-block work stripes
+int p61_work_stripes(fastecc_ctx* c, uint64_t** data_full, uint64_t** parity_full);
 // fastecc_encode on DEVICE memory for a caller that already holds the context's call lock (decode.hip: fastecc_repair)
 int encode_unlocked(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st);
 

@@ -190,23 +190,68 @@ int upload_table(uint32_t** dst, const std::vector<uint32_t>& src)
     return FASTECC_OK;
 }
 
+namespace {
+
+// build_level_table on the device: thread (l, i) writes entry 2^l + ((i mod 2^sl) << (l - sl)) + (i >> sl) = (root of order 2^(l+1))^i =
+// root_N^(i << (n-1-l)), Montgomery form.  A context needs four or five of these tables; walking 2^n powers per table on the host and
+// uploading them was most of what creating a context cost (the decoder's first fastecc_decode_prepare builds ~19 contexts).
+struct LevelStrides {
+    int sl[32];
+};
+__global__ __launch_bounds__(256) void level_table_kernel(uint32_t* __restrict__ tab, int n, uint32_t root_N, LevelStrides st)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (1u << n)) return;
+    if (idx == 0) {
+        tab[0] = 0;
+        return;
+    }
+    const int l = 31 - __clz(idx);
+    const uint32_t h = 1u << l, i = idx - h;
+    const int s = st.sl[l], t = l - s;
+    uint32_t r = 1, b = root_N;
+    for (uint32_t e = i << (n - 1 - l); e; e >>= 1) {  // e < 2^(n-1)
+        if (e & 1u) r = gf::mul(r, b);
+        b = gf::mul(b, b);
+    }
+    tab[h + (((i & ((1u << s) - 1u)) << t) | (i >> s))] = gf::mul(r, gf::MONT_ONE);
+}
+
+int device_level_table(uint32_t** dst, int n, uint32_t root_of_order_N, const std::vector<int>& sl)
+{
+    const size_t entries = std::max<size_t>((size_t)1 << n, 2);
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, entries * 4));
+    if (n < 1) {
+        HIP_TRY(hipMemset(*dst, 0, entries * 4));
+        return FASTECC_OK;
+    }
+    LevelStrides st{};
+    for (int l = 0; l < n && l < 32; l++) st.sl[l] = sl[l];
+    hipLaunchKernelGGL(level_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, nullptr, *dst, n, root_of_order_N, st);
+    HIP_TRY(hipGetLastError());
+    return FASTECC_OK;
+}
+
+}  // namespace
+
 // (Re)build the four twiddle tables for the current plans.  The device must be idle w.r.t. this context.
 int upload_twiddles(fastecc_ctx* c)
 {
     const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
     const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
     const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
-    int rc = upload_table(&c->tw_enc_dif, build_level_table(c->n, wNi, enc));  // interpolate: inverse roots (RS.cpp:41)
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_enc_dit, build_level_table(c->n, wN, enc_up));  // evaluate (RS.cpp:63)
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_fwd, build_level_table(c->n, wN, ntt));
-    if (rc == FASTECC_OK) rc = upload_table(&c->tw_ntt_inv, build_level_table(c->n, wNi, ntt));
+    int rc = device_level_table(&c->tw_enc_dif, c->n, wNi, enc);  // interpolate: inverse roots (RS.cpp:41)
+    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_enc_dit, c->n, wN, enc_up);  // evaluate (RS.cpp:63)
+    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_ntt_fwd, c->n, wN, ntt);
+    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_ntt_inv, c->n, wNi, ntt);
     if (rc == FASTECC_OK && c->fold > 0) {
         // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
         const int nf = c->n - c->fold;
         std::vector<int> sl(std::max(nf, 0), 0);
         for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
-        rc = upload_table(&c->tw_fold_dit, build_level_table(nf, gf::h_root((uint32_t)c->M), sl));
+        rc = device_level_table(&c->tw_fold_dit, nf, gf::h_root((uint32_t)c->M), sl);
     }
+    if (rc == FASTECC_OK) HIP_TRY(hipStreamSynchronize(nullptr));  // the tables are complete when this returns, like the uploads they replace
     return rc;
 }
 

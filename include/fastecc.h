@@ -60,7 +60,12 @@ enum {
      * Supported by create/destroy/encode/encode_blocks/ntt/check_range/decode_prepare/decode/repair/profile/plan_string and
      * fastecc_set_plan (0 = default: LDS tiles; 1..4 = register passes with that many radix-2 levels; 10+L / 20+L = tiles with a
      * 64 / 128 KiB exchange buffer); the 32-bit-word entry points
-     * (scale_blocks, gf_binary, set_option other than "decode_direct_max") return FASTECC_E_UNSUPPORTED.  k = 2^m, 1 <= m <= 24.
+     * (scale_blocks, gf_binary, set_option other than "decode_direct_max") return FASTECC_E_UNSUPPORTED.
+     * Codes: (2k,k) with k = 2^m, 1 <= m <= 24, run on the caller's stripes.  Any other k <= 2^24 with n - k <= N = 2^ceil(log2 k) follows
+     * the rules fastecc_create documents for GF(0xFFF00001) — the data zero-extended to N blocks, parity block j = block j * 2^fold of the
+     * (2N,N) parity, fold = min(log2 N - ceil(log2(n-k)), 4) — through padded copies of the stripes inside the context (two N-block work
+     * stripes: encode, decode_prepare, decode and repair on device memory, encode also on host memory; not encode_columns / ntt /
+     * check_range, and no n = 4k, 8k).
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
 };

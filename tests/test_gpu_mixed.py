@@ -393,8 +393,9 @@ def test_few_parity_blocks_of_mixed_radix_codes(torch_cuda, fe, oracle, k):
                 assert np.array_equal(to_host(out).reshape(m, S), want), (k, m, direct_max, enc.plan())
 
 
-def test_orders_above_2_20_repair_few_losses_only(torch_cuda, fe):
-    """k = 3 * 2^19 (transform order 1.5 M > 2^20): the locator tree does not exist there, the few-loss interpolation does."""
+def test_orders_above_2_20(torch_cuda, fe):
+    """k = 3 * 2^19 (transform order 1.5 M > 2^20; the code tolerates 1.5 M losses): up to 256 lost blocks take the direct path, more go
+    through the locator tree padded to 2^20 roots (the largest cyclic product this field has), and patterns beyond 2^20 erasures are refused."""
     torch = torch_cuda
     k, S = 3 << 19, 2
     g = torch.Generator(device="cuda:0")
@@ -404,13 +405,13 @@ def test_orders_above_2_20_repair_few_losses_only(torch_cuda, fe):
         par = torch.empty_like(x)
         enc.encode(x, par)
         rng = np.random.default_rng(8)
-        for count in (1, 16, 17, 200, 257):
+        for count in (1, 16, 17, 200, 257, 5000, (1 << 20) + 1):
             lost = rng.permutation(2 * k)[:count]
             lost[0] = int(rng.integers(0, k))
             dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
             dp[lost[lost < k]] = 0
             pp[lost[lost >= k] - k] = 0
-            if count > 256:
+            if count > (1 << 20):
                 with pytest.raises(fe.FastEccError) as ei:
                     enc.decode_prepare(dp, pp)
                 assert ei.value.code == fe.E_UNSUPPORTED

@@ -342,3 +342,56 @@ def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
             if N <= 64:
                 assert (orc61.decode(bad_x, bad_p, dp, pp) == x).all()
         enc.set_option("decode_direct_max", 16)
+
+
+@pytest.mark.parametrize("k,m,elems", [(100, 30, 8), (256, 64, 5), (1000, 1000, 4), (300, 512, 6), (4096, 256, 16), (5, 1, 3), (2048, 2048 // 16, 7)])
+def test_other_n_k_over_the_64_bit_field(torch_cuda, fe, orc61, k, m, elems):
+    """(n,k) other than (2N,N) over GF((2^61-1)^2): the code definition of the 32-bit field's rules (RS.md:23-33) — the k data blocks
+    zero-extended to N = 2^ceil(log2 k), parity block j = block j * 2^fold of the (2N,N) parity, fold = min(log2 N - ceil(log2 m), 4) —
+    checked against the oracle on the padded stripe; then n - k random losses over data and parity are decoded and repaired."""
+    torch = torch_cuda
+    rng = np.random.default_rng(k * 7 + m)
+    lg = max(1, int(np.ceil(np.log2(k))))
+    N = 1 << lg
+    stride = 1 << min(lg - int(np.ceil(np.log2(m))) if m > 1 else lg, 4)
+    x = rand_stripe(rng, k, elems)
+    xpad = np.zeros((N, 2 * elems), dtype=np.uint64)
+    xpad[:k] = x
+    want = orc61.encode(xpad)[::stride][:m]
+    with fe.Encoder(k + m, k, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        dx = to_dev(torch, x)
+        out = torch.full((m * 2 * elems,), 7, dtype=torch.int64, device="cuda:0")
+        enc.encode(dx, out)
+        torch.cuda.synchronize()
+        assert (to_host(out).reshape(m, 2 * elems) == want).all()
+        assert (to_host(dx).reshape(x.shape) == x).all()
+        host_out = np.empty_like(want)
+        enc.encode(x, host_out, mem=fe.MEM_HOST)
+        assert (host_out == want).all()
+        if m <= k:
+            enc.encode(dx)  # in place
+            got = to_host(dx).reshape(x.shape)
+            assert (got[:m] == want).all() and (got[m:] == x[m:]).all()
+        for nlost in sorted({1, min(m, 5), m}):
+            lost = rng.permutation(k + m)[:nlost]
+            dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+            dp[lost[lost < k]] = 0
+            pp[lost[lost >= k] - k] = 0
+            bad_x, bad_p = x.copy(), want.copy()
+            bad_x[dp == 0] = 11
+            bad_p[pp == 0] = 13
+            enc.decode_prepare(dp, pp)
+            d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+            enc.decode(d, q)
+            torch.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all(), nlost
+            assert (to_host(q).reshape(want.shape) == bad_p).all(), nlost
+            enc.repair(d, q)
+            torch.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
+        # one loss too many
+        if m < k:
+            dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+            dp[: m + 1] = 0
+            with pytest.raises(fe.FastEccError):
+                enc.decode_prepare(dp, pp)
