@@ -87,6 +87,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                const uint32_t* tw_dit, hipStream_t st, uint32_t col0 = 0, uint32_t width = 0, hipEvent_t first_done = nullptr,
                uint32_t batch = 1, const CallBounds& cb = CallBounds())
 {
+    if (!tw_dif || !tw_dit) return FASTECC_E_DEVICE;  // twiddle_table failed (detail recorded)
+    if (&plan == &c->encode_plan && !c->dscale) return FASTECC_E_UNSUPPORTED;  // create_ntt_ctx: no per-block factors, no encode
     if (width == 0) width = (uint32_t)c->S;
     in += col0;
     out += col0;
@@ -111,7 +113,8 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         }
         const bool above_mid = folded && p.mode == MODE_DIT;
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
-        const uint32_t* twd = above_mid ? c->tw_fold_dit : tw_dit;
+        const uint32_t* twd = above_mid ? twiddle_table(c, TW_FOLD_DIT) : tw_dit;
+        if (!twd) return FASTECC_E_DEVICE;
         const uint64_t rows_moved = !folded ? 2 * c->N : p.mode == MODE_DIF ? 2 * c->N : p.mode == MODE_MID ? c->N + c->M : 2 * c->M;
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), rows_moved * width * 4ull * batch);
         if (p.tile) {
@@ -271,7 +274,8 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
             f.out = work;
             f.dft = c->q_dft_inv;
             f.tw = c->q_tw_dif;
-            f.twl = c->tw_enc_dif;
+            f.twl = twiddle_table(c, TW_ENC_DIF);
+            if (!f.twl) return FASTECC_E_DEVICE;
             f.s = pd.s;
             f.in_rows = c->K != N1 ? (uint32_t)c->K : 0;
             snprintf(name, sizeof name, "fused%d_dif%d", c->q, pd.logr);
@@ -280,14 +284,15 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
         }
         CallBounds cbm;
         cbm.dscale_whole = true;
-        const int rcm = run_passes(c, c->encode_plan, work, work, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, (uint32_t)c->q, cbm);
+        const int rcm = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, (uint32_t)c->q, cbm);
         if (rcm != FASTECC_OK) return rcm;
         {
             f.in = work;
             f.out = parity;
             f.dft = c->q_dft_fwd;
             f.tw = c->q_tw_dit;
-            f.twl = c->tw_enc_dit;
+            f.twl = twiddle_table(c, TW_ENC_DIT);
+            if (!f.twl) return FASTECC_E_DEVICE;
             f.s = pu.s;
             f.in_rows = 0;
             f.out_rows = c->Mu != N1 ? (uint32_t)c->Mu : 0;
@@ -314,7 +319,7 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
     }
     CallBounds cb;
     cb.dscale_whole = true;
-    const int rc = run_passes(c, c->encode_plan, work, work, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, (uint32_t)c->q, cb);
+    const int rc = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, (uint32_t)c->q, cb);
     if (rc != FASTECC_OK) return rc;
     {
         a.in = work;
@@ -397,7 +402,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
     const int H = c->slabs;
     const bool slabbed = c->fold == 0 && c->cosets == 1 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
                          (c->S % (32u * H)) == 0;
-    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, 1, cb);
+    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, 1, cb);
 
     // Column slabs are independent transforms.  Slab h runs on its own stream and starts when slab h-1 has
     // finished its first pass, so that at any time the GPU holds one slab in each kind of pass: the
@@ -407,7 +412,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
         // one slab after the other on the caller's stream: a slab's three passes follow each other closely enough for the
         // second and third to find it in the memory-side cache (256 MB) when the slab is small enough
         for (int h = 0; h < H; h++) {
-            const int rc1 = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, st, h * width, width, nullptr, 1, cb);
+            const int rc1 = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, h * width, width, nullptr, 1, cb);
             if (rc1 != FASTECC_OK) return rc1;
         }
         return FASTECC_OK;
@@ -419,7 +424,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
         hipStream_t sh = c->slab_stream[h];
         HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
         if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));
-        rc = run_passes(c, c->encode_plan, data, parity, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width, c->slab_first_done[h], 1, cb);
+        rc = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), sh, h * width, width, c->slab_first_done[h], 1, cb);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipEventRecord(c->slab_done[h], sh));
         HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
@@ -443,7 +448,7 @@ int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, h
     const size_t pitch = (size_t)c->S * 4;
     if (H == 1) {
         HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
-        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, c->tw_enc_dif, c->tw_enc_dit, st);
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
         return FASTECC_OK;
@@ -459,7 +464,7 @@ int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, h
         HIP_TRY(hipMemcpy2DAsync(c->dbuf + (size_t)h * width, pitch, data + (size_t)h * width, pitch, (size_t)width * 4, c->N,
                                  hipMemcpyHostToDevice, sh));
         HIP_TRY(hipEventRecord(c->slab_first_done[h], sh));
-        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, c->tw_enc_dif, c->tw_enc_dit, sh, h * width, width);
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), sh, h * width, width);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpy2DAsync(parity + (size_t)h * width, pitch, c->dbuf + (size_t)h * width, pitch, (size_t)width * 4, c->N,
                                  hipMemcpyDeviceToHost, sh));
@@ -475,7 +480,7 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
         P61Hooks hk(c);
         return p61::ntt(c->p61, (uint64_t*)data, inverse, st, c->profiling ? &hk.h : nullptr);
     }
-    const uint32_t* tw = inverse ? c->tw_ntt_inv : c->tw_ntt_fwd;
+    const uint32_t* tw = inverse ? twiddle_table(c, TW_NTT_INV) : twiddle_table(c, TW_NTT_FWD);
     int rc = run_passes(c, c->ntt_plan, data, data, tw, tw, st);
     if (rc != FASTECC_OK) return rc;
     if (c->n >= 2) {
@@ -522,6 +527,7 @@ using CallLock = std::lock_guard<std::mutex>;
 
 static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64_t block_bytes, int field, int device, int fold,
                        int cosets, const uint32_t* custom_factor);
+static const uint32_t* const NTT_ONLY = reinterpret_cast<const uint32_t*>(~(uintptr_t)0);  // custom_factor value: see create_ntt_ctx
 
 // Turns a fresh (2N, N) context into the power-of-two core of a transform of order q * N: the per-block factors for all
 // q stripes (position j1*N + r holds coefficient q*bitrev(r) + j1 -> w_(2qN)^coefficient / (qN), RS.cpp:51-54 with qN for
@@ -789,16 +795,18 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
 
     // ---- tables: per-level twiddles for the plan, and the per-block factors w_2N^i / N of RS.cpp:51-54 ----
     const uint64_t N = k;
-    std::vector<uint32_t> dsc(N * cosets);
+    const bool ntt_only = custom_factor == NTT_ONLY;  // create_ntt_ctx: the stand-alone transform's passes only, no per-block factors
+    if (ntt_only) custom_factor = nullptr;
+    std::vector<uint32_t> dsc(ntt_only ? 0 : N * cosets);
     const uint32_t invN = gf::h_inv((uint32_t)N);
-    if (custom_factor) c->encode_direct_max = 0;  // a transform context is not the encoder's polynomial evaluation: always the pipeline
+    if (custom_factor || ntt_only) c->encode_direct_max = 0;  // a transform context is not the encoder's polynomial evaluation: always the pipeline
     for (int t = 0; t < cosets && custom_factor; t++) {
         for (uint64_t i = 0; i < N; i++) {
             const uint32_t f = custom_factor[i] >= gf::P ? custom_factor[i] - gf::P : custom_factor[i];
             dsc[bitrev_host((uint32_t)i, lg)] = gf::h_mont_mul(f, gf::MONT_R2);
         }
     }
-    for (int t = 0; t < cosets && !custom_factor; t++) {
+    for (int t = 0; t < cosets && !custom_factor && !ntt_only; t++) {
         // coset t: generator w_(2^j k)^c with j = floor(log2(t + 1)) + 1 and c the (t + 2 - 2^(j-1))-th odd number
         int j = 1;
         while ((1 << j) - 1 <= t) j++;
@@ -812,9 +820,9 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
         }
     }
     int rc = upload_twiddles(c);
-    if (rc == FASTECC_OK) rc = upload_table(&c->dscale, dsc);
+    if (rc == FASTECC_OK && !ntt_only) rc = upload_table(&c->dscale, dsc);
     if (rc == FASTECC_OK) {
-        const hipError_t e = hipMalloc((void**)&c->factor, N * 4);
+        const hipError_t e = hipMalloc((void**)&c->factor, (ntt_only ? 2 : N) * 4);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(factor)");
     }
     if (rc != FASTECC_OK) {
@@ -864,6 +872,47 @@ int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int
     return create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, factor);
 }
 
+int create_ntt_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int device)
+{
+    if (!out || log2k < 1 || log2k > 20 || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
+    *out = nullptr;
+    const uint64_t k = 1ull << log2k;
+    return create_impl(out, 2 * k, k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, 0, 1, NTT_ONLY);
+}
+
+namespace {
+// dscale[bitrev(m)] = m * scale in Montgomery form; scale_mm = scale * 2^64 mod p (mul_mont divides by 2^32 once)
+__global__ __launch_bounds__(256) void ramp_factor_kernel(uint32_t* __restrict__ dsc, uint32_t N, int lg, uint32_t scale_mm)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < N) dsc[__brev(m) >> (32 - lg)] = gf::mul_mont(m, scale_mm);
+}
+}  // namespace
+
+int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device)
+{
+    if (!out || log2k < 1 || log2k > 20 || fold < 0 || fold > 4 || fold > log2k || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
+    *out = nullptr;
+    const uint64_t k = 1ull << log2k;
+    int rc = create_impl(out, k + (k >> fold), k, log2k, block_bytes, FASTECC_FIELD_GF_FFF00001, device, fold, 1, NTT_ONLY);
+    if (rc != FASTECC_OK) return rc;
+    fastecc_ctx* c = *out;
+    DeviceGuard dg(device);
+    hipError_t e = dg.ok ? hipMalloc((void**)&c->dscale, k * 4) : hipErrorInvalidDevice;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ramp_factor_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, nullptr, c->dscale, (uint32_t)k, log2k,
+                           gf::h_to_mont(gf::h_to_mont(scale % gf::P)));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        rc = hip_fail(e, "create_ramp_transform_ctx");
+        fastecc_destroy(c);
+        *out = nullptr;
+    }
+    return rc;
+}
+
 int create_mixed_transform_ctx(fastecc_ctx** out, int q, int log2m, uint64_t block_bytes, const uint32_t* factor, int device)
 {
     if (!out || !factor || !radix_supported(q) || log2m < 1 || log2m > 20 || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
@@ -897,7 +946,7 @@ int mixed_dif(fastecc_ctx* c, const uint32_t* in, uint32_t* out, hipStream_t st)
     a.dft = c->q_dft_inv;
     a.tw = c->q_tw_dif;
     HIP_TRY(launch_radix(c->q, false, vec, a, st));
-    return run_passes(c, c->ntt_plan, out, out, c->tw_ntt_inv, c->tw_ntt_inv, st, 0, 0, nullptr, (uint32_t)c->q);
+    return run_passes(c, c->ntt_plan, out, out, twiddle_table(c, TW_NTT_INV), twiddle_table(c, TW_NTT_INV), st, 0, 0, nullptr, (uint32_t)c->q);
 }
 
 int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit, bool inverse_roots, uint32_t width, hipStream_t st)
@@ -905,7 +954,7 @@ int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit
     if (c->p61 || c->sharded || c->q > 1 || c->ntt_plan.empty() || width == 0 || width > c->S) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
-    const uint32_t* tw = inverse_roots ? c->tw_ntt_inv : c->tw_ntt_fwd;
+    const uint32_t* tw = inverse_roots ? twiddle_table(c, TW_NTT_INV) : twiddle_table(c, TW_NTT_FWD);
     if (!dit) return run_passes(c, c->ntt_plan, in, out, tw, tw, st, 0, width);
     // the stand-alone plan mirrored: the same chunks bottom up as DIT passes; level for level the same register runs, so
     // the level-packed tables of the DIF plan serve both
@@ -927,7 +976,7 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     CallBounds cb;
     cb.gather_odd = odd_blocks;
     cb.gather_factor = row_factor;
-    return run_passes(c, c->encode_plan, even_blocks, out, c->tw_enc_dif, c->tw_enc_dit, st, 0, 0, nullptr, 1, cb);
+    return run_passes(c, c->encode_plan, even_blocks, out, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, 1, cb);
 }
 
 bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
@@ -1093,7 +1142,7 @@ int fastecc_encode_columns(fastecc_ctx* c, const void* data, void* parity, uint6
         return p61::encode_columns(c->p61, (const uint64_t*)data, (uint64_t*)parity, col0 / 4, width / 4, (hipStream_t)stream,
                                    c->profiling ? &hk.h : nullptr);
     }
-    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream,
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), (hipStream_t)stream,
                       (uint32_t)col0, (uint32_t)width);
 }
 
@@ -1107,7 +1156,7 @@ int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     CallLock lk(c->mu);
-    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, c->tw_enc_dif, c->tw_enc_dit, (hipStream_t)stream, 0, 0,
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), (hipStream_t)stream, 0, 0,
                       nullptr, (uint32_t)count);
 }
 

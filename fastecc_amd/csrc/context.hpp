@@ -110,6 +110,7 @@ struct fastecc_ctx {
     uint32_t* tw_enc_dit = nullptr;  // forward roots, same ordering (the DIT passes mirror the DIF ones)
     uint32_t* tw_ntt_fwd = nullptr;  // forward roots, ordered for the stand-alone transform's passes
     uint32_t* tw_ntt_inv = nullptr;  // inverse roots, same ordering
+    unsigned tw_ready = 0;           // which of the five tables hold the current plan's values (bit TW_*): each is built on the device at first use
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
@@ -169,7 +170,11 @@ const char* pass_name(const Pass& p, int vec, char* buf, size_t cap);
 std::vector<int> level_strides(const std::vector<Pass>& plan, int n, bool up = false);
 std::vector<uint32_t> build_level_table(int n, uint32_t root_of_order_N, const std::vector<int>& sl);
 int upload_table(uint32_t** dst, const std::vector<uint32_t>& src);
-int upload_twiddles(fastecc_ctx* c);  // (re)build the four twiddle tables for the current plans; the device must be idle w.r.t. this context
+int upload_twiddles(fastecc_ctx* c);  // the plans changed: every twiddle table is rebuilt at its next use; the device must be idle w.r.t. this context
+// The table `which` for the current plans, built on the context's device (the current device) at first use: a context that only ever encodes
+// never builds the stand-alone transform's tables and vice versa (the decoder's ~19 internal contexts each use one kind).  nullptr on failure.
+enum { TW_ENC_DIF = 0, TW_ENC_DIT = 1, TW_NTT_FWD = 2, TW_NTT_INV = 3, TW_FOLD_DIT = 4 };
+const uint32_t* twiddle_table(fastecc_ctx* c, int which);
 
 using CallLock = std::lock_guard<std::mutex>;
 

@@ -558,21 +558,30 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
     if (!d->pattern_ntt) {
-        const std::vector<uint32_t> ones(NC, 1u);
-        const int rc = mixed ? create_mixed_transform_ctx(&d->pattern_ntt, ci.q, lgc, 8, ones.data(), ci.device)
-                             : create_transform_ctx(&d->pattern_ntt, lgc, 8, 0, ones.data(), ci.device);
+        int rc;
+        if (mixed) {
+            const std::vector<uint32_t> ones(NC, 1u);
+            rc = create_mixed_transform_ctx(&d->pattern_ntt, ci.q, lgc, 8, ones.data(), ci.device);
+        } else {
+            rc = create_ntt_ctx(&d->pattern_ntt, lgc, 8, ci.device);  // only its stand-alone transform is used
+        }
         if (rc != FASTECC_OK) return rc;
     }
     pt.mark("pattern_ntt context");
     if (!d->pattern_buf) DEC_TRY(hipMalloc((void**)&d->pattern_buf, 2 * NC * 4));
     if (!d->transform) {
-        std::vector<uint32_t> factor(NC);
+        // x p'(x): coefficient m times m, and the 1/NC of the inverse transform.  fold e: only the data positions (multiples of 2^e) are
+        // evaluated (mixed radix: all positions, the even ones are used)
         const uint32_t inv_nc = gf::h_inv((uint32_t)NC);
-        const uint32_t inv_nc_m = gf::h_to_mont(inv_nc);
-        for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mont_mul((uint32_t)m, inv_nc_m);  // x p'(x): coefficient m times m, and the 1/NC of the inverse transform
-        // fold e: only the data positions (multiples of 2^e) are evaluated (mixed radix: all positions, the even ones are used)
-        const int rc = mixed ? create_mixed_transform_ctx(&d->transform, ci.q, lgc, ci.words * 4, factor.data(), ci.device)
-                             : create_transform_ctx(&d->transform, lgc, ci.words * 4, e, factor.data(), ci.device);
+        int rc;
+        if (mixed) {
+            std::vector<uint32_t> factor(NC);
+            const uint32_t inv_nc_m = gf::h_to_mont(inv_nc);
+            for (uint64_t m = 0; m < NC; m++) factor[m] = gf::h_mont_mul((uint32_t)m, inv_nc_m);
+            rc = create_mixed_transform_ctx(&d->transform, ci.q, lgc, ci.words * 4, factor.data(), ci.device);
+        } else {
+            rc = create_ramp_transform_ctx(&d->transform, lgc, ci.words * 4, e, inv_nc, ci.device);
+        }
         if (rc != FASTECC_OK) return rc;
     }
     pt.mark("transform context");
@@ -581,9 +590,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         for (fastecc_ctx* t : d->tree_ctx)
             if (t) fastecc_destroy(t);
         d->tree_ctx.assign(lgT, nullptr);
-        const std::vector<uint32_t> ones((size_t)T, 1u);
         for (int k = leaf_log; k < lgT; k++) {
-            const int rc = create_transform_ctx(&d->tree_ctx[k], k + 1, 4 * (T >> k), 0, ones.data(), ci.device);
+            const int rc = create_ntt_ctx(&d->tree_ctx[k], k + 1, 4 * (T >> k), ci.device);
             if (rc != FASTECC_OK) return rc;
         }
         for (uint32_t** b : {&d->tree_x, &d->tree_f, &d->tree_y, &d->tree_p, &d->roots, &d->dev_erased}) {

@@ -78,6 +78,10 @@ void set_error_detail(const char* what, hipError_t e);
 // output block.  fastecc_encode(ctx, in, out, FASTECC_MEM_DEVICE, stream) runs it; k may be 2^20 (no root of order 2k
 // is needed).  The encoder of RS.cpp:40-63 is the case factor[m] = w_2k^m / k.
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device);
+// create_transform_ctx with factor[m] = m * scale, the table written by a kernel (the decoder's x p'(x) transform: scale = 1 / 2^log2k)
+int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device);
+// A context for stand-alone transforms only (fastecc_ntt, transform_bitrev): no per-block factor table is built, fastecc_encode is unsupported.
+int create_ntt_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int device);
 // The same for a transform of order q * 2^log2m (q an odd radix of mixed_kernels.hip): factor has q << log2m entries by
 // coefficient index; fastecc_encode(ctx, in, out, DEVICE, stream) maps all q << log2m blocks, in place if in == out.
 int create_mixed_transform_ctx(fastecc_ctx** out, int q, int log2m, uint64_t block_bytes, const uint32_t* factor, int device);

@@ -234,25 +234,38 @@ int device_level_table(uint32_t** dst, int n, uint32_t root_of_order_N, const st
 
 }  // namespace
 
-// (Re)build the four twiddle tables for the current plans.  The device must be idle w.r.t. this context.
+// The plans changed (or the context is new): the tables are rebuilt when they are next used.  The device must be idle w.r.t. this context.
 int upload_twiddles(fastecc_ctx* c)
 {
+    c->tw_ready = 0;
+    return FASTECC_OK;
+}
+
+const uint32_t* twiddle_table(fastecc_ctx* c, int which)
+{
+    uint32_t** slot = which == TW_ENC_DIF ? &c->tw_enc_dif : which == TW_ENC_DIT ? &c->tw_enc_dit : which == TW_NTT_FWD ? &c->tw_ntt_fwd
+                    : which == TW_NTT_INV ? &c->tw_ntt_inv : &c->tw_fold_dit;
+    if (c->tw_ready & (1u << which)) return *slot;
     const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
-    const std::vector<int> enc = level_strides(c->encode_plan, c->n), ntt = level_strides(c->ntt_plan, c->n);
-    const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
-    int rc = device_level_table(&c->tw_enc_dif, c->n, wNi, enc);  // interpolate: inverse roots (RS.cpp:41)
-    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_enc_dit, c->n, wN, enc_up);  // evaluate (RS.cpp:63)
-    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_ntt_fwd, c->n, wN, ntt);
-    if (rc == FASTECC_OK) rc = device_level_table(&c->tw_ntt_inv, c->n, wNi, ntt);
-    if (rc == FASTECC_OK && c->fold > 0) {
+    int rc = FASTECC_OK;
+    switch (which) {
+    case TW_ENC_DIF: rc = device_level_table(slot, c->n, wNi, level_strides(c->encode_plan, c->n)); break;        // interpolate: inverse roots (RS.cpp:41)
+    case TW_ENC_DIT: rc = device_level_table(slot, c->n, wN, level_strides(c->encode_plan, c->n, true)); break;   // evaluate (RS.cpp:63)
+    case TW_NTT_FWD: rc = device_level_table(slot, c->n, wN, level_strides(c->ntt_plan, c->n)); break;
+    case TW_NTT_INV: rc = device_level_table(slot, c->n, wNi, level_strides(c->ntt_plan, c->n)); break;
+    default: {
         // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
+        const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
         const int nf = c->n - c->fold;
         std::vector<int> sl(std::max(nf, 0), 0);
         for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
-        rc = device_level_table(&c->tw_fold_dit, nf, gf::h_root((uint32_t)c->M), sl);
+        rc = device_level_table(slot, nf, gf::h_root((uint32_t)c->M), sl);
     }
-    if (rc == FASTECC_OK) HIP_TRY(hipStreamSynchronize(nullptr));  // the tables are complete when this returns, like the uploads they replace
-    return rc;
+    }
+    if (rc == FASTECC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize(twiddle table)");
+    if (rc != FASTECC_OK) return nullptr;
+    c->tw_ready |= 1u << which;
+    return *slot;
 }
 
 }  // namespace fastecc
