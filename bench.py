@@ -735,19 +735,34 @@ def main():
             slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
             pslab = torch.empty_like(slab)
             wsp = {}
+            # The root keeps its slab at the full block pitch ([k][world*w] arrays, its own columns filled): with "row_pitch_words" its encoder
+            # reads the sub-slab there and writes the parity straight into the full parity blocks, so the root's part is neither sent nor
+            # re-interleaved (GF(0xFFF00001) contexts; the 64-bit field keeps the contiguous form).
+            in_place = rank == 0 and not p61
+            penc = None
+            gslab = slab
+            if in_place:
+                penc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
+                tune(penc)
+                penc.set_option("row_pitch_words", words)
+                full_data = torch.zeros((k, world, sub, wsub), dtype=slab.dtype, device=device)
+                full_data[:, 0] = slab.permute(1, 0, 2)
+                gslab = full_data[:, 0].permute(1, 0, 2)  # [sub, k, wsub] views, row stride = the full block
+
+            def gather_encode(d, o):
+                (senc if d.is_contiguous() else penc).encode(d, o, stream=torch.cuda.current_stream().cuda_stream)
 
             def encode_all():
                 for h in range(sub):
                     senc.encode(slab[h], pslab[h], stream=stream)
 
             modes = {"compute_only": encode_all,
-                     "with_gather": lambda: sharding.encode_sub_slabs_and_gather(
-                         slab, lambda d, o: senc.encode(d, o, stream=torch.cuda.current_stream().cuda_stream), k, dst=0, workspace=wsp,
-                         collective_on_host=backend != "nccl")}
+                     "with_gather": lambda: sharding.encode_sub_slabs_and_gather(gslab, gather_encode, k, dst=0, workspace=wsp,
+                                                                                collective_on_host=backend != "nccl", root_in_place=in_place)}
             sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d "
                                "contiguous sub-slab(s); with_gather adds the RCCL gather of the parity into full blocks on rank 0: no pack, "
-                               "the root's own part is encoded where it is gathered, transfers and one re-interleaving kernel per sub-slab "
-                               "run on a side stream under the next sub-slab's encode" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+                               "the root encodes its own part straight into the full blocks (row pitch = the block), the other ranks' parts travel "
+                               "and are re-interleaved by one kernel per sub-slab on a side stream under the next sub-slab's encode" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
                        "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
             for name, fn in modes.items():
                 for _ in range(max(1, args.warmup)):
@@ -756,7 +771,7 @@ def main():
                 sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
             # what was timed is also right: the gathered blocks on rank 0 hold every rank's slab where it belongs
             full = wsp.get("parity_full")
-            mine = (wsp["recv"][:, rank] if rank == 0 else wsp["send"]).permute(1, 0, 2).reshape(k, w).to(torch.int64)
+            mine = (full[:, :w].view(k, sub, wsub).permute(1, 0, 2) if rank == 0 else wsp["send"]).permute(1, 0, 2).reshape(k, w).to(torch.int64)
             sums = torch.stack([mine.sum(), (mine * torch.arange(1, w + 1, device=device)).sum()])  # wraps mod 2^64: fine for a checksum
             if world > 1:
                 sums = sums.to(device if backend == "nccl" else "cpu")
@@ -774,6 +789,8 @@ def main():
                     ok = ok and int(part.sum()) == int(want[0]) and int((part * torch.arange(1, w + 1, device=part.device)).sum()) == int(want[1])
                 sharded["gather_check"] = "ok" if ok else "FAILED"
             senc.close()
+            if penc is not None:
+                penc.close()
             del wsp, slab, pslab
         except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of this mode
             sharded = {"error": repr(e)}

@@ -149,7 +149,8 @@ def split_into_sub_slabs(slab, sub_slabs):
     return slab.view(rows, sub_slabs, w // sub_slabs).permute(1, 0, 2).contiguous()
 
 
-def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=None, dst=0, group=None, collective_on_host=False, workspace=None):
+def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=None, dst=0, group=None, collective_on_host=False, workspace=None,
+                                root_in_place=False):
     """The gather of BASELINE configs[3] without a pack and with ONE re-interleaving kernel per sub-slab on the root.
 
     A rank's slab is resident as H contiguous SUB-SLABS (data_sub: [H, k, ws], words [rank*w + h*ws, ...) of every block, w = H*ws),
@@ -161,6 +162,10 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
                                                   on a side stream, so sub-slab h travels while sub-slab h+1 is being encoded
         parity_full[:, g*w + h*ws ...] <- recv    root: one strided kernel for all `world` pieces of the sub-slab, on the side
                                                   stream as well (it overlaps the next encode and the next transfer)
+
+    root_in_place: the root's encode_fn accepts row-strided tensors (an encoder with the "row_pitch_words" option set to the full block), its
+    data sub-slabs are views into a [k, world*w] array, and its parity is written straight into its columns of parity_full — the root's part
+    is then neither gathered nor re-interleaved (at world = 1 the call is the encode itself).
 
     Returns (this rank's parity sub-slabs [H, rows, ws], parity_full [rows, world*w] on the root or None).  workspace: dict keeping
     the buffers and the side stream between calls.  collective_on_host: the CPU / gloo form of the same control flow (tests).
@@ -187,10 +192,15 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
 
     # root: [H][world][rows][ws], its own results land in [:, rank]; other ranks: [H][rows][ws]
     recv = buf("recv", (H, world, parity_rows, ws)) if root else None
-    mine = recv[:, rank] if root else buf("send", (H, parity_rows, ws))
     if root and parity_full is None:
         parity_full = buf("parity_full", (parity_rows, world * w))
     full4 = parity_full.view(parity_rows, world, H, ws) if root else None
+    in_place = bool(root_in_place and root)
+    if in_place:
+        mine = full4[:, rank].permute(1, 0, 2)  # [H, rows, ws] views into the full blocks
+        others = [g for g in range(world) if g != rank]
+    else:
+        mine = recv[:, rank] if root else buf("send", (H, parity_rows, ws))
     on_gpu = dev.type == "cuda" and not collective_on_host
     if on_gpu:
         side = ws_.get("side_stream")
@@ -203,19 +213,29 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if world > 1:
-                    dist.gather(mine[h], gather_list=[recv[h, g] for g in range(world)] if root else None, dst=dst, group=group, async_op=True).wait()
-                if root:
+                    piece = recv[h, rank] if in_place else mine[h]  # in place: the root's slot of the gather is a dummy, its part is already home
+                    dist.gather(piece, gather_list=[recv[h, g] for g in range(world)] if root else None, dst=dst, group=group, async_op=True).wait()
+                if root and not in_place:
                     full4[:, :, h, :].copy_(recv[h].permute(1, 0, 2), non_blocking=True)
+                elif root and others:
+                    idx = ws_.get("others_idx")
+                    if idx is None:
+                        idx = ws_["others_idx"] = torch.tensor(others, device=dev)
+                    full4[:, :, h, :].index_copy_(1, idx, recv[h].index_select(0, idx).permute(1, 0, 2))
         else:
             if world > 1:
-                piece = mine[h].cpu() if collective_on_host else mine[h]
+                piece = mine[h].contiguous().cpu() if collective_on_host else mine[h].contiguous()
                 got = [torch.empty_like(piece) for _ in range(world)] if root else None
                 dist.gather(piece, gather_list=got, dst=dst, group=group)
                 if root:
                     for g in range(world):
-                        recv[h, g].copy_(got[g])
-            if root:
+                        if not (in_place and g == rank):
+                            recv[h, g].copy_(got[g])
+            if root and not in_place:
                 full4[:, :, h, :].copy_(recv[h].permute(1, 0, 2))
+            elif root:
+                for g in others:
+                    full4[:, g, h, :].copy_(recv[h, g])
     if on_gpu:
         main.wait_stream(side)  # the call behaves as one operation on the caller's stream
     return mine, (parity_full if root else None)

@@ -120,9 +120,9 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * RS.cpp:40-63 with N1 for N (k < N1: zero extension as in RS.md:23-33; the first n - k <= N1 of the N1 parity blocks
  * are the parity).  With q = 1 this IS fastecc_create; otherwise it is a different code than the zero-extended power-of-
  * two one fastecc_create builds for the same (n,k) — a stripe must be decoded with the flags it was encoded with.
- * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile, and decode_prepare / decode / repair for
- * orders up to 2^20 (the locator's product tree needs w_T, T the power of two >= the order; patterns of at most 16 lost blocks
- * do not use it and are repaired at every order).  The odd-radix
+ * k <= 15 * 2^19.  GF(0xFFF00001); encode, encode_blocks, check_range, set_plan, profile, and decode_prepare / decode / repair
+ * (orders above 2^20: patterns of up to 2^20 erasures — the locator's product tree needs w_T for its T padded roots and this field
+ * stops at order 2^20; patterns of at most 256 lost blocks do not use the tree at any order).  The odd-radix
  * level is fused into the outermost tile passes where a shape exists (2^m with m <= 16..18 depending on q: three trips through
  * HBM, like the power-of-two orders; option "fuse_radix" = 0 gives it its own two passes); measured against zero extension in
  * profiles/r02/mixed_radix_bench.jsonl: faster than zero extension for q <= 9.

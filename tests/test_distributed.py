@@ -73,6 +73,25 @@ def _worker(rank, world, port, N, S, sub_slabs, use_gpu, q):
             got_mine = mine.permute(1, 0, 2).reshape(N, w).cpu().numpy().view(np.uint32)
             ok_slab = ok_slab and np.array_equal(got_mine, want[:, rank * w:(rank + 1) * w])
             ok_cols = ok_cols and ((full2 is None) if rank != 0 else np.array_equal(full2.cpu().numpy().view(np.uint32), want))
+        # (1a') the root's slab lives in full-pitch arrays and its parity is written straight into the full blocks
+        if rank == 0:
+            full_data = torch.zeros((N, world, H, w // H), dtype=torch.int32, device=my_slab.device)
+            full_data[:, 0] = my_slab.view(N, H, w // H)
+            sub0 = full_data[:, 0].permute(1, 0, 2)
+        else:
+            sub0 = sub
+        if use_gpu:
+            pitched = fastecc_amd.Encoder(2 * N, N, 4 * (w // H), device=0)
+            pitched.set_option("row_pitch_words", world * w)
+            def sub_fn2(d, o):
+                (sub_enc if d.is_contiguous() else pitched).encode(d, o)
+        else:
+            sub_fn2 = sub_fn
+        mine3, full3 = sharding.encode_sub_slabs_and_gather(sub0, sub_fn2, N, dst=0, collective_on_host=use_gpu, workspace={}, root_in_place=True)
+        if use_gpu:
+            torch.cuda.synchronize()
+            pitched.close()
+        ok_cols = ok_cols and ((full3 is None) if rank != 0 else np.array_equal(full3.cpu().numpy().view(np.uint32), want))
         if use_gpu:
             sub_enc.close()
 
