@@ -16,6 +16,10 @@ except Exception as e:
     print("p61 parse failed", e)
 PY
 FASTECC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --log2k 16 > "$OUT/bench_gloo2.json" 2> "$OUT/bench_gloo2.err"; echo "gloo2 rc=$?"; tail -c 1800 "$OUT/bench_gloo2.json"; tail -3 "$OUT/bench_gloo2.err"
+FASTECC_TRACE_PREPARE=1 timeout 300 python tools/trace_prepare.py > "$OUT/prepare_trace.txt" 2>&1; grep -v amdgpu "$OUT/prepare_trace.txt"
+R=$(pwd)
+for E in 16 64 256; do bash tools/prof_traffic.sh "$OUT/t$E" python $R/tools/run_direct_decode.py $E 2 > "$OUT/traffic$E.json" 2>&1; done
+timeout 300 python tools/bench_decode.py > "$OUT/decode_bench.json" 2> "$OUT/decode_bench.err"; tail -c 600 "$OUT/decode_bench.json"; echo
 timeout 600 python tools/bench_direct.py > "$OUT/direct_bench.jsonl" 2> "$OUT/direct_bench.err"; echo "direct rc=$?"; python - "$OUT/direct_bench.jsonl" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):

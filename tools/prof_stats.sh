@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/stats}
 shift || true
 REPO=$(pwd); export TMPDIR=/tmp
-if [ $# -eq 0 ]; then set -- python "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-sharded --no-parity-check; fi
+if [ $# -eq 0 ]; then set -- python "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-sharded --no-parity-check --no-other-paths; fi
 mkdir -p "$OUT"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$REPO/$OUT" -o bench --output-format csv -- "$@" ) > "$OUT/run.log" 2>&1
 ls "$OUT" >> "$OUT/run.log"
