@@ -52,6 +52,14 @@ __device__ __forceinline__ uint32_t dev_pow(uint32_t x, uint32_t e)
     return r;
 }
 
+// Weight table layout: [rows][pad] for pad <= 16; beyond that [pad / 16][rows][16] — one 64-byte run per row and sweep of 16 outputs, so that
+// the builders (one thread per row, walking the outputs) and the VALU kernel (one scalar load per row and sweep) both touch whole 64-byte
+// runs.  ([rows][pad] with pad up to 256 made every access of the row-walking builders its own cache line: 15 GB of HBM traffic for a 0.5 GB table.)
+__host__ __device__ __forceinline__ size_t coef_index(uint32_t row, uint32_t out, uint32_t rows, uint32_t pad)
+{
+    return pad <= 16u ? (size_t)row * pad + out : ((size_t)(out >> 4) * rows + row) * 16u + (out & 15u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // VALU form
 // ------------------------------------------------------------------------------------------------
@@ -106,7 +114,9 @@ __global__ __launch_bounds__(256) void direct_accumulate_kernel(const AccArgs a)
 #pragma unroll
         for (int v = 0; v < V; ++v) lo[j][v] = 0, hi[j][v] = 0;
     const uint32_t u0 = a.row_begin + chunk * a.rows_per_chunk, u1 = min(u0 + a.rows_per_chunk, a.rows);
-    const_u32_ptr coef = as_constant(a.coef) + (size_t)sweep * EB;
+    // pad <= 16: one sweep, rows of `pad` weights; else sweep-major runs of 16 (coef_index)
+    const uint32_t cstride = a.pad <= 16u ? a.pad : 16u;
+    const_u32_ptr coef = as_constant(a.coef) + (size_t)sweep * a.rows * 16u;
     for (uint32_t ub = u0; ub < u1; ub += U) {
         uint32_t w[U][EB], x[U][V];
 #pragma unroll
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256) void direct_accumulate_kernel(const AccArgs a)
 #pragma unroll
             for (int j = 0; j < EB; ++j) w[i][j] = 0;
             if (in) {
-                const_u32_ptr cf = coef + (size_t)u * a.pad;
+                const_u32_ptr cf = coef + (size_t)u * cstride;
 #pragma unroll
                 for (int j = 0; j < EB; ++j) w[i][j] = cf[j];
             }
@@ -192,8 +202,8 @@ __device__ __forceinline__ uint32_t balanced_digits(uint32_t x)
 // Lane l: m = l & 31 = 4 j' + b (output 8 mt + j', digit b of the weight), half = l >> 5; its 16 bytes, index 4 i + a: digit b of
 // 256^a * w[row 8 ks + 4 half + i][output] — k' = (row, a) pairs with digit a of the data word of that row (B operand, same index).
 // frag[(ks * MTtot + mt) * 64 + l] as uint4.  coef: [rows][pad] Montgomery form.
-__global__ __launch_bounds__(256) void mfma_weights_kernel(const uint32_t* __restrict__ coef, uint4* __restrict__ frag, uint32_t rows, uint32_t pad, uint32_t mt_total,
-                                                           uint64_t total)
+__global__ __launch_bounds__(256) void mfma_weights_kernel(const uint32_t* __restrict__ coef, uint4* __restrict__ frag, uint32_t rows, uint32_t table_rows, uint32_t pad,
+                                                           uint32_t mt_total, uint64_t total)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256) void mfma_weights_kernel(const uint32_t* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint64_t u = 8ull * ks + 4u * half + i;
-        uint32_t w = (u < rows && out < pad) ? gf::mul_mont(coef[u * pad + out], 1u) : 0u;  // plain representative
+        uint32_t w = (u < rows && out < pad) ? gf::mul_mont(coef[coef_index((uint32_t)u, out, table_rows, pad)], 1u) : 0u;  // plain representative
         uint32_t packed = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -371,20 +381,20 @@ __global__ __launch_bounds__(256) void lagrange_coef_kernel(uint32_t* __restrict
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const uint32_t xi = dev_pow(wd, i);
-    uint32_t* row = coef + (size_t)i * pad;
+    auto at = [&](int t) -> uint32_t& { return coef[coef_index(i, (uint32_t)t, K, (uint32_t)pad)]; };
     uint32_t run = 1;
     for (int t = 0; t < outputs; ++t) {
-        row[t] = run;
+        at(t) = run;
         run = gf::mul(run, gf::sub(params[t], xi));  // never zero: a parity point is not a data point
     }
     uint32_t inv = dev_pow(run, gf::P - 2u);
     for (int t = outputs - 1; t >= 0; --t) {
         const uint32_t d = gf::sub(params[t], xi);
-        const uint32_t invd = gf::mul(inv, row[t]);  // 1 / (y_t - x_i)
+        const uint32_t invd = gf::mul(inv, at(t));  // 1 / (y_t - x_i)
         inv = gf::mul(inv, d);
-        row[t] = gf::mul(gf::mul(gf::mul(params[DIRECT_CAP + t], xi), invd), gf::MONT_ONE);
+        at(t) = gf::mul(gf::mul(gf::mul(params[DIRECT_CAP + t], xi), invd), gf::MONT_ONE);
     }
-    for (int t = outputs; t < pad; ++t) row[t] = 0;
+    for (int t = outputs; t < pad; ++t) at(t) = 0;
 }
 
 // Interpolation on the N nodes {x_i : i not lost} + {y_a}: R the lost data rows (points x_r), A as many surviving parity points y_a,
@@ -404,30 +414,31 @@ __global__ __launch_bounds__(256) void interp_params_kernel(uint32_t* __restrict
     }
     params[2 * DIRECT_CAP + r] = gf::sub(0u, gf::mul(A, dev_pow(gf::mul(xr, Rr), gf::P - 2u)));
 }
-__global__ __launch_bounds__(256) void interp_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t wd, uint32_t K, int ed, int pad)
+__global__ __launch_bounds__(256) void interp_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t wd, uint32_t K, uint32_t rows, int ed,
+                                                          int pad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const uint32_t xi = dev_pow(wd, i);
-    uint32_t* row = coef + (size_t)i * pad;
+    auto at = [&](int t) -> uint32_t& { return coef[coef_index(i, (uint32_t)t, rows, (uint32_t)pad)]; };
     uint32_t A = 1, run = 1;
     for (int t = 0; t < ed; ++t) {
         A = gf::mul(A, gf::sub(xi, params[DIRECT_CAP + t]));
-        row[t] = run;  // prod_{s < t} (x_i - x_s)
+        at(t) = run;  // prod_{s < t} (x_i - x_s)
         run = gf::mul(run, gf::sub(xi, params[t]));
     }
     if (run == 0) {  // x_i is one of the lost points: the row is not a node
-        for (int t = 0; t < pad; ++t) row[t] = 0;
+        for (int t = 0; t < pad; ++t) at(t) = 0;
         return;
     }
     const uint32_t base = gf::mul(xi, dev_pow(A, gf::P - 2u));  // x_i / A(x_i)
     uint32_t suf = 1;
     for (int r = ed - 1; r >= 0; --r) {
-        const uint32_t v = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + r], base), row[r]), suf);
+        const uint32_t v = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + r], base), at(r)), suf);
         suf = gf::mul(suf, gf::sub(xi, params[r]));
-        row[r] = gf::mul(v, gf::MONT_ONE);
+        at(r) = gf::mul(v, gf::MONT_ONE);
     }
-    for (int t = ed; t < pad; ++t) row[t] = 0;
+    for (int t = ed; t < pad; ++t) at(t) = 0;
 }
 // thread (a, r): the weight of parity node a in lost row r -> coef[K + a][r]
 __global__ __launch_bounds__(256) void interp_node_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t K, uint32_t N, int ed, int pad)
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(256) void interp_node_kernel(uint32_t* __restrict__
         const uint32_t den = gf::mul(gf::mul(gf::mul(xr, Rr), gf::sub(dev_pow(ya, N), 1u)), Aa_ya);
         v = gf::mul(gf::mul(num, dev_pow(den, gf::P - 2u)), gf::MONT_ONE);
     }
-    coef[((size_t)K + a) * pad + r] = v;
+    coef[coef_index(K + (uint32_t)a, (uint32_t)r, K + (uint32_t)ed, (uint32_t)pad)] = v;
 }
 
 int hip_code(const char* what, hipError_t e)
@@ -560,7 +571,7 @@ int direct_build_interp(DirectPass* p, uint32_t wd, uint64_t N, uint32_t K, cons
     DIR_TRY(hipMemcpyAsync(p->lists, node_rows.data(), ed * 4, hipMemcpyHostToDevice, st));
     DIR_TRY(hipMemcpyAsync(p->lists + DIRECT_CAP, pos.data(), ed * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(interp_params_kernel, dim3((ed + 255) / 256), dim3(256), 0, st, p->params, ed);
-    hipLaunchKernelGGL(interp_coef_kernel, dim3((K + 255) / 256), dim3(256), 0, st, p->coef, p->params, wd, K, ed, p->pad);
+    hipLaunchKernelGGL(interp_coef_kernel, dim3((K + 255) / 256), dim3(256), 0, st, p->coef, p->params, wd, K, K + (uint32_t)ed, ed, p->pad);
     hipLaunchKernelGGL(interp_node_kernel, dim3((unsigned)(((uint64_t)ed * p->pad + 255) / 256)), dim3(256), 0, st, p->coef, p->params, K, (uint32_t)(N % gf::P), ed, p->pad);
     DIR_TRY(hipGetLastError());
     DIR_TRY(hipStreamSynchronize(st));
@@ -624,7 +635,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
             const uint64_t count = (uint64_t)steps_alloc * mt_total * 64u;
             const int rc = ensure(p->frag, p->frag_count, count);
             if (rc != FASTECC_OK) return rc;
-            hipLaunchKernelGGL(mfma_weights_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, p->coef, p->frag, bulk, (uint32_t)p->pad, mt_total, count);
+            hipLaunchKernelGGL(mfma_weights_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, p->coef, p->frag, bulk, rows, (uint32_t)p->pad, mt_total, count);
             DIR_TRY(hipGetLastError());
             p->frag_valid = true;
             p->mfma_pad = pad;

@@ -213,7 +213,9 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if world > 1:
-                    piece = recv[h, rank] if in_place else mine[h]  # in place: the root's slot of the gather is a dummy, its part is already home
+                    # in place: the root's part is already home; its slot of the gather gets a scratch tensor (distinct memory from the
+                    # receive slot, so that no backend has to cope with an input that aliases its own output)
+                    piece = buf("root_dummy", (parity_rows, ws)) if in_place else mine[h]
                     dist.gather(piece, gather_list=[recv[h, g] for g in range(world)] if root else None, dst=dst, group=group, async_op=True).wait()
                 if root and not in_place:
                     full4[:, :, h, :].copy_(recv[h].permute(1, 0, 2), non_blocking=True)
