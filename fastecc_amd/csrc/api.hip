@@ -970,7 +970,8 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     if (c->encode_plan.empty() || c->p61) return FASTECC_E_UNSUPPORTED;
     const Pass& p0 = c->encode_plan[0];
     if (p0.mode != MODE_DIF || p0.s < 1 || (p0.tile && p0.wide != 2)) return FASTECC_E_UNSUPPORTED;
-    if (c->fold == 0 && c->cosets == 1) return FASTECC_E_UNSUPPORTED;  // needs the staged form (first pass writes the scratch stripe)
+    // unstaged plans (fold 0: the first pass writes `out`, the rest runs in place on it) recognise the first pass by its source: `out` must be another buffer
+    if (c->fold == 0 && c->cosets == 1 && (const uint32_t*)out == even_blocks) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     CallBounds cb;

@@ -47,6 +47,12 @@ struct DecodeState {
     uint32_t* fin_first_pass = nullptr;  // the same in the order the transform's first pass reads them (may equal fin)
     uint32_t* srcmap = nullptr;        // per codeword position: the block that sits there (row, bit 31 = parity stripe)
     uint32_t* gout = nullptr;          // k factors by data block: 1 / (w^2i l'(w^2i)) (Montgomery) if erased, else 0
+    // fastecc_repair of the (2k,k) layout in ONE transform: the same x p'(x) evaluated at ALL 2k positions (fold 0) gives the lost parity
+    // blocks as well, f(w^u) = (x p')(w^u) / (w^u l'(w^u)) at odd u — instead of decoding the data and encoding it once more
+    fastecc_ctx* transform_full = nullptr;
+    uint32_t* gout_par = nullptr;       // k factors by parity block: 1 / (w^(2q+1) l'(w^(2q+1))) (Montgomery) if erased, else 0
+    uint32_t* recovered_full = nullptr; // 2k blocks: x p'(x) at every position (lazy: 4 GiB at the headline size)
+    bool full_ok = false;               // transform_full's first pass reads the factors in the same order as transform's
     uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
     // fastecc_decode_prepare's device state (lazy): the product tree of the locator
@@ -85,6 +91,9 @@ void destroy_decode_state(DecodeState* d)
 {
     if (!d) return;
     if (d->transform) fastecc_destroy(d->transform);
+    if (d->transform_full) fastecc_destroy(d->transform_full);
+    if (d->gout_par) (void)hipFree(d->gout_par);
+    if (d->recovered_full) (void)hipFree(d->recovered_full);
     if (d->pattern_ntt) fastecc_destroy(d->pattern_ntt);
     if (d->pattern_buf) (void)hipFree(d->pattern_buf);
     if (d->fin_first_pass && d->fin_first_pass != d->fin) (void)hipFree(d->fin_first_pass);
@@ -208,7 +217,8 @@ __global__ __launch_bounds__(256) void locator_columns_kernel(const uint32_t* __
 //   gout[i] = 1 / (w^u l'(w^u)) (Montgomery) for erased data block i at u = i << e   (x l')(w^u) = (x L')(w^u) w^(-u pad) there
 __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __restrict__ lv, const uint32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ wpow, uint32_t* __restrict__ fin, uint32_t* __restrict__ gout,
-                                                            uint32_t NC, uint32_t pad, int e, uint32_t user_k, uint32_t q, int lg2)
+                                                            uint32_t NC, uint32_t pad, int e, uint32_t user_k, uint32_t q, int lg2,
+                                                            uint32_t* __restrict__ gout_par = nullptr)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
@@ -228,6 +238,8 @@ __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __re
         uint32_t g = 0;
         if (st == ST_LOST && i < user_k) g = gf::mul(dev_pow(gf::mul(lv[2 * at + 1], corr), gf::P - 2u), gf::MONT_ONE);
         gout[i] = g;
+    } else if (gout_par) {  // (2k,k) layout: odd u is parity block u >> 1
+        gout_par[u >> 1] = st == ST_LOST ? gf::mul(dev_pow(gf::mul(lv[2 * at + 1], corr), gf::P - 2u), gf::MONT_ONE) : 0u;
     }
 }
 
@@ -624,6 +636,19 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));
     if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
+    if (d->standard && d->erased_parity != 0) {
+        // repair in one transform (see DecodeState::transform_full): built when a pattern first loses data AND parity
+        if (!d->gout_par) DEC_TRY(hipMalloc((void**)&d->gout_par, N * 4));
+        if (!d->transform_full) {
+            const int rc = create_ramp_transform_ctx(&d->transform_full, lgc, ci.words * 4, 0, gf::h_inv((uint32_t)NC), ci.device);
+            if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM) return rc;
+            std::vector<uint32_t> o1, o2;
+            d->full_ok = d->transform_full && gather_tile_order(d->transform, o1) == gather_tile_order(d->transform_full, o2) && o1 == o2;
+            if (getenv("FASTECC_TRACE_PREPARE"))
+                fprintf(stderr, "[fastecc prepare] one-transform repair: context %s, same first-pass order %d (%s | %s)\n", d->transform_full ? "built" : "none",
+                        (int)d->full_ok, fastecc_plan_string(d->transform), d->transform_full ? fastecc_plan_string(d->transform_full) : "");
+        }
+    }
     // mixed radix: the work stripe of all NC positions, transformed in place; else the N recovered data positions
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, (mixed ? NC : N) * ci.words * 4));
     if (d->standard && !d->tile_order_valid) {
@@ -682,7 +707,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK) return rc;
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
-                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc);
+                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc,
+                       d->standard && d->erased_parity != 0 ? d->gout_par : nullptr);
     DEC_TRY(hipGetLastError());
     if (d->fin_first_pass != d->fin) {
         hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);
@@ -800,7 +826,33 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
             if (rc != FASTECC_OK) return rc;
         }
     } else {
-    if (d->erased_data != 0) {
+    bool repaired_in_one_pass = false;
+    if (rebuild && d->erased_data != 0 && d->standard && d->transform_full && d->full_ok && d->gout_par) {
+        // fastecc_repair, (2k,k) layout: x p'(x) at all 2k positions — the even rows give the lost data, the odd rows the lost parity
+        const uint32_t S = (uint32_t)ci.words;
+        hipError_t e_alloc = hipSuccess;
+        if (!d->recovered_full) e_alloc = hipMalloc((void**)&d->recovered_full, d->positions * (size_t)S * 4);
+        if (e_alloc != hipSuccess) (void)hipGetLastError();  // no room for the 2k-block stripe: the two-step form below
+        const int rc = e_alloc == hipSuccess ? run_gathered(d->transform_full, ddata, dparity, d->fin_first_pass, d->recovered_full, st) : FASTECC_E_UNSUPPORTED;
+        if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+        if (rc == FASTECC_OK) {
+            uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
+            const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)dpar_out | (uintptr_t)d->recovered_full) & 15u) == 0);
+            const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+            const uint64_t items = N * col_chunks;
+            const dim3 grid((unsigned)((items + 3) / 4));
+            if (v4) {
+                hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered_full, ddata, d->gout, S, 2u * S, S, col_chunks, items);
+                hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered_full + S, dpar_out, d->gout_par, S, 2u * S, S, col_chunks, items);
+            } else {
+                hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered_full, ddata, d->gout, S, 2u * S, S, col_chunks, items);
+                hipLaunchKernelGGL(decode_scatter_kernel<1>, grid, dim3(256), 0, st, d->recovered_full + S, dpar_out, d->gout_par, S, 2u * S, S, col_chunks, items);
+            }
+            DEC_TRY(hipGetLastError());
+            repaired_in_one_pass = true;
+        }
+    }
+    if (d->erased_data != 0 && !repaired_in_one_pass) {
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).
     // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
     // position whose factor is zero, instead of a tile that reads first and multiplies by zero afterwards.
@@ -833,7 +885,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         DEC_TRY(hipGetLastError());
     }
     }
-    if (rebuild) {
+    if (rebuild && !repaired_in_one_pass) {
         // the lost parity blocks are whatever the encoder makes of the (now complete) data: one more encode into a stripe
         // of the decoder's, from which only the lost blocks are copied — the surviving ones are left as they are
         if (!d->parity_again) DEC_TRY(hipMalloc((void**)&d->parity_again, parity_bytes));
