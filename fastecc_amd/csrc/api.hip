@@ -350,12 +350,15 @@ static bool direct_encode_applies(const fastecc_ctx* c, const void* data = nullp
 int encode_device(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     if (direct_encode_applies(c, data, parity)) {
-        if (!c->direct_enc) {
-            const int rc = direct_encode_build(&c->direct_enc, (uint64_t)c->q * c->N, c->K, c->Mu, c->fold, c->S);  // q > 1: the mixed-radix order
-            if (rc != FASTECC_OK) return rc;
+        // out of memory for the weight tables or the partial sums is not an error: the transform pipeline below needs neither
+        int rc = FASTECC_OK;
+        if (!c->direct_enc) rc = direct_encode_build(&c->direct_enc, (uint64_t)c->q * c->N, c->K, c->Mu, c->fold, c->S);  // q > 1: the mixed-radix order
+        if (rc == FASTECC_OK) {
+            ProfScope ps(c, st, "direct_encode", (c->K + c->Mu) * c->S * 4ull);
+            rc = direct_encode_run(c->direct_enc, data, parity, c->direct_kernel, st);
         }
-        ProfScope ps(c, st, "direct_encode", (c->K + c->Mu) * c->S * 4ull);
-        return direct_encode_run(c->direct_enc, data, parity, c->direct_kernel, st);
+        if (rc != FASTECC_E_NOMEM) return rc;
+        (void)hipGetLastError();
     }
     if (c->q > 1) return encode_mixed(c, data, parity, st);
     if (c->K == c->N && c->Mu == c->M) return encode_pow2(c, data, parity, st);

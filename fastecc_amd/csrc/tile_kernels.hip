@@ -165,7 +165,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, u
 }
 
 template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1>
-__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || (SPLIT > 1 && MODE == MODE_MID) ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
+__global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || SPLIT > 1 ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
     // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
