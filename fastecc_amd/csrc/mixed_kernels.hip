@@ -210,8 +210,10 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
     const uint32_t tile = blockIdx.x;
     const uint32_t cc = tile % a.col_chunks;
     const uint32_t grp = tile / a.col_chunks;
-    const uint32_t col = cc * 64u + lane;
-    const bool live = col < a.S;
+    // Lanes beyond a ragged block end work on the block's last column as well (same loads, same arithmetic, identical stores from the same
+    // wave), so the kernel has no divergent region: an "if (live)" around the stores made the compiler sink the q-point transforms of the DIT
+    // form into that branch and fetch all their constants at its top (up to 134 SGPR spills, round 2).
+    const uint32_t col = min(cc * 64u + lane, a.S - 1u);
     const int s = a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const uint32_t row = (uint32_t)i * a.M + row0 + (row_of(0, j) << s);
-                x[i][j][0] = (live && (a.in_rows == 0 || row < a.in_rows)) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
+                x[i][j][0] = (a.in_rows == 0 || row < a.in_rows) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
             }
 #pragma unroll
         for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
@@ -285,12 +287,10 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
                 if (p > 0) exchange(y, p - 1, p);
                 levels(y, p);
             }
-            if (live) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
-                    __builtin_nontemporal_store(y[k][0], a.out + (size_t)row * a.ld + col);
-                }
+            for (int k = 0; k < R; ++k) {
+                const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
+                __builtin_nontemporal_store(y[k][0], a.out + (size_t)row * a.ld + col);
             }
         }
     } else {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
-                x[j1][k][0] = live ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
+                x[j1][k][0] = __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col);
             }
 #pragma unroll
         for (int j1 = 0; j1 < Q; ++j1) {
@@ -312,15 +312,13 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
-        if (live) {
 #pragma unroll
-            for (int t = 0; t < Q; ++t)
+        for (int t = 0; t < Q; ++t)
 #pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const uint32_t row = (uint32_t)t * a.M + row0 + (row_of(0, j) << s);
-                    if (a.out_rows == 0 || row < a.out_rows) __builtin_nontemporal_store(x[out_slot<Q>(t)][j][0], a.out + (size_t)row * a.ld + col);
-                }
-        }
+            for (int j = 0; j < R; ++j) {
+                const uint32_t row = (uint32_t)t * a.M + row0 + (row_of(0, j) << s);
+                if (a.out_rows == 0 || row < a.out_rows) __builtin_nontemporal_store(x[out_slot<Q>(t)][j][0], a.out + (size_t)row * a.ld + col);
+            }
     }
 }
 
