@@ -846,6 +846,15 @@ DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
 p61::Decoder*& decoder61_of(fastecc_ctx* c) { return c->decoder61; }
 p61::Path* p61_path_of(fastecc_ctx* c) { return c->p61; }
+const p61::LaunchHooks* p61_profile_hooks(fastecc_ctx* c, void** keep)
+{
+    *keep = nullptr;
+    if (!c->profiling) return nullptr;
+    P61Hooks* hk = new (std::nothrow) P61Hooks(c);
+    *keep = hk;
+    return hk ? &hk->h : nullptr;
+}
+void p61_profile_done(void* keep) { delete (P61Hooks*)keep; }
 std::mutex& mutex_of(fastecc_ctx* c) { return c->mu; }
 fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes)
 {

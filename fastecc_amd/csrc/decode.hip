@@ -748,6 +748,8 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         int rc61 = call.begin((hipStream_t)stream);  // the decoder's work stripe and tables are internal buffers
         if (rc61 != FASTECC_OK) return rc61;
         const CtxInfo ci61 = info_of(c);
+        void* prof61 = nullptr;
+        const p61::LaunchHooks* hooks61 = p61_profile_hooks(c, &prof61);
         if (ci61.zero_extended) {
             // codes other than (2N,N): decode the padded (2N,N) codeword in the context's two work stripes and copy the caller's blocks back
             if (mem_kind != FASTECC_MEM_DEVICE) {
@@ -766,17 +768,19 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
                 step(hipMemsetAsync((char*)wd + ci61.user_k * row, 0, (ci61.k - ci61.user_k) * row, st61), "hipMemsetAsync");
                 step(hipMemcpy2DAsync(wp, prow, parity, row, row, ci61.user_m, hipMemcpyDeviceToDevice, st61), "hipMemcpy2DAsync(parity)");
             }
-            if (rc61 == FASTECC_OK) rc61 = p61::decode(d61, wd, wp, parity_out ? p61_path_of(c) : nullptr, st61, nullptr);
+            if (rc61 == FASTECC_OK) rc61 = p61::decode(d61, wd, wp, parity_out ? p61_path_of(c) : nullptr, st61, hooks61);
             if (rc61 == FASTECC_OK) {
                 step(hipMemcpyAsync(data, wd, ci61.user_k * row, hipMemcpyDeviceToDevice, st61), "hipMemcpyAsync(data back)");
                 if (parity_out) step(hipMemcpy2DAsync(parity_out, row, wp, prow, row, ci61.user_m, hipMemcpyDeviceToDevice, st61), "hipMemcpy2DAsync(parity back)");
             }
+            p61_profile_done(prof61);
             const int rc_end61 = call.end((hipStream_t)stream);
             return rc61 != FASTECC_OK ? rc61 : rc_end61;
         }
         rc61 = mem_kind == FASTECC_MEM_DEVICE
-                   ? p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr)
-                   : p61::decode_host(d61, data, const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, nullptr);
+                   ? p61::decode(d61, (uint64_t*)data, (uint64_t*)const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, hooks61)
+                   : p61::decode_host(d61, data, const_cast<void*>(parity), parity_out ? p61_path_of(c) : nullptr, (hipStream_t)stream, hooks61);
+        p61_profile_done(prof61);
         const int rc_end = call.end((hipStream_t)stream);
         return rc61 != FASTECC_OK ? rc61 : rc_end;
     }

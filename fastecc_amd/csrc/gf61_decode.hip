@@ -205,9 +205,9 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ dat
     st(work + ((uint64_t)u * elems + col) * 2, v);
 }
 
-// data[i] = work[2i] * gout[i] for the erased data blocks (gout != 0)
+// data[i] = work[stride * i] * gout[i] for the erased data blocks (gout != 0)
 __global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ work, uint64_t* __restrict__ data, const uint64_t* __restrict__ gout,
-                                                 uint32_t elems, uint32_t col_chunks, uint64_t items)
+                                                 uint32_t elems, uint32_t col_chunks, uint64_t items, uint32_t stride)
 {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ wo
     const uint32_t col = cc * 64u + lane;
     if (col >= elems) return;
     const gf61::Opaque k = gf61::make_opaque();
-    const Elem v = gf61::mul(ld(work + ((uint64_t)(2u * i) * elems + col) * 2), gf61::make_twiddle(gre, gim), k);
+    const Elem v = gf61::mul(ld(work + ((uint64_t)stride * i * elems + col) * 2), gf61::make_twiddle(gre, gim), k);  // stride 2: row 2i of the 2k outputs
     st(data + ((uint64_t)i * elems + col) * 2, gf61::canon(v));
 }
 
@@ -370,6 +370,8 @@ struct Decoder {
     uint32_t* erased = nullptr;
     uint8_t* state = nullptr;
     uint64_t* work = nullptr;          // 2k blocks (lazy)
+    Path* half = nullptr;              // size k, 6-level MID: the DIT passes and tables of the folded transform (gf61_path.hpp: encode_fold)
+    uint64_t* rec = nullptr;           // k blocks: x p'(x) at the data positions, written by the folded transform (lazy)
     uint64_t* again = nullptr;         // k parity blocks of the re-encode (lazy, repair only)
     uint64_t* stage = nullptr;         // data + parity stripes of a host-memory call (lazy)
     uint64_t erased_data = 0, erased_parity = 0;
@@ -393,10 +395,11 @@ void destroy_decoder(Decoder* d)
 {
     if (!d) return;
     destroy(d->transform);
+    destroy(d->half);
     destroy(d->pattern);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
-                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
+                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->rec, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
                     (void*)d->direct_inv, (void*)d->direct_pos, (void*)d->direct_partial, (void*)d->direct_wpow, (void*)d->direct_state})
         if (b) (void)hipFree(b);
     delete d;
@@ -520,7 +523,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             factor[2 * m] = f.re;
             factor[2 * m + 1] = f.im;
         }
-        int rc = create_transform(&d->transform, log2k + 1, elems, factor.data(), detail, cap);
+        // only the even (data) positions of this transform are wanted: a 7-level MID here pairs with the 6-level MID of a size-k path,
+        // whose DIT passes finish the folded transform (encode_fold); where no such pair of plans exists all 2k outputs are computed
+        int rc = create_transform_mid(&d->transform, log2k + 1, elems, factor.data(), 7, detail, cap);
+        if (rc == FASTECC_OK && log2k >= 6) rc = create_transform_mid(&d->half, log2k, elems, nullptr, 6, detail, cap);
         if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + 1, 2, detail, cap);  // only its stand-alone transform is used
         if (rc != FASTECC_OK) return rc;
         d->tree.assign(lgT, nullptr);
@@ -637,11 +643,22 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
             hipLaunchKernelGGL(k_gather, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, elems, col_chunks, items);
             D61_TRY(hipGetLastError());
         }
-        const int rc = encode(d->transform, d->work, d->work, s0, hooks);  // x p'(x) on all 2k points; the even ones are wanted
-        if (rc != FASTECC_OK) return rc;
+        // x p'(x) at the even (data) positions only where the plans pair up (encode_fold), else on all 2k points
+        int rc = FASTECC_E_UNSUPPORTED;
+        if (d->half) {
+            if (!d->rec) D61_TRY(hipMalloc((void**)&d->rec, d->N * d->elems * 16));
+            rc = encode_fold(d->transform, d->half, d->work, d->work, d->rec, s0, hooks);
+            if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+        }
+        const bool folded = rc == FASTECC_OK;
+        if (!folded) {
+            rc = encode(d->transform, d->work, d->work, s0, hooks);
+            if (rc != FASTECC_OK) return rc;
+        }
         {
             const uint64_t items = d->N * col_chunks;
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->work, data, d->gout, elems, col_chunks, items);
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, folded ? d->rec : d->work, data, d->gout, elems, col_chunks, items,
+                               folded ? 1u : 2u);
             D61_TRY(hipGetLastError());
         }
     }

@@ -33,7 +33,7 @@ namespace p61 {
 
 namespace {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3 };
 
 // forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
 struct SmallRoots {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     // value to the same address from the same wave — so the kernel has no divergent region at all.  (With an "if (live)" around the stores
     // the compiler sinks the whole second half of the tile into that branch, where its scheduling barriers no longer apply.)
     const uint32_t col = min(cc * 64u + lane, a.elems - 1u);
-    const int s = MODE == MODE_MID ? 0 : a.s;
+    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD) ? 0 : a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
     const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
@@ -398,30 +398,32 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
             store_elem(a.out + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);
     };
     // write the registers in one layout, read them back in the other; nobody may still be reading the buffer on entry
-    auto exchange = [&](auto wrow, auto rrow) {
+    auto exchange_of = [&](auto& v, auto wrow, auto rrow) {
+        constexpr int CNT = (int)(sizeof(v) / sizeof(v[0]));
 #pragma unroll
         for (int round = 0; round < SPLIT; ++round) {
             const bool mine = SPLIT == 1 || my_round == (uint32_t)round;
             if (mine) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) {
+                for (int j = 0; j < CNT; ++j) {
                     u64x2 t;
-                    t.x = x[j].re;
-                    t.y = x[j].im;
+                    t.x = v[j].re;
+                    t.y = v[j].im;
                     my_lds[wrow(j) * WS] = t;
                 }
             }
             __syncthreads();
             if (mine) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) {
+                for (int j = 0; j < CNT; ++j) {
                     const u64x2 t = my_lds[rrow(j) * WS];
-                    x[j] = Elem{t.x, t.y};
+                    v[j] = Elem{t.x, t.y};
                 }
             }
             if (round + 1 < SPLIT) __syncthreads();
         }
     };
+    auto exchange = [&](auto wrow, auto rrow) { exchange_of(x, wrow, rrow); };
 
     const uint32_t off_a = (g << s) + lo;  // layout A: x[j] = block (.. + j * 2^(s+L2) + off_a)
     if constexpr (MODE == MODE_DIF) {
@@ -436,6 +438,32 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
         exchange(row_b, row_a);
         dit_levels<LOGR, false, false>(x, a.tw_dit, off_a, s + L2, k, a.sr);
         store(row_a);
+    } else if constexpr (MODE == MODE_MID_FOLD) {
+        // MID of a transform of which only the EVEN output positions are wanted (the decoder's x p'(x), gf61_decode.hip): at the first DIT
+        // level an even position is a + b, and what is left is a DIT of half the size on the surviving positions — level l of this transform
+        // on even positions is level l - 1 of the half-size one.  So after the per-block factor the R registers fold to R/2, and the rest
+        // of the tile is the second half of a (LOGT-1)-level MID tile of the HALF-size transform: its low L2 levels in registers, one
+        // exchange, its high LOGR-1 levels with that transform's collected twiddles (a.tw_dit = the half-size path's table), and the
+        // T/2 rows go to the half-size stripe `out`.
+        static_assert(LOGR - 1 >= L2, "the folded tile keeps its low levels in registers");
+        constexpr int RH = R / 2;
+        load(row_a);
+        dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
+        exchange(row_a, row_b);
+        dif_levels<LOGR, true, true, L2>(x, a.tw_dif, 0u, 0, k, a.sr);
+        const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
+        Elem y[RH];
+#pragma unroll
+        for (int j = 0; j < RH; ++j) y[j] = Elem{gf61::add(x[2 * j].re, x[2 * j + 1].re, k), gf61::add(x[2 * j].im, x[2 * j + 1].im, k)};
+        dit_levels<LOGR - 1, true, false, L2>(y, a.tw_dit, 0u, 0, k, a.sr);
+        __syncthreads();  // every lane has finished reading the first exchange
+        exchange_of(y, [&](int j) { return g * RH + (uint32_t)j; }, [&](int j) { return (uint32_t)j * G + g; });
+        dit_levels<LOGR - 1, false, false>(y, a.tw_dit, g, L2, k, a.sr);
+        const uint64_t half0 = (uint64_t)hi << (LOGT - 1);
+#pragma unroll
+        for (int j = 0; j < RH; ++j) store_elem(a.out + (half0 + (uint32_t)j * G + g) * row_words + 2u * col, CANON ? gf61::canon(y[j]) : y[j]);
     } else {
         load(row_a);
         dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
@@ -538,6 +566,9 @@ hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const Pass
     switch (mode) {  // a DIF tile is never the last pass of a transform (the plans end on MID, DIT or a register pass)
     case MODE_DIF: return inverse_roots ? launch_tile_one<LOGT, MODE_DIF, false, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIF, false, SPLIT, false>(a, tiles, st);
     case MODE_DIT: return canon ? launch_tile_one<LOGT, MODE_DIT, true, SPLIT, false>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIT, false, SPLIT, false>(a, tiles, st);
+    case MODE_MID_FOLD:
+        if constexpr (LOGT == 7) return launch_tile_one<LOGT, MODE_MID_FOLD, false, SPLIT, true>(a, tiles, st);
+        else return hipErrorInvalidValue;
     default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT, true>(a, tiles, st);
     }
 }
@@ -550,6 +581,7 @@ struct Path {
     int levels = DEFAULT_LEVELS;  // levels per register pass
     bool tiles = true;            // LDS-tiled passes where a chunk of the plan has a tile shape
     int split = 2;                // 7-level tiles: exchange rounds (2 = 64 KiB of LDS, two workgroups per CU)
+    int force_mid = 0;            // > 0: MID covers exactly that many levels (the decoder's folded transform pairs a 7-level MID with a 6-level one)
     std::vector<Pass> enc, fwd;  // encode plan; stand-alone transform plan (all DIF, then the block permutation)
     uint64_t* tw_fwd = nullptr;  // forward roots, level-packed for the encode plan
     uint64_t* tw_inv = nullptr;  // inverse roots, the same packing
@@ -581,7 +613,7 @@ struct Chunking {
 
 int reg_passes(int levels, int L) { return (levels + L - 1) / L; }
 
-Chunking choose_chunks(int n, int L, bool tiles)
+Chunking choose_chunks(int n, int L, bool tiles, int force_mid = 0)
 {
     Chunking best;
     auto consider = [&](int mid, const std::vector<int>& outer) {
@@ -601,6 +633,7 @@ Chunking choose_chunks(int n, int L, bool tiles)
     const int mid_max = std::min(n, tiles ? 7 : L);
     for (int mid = 1; mid <= mid_max; mid++) {
         if (!tiles && mid != mid_max) continue;
+        if (force_mid > 0 && mid != force_mid) continue;
         const int rest = n - mid;
         if (rest == 0) {
             consider(mid, {});
@@ -647,7 +680,8 @@ void push_chunk(std::vector<Pass>& plan, int mode, int levels, int s, int L, boo
 void build_plans(Path* p)
 {
     const int n = p->n, L = p->levels;
-    Chunking ch = choose_chunks(n, L, p->tiles);
+    Chunking ch = choose_chunks(n, L, p->tiles, p->force_mid);
+    if (ch.trips == (1 << 30)) ch = choose_chunks(n, L, p->tiles);  // the forced size does not exist for this n
     // a register MID pass covers at most L levels: the rest of a longer MID chunk becomes DIF / DIT passes around it
     int mid = ch.mid;
     std::vector<int> outer = ch.outer;
@@ -828,7 +862,51 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
 
 int create(Path** out, int n, uint64_t elems, char* detail, size_t cap) { return create_transform(out, n, elems, nullptr, detail, cap); }
 
-int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t cap)
+int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t cap) { return create_transform_mid(out, n, elems, factor, 0, detail, cap); }
+
+// The decoder's folded transform (only the even output positions of a size-2^(n+1) transform are wanted): `big` is that transform with a
+// 7-level MID tile, `half` a size-2^n path with a 6-level MID tile.  DIF passes of `big` (in -> work, then in place), the folding MID tile
+// (work -> out, 2^n blocks), DIT passes of `half` above its MID, in place on `out`.  FASTECC_E_UNSUPPORTED when the two plans do not pair up.
+int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks)
+{
+    if (!big || !half || big->n != half->n + 1 || big->elems != half->elems) return FASTECC_E_UNSUPPORTED;
+    size_t mb = 0, mh = 0;
+    while (mb < big->enc.size() && big->enc[mb].mode != MODE_MID) mb++;
+    while (mh < half->enc.size() && half->enc[mh].mode != MODE_MID) mh++;
+    if (mb == big->enc.size() || mh == half->enc.size()) return FASTECC_E_UNSUPPORTED;
+    const Pass &qb = big->enc[mb], &qh = half->enc[mh];
+    if (!qb.tile || qb.logr != 7 || !qh.tile || qh.logr != 6 || big->split != half->split) return FASTECC_E_UNSUPPORTED;
+    const std::vector<Pass> down(big->enc.begin(), big->enc.begin() + mb), up(half->enc.begin() + mh + 1, half->enc.end());
+    const uint64_t* src = in;
+    if (!down.empty()) {
+        const int rc = run_passes(big, down, in, work, big->tw_inv, big->tw_fwd, true, st, hooks);
+        if (rc != FASTECC_OK) return rc;
+        src = work;
+    }
+    {
+        PassArgs a{};
+        a.in = src;
+        a.out = out;
+        a.tw_dif = big->tw_inv;
+        a.tw_dit = half->tw_fwd;
+        a.dscale = big->dscale;
+        a.elems = (uint32_t)big->elems;
+        a.pitch = (uint32_t)big->elems;
+        a.col_chunks = (uint32_t)((big->elems + 63) / 64);
+        a.items = (big->N >> 7) * a.col_chunks;
+        a.s = 0;
+        a.sr = big->sr;
+        if (a.items > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
+        Scope sc(hooks, st, "p61_tile_mid7_fold", (big->N + half->N) * big->elems * 16ull);
+        const hipError_t e = big->split == 2 ? launch_tile_mode<7, 2>(MODE_MID_FOLD, false, true, a, (unsigned)a.items, st)
+                                             : launch_tile_mode<7, 1>(MODE_MID_FOLD, false, true, a, (unsigned)a.items, st);
+        if (e != hipSuccess) return fail(nullptr, 0, e, "p61 folding MID tile");
+    }
+    if (up.empty()) return FASTECC_OK;  // (the MID tile then wrote lazy values: the caller's next step accepts them)
+    return run_passes(half, up, out, out, half->tw_inv, half->tw_fwd, true, st, hooks);
+}
+
+int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t cap)
 {
     *out = nullptr;
     if (n < 1 || n > MAX_LOG2_K || elems == 0 || elems > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
@@ -837,6 +915,7 @@ int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, 
     p->n = n;
     p->N = 1ull << n;
     p->elems = elems;
+    p->force_mid = force_mid;
     {
         const gf61::Elem w16 = gf61::h_root(16);
         for (int i = 0; i < 4; i++) {

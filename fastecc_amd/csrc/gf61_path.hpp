@@ -25,6 +25,11 @@ int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
 // with the forward roots — with a caller's factors (2 * 2^n words, (re, im) by coefficient index) instead of the encoder's
 // w_2N^m / N; no root of order 2^(n+1) is needed.  The decoder's x p'(x) transform (gf61_decode.hip) is factor[m] = m / 2^n.
 int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t detail_cap);
+// create_transform with the MID pass forced to `force_mid` levels (0 = the plan's own choice, also when no such plan exists)
+int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t detail_cap);
+// Only the EVEN output positions of `big`'s transform (size 2^(n+1), created with force_mid = 7): DIF passes of `big`, a MID tile that folds
+// the first DIT level away, DIT passes of `half` (size 2^n, force_mid = 6).  in: 2^(n+1) blocks; work: 2^(n+1) blocks (may be `in`); out: 2^n blocks.
+int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks);
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);

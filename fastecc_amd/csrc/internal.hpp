@@ -63,9 +63,13 @@ Sharded*& sharded_of(fastecc_ctx* c);
 namespace p61 {
 struct Decoder;
 struct Path;
+struct LaunchHooks;
 }
 p61::Decoder*& decoder61_of(fastecc_ctx* c);  // the erasure decoder of a GF((2^61-1)^2) context (gf61_decode.hip)
 p61::Path* p61_path_of(fastecc_ctx* c);       // its encoder
+// fastecc_profile_* over the launches of a p61 call: nullptr unless the context is profiling; *keep goes to p61_profile_done after the call
+const p61::LaunchHooks* p61_profile_hooks(fastecc_ctx* c, void** keep);
+void p61_profile_done(void* keep);
 std::mutex& mutex_of(fastecc_ctx* c);
 // a context that owns nothing but its geometry: fastecc_create_sharded hangs the per-device contexts on it
 fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, uint64_t block_bytes);

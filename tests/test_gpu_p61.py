@@ -306,6 +306,41 @@ def test_decode_at_2_16_blocks(torch_cuda, fe):
         assert torch.equal(d, x) and torch.equal(q, par)
 
 
+@pytest.mark.parametrize("logn,elems", [(6, 3), (7, 70), (9, 64), (13, 20), (14, 64)])
+def test_decode_transform_is_folded(torch_cuda, fe, logn, elems):
+    """Only the k data positions of the decoder's 2k-point transform are read, so it runs as big DIF passes, one folding MID tile
+    (y[j] = x[2j] + x[2j+1] between the halves of a 7-level MID) and the DIT passes of the size-k path: the profile shows that kernel,
+    and the decode is the same as before (round trip)."""
+    torch = torch_cuda
+    N = 1 << logn
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(logn)
+    x = torch.randint(0, P61, (N * 2 * elems,), dtype=torch.int64, device="cuda:0", generator=g)
+    par = torch.empty_like(x)
+    rng = np.random.default_rng(logn)
+    lost = rng.permutation(2 * N)[: N - 1]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    with encoder(fe, N, elems) as enc:
+        enc.encode(x, par)
+        d, q = x.clone(), par.clone()
+        d.view(N, 2 * elems)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+        q.view(N, 2 * elems)[torch.from_numpy(pp == 0).to("cuda:0")] = -1
+        enc.decode_prepare(dp, pp)
+        enc.profile(True)
+        enc.profile_reset()
+        enc.decode(d, q)
+        torch.cuda.synchronize()
+        prof = enc.profile_read()
+        enc.profile(False)
+        assert prof.get("p61_tile_mid7_fold", (0, 0, 0))[1] == 1, prof
+        assert torch.equal(d, x)
+        enc.repair(d.clone(), q)
+        torch.cuda.synchronize()
+        assert torch.equal(q, par)
+
+
 @pytest.mark.parametrize("N,elems", [(2, 3), (16, 70), (1024, 9), (1 << 14, 4)])
 def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
     """Up to 16 lost blocks: recomputed straight from the survivors (no locator tree, no transform); same bits as the transform
