@@ -244,8 +244,39 @@ __global__ __launch_bounds__(256) void k_restore(const uint64_t* __restrict__ ag
 constexpr int DIRECT_MAX = 16;
 constexpr uint32_t DIRECT_ROWS = 512, DIRECT_SEGS = 32;
 
+// ---- lazy accumulation: no reduction per term ----
+// A weight component c < 2^61 is wave-uniform.  With c' = c * 2^32 mod p (a rotation of its 61 bits) a data component a = a1 2^32 + a0 (ANY 64-bit
+// word) gives a * c = a0 * c + a1 * c' (mod p), and with c = l0 + l1 2^21 + l2 2^42 (limbs of 21, 21, 19 bits) every partial product is below 2^53:
+// a sum of 4 products per row over DIRECT_ROWS = 512 rows stays below 2^64 in a plain 64-bit accumulator — one v_mad_u64_u32 per product, no carry,
+// no fold.  re = a c + b (p - d), im = a d + b c: 24 multiply-adds per term (the reducing form: 16 + limb splits + three folds = 58 instructions).
+// The 18 limbs of a weight — of c, c', d, d', e = p - d, e' — are what the table holds (COEF_WORDS 32-bit words per entry, all zero for a zero weight):
+// splitting them in the kernel costs 35 scalar instructions per term, and the scalar unit, shared by the four SIMDs of a CU, then limits the kernel
+// (measured: 16 lost blocks 3.0 ms against 3.6 for the reducing form).  The three sums of a component are put together once per chunk.
+constexpr int COEF_WORDS = 18;
+struct Limbs {
+    uint32_t l0, l1, l2;
+};
+__device__ __forceinline__ Limbs limbs_of(uint64_t v) { return Limbs{(uint32_t)v & 0x1FFFFFu, (uint32_t)(v >> 21) & 0x1FFFFFu, (uint32_t)(v >> 42)}; }
+__device__ __forceinline__ uint64_t times_2_32(uint64_t v) { return ((v << 32) & gf61::P) | (v >> 29); }  // v <= p: v 2^32 mod p (or p for v = p)
+struct Acc3 {
+    uint64_t t0, t1, t2;
+};
+__device__ __forceinline__ void mac3(Acc3& s, uint32_t x, const Limbs& w)
+{
+    s.t0 += (uint64_t)x * w.l0;
+    s.t1 += (uint64_t)x * w.l1;
+    s.t2 += (uint64_t)x * w.l2;
+}
+// t0 + t1 2^21 + t2 2^42 (mod p) as a lazy value (< 2^61 + 4)
+__device__ __forceinline__ uint64_t gather3(const Acc3& s)
+{
+    auto fold = [](uint64_t t) { return (t & gf61::P) + (t >> 61); };                                       // < 2^61 + 8
+    auto shl = [](uint64_t y, int sh) { return ((y << sh) & gf61::P) + (y >> (61 - sh)); };                // y < 2^62: y 2^sh mod p, < 2^61 + 2^(sh + 1)
+    return fold(fold(s.t0) + shl(fold(s.t1), 21) + shl(fold(s.t2), 42));                                    // the sum is below 2^63
+}
+
 // coef[u][j] = -w^(u - e_j) * prod_{i != j} (w^u - w^e_i) / prod_{i != j} (w^e_j - w^e_i) on surviving positions, 0 on lost ones
-__global__ __launch_bounds__(256) void k_direct_coef(uint64_t* __restrict__ coef, const uint64_t* __restrict__ wpow, const uint8_t* __restrict__ state,
+__global__ __launch_bounds__(256) void k_direct_coef(uint32_t* __restrict__ coef, const uint64_t* __restrict__ wpow, const uint8_t* __restrict__ state,
                                                      const uint32_t* __restrict__ epos, const uint64_t* __restrict__ inv, uint32_t NC, int e, int pad)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,54 +296,98 @@ __global__ __launch_bounds__(256) void k_direct_coef(uint64_t* __restrict__ coef
             const uint32_t ej = epos[j];
             v = mulc(v, ld(wpow + 2ull * (u >= ej ? u - ej : u + NC - ej)), k);
         }
-        st(coef + 2ull * ((uint64_t)u * pad + j), v);
+        uint32_t* o = coef + ((uint64_t)u * pad + j) * COEF_WORDS;
+        if ((v.re | v.im) == 0) {
+            for (int i = 0; i < COEF_WORDS; ++i) o[i] = 0;
+            continue;
+        }
+        const uint64_t e = gf61::P - v.im;
+        const uint64_t parts[6] = {v.re, times_2_32(v.re), v.im, times_2_32(v.im), e, times_2_32(e)};
+        for (int i = 0; i < 6; ++i) {
+            const Limbs l = limbs_of(parts[i]);
+            o[3 * i] = l.l0;
+            o[3 * i + 1] = l.l1;
+            o[3 * i + 2] = l.l2;
+        }
     }
 }
 
-// partial[chunk][j][col] = sum over the chunk's positions of block(u)[col] * coef[u][j] (lazy values); a wave owns (chunk, 64 element columns)
+// partial[chunk][j][col] = sum over the chunk's positions of block(u)[col] * coef[u][j] (lazy values); a wave owns (chunk, 64 element columns, a sweep
+// of EB outputs: blockIdx.y)
 template <int EB>
 __global__ __launch_bounds__(256) void k_direct_accumulate(const uint64_t* __restrict__ data, const uint64_t* __restrict__ parity,
-                                                           const uint64_t* __restrict__ coef, uint64_t* __restrict__ partial, uint32_t elems, uint32_t NC,
-                                                           uint32_t col_chunks, uint64_t items)
+                                                           const uint32_t* __restrict__ coef, uint64_t* __restrict__ partial, uint32_t elems, uint32_t NC,
+                                                           uint32_t col_chunks, uint64_t items, uint32_t pad)
 {
-    constexpr int U = 4;
+    constexpr int U = EB >= 8 ? 2 : 4;      // rows per trip of the loop; the next trip's rows are requested before this trip's arithmetic
+    constexpr int G = EB >= 4 ? 4 : EB;     // outputs and
+    constexpr int RB = EB >= 4 ? 1 : 4 / EB;  // rows whose limbs come in one scalar fetch (72 SGPRs); rows are adjacent in the table when pad == EB (EB < 8)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
     if (item >= items) return;
+    const uint32_t j0 = blockIdx.y * EB;
     const uint32_t cc = (uint32_t)(item % col_chunks);
     const uint32_t chunk = (uint32_t)(item / col_chunks);
-    const uint32_t col = cc * 64u + lane;
-    const bool live = col < elems;
-    const gf61::Opaque k = gf61::make_opaque();
-    Elem acc[EB];
+    const uint32_t col = min(cc * 64u + lane, elems - 1u);  // lanes past a ragged end repeat the last column (same loads, same stores)
+    Acc3 re[EB], im[EB];
 #pragma unroll
-    for (int j = 0; j < EB; ++j) acc[j] = Elem{0, 0};
+    for (int j = 0; j < EB; ++j) re[j] = im[j] = Acc3{0, 0, 0};
     const uint32_t u0 = chunk * DIRECT_ROWS, u1 = min(u0 + DIRECT_ROWS, NC);
+    auto fetch = [&](Elem* x, uint32_t ub) {  // what stands in a lost block's place meets zero coefficients
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t u = min(ub + i, u1 - 1u);
+            x[i] = ld(((u & 1u) ? parity : data) + ((uint64_t)(u >> 1) * elems + col) * 2);
+        }
+    };
+    Elem xn[U];
+    fetch(xn, u0);
     for (uint32_t ub = u0; ub < u1; ub += U) {
         Elem x[U];
 #pragma unroll
-        for (int i = 0; i < U; ++i) {  // all U rows in flight; what stands in a lost block's place meets zero coefficients
-            const uint32_t u = ub + i;
-            x[i] = (u < u1 && live) ? ld(((u & 1u) ? parity : data) + ((uint64_t)(u >> 1) * elems + col) * 2) : Elem{0, 0};
-        }
+        for (int i = 0; i < U; ++i) x[i] = xn[i];
+        fetch(xn, min(ub + U, u1 - 1u));
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const uint32_t u = ub + i;
-            if (u >= u1) continue;
-            const_u64_ptr cf = as_constant(coef) + 2ull * ((uint64_t)u * EB);
+        for (int ib = 0; ib < U; ib += RB) {
 #pragma unroll
-            for (int j = 0; j < EB; ++j) {
-                const uint64_t cre = cf[2 * j], cim = cf[2 * j + 1];
-                if ((cre | cim) == 0) continue;  // wave-uniform
-                acc[j] = gf61::add(acc[j], gf61::mul(x[i], gf61::make_twiddle(cre, cim), k), k);
+            for (int g = 0; g < EB; g += G) {
+                // (the table has four rows more than NC: a fetch that starts at a row below NC stays inside it)
+                const __attribute__((address_space(4))) uint32_t* cf =
+                    (const __attribute__((address_space(4))) uint32_t*)(coef + ((uint64_t)(ub + ib) * pad + j0 + g) * COEF_WORDS);
+                uint32_t w[RB * G * COEF_WORDS];  // pinned, so that the loads are not sunk into each output's branch
+#pragma unroll
+                for (int t = 0; t < RB * G * COEF_WORDS; ++t) w[t] = cf[t];
+#pragma unroll
+                for (int t = 0; t < RB * G * COEF_WORDS; ++t) asm volatile("" : "+s"(w[t]));
+#pragma unroll
+                for (int ir = 0; ir < RB; ++ir) {
+                    const int i = ib + ir;
+                    if (ub + i >= u1) continue;
+                    const uint32_t a0 = (uint32_t)x[i].re, a1 = (uint32_t)(x[i].re >> 32), b0 = (uint32_t)x[i].im, b1 = (uint32_t)(x[i].im >> 32);
+#pragma unroll
+                    for (int jj = 0; jj < G; ++jj) {
+                        const uint32_t* q = w + (ir * G + jj) * COEF_WORDS;
+                        if ((q[0] | q[1] | q[2] | q[6] | q[7] | q[8]) == 0) continue;  // wave-uniform: a lost position, or a padding output
+                        const Limbs C{q[0], q[1], q[2]}, C2{q[3], q[4], q[5]}, D{q[6], q[7], q[8]}, D2{q[9], q[10], q[11]}, E{q[12], q[13], q[14]},
+                            E2{q[15], q[16], q[17]};
+                        const int j = g + jj;
+                        mac3(re[j], a0, C);
+                        mac3(re[j], a1, C2);
+                        mac3(re[j], b0, E);
+                        mac3(re[j], b1, E2);
+                        mac3(im[j], a0, D);
+                        mac3(im[j], a1, D2);
+                        mac3(im[j], b0, C);
+                        mac3(im[j], b1, C2);
+                    }
+                }
             }
         }
     }
-    if (live) {
 #pragma unroll
-        for (int j = 0; j < EB; ++j) st(partial + 2ull * (((uint64_t)chunk * EB + j) * elems + col), acc[j]);
-    }
+    for (int j = 0; j < EB; ++j)
+        st(partial + 2ull * (((uint64_t)chunk * pad + j0 + j) * elems + col), Elem{gather3(re[j]), gather3(im[j])});
 }
 
 __global__ __launch_bounds__(256) void k_direct_reduce1(const uint64_t* __restrict__ partial, uint64_t* __restrict__ stage, uint32_t elems, uint32_t chunks,
@@ -378,7 +453,7 @@ struct Decoder {
     bool built = false;  // contexts, buffers and the w^u table exist
     // few losses: the direct path
     int direct = 0, direct_pad = 0;
-    uint64_t* direct_coef = nullptr;     // [NC][pad] elements
+    uint32_t* direct_coef = nullptr;     // [NC][pad][COEF_WORDS]: the limbs of each weight
     uint64_t direct_coef_elems = 0;
     uint64_t* direct_inv = nullptr;      // [DIRECT_MAX] elements
     uint32_t* direct_pos = nullptr;      // [DIRECT_MAX]
@@ -476,12 +551,12 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             }
             if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC));
             // [NC][pad] weights: sized for this pattern's pad (1 GiB instead of 8 GiB at NC = 2^25 for one lost block), grown on demand
-            const uint64_t coef_elems = NC * (uint64_t)pad;
+            const uint64_t coef_elems = (NC + 4) * (uint64_t)pad;  // (k_direct_accumulate fetches the rows of a trip together)
             if (d->direct_coef_elems < coef_elems) {
                 if (d->direct_coef) (void)hipFree(d->direct_coef);
                 d->direct_coef = nullptr;
                 d->direct_coef_elems = 0;
-                D61_TRY(hipMalloc((void**)&d->direct_coef, coef_elems * 16));
+                D61_TRY(hipMalloc((void**)&d->direct_coef, coef_elems * COEF_WORDS * 4));
                 d->direct_coef_elems = coef_elems;
             }
             if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, DIRECT_MAX * 16));
@@ -618,13 +693,14 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         const uint32_t NC = (uint32_t)d->NC, chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
         const uint64_t items = (uint64_t)chunks * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
-#define FASTECC_DIRECT61(EB) hipLaunchKernelGGL(k_direct_accumulate<EB>, grid, dim3(256), 0, s0, data, parity, d->direct_coef, d->direct_partial, elems, NC, col_chunks, items)
+#define FASTECC_DIRECT61(EB)                                                                                                                     \
+    hipLaunchKernelGGL(k_direct_accumulate<EB>, dim3(grid.x, (unsigned)(d->direct_pad / EB)), dim3(256), 0, s0, data, parity, d->direct_coef, d->direct_partial, \
+                       elems, NC, col_chunks, items, (uint32_t)d->direct_pad)
         switch (d->direct_pad) {
             case 1: FASTECC_DIRECT61(1); break;
             case 2: FASTECC_DIRECT61(2); break;
             case 4: FASTECC_DIRECT61(4); break;
-            case 8: FASTECC_DIRECT61(8); break;
-            default: FASTECC_DIRECT61(16); break;
+            default: FASTECC_DIRECT61(8); break;  // 8, 16, ...: sweeps of 8 outputs
         }
 #undef FASTECC_DIRECT61
         D61_TRY(hipGetLastError());
