@@ -714,24 +714,36 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
     }
     if (d->erased_data != 0) {
         if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
-        {
+        // x p'(x) at the even (data) positions only where the plans pair up (encode_fold) — then the gather rides in the first DIF tile and the
+        // scatter in the last DIT tile where there are such passes — else on all 2k points
+        const int caps = d->half ? fold_caps(d->transform, d->half) : 0;
+        const bool fused_gather = (caps & FOLD_GATHERS) != 0, fused_scatter = (caps & FOLD_SCATTERS) != 0;
+        if (!fused_gather) {
             const uint64_t items = d->NC * col_chunks;
             hipLaunchKernelGGL(k_gather, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, elems, col_chunks, items);
             D61_TRY(hipGetLastError());
         }
-        // x p'(x) at the even (data) positions only where the plans pair up (encode_fold), else on all 2k points
         int rc = FASTECC_E_UNSUPPORTED;
-        if (d->half) {
+        if (caps & FOLD_PAIRS) {
             if (!d->rec) D61_TRY(hipMalloc((void**)&d->rec, d->N * d->elems * 16));
-            rc = encode_fold(d->transform, d->half, d->work, d->work, d->rec, s0, hooks);
-            if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+            FoldEnds ends;
+            if (fused_gather) {
+                ends.parity = parity;
+                ends.fin = d->fin;
+            }
+            if (fused_scatter) {
+                ends.gout = d->gout;
+                ends.data_out = data;
+            }
+            rc = encode_fold(d->transform, d->half, fused_gather ? data : d->work, d->work, d->rec, s0, hooks, &ends);
+            if (rc != FASTECC_OK) return rc;
         }
         const bool folded = rc == FASTECC_OK;
         if (!folded) {
             rc = encode(d->transform, d->work, d->work, s0, hooks);
             if (rc != FASTECC_OK) return rc;
         }
-        {
+        if (!(folded && fused_scatter)) {
             const uint64_t items = d->N * col_chunks;
             hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, folded ? d->rec : d->work, data, d->gout, elems, col_chunks, items,
                                folded ? 1u : 2u);

@@ -33,7 +33,7 @@ namespace p61 {
 
 namespace {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5 };
 
 // forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
 struct SmallRoots {
@@ -52,6 +52,10 @@ struct PassArgs {
     uint64_t items;          // (N >> r) * col_chunks
     int s;                   // log2 of the smallest stride of the pass
     SmallRoots sr;
+    // the decoder's fused ends (MODE_DIF_GATHER, MODE_DIT_SCATTER): row u of the input is (u even ? in : in2)[u / 2] times side[u], read
+    // only where side[u] != 0; row i of the output is stored, times side[i], only where side[i] != 0
+    const uint64_t* in2;
+    const uint64_t* side;
 };
 
 using gf61::Elem;
@@ -426,18 +430,44 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     auto exchange = [&](auto wrow, auto rrow) { exchange_of(x, wrow, rrow); };
 
     const uint32_t off_a = (g << s) + lo;  // layout A: x[j] = block (.. + j * 2^(s+L2) + off_a)
-    if constexpr (MODE == MODE_DIF) {
-        load(row_a);
+    if constexpr (MODE == MODE_DIF || MODE == MODE_DIF_GATHER) {
+        if constexpr (MODE == MODE_DIF_GATHER) {
+            // the decoder's gather in the first pass of its transform: position u is data block u/2 or parity block u/2 times a per-position
+            // factor (wave-uniform), and an erased position (factor 0) is a zero row that is never read
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint64_t u = block0 + ((uint64_t)row_a(j) << s);
+                const uint64_t fre = as_constant(a.side)[2 * u], fim = as_constant(a.side)[2 * u + 1];
+                x[j] = Elem{0, 0};
+                if ((fre | fim) != 0)
+                    x[j] = gf61::mul(load_elem(((u & 1u) ? a.in2 : a.in) + (u >> 1) * row_words + 2u * col), gf61::make_twiddle(fre, fim), k);
+            }
+        } else {
+            load(row_a);
+        }
         dif_levels<LOGR, false, INV>(x, a.tw_dif, off_a, s + L2, k, a.sr);
         exchange(row_a, row_b);
         dif_levels<LOGR, false, INV, L2>(x, a.tw_dif, lo, s, k, a.sr);
         store(row_b);
-    } else if constexpr (MODE == MODE_DIT) {
+    } else if constexpr (MODE == MODE_DIT || MODE == MODE_DIT_SCATTER) {
         load(row_b);
         dit_levels<LOGR, false, false, L2>(x, a.tw_dit, lo, s, k, a.sr);
         exchange(row_b, row_a);
         dit_levels<LOGR, false, false>(x, a.tw_dit, off_a, s + L2, k, a.sr);
-        store(row_a);
+        if constexpr (MODE == MODE_DIT_SCATTER) {
+            // the decoder's scatter in the last pass: only the rows it is rebuilding leave, each times its factor, canonical
+#pragma unroll
+            for (int j = 0; j < R; ++j) asm volatile("" : "+v"(x[j].re), "+v"(x[j].im));  // (or the last level's butterflies sink into the branches below)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint64_t i = block0 + ((uint64_t)row_a(j) << s);
+                const uint64_t fre = as_constant(a.side)[2 * i], fim = as_constant(a.side)[2 * i + 1];
+                if ((fre | fim) != 0) store_elem(a.out + i * row_words + 2u * col, gf61::canon(gf61::mul(x[j], gf61::make_twiddle(fre, fim), k)));
+                __builtin_amdgcn_sched_barrier(0);  // one row at a time: the products of all R rows at once do not fit the registers
+            }
+        } else {
+            store(row_a);
+        }
     } else if constexpr (MODE == MODE_MID_FOLD) {
         // MID of a transform of which only the EVEN output positions are wanted (the decoder's x p'(x), gf61_decode.hip): at the first DIT
         // level an even position is a + b, and what is left is a DIT of half the size on the surviving positions — level l of this transform
@@ -569,6 +599,8 @@ hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const Pass
     case MODE_MID_FOLD:
         if constexpr (LOGT == 7) return launch_tile_one<LOGT, MODE_MID_FOLD, false, SPLIT, true>(a, tiles, st);
         else return hipErrorInvalidValue;
+    case MODE_DIF_GATHER: return launch_tile_one<LOGT, MODE_DIF_GATHER, false, SPLIT, true>(a, tiles, st);
+    case MODE_DIT_SCATTER: return launch_tile_one<LOGT, MODE_DIT_SCATTER, true, SPLIT, false>(a, tiles, st);
     default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT, true>(a, tiles, st);
     }
 }
@@ -809,17 +841,40 @@ struct Scope {
 };
 
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
+// The decoder's ends of a run of passes (encode_fold): the first pass gathers, the last one scatters (see PassArgs).
+struct FusedEnds {
+    const uint64_t* first_in2 = nullptr;
+    const uint64_t* first_side = nullptr;  // set: plan[0] must be a DIF tile
+    const uint64_t* last_side = nullptr;   // set: plan.back() must be a canonical DIT tile; it then writes to last_out
+    uint64_t* last_out = nullptr;
+};
+
 int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint64_t* out, const uint64_t* tw_dif,
-               const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks, uint64_t col0 = 0, uint64_t width = 0)
+               const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks, uint64_t col0 = 0, uint64_t width = 0,
+               const FusedEnds* ends = nullptr)
 {
     if (width == 0) width = p->elems;
     in += 2 * col0;  // element columns [col0, col0 + width) of every block: independent transforms
     out += 2 * col0;
     const uint64_t* src = in;
-    for (const Pass& q : plan) {
+    for (size_t qi = 0; qi < plan.size(); qi++) {
+        const Pass& q = plan[qi];
+        int mode = q.mode;
         PassArgs a{};
         a.in = src;
         a.out = out;
+        if (ends && ends->first_side && qi == 0) {
+            if (!q.tile || q.mode != MODE_DIF || !inverse_roots) return FASTECC_E_UNSUPPORTED;
+            mode = MODE_DIF_GATHER;
+            a.in2 = ends->first_in2;
+            a.side = ends->first_side;
+        }
+        if (ends && ends->last_side && qi + 1 == plan.size()) {
+            if (!q.tile || q.mode != MODE_DIT || !q.canon || mode != q.mode) return FASTECC_E_UNSUPPORTED;
+            mode = MODE_DIT_SCATTER;
+            a.side = ends->last_side;
+            a.out = ends->last_out;
+        }
         a.tw_dif = tw_dif;
         a.tw_dit = tw_dit;
         a.dscale = p->dscale;
@@ -833,14 +888,15 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         if (blocks > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
         const dim3 grid((unsigned)blocks);
         char name[32];
-        snprintf(name, sizeof name, "p61_%s%s%d", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr);
+        snprintf(name, sizeof name, "p61_%s%s%d%s", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr,
+                 mode == MODE_DIF_GATHER ? "_gather" : mode == MODE_DIT_SCATTER ? "_scatter" : "");
         Scope sc(hooks, st, name, 2ull * p->N * width * 16ull);
         hipError_t e;
         if (q.tile) {
-            if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
-            else if (q.logr == 6) e = launch_tile_mode<6, 1>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
-            else if (p->split == 2) e = launch_tile_mode<7, 2>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
-            else e = launch_tile_mode<7, 1>(q.mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else if (q.logr == 6) e = launch_tile_mode<6, 1>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else if (p->split == 2) e = launch_tile_mode<7, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            else e = launch_tile_mode<7, 1>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             if (e != hipSuccess) return fail(nullptr, 0, e, "p61 tile pass");
             src = out;
             continue;
@@ -867,19 +923,48 @@ int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, 
 // The decoder's folded transform (only the even output positions of a size-2^(n+1) transform are wanted): `big` is that transform with a
 // 7-level MID tile, `half` a size-2^n path with a 6-level MID tile.  DIF passes of `big` (in -> work, then in place), the folding MID tile
 // (work -> out, 2^n blocks), DIT passes of `half` above its MID, in place on `out`.  FASTECC_E_UNSUPPORTED when the two plans do not pair up.
-int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks)
+namespace {
+// the two paths pair up when big's MID is a 7-level tile and half's a 6-level one (same exchange split)
+bool fold_pairs(Path* big, Path* half, size_t* mb_out, size_t* mh_out)
 {
-    if (!big || !half || big->n != half->n + 1 || big->elems != half->elems) return FASTECC_E_UNSUPPORTED;
+    if (!big || !half || big->n != half->n + 1 || big->elems != half->elems) return false;
     size_t mb = 0, mh = 0;
     while (mb < big->enc.size() && big->enc[mb].mode != MODE_MID) mb++;
     while (mh < half->enc.size() && half->enc[mh].mode != MODE_MID) mh++;
-    if (mb == big->enc.size() || mh == half->enc.size()) return FASTECC_E_UNSUPPORTED;
+    if (mb == big->enc.size() || mh == half->enc.size()) return false;
     const Pass &qb = big->enc[mb], &qh = half->enc[mh];
-    if (!qb.tile || qb.logr != 7 || !qh.tile || qh.logr != 6 || big->split != half->split) return FASTECC_E_UNSUPPORTED;
+    if (!qb.tile || qb.logr != 7 || !qh.tile || qh.logr != 6 || big->split != half->split) return false;
+    *mb_out = mb;
+    *mh_out = mh;
+    return true;
+}
+}  // namespace
+
+int fold_caps(Path* big, Path* half)
+{
+    size_t mb = 0, mh = 0;
+    if (!fold_pairs(big, half, &mb, &mh)) return 0;
+    int caps = FOLD_PAIRS;
+    if (mb > 0 && big->enc[0].tile && big->enc[0].mode == MODE_DIF) caps |= FOLD_GATHERS;
+    if (mh + 1 < half->enc.size() && half->enc.back().tile && half->enc.back().mode == MODE_DIT && half->enc.back().canon) caps |= FOLD_SCATTERS;
+    return caps;
+}
+
+int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks, const FoldEnds* ends)
+{
+    size_t mb = 0, mh = 0;
+    if (!fold_pairs(big, half, &mb, &mh)) return FASTECC_E_UNSUPPORTED;
+    const int caps = fold_caps(big, half);
+    if (ends && ((ends->fin && !(caps & FOLD_GATHERS)) || (ends->gout && !(caps & FOLD_SCATTERS)))) return FASTECC_E_UNSUPPORTED;
     const std::vector<Pass> down(big->enc.begin(), big->enc.begin() + mb), up(half->enc.begin() + mh + 1, half->enc.end());
     const uint64_t* src = in;
     if (!down.empty()) {
-        const int rc = run_passes(big, down, in, work, big->tw_inv, big->tw_fwd, true, st, hooks);
+        FusedEnds fe;
+        if (ends && ends->fin) {
+            fe.first_in2 = ends->parity;
+            fe.first_side = ends->fin;
+        }
+        const int rc = run_passes(big, down, in, work, big->tw_inv, big->tw_fwd, true, st, hooks, 0, 0, &fe);
         if (rc != FASTECC_OK) return rc;
         src = work;
     }
@@ -903,7 +988,12 @@ int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint6
         if (e != hipSuccess) return fail(nullptr, 0, e, "p61 folding MID tile");
     }
     if (up.empty()) return FASTECC_OK;  // (the MID tile then wrote lazy values: the caller's next step accepts them)
-    return run_passes(half, up, out, out, half->tw_inv, half->tw_fwd, true, st, hooks);
+    FusedEnds fe;
+    if (ends && ends->gout) {
+        fe.last_side = ends->gout;
+        fe.last_out = ends->data_out;
+    }
+    return run_passes(half, up, out, out, half->tw_inv, half->tw_fwd, true, st, hooks, 0, 0, &fe);
 }
 
 int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t cap)

@@ -29,7 +29,22 @@ int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, 
 int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t detail_cap);
 // Only the EVEN output positions of `big`'s transform (size 2^(n+1), created with force_mid = 7): DIF passes of `big`, a MID tile that folds
 // the first DIT level away, DIT passes of `half` (size 2^n, force_mid = 6).  in: 2^(n+1) blocks; work: 2^(n+1) blocks (may be `in`); out: 2^n blocks.
-int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks);
+// FASTECC_E_UNSUPPORTED if the plans of the two do not pair up.
+// ends (optional): the decoder's gather and scatter run inside the first and the last pass —
+//   fin  != null: `in` is the data stripe, `parity` the parity stripe; position u of the input is (u even ? data : parity)[u / 2] * fin[u], read
+//                 only where fin[u] != 0 (needs FOLD_GATHERS);
+//   gout != null: row i of the result is written to data_out[i], times gout[i], canonical, only where gout[i] != 0 (needs FOLD_SCATTERS);
+//                 `out` then holds intermediate values only.
+struct FoldEnds {
+    const uint64_t* parity = nullptr;
+    const uint64_t* fin = nullptr;
+    const uint64_t* gout = nullptr;
+    uint64_t* data_out = nullptr;
+};
+enum { FOLD_PAIRS = 1, FOLD_GATHERS = 2, FOLD_SCATTERS = 4 };
+int fold_caps(Path* big, Path* half);  // what encode_fold can do with these two paths
+int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks,
+                const FoldEnds* ends = nullptr);
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);

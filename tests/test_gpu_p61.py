@@ -306,11 +306,12 @@ def test_decode_at_2_16_blocks(torch_cuda, fe):
         assert torch.equal(d, x) and torch.equal(q, par)
 
 
-@pytest.mark.parametrize("logn,elems", [(6, 3), (7, 70), (9, 64), (13, 20), (14, 64)])
+@pytest.mark.parametrize("logn,elems", [(6, 3), (7, 70), (9, 64), (12, 70), (13, 20), (14, 64), (18, 2)])
 def test_decode_transform_is_folded(torch_cuda, fe, logn, elems):
     """Only the k data positions of the decoder's 2k-point transform are read, so it runs as big DIF passes, one folding MID tile
     (y[j] = x[2j] + x[2j+1] between the halves of a 7-level MID) and the DIT passes of the size-k path: the profile shows that kernel,
-    and the decode is the same as before (round trip)."""
+    and the decode is the same as before (round trip).  Where the plan has them, the first DIF tile also gathers (codeword position -> data or parity
+    block, times l(w^u), erased positions never read) and the last DIT tile scatters (only the rebuilt blocks are written, times their factor)."""
     torch = torch_cuda
     N = 1 << logn
     g = torch.Generator(device="cuda:0")
@@ -335,6 +336,9 @@ def test_decode_transform_is_folded(torch_cuda, fe, logn, elems):
         prof = enc.profile_read()
         enc.profile(False)
         assert prof.get("p61_tile_mid7_fold", (0, 0, 0))[1] == 1, prof
+        if logn in (12, 13, 18):
+            # the transform starts with a DIF tile and ends with a DIT tile there: the gather and the scatter ride in them (6- and 7-level forms)
+            assert any(name.endswith("_gather") for name in prof) and any(name.endswith("_scatter") for name in prof), prof
         assert torch.equal(d, x)
         enc.repair(d.clone(), q)
         torch.cuda.synchronize()
