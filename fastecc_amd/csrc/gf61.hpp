@@ -36,7 +36,16 @@ struct Elem {
 };
 
 // ---- host-side exact arithmetic (table generation and the scalar entry points of the ABI) ----
-inline uint64_t h_mulp(uint64_t x, uint64_t y) { return (uint64_t)(((unsigned __int128)x * y) % P); }
+inline uint64_t h_mulp(uint64_t x, uint64_t y)
+{
+    // any 64-bit x, y.  2^61 = 1 (mod p): the 128-bit product folds in 61-bit pieces — no division (the tables of a decoder are
+    // millions of these products on the host)
+    const unsigned __int128 t = (unsigned __int128)x * y;
+    const unsigned __int128 hi = t >> 61;  // < 2^67
+    uint64_t r = ((uint64_t)t & P) + ((uint64_t)hi & P) + (uint64_t)(hi >> 61);  // < 2^62 + 2^6
+    r = (r & P) + (r >> 61);
+    return r >= P ? r - P : r;
+}
 inline uint64_t h_addp(uint64_t x, uint64_t y)
 {
     const uint64_t s = x + y;
@@ -208,6 +217,17 @@ GF61_D Elem sub_raw(Elem x, Elem y) { return Elem{sub_raw(x.re, y.re), sub_raw(x
 GF61_D Elem sub_raw4(Elem x, Elem y) { return Elem{sub_raw4(x.re, y.re), sub_raw4(x.im, y.im)}; }
 GF61_D Elem fold(Elem x, const Opaque& k) { return Elem{fold(x.re, k), fold(x.im, k)}; }
 GF61_D Elem canon(Elem x) { return Elem{canon(x.re), canon(x.im)}; }
+// both operands per lane (the twiddle's limbs then live in VGPRs): canonical x canonical -> canonical.  Table builders, not transforms.
+GF61_D Elem mul_canon(Elem x, Elem y, const Opaque& k) { return canon(mul(x, make_twiddle(y.re, y.im), k)); }
+GF61_D Elem pow_canon(Elem x, uint64_t e, const Opaque& k)
+{
+    Elem r{1, 0};
+    for (; e; e >>= 1) {
+        if (e & 1u) r = mul_canon(r, x, k);
+        x = mul_canon(x, x, k);
+    }
+    return r;
+}
 #endif
 
 }  // namespace gf61

@@ -6,7 +6,7 @@
 // everywhere (c[u] l(w^u) on survivors, 0 on erasures), and f(w^e) = [x p'(x)](w^e) / (w^e l'(w^e)).  Data-parallel part:
 //   gather   work[u] = codeword[u] * l(w^u)                              (erased positions: zeros, nothing is read)
 //   x p'(x)  one pass of the encoder's own pipeline one size up: inverse transform of size 2k, the block holding coefficient
-//            m times m / 2k, forward transform  (gf61_kernels.hip with a custom factor table: p61::create_transform)
+//            m times m / 2k, forward transform  (gf61_kernels.hip with the factor m / 2k: p61::create_transform, FACTOR_INDEX)
 //   scatter  data[i] = work[2i] / (w^2i l'(w^2i))  for the erased data blocks
 // Pattern-only part (decode_prepare), on the device: l by a full product tree over the zero-padded erasure list (a zero root is
 // a factor x, undone by a table lookup per position), every level ONE batch of cyclic products — all polynomials of a level
@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <new>
+#include <chrono>
 #include <vector>
 
 #include "../../include/fastecc.h"
@@ -419,6 +420,19 @@ __global__ __launch_bounds__(256) void k_direct_reduce2(const uint64_t* __restri
     st(((pos & 1u) ? parity : data) + ((uint64_t)(pos >> 1) * elems + col) * 2, gf61::canon(v));
 }
 
+// FASTECC_TRACE_PREPARE=1: wall-clock of the phases of the first decode_prepare on stderr (as decode.hip does for the 32-bit field)
+struct PhaseTimer {
+    bool on = getenv("FASTECC_TRACE_PREPARE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fastecc prepare p61] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int fail(char* detail, size_t cap, hipError_t e, const char* what)
 {
     if (detail && cap) snprintf(detail, cap, "%s: %s", what, hipGetErrorString(e));
@@ -591,24 +605,22 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     // ---- built once; a failure half way leaves no decoder behind (the next call starts from scratch) ----
     auto build_once = [&]() -> int {
-        std::vector<uint64_t> factor(2 * NC);
-        const gf61::Elem inv_nc = gf61::h_inv(gf61::Elem{NC % P, 0});
-        for (uint64_t m = 0; m < NC; m++) {
-            const gf61::Elem f = gf61::h_mul(gf61::Elem{m % P, 0}, inv_nc);
-            factor[2 * m] = f.re;
-            factor[2 * m + 1] = f.im;
-        }
+        PhaseTimer pt;
         // only the even (data) positions of this transform are wanted: a 7-level MID here pairs with the 6-level MID of a size-k path,
         // whose DIT passes finish the folded transform (encode_fold); where no such pair of plans exists all 2k outputs are computed
-        int rc = create_transform_mid(&d->transform, log2k + 1, elems, factor.data(), 7, detail, cap);
-        if (rc == FASTECC_OK && log2k >= 6) rc = create_transform_mid(&d->half, log2k, elems, nullptr, 6, detail, cap);
+        int rc = create_transform_mid(&d->transform, log2k + 1, elems, FACTOR_INDEX, 7, detail, cap);
+        pt.mark("transform path");
+        if (rc == FASTECC_OK && log2k >= 6) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, 6, detail, cap);
+        pt.mark("half path");
         if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + 1, 2, detail, cap);  // only its stand-alone transform is used
+        pt.mark("pattern path");
         if (rc != FASTECC_OK) return rc;
         d->tree.assign(lgT, nullptr);
         for (int k = leaf_log; k < lgT; k++) {
             rc = create(&d->tree[k], k + 1, T >> k, detail, cap);
             if (rc != FASTECC_OK) return rc;
         }
+        pt.mark("tree paths");
         d->T = T;
         D61_TRY(hipMalloc((void**)&d->tree_x, 2 * T * 16));
         D61_TRY(hipMalloc((void**)&d->tree_y, 2 * T * 16));
@@ -624,6 +636,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, nullptr, d->wpow, w.re, w.im, (uint32_t)NC);
         D61_TRY(hipGetLastError());
         d->built = true;
+        pt.mark("buffers, w^u");
         return FASTECC_OK;
     };
     if (!d->built) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ void store_elem(uint64_t* p, Elem e)
 // elements and 4 levels: 19 general products instead of 32 (17 -> 4 in the runs next to the per-block factor, where off = 0
 // and nothing is left to collect).  Exact arithmetic: every stored word is the same field element as before.
 //
-// Tables (host: build_run_table): the run of levels [sl, sl + r) owns entries [2^(sl+r), 2^(sl+r+1)); entry
+// Tables (k_run_table): the run of levels [sl, sl + r) owns entries [2^(sl+r), 2^(sl+r+1)); entry
 // (off << r) + j is (root of order 2^(sl+r))^(off * bitrev_r(j)): the 2^r - 1 values a wave needs are contiguous.
 enum { K_ONE, K_I, K_W8, K_W8I, K_GEN };
 constexpr int small_kind(int t, int m)
@@ -775,29 +775,52 @@ std::vector<Run> runs_of(const std::vector<Pass>& plan)
 
 // Collected twiddles (see dif_levels): the run of levels [sl, sl + r) owns entries [2^(sl+r), 2^(sl+r+1)); entry
 // (off << r) + j = (root of order 2^(sl+r))^(off * bitrev_r(j)).  2N entries of 16 bytes.  Replaces the roots[] array of
-// ntt.cpp:397-402 and the running root_i *= root of ntt.cpp:270-281.
-std::vector<uint64_t> build_run_table(int n, gf61::Elem root_of_order_N, const std::vector<Run>& runs)
+// ntt.cpp:397-402 and the running root_i *= root of ntt.cpp:270-281.  Built on the device: every entry is one power (a decoder owns some twenty
+// paths; their tables on the host, 10 ns per product, were most of its first fastecc_decode_prepare).
+__global__ __launch_bounds__(256) void k_run_table(uint64_t* __restrict__ tab, uint64_t root_re, uint64_t root_im, int sl, int r)
 {
-    std::vector<uint64_t> tab(4 * std::max<size_t>((size_t)1 << n, 2), 0);
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // (off << r) + j
+    if (t >= (1ull << (sl + r))) return;
+    const uint64_t off = t >> r, j = t & ((1ull << r) - 1u);
+    const uint64_t i = r ? __brevll(j) >> (64 - r) : 0;  // i = bitrev_r(j)
+    const gf61::Opaque k = gf61::make_opaque();
+    const Elem w = gf61::pow_canon(Elem{root_re, root_im}, off * i, k);
+    const uint64_t entry = (1ull << (sl + r)) + t;
+    tab[2 * entry] = w.re;
+    tab[2 * entry + 1] = w.im;
+}
+
+// per-block factors c * w^i (RS.cpp:51-54: c = 1/N, w of order 2N), stored by position: position q holds coefficient bitrev_n(q)
+// (by_index: c * i instead — the derivative's factor in the decoder's x p'(x), gf61_decode.hip)
+__global__ __launch_bounds__(256) void k_block_factors(uint64_t* __restrict__ d, uint64_t c_re, uint64_t c_im, uint64_t w_re, uint64_t w_im, int n,
+                                                       bool by_index)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (q >= (1ull << n)) return;
+    const uint64_t i = n ? __brevll(q) >> (64 - n) : 0;
+    const gf61::Opaque k = gf61::make_opaque();
+    const Elem v = gf61::mul_canon(by_index ? Elem{i, 0} : gf61::pow_canon(Elem{w_re, w_im}, i, k), Elem{c_re, c_im}, k);
+    d[2 * q] = v.re;
+    d[2 * q + 1] = v.im;
+}
+
+int device_run_table(uint64_t** dst, int n, gf61::Elem root_of_order_N, const std::vector<Run>& runs, char* detail, size_t cap)
+{
+    const size_t words = 4 * std::max<size_t>((size_t)1 << n, 2);
+    hipError_t e = hipSuccess;
+    if (!*dst) e = hipMalloc((void**)dst, words * 8);
+    if (e != hipSuccess) return fail(detail, cap, e, "hipMalloc(gf61 table)");
+    e = hipMemsetAsync(*dst, 0, words * 8, nullptr);
+    if (e != hipSuccess) return fail(detail, cap, e, "hipMemsetAsync(gf61 table)");
     for (const Run& run : runs) {
-        const int e = run.sl + run.r;
-        const uint64_t R = 1ull << run.r;
-        const gf61::Elem root = gf61::h_pow(root_of_order_N, 1ull << (n - e));  // order 2^e
-        gf61::Elem wo{1, 0};  // root^off
-        for (uint64_t off = 0; off < (1ull << run.sl); off++) {
-            gf61::Elem w{1, 0};  // wo^i
-            for (uint64_t i = 0; i < R; i++) {
-                uint64_t j = 0;  // i = bitrev_r(j)
-                for (int b = 0; b < run.r; b++) j |= ((i >> b) & 1ull) << (run.r - 1 - b);
-                const uint64_t entry = (1ull << e) + (off << run.r) + j;
-                tab[2 * entry] = w.re;
-                tab[2 * entry + 1] = w.im;
-                w = gf61::h_mul(w, wo);
-            }
-            wo = gf61::h_mul(wo, root);
-        }
+        const int lev = run.sl + run.r;
+        const gf61::Elem root = gf61::h_pow(root_of_order_N, 1ull << (n - lev));  // order 2^(sl + r)
+        const uint64_t count = 1ull << lev;
+        hipLaunchKernelGGL(k_run_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, *dst, root.re, root.im, run.sl, run.r);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(detail, cap, e, "gf61 twiddle table kernel");
     }
-    return tab;
+    return FASTECC_OK;
 }
 
 int upload(uint64_t** dst, const std::vector<uint64_t>& src, char* detail, size_t cap)
@@ -810,19 +833,20 @@ int upload(uint64_t** dst, const std::vector<uint64_t>& src, char* detail, size_
     return FASTECC_OK;
 }
 
+// (kernels on the null stream; the caller synchronises once all tables of a path are under way)
 int upload_tables(Path* p, char* detail, size_t cap)
 {
     const gf61::Elem wN = gf61::h_root(p->N), wNi = gf61::h_inv(wN);
     const std::vector<Run> sl = runs_of(p->enc), sl_ntt = runs_of(p->fwd);
-    int rc = upload(&p->tw_fwd, build_run_table(p->n, wN, sl), detail, cap);
-    if (rc == FASTECC_OK) rc = upload(&p->tw_inv, build_run_table(p->n, wNi, sl), detail, cap);
+    int rc = device_run_table(&p->tw_fwd, p->n, wN, sl, detail, cap);
+    if (rc == FASTECC_OK) rc = device_run_table(&p->tw_inv, p->n, wNi, sl, detail, cap);
     if (sl_ntt == sl) {
         if (p->tw_ntt_fwd) (void)hipFree(p->tw_ntt_fwd);
         if (p->tw_ntt_inv) (void)hipFree(p->tw_ntt_inv);
         p->tw_ntt_fwd = p->tw_ntt_inv = nullptr;
     } else {
-        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_fwd, build_run_table(p->n, wN, sl_ntt), detail, cap);
-        if (rc == FASTECC_OK) rc = upload(&p->tw_ntt_inv, build_run_table(p->n, wNi, sl_ntt), detail, cap);
+        if (rc == FASTECC_OK) rc = device_run_table(&p->tw_ntt_fwd, p->n, wN, sl_ntt, detail, cap);
+        if (rc == FASTECC_OK) rc = device_run_table(&p->tw_ntt_inv, p->n, wNi, sl_ntt, detail, cap);
     }
     return rc;
 }
@@ -840,7 +864,6 @@ struct Scope {
     }
 };
 
-// inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
 // The decoder's ends of a run of passes (encode_fold): the first pass gathers, the last one scatters (see PassArgs).
 struct FusedEnds {
     const uint64_t* first_in2 = nullptr;
@@ -849,6 +872,7 @@ struct FusedEnds {
     uint64_t* last_out = nullptr;
 };
 
+// inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
 int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint64_t* out, const uint64_t* tw_dif,
                const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks, uint64_t col0 = 0, uint64_t width = 0,
                const FusedEnds* ends = nullptr)
@@ -916,9 +940,9 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
 
 }  // namespace
 
-int create(Path** out, int n, uint64_t elems, char* detail, size_t cap) { return create_transform(out, n, elems, nullptr, detail, cap); }
+int create(Path** out, int n, uint64_t elems, char* detail, size_t cap) { return create_transform(out, n, elems, FACTOR_ENCODE, detail, cap); }
 
-int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t cap) { return create_transform_mid(out, n, elems, factor, 0, detail, cap); }
+int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail, size_t cap) { return create_transform_mid(out, n, elems, factor, 0, detail, cap); }
 
 // The decoder's folded transform (only the even output positions of a size-2^(n+1) transform are wanted): `big` is that transform with a
 // 7-level MID tile, `half` a size-2^n path with a 6-level MID tile.  DIF passes of `big` (in -> work, then in place), the folding MID tile
@@ -996,7 +1020,7 @@ int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint6
     return run_passes(half, up, out, out, half->tw_inv, half->tw_fwd, true, st, hooks, 0, 0, &fe);
 }
 
-int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t cap)
+int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int force_mid, char* detail, size_t cap)
 {
     *out = nullptr;
     if (n < 1 || n > MAX_LOG2_K || elems == 0 || elems > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
@@ -1016,19 +1040,22 @@ int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* fact
     }
     build_plans(p);
 
-    // per-block factors w_2N^i / N (RS.cpp:51-54), stored by position: position q holds coefficient bitrev(q)
-    std::vector<uint64_t> dsc(2 * p->N);
-    const gf61::Elem w2N = gf61::h_root(2 * p->N);
-    gf61::Elem d = gf61::h_inv(gf61::Elem{p->N % gf61::P, 0});
-    for (uint64_t i = 0; i < p->N; i++) {
-        uint64_t r = 0;
-        for (int b = 0; b < n; b++) r |= ((i >> b) & 1ull) << (n - 1 - b);
-        dsc[2 * r] = factor ? factor[2 * i] % gf61::P : d.re;  // a custom per-coefficient factor (the decoder's m / N), else the encoder's
-        dsc[2 * r + 1] = factor ? factor[2 * i + 1] % gf61::P : d.im;
-        d = gf61::h_mul(d, w2N);
-    }
+    // per-block factors w_2N^i / N (RS.cpp:51-54) — or i / N, the decoder's — stored by position: position q holds coefficient bitrev(q)
     int rc = upload_tables(p, detail, cap);
-    if (rc == FASTECC_OK) rc = upload(&p->dscale, dsc, detail, cap);
+    if (rc == FASTECC_OK) {
+        const gf61::Elem w2N = gf61::h_root(2 * p->N), c = gf61::h_inv(gf61::Elem{p->N % gf61::P, 0});
+        hipError_t e = hipMalloc((void**)&p->dscale, 2 * p->N * 8);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_block_factors, dim3((unsigned)((p->N + 255) / 256)), dim3(256), 0, nullptr, p->dscale, c.re, c.im, w2N.re, w2N.im, n,
+                               factor == FACTOR_INDEX);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail(detail, cap, e, "gf61 block factors");
+    }
+    if (rc == FASTECC_OK) {
+        const hipError_t e = hipStreamSynchronize(nullptr);  // the tables are complete before any stream may use the path
+        if (e != hipSuccess) rc = fail(detail, cap, e, "gf61 tables");
+    }
     if (rc != FASTECC_OK) {
         destroy(p);
         return rc;
@@ -1098,7 +1125,12 @@ int set_plan(Path* p, int plan, char* detail, size_t cap)
     p->tiles = plan == 0 || kind >= 1;
     p->split = kind == 2 ? 1 : 2;
     build_plans(p);
-    return upload_tables(p, detail, cap);
+    int rc = upload_tables(p, detail, cap);
+    if (rc == FASTECC_OK) {
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) rc = fail(detail, cap, e, "gf61 tables");
+    }
+    return rc;
 }
 
 const char* plan_string(const Path* p) { return p->text.c_str(); }

@@ -21,12 +21,13 @@ struct LaunchHooks {
 constexpr int MAX_LOG2_K = 24;   // 3 tables of 16 * k bytes
 constexpr int DEFAULT_LEVELS = 4;
 int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
-// The same pipeline — DIF over all levels with the inverse roots, the block holding coefficient m times factor[m], DIT back
-// with the forward roots — with a caller's factors (2 * 2^n words, (re, im) by coefficient index) instead of the encoder's
-// w_2N^m / N; no root of order 2^(n+1) is needed.  The decoder's x p'(x) transform (gf61_decode.hip) is factor[m] = m / 2^n.
-int create_transform(Path** out, int n, uint64_t elems, const uint64_t* factor, char* detail, size_t detail_cap);
+// The same pipeline — DIF over all levels with the inverse roots, the block holding coefficient m times its factor, DIT back
+// with the forward roots — with the factor m / 2^n (FACTOR_INDEX: the decoder's x p'(x) transform, gf61_decode.hip; no root of order
+// 2^(n+1) is needed) instead of the encoder's w_2N^m / N (FACTOR_ENCODE).  All tables of a path are built by kernels.
+enum { FACTOR_ENCODE = 0, FACTOR_INDEX = 1 };
+int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail, size_t detail_cap);
 // create_transform with the MID pass forced to `force_mid` levels (0 = the plan's own choice, also when no such plan exists)
-int create_transform_mid(Path** out, int n, uint64_t elems, const uint64_t* factor, int force_mid, char* detail, size_t detail_cap);
+int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int force_mid, char* detail, size_t detail_cap);
 // Only the EVEN output positions of `big`'s transform (size 2^(n+1), created with force_mid = 7): DIF passes of `big`, a MID tile that folds
 // the first DIT level away, DIT passes of `half` (size 2^n, force_mid = 6).  in: 2^(n+1) blocks; work: 2^(n+1) blocks (may be `in`); out: 2^n blocks.
 // FASTECC_E_UNSUPPORTED if the plans of the two do not pair up.

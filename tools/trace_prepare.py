@@ -11,9 +11,10 @@ import torch  # noqa: E402
 
 import fastecc_amd as fe  # noqa: E402
 
-k = 1 << 19
+p61 = len(sys.argv) > 1 and sys.argv[1] == "p61"   # the 64-bit field at (2^19, 2^18)
+k = 1 << (18 if p61 else 19)
 torch.zeros(1, device="cuda:0")
-with fe.Encoder(2 * k, k, 4096) as enc:
+with fe.Encoder(2 * k, k, 4096, field=fe.FIELD_GF_P61_SQUARED if p61 else fe.FIELD_GF_FFF00001) as enc:
     rng = np.random.default_rng(1)
     for round_ in range(2):
         lost = rng.permutation(2 * k)[:2000]
