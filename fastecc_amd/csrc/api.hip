@@ -138,6 +138,17 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.in_odd = cb.gather_odd;
                 a.row_factor = cb.gather_factor;
             }
+            int mode = p.mode;
+            if (cb.rows_factor && src == in && p.mode == MODE_DIF) {  // split decoder: blocks times their factors on the way in
+                mode = MODE_DIF_ROWS;
+                a.row_factor = cb.rows_factor;
+                a.groups = cb.groups;
+            }
+            if (cb.addend && p.mode == MODE_MID) {
+                mode = MODE_MID_ADD;
+                a.addend = cb.addend + col0;
+                a.addend_factor = cb.addend_factor;
+            }
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.split2 = c->split2;
             a.xcd_swizzle = c->xcd_swizzle;
@@ -146,7 +157,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
             // and keeping them cacheable is worth 1.2-1.4x (profiles/r01/ablation_dif_tiles.md).
             const bool rows_aligned = ((c->ld * 4) % 128) == 0;
             a.cache_policy = !rows_aligned ? 0 : p.mode == MODE_MID ? (c->cache_policy >> 2) & 3 : c->cache_policy & 3;
-            HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, p.mode, a, st));
+            HIP_TRY(launch_tile(p.logr, p.pair, p.rlog, mode, a, st));
         } else {
             PassArgs a{};
             a.in = src;
@@ -167,6 +178,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.in_odd = cb.gather_odd;
                 a.row_factor = cb.gather_factor;
             }
+            if ((cb.rows_factor && src == in) || (cb.addend && p.mode == MODE_MID)) return FASTECC_E_UNSUPPORTED;  // tile passes only
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
         return FASTECC_OK;
@@ -840,12 +852,17 @@ namespace fastecc {
 
 CtxInfo info_of(const fastecc_ctx* c)
 {
-    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max, c->direct_kernel, c->p61_stride};
+    return CtxInfo{c->device, c->field, c->fold, c->cosets, c->n, c->N, c->S, c->ld, c->K != c->N || c->Mu != c->M, c->K, c->Mu, c->q, c->decode_direct_max, c->direct_kernel, c->p61_stride, c->decode_split};
 }
 DecodeState*& decoder_of(fastecc_ctx* c) { return c->decoder; }
 Sharded*& sharded_of(fastecc_ctx* c) { return c->sharded; }
 p61::Decoder*& decoder61_of(fastecc_ctx* c) { return c->decoder61; }
 p61::Path* p61_path_of(fastecc_ctx* c) { return c->p61; }
+void* profile_scope_begin(fastecc_ctx* c, hipStream_t st, const char* name, uint64_t bytes)
+{
+    return c->profiling ? new (std::nothrow) ProfScope(c, st, name, bytes) : nullptr;
+}
+void profile_scope_end(void* scope) { delete (ProfScope*)scope; }
 const p61::LaunchHooks* p61_profile_hooks(fastecc_ctx* c, void** keep)
 {
     *keep = nullptr;
@@ -893,15 +910,15 @@ int create_ntt_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int devic
 }
 
 namespace {
-// dscale[bitrev(m)] = m * scale in Montgomery form; scale_mm = scale * 2^64 mod p (mul_mont divides by 2^32 once)
-__global__ __launch_bounds__(256) void ramp_factor_kernel(uint32_t* __restrict__ dsc, uint32_t N, int lg, uint32_t scale_mm)
+// dscale[bitrev(m)] = m * scale + offset in Montgomery form; scale_mm = scale * 2^64 mod p (mul_mont divides by 2^32 once), offset_m = offset * 2^32
+__global__ __launch_bounds__(256) void ramp_factor_kernel(uint32_t* __restrict__ dsc, uint32_t N, int lg, uint32_t scale_mm, uint32_t offset_m)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < N) dsc[__brev(m) >> (32 - lg)] = gf::mul_mont(m, scale_mm);
+    if (m < N) dsc[__brev(m) >> (32 - lg)] = gf::add(gf::mul_mont(m, scale_mm), offset_m);
 }
 }  // namespace
 
-int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device)
+int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device, uint32_t offset)
 {
     if (!out || log2k < 1 || log2k > 20 || fold < 0 || fold > 4 || fold > log2k || block_bytes == 0 || (block_bytes % 4)) return FASTECC_E_INVAL;
     *out = nullptr;
@@ -913,7 +930,7 @@ int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes
     hipError_t e = dg.ok ? hipMalloc((void**)&c->dscale, k * 4) : hipErrorInvalidDevice;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ramp_factor_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, nullptr, c->dscale, (uint32_t)k, log2k,
-                           gf::h_to_mont(gf::h_to_mont(scale % gf::P)));
+                           gf::h_to_mont(gf::h_to_mont(scale % gf::P)), gf::h_to_mont(offset % gf::P));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
@@ -1012,6 +1029,43 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
                         order[k++] = pos0 + ((g + 2 * i * G + half * G + far * (T / 2)) << s);
     }
     return true;
+}
+
+// ---- the decoder's split transform (decode.hip, "even / odd split") on a context of k blocks whose per-block factors are (2m + k) / 2k ----
+bool split_decode_supported(const fastecc_ctx* c)
+{
+    if (c->p61 || c->q > 1 || c->fold != 0 || c->cosets != 1 || c->encode_plan.size() != 3 || !c->dscale || c->ld != c->S) return false;
+    const Pass &p0 = c->encode_plan[0], &p1 = c->encode_plan[1], &p2 = c->encode_plan[2];
+    // a slim pair tile down, the split 1024-block MID tile, the same slim tile up: k = 2^18, 2^19 with the default plan
+    return p0.mode == MODE_DIF && p0.tile && p0.pair && p0.rlog == 4 && !p0.wide && p1.mode == MODE_MID && p1.tile && p1.pair && p1.logr == 10 && c->split2 &&
+           p2.mode == MODE_DIT && p2.tile;
+}
+
+uint32_t split_decode_groups(const fastecc_ctx* c) { return 1u << c->encode_plan[0].s; }       // block groups of the first pass
+uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_plan[0].logr; }  // blocks per group: i = group + (t << s)
+
+int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
+                     uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, hipStream_t st)
+{
+    if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return FASTECC_E_DEVICE;
+    const uint32_t *twd = twiddle_table(c, TW_ENC_DIF), *twu = twiddle_table(c, TW_ENC_DIT);
+    const std::vector<Pass> first{c->encode_plan[0]};
+    // the levels MID takes on its way down, as a DIF tile of their own (the level tables are packed by level: the same table serves)
+    const std::vector<Pass> low{Pass{MODE_DIF, c->encode_plan[1].logr, 0, true, true, 5}};
+    const std::vector<Pass> rest{c->encode_plan[1], c->encode_plan[2]};
+    CallBounds cq, cr, cm;
+    cq.rows_factor = data_rows_factor;
+    cr.rows_factor = parity_rows_factor;
+    cr.groups = parity_groups;
+    cm.addend = r2;
+    cm.addend_factor = parity_pos_factor;
+    int rc = run_passes(c, first, data, q, twd, twu, st, 0, 0, nullptr, 1, cq);            // q~ : top levels of the data half
+    if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use
+    if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st);                              // r~ : low levels (r1 is zero outside those groups)
+    if (rc == FASTECC_OK) rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, cm);         // g = fq q~ + fr r~, and the transform back up
+    return rc;
 }
 
 CallScope::CallScope(fastecc_ctx* c) : c_(c) { c_->mu.lock(); }

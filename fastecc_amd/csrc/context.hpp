@@ -50,6 +50,12 @@ struct CallBounds {
     const uint32_t* gather_odd = nullptr;
     const uint32_t* gather_factor = nullptr;
     bool dscale_whole = false;  // batch > 1: the per-block factor table covers the whole batch (mixed-radix transforms)
+    // split decoder (run_split_decode): per-block factors of a DIF tile that starts the plan (tile order; MODE_DIF_ROWS), the number of
+    // block groups of that pass to run (0 = all), and the MID tile's addend stripe with its per-position factors (MODE_MID_ADD)
+    const uint32_t* rows_factor = nullptr;
+    uint32_t groups = 0;
+    const uint32_t* addend = nullptr;
+    const uint32_t* addend_factor = nullptr;
 };
 
 }  // namespace fastecc
@@ -130,6 +136,7 @@ struct fastecc_ctx {
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
     DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
     int encode_direct_max = 160;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 32
+    int decode_split = 1;         // (2k,k) codes: 1 = the decoder's transform as two half-size ones (decode.hip, "even / odd split"), 0 = one of size 2k
     int decode_direct_max = 256;  // up to this many lost blocks are recomputed directly (direct.hip), 0 = always the transform; 96 without the MFMA kernel
     int direct_kernel = 0;        // 0 choose, 1 VALU, 2 MFMA
     int slab_mode = 0;       // how `slabs` > 1 are scheduled (fastecc_set_option "slab_mode")

@@ -54,6 +54,18 @@ struct DecodeState {
     uint32_t* recovered_full = nullptr; // 2k blocks: x p'(x) at every position (lazy: 4 GiB at the headline size)
     bool full_ok = false;               // transform_full's first pass reads the factors in the same order as transform's
     uint32_t* recovered = nullptr;     // k blocks: x p'(x) at the data positions
+    // (2k,k) layout, the transform as two half-size ones ("even / odd split" below)
+    fastecc_ctx* split = nullptr;           // k blocks, per-block factor (2m + k) / 2k
+    uint32_t* split_order = nullptr;        // k words: the block each slot of its first pass holds (gather_tile_order)
+    uint32_t* split_rows_data = nullptr;    // k words, that order: l(w^2i) of the surviving data blocks (0: lost)
+    uint32_t* split_rows_parity = nullptr;  // k words, that order: l(w^(2i+1)) of the parity blocks in use (0: lost or unused)
+    uint32_t* split_pos_parity = nullptr;   // k words by position: -w^(-m) / 2 at position bitrev(m)
+    uint32_t* split_r1 = nullptr;           // k blocks: the parity half after its first pass (zero outside the groups in use)
+    uint32_t* split_r2 = nullptr;           // k blocks: ... after all DIF levels
+    uint32_t split_groups = 0;              // block groups of the parity stripe this pattern reads
+    uint32_t split_dirty = 0;               // groups of split_r1 that may hold non-zero rows
+    bool split_ready = false;               // this pattern decodes through the split transform
+    bool split_unavailable = false;         // it could not be built on this context (plan shape, memory): the 2k-point transform serves
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
     // fastecc_decode_prepare's device state (lazy): the product tree of the locator
     uint64_t tree_T = 0;                   // padded number of roots: the smallest power of two >= the most losses a code tolerates
@@ -92,6 +104,9 @@ void destroy_decode_state(DecodeState* d)
     if (!d) return;
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
+    if (d->split) fastecc_destroy(d->split);
+    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_pos_parity, d->split_r1, d->split_r2})
+        if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
     if (d->pattern_ntt) fastecc_destroy(d->pattern_ntt);
@@ -117,7 +132,8 @@ namespace {
 // fastecc_decode_prepare on the device.  All values are plain representatives unless a table is consumed by
 // gf::mul_mont, in which case it is stored in Montgomery form (x * 2^32 mod p = gf::mul(x, MONT_ONE)).
 // ------------------------------------------------------------------------------------------------
-enum : uint32_t { ST_LOST = 0, ST_HELD = 1, ST_ZERO = 2 };
+// ST_UNUSED: a surviving parity block the split transform does not read — a root of the locator like a lost one, but nothing to rebuild
+enum : uint32_t { ST_LOST = 0, ST_HELD = 1, ST_ZERO = 2, ST_UNUSED = 3 };
 constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;  // the lowest levels of the tree are one schoolbook kernel: 16 roots per thread
 
 __device__ __forceinline__ uint32_t dev_pow(uint32_t x, uint32_t e)
@@ -241,6 +257,25 @@ __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __re
     } else if (gout_par) {  // (2k,k) layout: odd u is parity block u >> 1
         gout_par[u >> 1] = st == ST_LOST ? gf::mul(dev_pow(gf::mul(lv[2 * at + 1], corr), gf::P - 2u), gf::MONT_ONE) : 0u;
     }
+}
+
+// split transform: the per-block factors of the two half stripes in the order the first pass reads them, from fin (by codeword position)
+__global__ __launch_bounds__(256) void split_rows_kernel(const uint32_t* __restrict__ fin, const uint32_t* __restrict__ order, uint32_t* __restrict__ rows_data,
+                                                         uint32_t* __restrict__ rows_parity, uint32_t k)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= k) return;
+    const uint32_t i = order[slot];
+    rows_data[slot] = fin[2u * i];
+    rows_parity[slot] = fin[2u * i + 1u];
+}
+// ... and the factor of the parity half's coefficients, by position: -w^(-m) / 2 (Montgomery) at position bitrev(m); wpow[u] = w^u, w of order 2k
+__global__ __launch_bounds__(256) void split_pos_kernel(const uint32_t* __restrict__ wpow, uint32_t* __restrict__ pos, uint32_t k, int lg, uint32_t neg_half)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= k) return;
+    const uint32_t w = wpow[m == 0 ? 0 : 2u * k - m];
+    pos[__brev(m) >> (32 - lg)] = gf::mul(gf::mul(w, neg_half), gf::MONT_ONE);
 }
 
 __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ order, uint32_t* __restrict__ dst,
@@ -525,12 +560,33 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         state[u] = held ? HELD : LOST;
         srcmap[u] = ((uint32_t)q | 0x80000000u) & (0u - held);
     }
+    // (2k,k) layout, split transform: recovering e lost data blocks takes e parity blocks, not all of them — the surviving parity blocks of
+    // the first few block groups of the parity stripe (group g = blocks g + (t << 10): what one tile of the first pass reads).  The others
+    // are left unread: roots of the locator like the lost ones.
+    uint32_t split_groups = 0;
+    const bool want_split = ci.decode_split && !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended && ci.log2k >= 18 && erased_data != 0;
+    if (want_split) {
+        constexpr uint32_t GROUPS = 1024;
+        uint32_t held_in[GROUPS] = {};
+        for (uint64_t q = 0; q < N; q++) held_in[q & (GROUPS - 1u)] += state[2 * q + 1] == HELD;
+        uint64_t have = 0;
+        while (split_groups < GROUPS && have < erased_data) have += held_in[split_groups++];
+        if (have >= erased_data) {
+            for (uint64_t q = 0; q < N; q++) {
+                const uint32_t drop = ((uint32_t)q & (GROUPS - 1u)) >= split_groups && state[2 * q + 1] == HELD;
+                state[2 * q + 1] = drop ? (uint8_t)ST_UNUSED : state[2 * q + 1];
+                srcmap[2 * q + 1] &= 0u - (1u - drop);
+            }
+        } else {
+            split_groups = 0;  // not decodable: refused below
+        }
+    }
     std::vector<uint32_t> erased(NC + 1);
     {
         uint64_t count = 0;
         for (uint64_t u = 0; u < NC; u++) {
             erased[count] = (uint32_t)u;
-            count += state[u] == LOST;
+            count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
         }
         erased.resize(count);
     }
@@ -663,6 +719,39 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     }
     // mixed radix: the work stripe of all NC positions, transformed in place; else the N recovered data positions
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, (mixed ? NC : N) * ci.words * 4));
+    d->split_ready = false;
+    if (split_groups != 0 && !d->split_unavailable && !d->split) {
+        // ---- the split transform's context and tables (once).  Anything missing — a plan without the tile shapes, no memory for the two extra
+        // stripes — leaves the 2k-point transform in charge; the pattern's unused parity blocks are unused there as well. ----
+        const int rc_split = [&]() -> int {
+            // per-block factor (2m + k) / 2k = m / k + 1 / 2
+            int rc = create_ramp_transform_ctx(&d->split, ci.log2k, ci.words * 4, 0, gf::h_inv((uint32_t)N), ci.device, gf::h_inv(2u));
+            if (rc != FASTECC_OK) return rc;
+            std::vector<uint32_t> order;
+            if (!split_decode_supported(d->split) || split_decode_groups(d->split) != 1024u || !gather_tile_order(d->split, order)) return FASTECC_E_UNSUPPORTED;
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_pos_parity}) DEC_TRY(hipMalloc((void**)b, N * 4));
+            DEC_TRY(hipMemcpy(d->split_order, order.data(), N * 4, hipMemcpyHostToDevice));
+            DEC_TRY(hipMalloc((void**)&d->split_r1, N * ci.words * 4));
+            DEC_TRY(hipMalloc((void**)&d->split_r2, N * ci.words * 4));
+            DEC_TRY(hipMemsetAsync(d->split_r1, 0, N * ci.words * 4, st));
+            d->split_dirty = 0;
+            const uint32_t neg_half = (uint32_t)(gf::P - gf::h_inv(2u));
+            hipLaunchKernelGGL(split_pos_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d->wpow, d->split_pos_parity, (uint32_t)N, ci.log2k, neg_half);
+            DEC_TRY(hipGetLastError());
+            return FASTECC_OK;
+        }();
+        if (rc_split != FASTECC_OK) {
+            if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
+            (void)hipGetLastError();
+            if (d->split) fastecc_destroy(d->split);
+            d->split = nullptr;
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_pos_parity, &d->split_r1, &d->split_r2}) {
+                if (*b) (void)hipFree(*b);
+                *b = nullptr;
+            }
+            d->split_unavailable = true;
+        }
+    }
     if (d->standard && !d->tile_order_valid) {
         std::vector<uint32_t> order;
         if (gather_tile_order(d->transform, order)) {
@@ -725,6 +814,19 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (d->fin_first_pass != d->fin) {
         hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);
         DEC_TRY(hipGetLastError());
+    }
+    if (split_groups != 0 && d->split) {
+        hipLaunchKernelGGL(split_rows_kernel, grid(N), dim3(256), 0, st, d->fin, d->split_order, d->split_rows_data, d->split_rows_parity, (uint32_t)N);
+        DEC_TRY(hipGetLastError());
+        if (d->split_dirty > split_groups) {
+            // rows of groups this pattern does not write any more: group g = blocks g + (t << 10)
+            const size_t row = ci.words * 4;
+            DEC_TRY(hipMemset2DAsync(d->split_r1 + (size_t)split_groups * ci.words, 1024 * row, 0, (d->split_dirty - split_groups) * row,
+                                     split_decode_group_rows(d->split), st));
+            d->split_dirty = split_groups;
+        }
+        d->split_groups = split_groups;
+        d->split_ready = true;
     }
     DEC_TRY(hipStreamSynchronize(st));
     pt.mark("this pattern (device)");
@@ -872,7 +974,20 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     // The (2k,k) layout lets the transform's first pass read the two halves of the codeword itself (no gather pass).
     // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
     // position whose factor is zero, instead of a tile that reads first and multiplies by zero afterwards.
-    int rc = d->standard ? run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st) : FASTECC_E_UNSUPPORTED;
+    int rc = FASTECC_E_UNSUPPORTED;
+    if (d->split_ready) {
+        // two half-size transforms instead of one of size 2k (see "even / odd split")
+        void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
+        rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
+                              d->split_r2, st);
+        profile_scope_end(scope);
+        if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
+    }
+    if (rc == FASTECC_E_UNSUPPORTED && d->standard) {
+        void* scope = profile_scope_begin(c, st, "decode_transform_2k", 3 * N * block);
+        rc = run_gathered(d->transform, ddata, dparity, d->fin_first_pass, d->recovered, st);
+        profile_scope_end(scope);
+    }
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = d->recovered;

@@ -56,6 +56,7 @@ struct CtxInfo {
     int direct_max;            // decoder: patterns with at most this many lost blocks take the direct path (option "decode_direct_max")
     int direct_kernel;         // 0 choose, 1 VALU, 2 MFMA (option "direct_kernel")
     int p61_stride;            // GF((2^61-1)^2) codes other than (2N,N): parity block j = block j * p61_stride of the (2N,N) parity
+    int decode_split;          // option "decode_split"
 };
 CtxInfo info_of(const fastecc_ctx* c);
 DecodeState*& decoder_of(fastecc_ctx* c);
@@ -68,6 +69,9 @@ struct LaunchHooks;
 p61::Decoder*& decoder61_of(fastecc_ctx* c);  // the erasure decoder of a GF((2^61-1)^2) context (gf61_decode.hip)
 p61::Path* p61_path_of(fastecc_ctx* c);       // its encoder
 // fastecc_profile_* over the launches of a p61 call: nullptr unless the context is profiling; *keep goes to p61_profile_done after the call
+// one record of fastecc_profile_* around a step of the decoder (its inner contexts are not the caller's): nullptr unless the context is profiling
+void* profile_scope_begin(fastecc_ctx* c, hipStream_t st, const char* name, uint64_t bytes);
+void profile_scope_end(void* scope);
 const p61::LaunchHooks* p61_profile_hooks(fastecc_ctx* c, void** keep);
 void p61_profile_done(void* keep);
 std::mutex& mutex_of(fastecc_ctx* c);
@@ -83,7 +87,7 @@ void set_error_detail(const char* what, hipError_t e);
 // is needed).  The encoder of RS.cpp:40-63 is the case factor[m] = w_2k^m / k.
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device);
 // create_transform_ctx with factor[m] = m * scale, the table written by a kernel (the decoder's x p'(x) transform: scale = 1 / 2^log2k)
-int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device);
+int create_ramp_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, uint32_t scale, int device, uint32_t offset = 0);  // factor m * scale + offset
 // A context for stand-alone transforms only (fastecc_ntt, transform_bitrev): no per-block factor table is built, fastecc_encode is unsupported.
 int create_ntt_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int device);
 // The same for a transform of order q * 2^log2m (q an odd radix of mixed_kernels.hip): factor has q << log2m entries by
@@ -106,6 +110,16 @@ int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit
 // else fills `order` with order[i] = codeword position whose factor is entry i of the table (two-window DIF tile:
 // the factors of one wave are contiguous).
 bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
+// The decoder's split transform (decode.hip, "even / odd split") on a context of k blocks created by create_ramp_transform_ctx with the factor
+// (2m + k) / 2k: data and parity stripes each through the plan's first DIF tile with per-block factors (tile order: gather_tile_order; a zero
+// factor = block not used), the parity half only in its first `parity_groups` block groups (group g = blocks g + (t << s), t < group_rows; the
+// rest of r1 must be zero and stays zero), its low levels as a DIF tile of their own (r1 -> r2), then MID on q with + r2[p] * parity_pos_factor[p]
+// and the plan's DIT tile.  q, r1, r2: k blocks each; the result, x p'(x) at the data positions, is left in q.
+bool split_decode_supported(const fastecc_ctx* c);
+uint32_t split_decode_groups(const fastecc_ctx* c);
+uint32_t split_decode_group_rows(const fastecc_ctx* c);
+int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
+                     uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, hipStream_t st);
 // The k-block work stripe of a fold > 0 / multi-coset context (allocated on first use); a caller may build its input
 // there and pass it as `data` to fastecc_encode, which then runs the DIF half in place.
 int scratch_of(fastecc_ctx* c, uint32_t** out);

@@ -6,7 +6,10 @@
 
 namespace fastecc {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2 };
+// MODE_DIF_ROWS / MODE_MID_ADD: tile passes of the decoder's split transform (tile_kernels.hip; decode.hip "even / odd split"):
+// a DIF tile whose input blocks are multiplied by per-block factors (TileArgs::row_factor, tile order), and a MID tile that adds
+// addend[p] * addend_factor[p] to block p between its two halves.
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4 };
 
 // Arguments of one register pass (kernels.hip: ntt_pass_kernel).
 struct PassArgs {
@@ -59,6 +62,9 @@ struct TileArgs {
     int fold;             // MID only: keep the blocks whose position is a multiple of 2^fold, stored at position >> fold
     int xcd_swizzle;      // 0 off, 1 contiguous column chunks per XCD, 2 whole block groups per XCD (workgroup b -> XCD b % 8)
     uint32_t dscale_whole;  // as PassArgs::dscale_whole
+    const uint32_t* addend;         // MODE_MID_ADD: a stripe in the position order MID's first half leaves (block p = coefficient bitrev(p))
+    const uint32_t* addend_factor;  // ... and its per-position factors (Montgomery form), laid out like dscale
+    uint32_t groups;                // > 0: only the first `groups` block groups of the pass are run (MODE_DIF_ROWS: the others are known to be zero)
 };
 
 // Arguments of the odd-radix pass of a transform of order q * 2^m (mixed_kernels.hip: radix_kernel).

@@ -88,6 +88,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         c->decode_direct_max = value;
         return FASTECC_OK;
     }
+    if (!strcmp(name, "decode_split")) {  // (2k,k) codes, from the next fastecc_decode_prepare: see context.hpp
+        if (value < 0 || value > 1) return FASTECC_E_INVAL;
+        c->decode_split = value;
+        return FASTECC_OK;
+    }
     if (!strcmp(name, "direct_kernel")) {  // 0 = choose, 1 = VALU, 2 = MFMA where the stripes allow it; decoder: from the next decode_prepare
         if (value < 0 || value > 2) return FASTECC_E_INVAL;
         c->direct_kernel = value;

@@ -145,6 +145,7 @@ struct TileView {
     uint32_t lo, hi;          // tile group: stripe block of tile block q is (hi << (s+LOGT)) + lo + (q << s)
     uint32_t dead_mask;       // all ones in lanes whose column does not exist
     __amdgpu_buffer_rsrc_t in, out;
+    __amdgpu_buffer_rsrc_t add;  // MODE_MID_ADD: the tile's blocks of TileArgs::addend
     // WIDE tiles only: descriptors of the upper half of the tile's blocks (block T/2 onwards).  A tile whose blocks span
     // up to 2^33 bytes is then addressed as two windows of < 2^32 bytes each.
     __amdgpu_buffer_rsrc_t in_hi, out_hi;
@@ -170,7 +171,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
     // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
-    static_assert(NWIN == 1 || (PAIR && MODE != MODE_MID), "windows: outer pair tiles only");
+    constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD;
+    static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
+    static_assert(MODE != MODE_DIF_ROWS || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
+    static_assert(MODE != MODE_MID_ADD || PAIR, "addend: pair tiles");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
     static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
@@ -183,10 +187,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     const uint32_t c = PAIR ? (lane & 31u) : lane;
     const uint32_t half = PAIR ? (lane >> 5) : 0u;
     const uint32_t upper_mask = 0u - half;  // all ones in the high half-wave of a PAIR tile
-    const int s = MODE == MODE_MID ? 0 : a.s;
+    const int s = MIDK ? 0 : a.s;
     // MID with fewer parity than data blocks: only output positions that are multiples of 2^fold are kept, stored
     // at position >> fold.  fold <= L2, so whether a wave's blocks survive depends on g alone.
-    const int fold = MODE == MODE_MID ? a.fold : 0;
+    const int fold = MIDK ? a.fold : 0;
     // Decoder's first pass (WIDE DIF tiles only): input block u is block u/2 of `in` (u even) or `in_odd` (u odd) times
     // row_factor[u].  s >= 1, so a whole tile reads ONE of the two buffers, as a tile with half the block stride.
     const bool gather = WIDE && MODE == MODE_DIF && a.row_factor != nullptr;  // uniform
@@ -240,6 +244,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const size_t out_block0 = fold ? (size_t)((v.hi << LOGT) >> fold) : block0;
         v.in = make_desc(a.in + origin, window(a.in_rows, block0));
         v.out = make_desc(a.out + (fold ? out_block0 * a.ld + cc * W : origin), window(a.out_rows, out_block0));
+        if constexpr (MODE == MODE_MID_ADD) v.add = make_desc(a.addend + origin);
         if constexpr (MULTI) {
             v.in_base = a.in + origin;
             v.out_base = a.out + origin;
@@ -435,7 +440,19 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 
         const uint32_t off = (g << s) + v.lo;
         const bool compute = !(a.debug & 1u), stores = !(a.debug & 2u);  // uniform; always true outside experiments
-        if constexpr (MODE == MODE_DIF || MODE == MODE_MID) {
+        if constexpr (DIFK || MIDK) {
+            if constexpr (MODE == MODE_DIF_ROWS) {
+                // the split decoder's first pass: every input block times its factor (a zero factor: an erased or unused block).  Factors in TILE
+                // order like the gather's below.
+                const_u32_ptr f = as_constant(a.row_factor) + (((size_t)(v.hi << s) + v.lo) * G + g) * (2 * R);
+#pragma unroll
+                for (int j = 0; j < R; j += 2) {
+                    const uint32_t f0 = pair_twiddle<LOGR>(f[2 * j + 0], f[2 * j + 1], upper_mask);
+                    const uint32_t f1 = pair_twiddle<LOGR>(f[2 * j + 2], f[2 * j + 3], upper_mask);
+                    x[j][0] = gf::mul_mont(x[j][0], f0);
+                    x[j + 1][0] = gf::mul_mont(x[j + 1][0], f1);
+                }
+            }
             if constexpr (WIDE && MODE == MODE_DIF) {
                 if (gather) {
                     // paired order: register 2i holds tile block g + 2i*G (+ G in the high half-wave), register 2i+1 that
@@ -457,7 +474,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
             }
             exchange(x, lds_a, qa_u, G, lds_b, qb_u, 1);
-            if constexpr (MODE == MODE_DIF) {
+            if constexpr (DIFK) {
                 if (compute) {
                     if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
                     else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
@@ -485,6 +502,30 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                     for (int i = 0; i < CH; ++i) {
                         const uint32_t f = PAIR ? pair_twiddle<LOGR>(dl[i], dh[i], upper_mask) : dl[i];
                         x[k0 + i][0] = gf::mul_mont(x[k0 + i][0], f);
+                    }
+                }
+                if constexpr (MODE == MODE_MID_ADD) {
+                    // + addend[p] * addend_factor[p]: the other half of the split decoder's coefficient vector (layout B: this lane's blocks
+                    // qb_u + k (+ R in the high half-wave), the same run of positions as the factors above)
+                    const_u32_ptr e = as_constant(a.addend_factor) + ((size_t)v.hi << LOGT) + qb_u;
+#pragma unroll
+                    for (int k0 = 0; k0 < R; k0 += CH) {
+                        uint32_t y[CH], el[CH], eh[CH];
+                        {
+                            const uint32_t voff = lane_b | v.dead_mask;
+                            uint32_t soff = (qb_u + k0) * row_bytes;
+#pragma unroll
+                            for (int i = 0; i < CH; ++i) {
+                                y[i] = __builtin_amdgcn_raw_buffer_load_b32(v.add, voff, soff, 2);
+                                soff += row_bytes;
+                                asm volatile("" : "+s"(soff));
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) el[i] = e[k0 + i], eh[i] = e[R + k0 + i];
+#pragma unroll
+                        for (int i = 0; i < CH; ++i)
+                            x[k0 + i][0] = gf::add(x[k0 + i][0], gf::mul_mont(y[i], pair_twiddle<LOGR>(el[i], eh[i], upper_mask)));
                     }
                 }
                 dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
@@ -541,7 +582,12 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
     }
     TileArgs b = a;
     b.col_chunks = (a.S + C::W - 1) / C::W;
-    const uint64_t tiles = ((uint64_t)(a.batch > 1 ? a.batch : 1u) << (a.n - LOGT)) * b.col_chunks;
+    uint64_t tiles = ((uint64_t)(a.batch > 1 ? a.batch : 1u) << (a.n - LOGT)) * b.col_chunks;
+    if (a.groups) {  // the first block groups only: tile index = group * col_chunks + column chunk in every order but the XCD order 2
+        if (a.batch > 1 || (uint64_t)a.groups * b.col_chunks > tiles) return hipErrorInvalidValue;
+        tiles = (uint64_t)a.groups * b.col_chunks;
+        if (b.xcd_swizzle == 2) b.xcd_swizzle = 0;
+    }
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     b.tiles = (uint32_t)tiles;
     uint64_t blocks = tiles;
@@ -592,9 +638,17 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             switch (mode) {
                 case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2>(a, st);
                 case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
+                case MODE_MID_ADD: return launch_one<LOGT, LOGR, PAIR, MODE_MID_ADD, 2>(a, st);
+                case MODE_DIF_ROWS: return hipErrorInvalidValue;
                 default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
             }
         }
+    }
+    // the split decoder's shapes (tile_split_supported): slim outer pair tiles with per-block factors; the addend MID only as above
+    if (mode == MODE_MID_ADD) return hipErrorInvalidValue;
+    if (mode == MODE_DIF_ROWS) {
+        if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
+        else return hipErrorInvalidValue;
     }
     switch (mode) {
         case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF>(a, st);
@@ -634,7 +688,7 @@ hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& 
     if (!tile_supported(logt, pair, logr) || a.n < logt) return hipErrorInvalidValue;
     if (a.fold < 0 || (a.fold > 0 && (mode != MODE_MID || a.fold > tile_max_fold(logt, pair, logr)))) return hipErrorInvalidValue;
     if (logr == 4) {
-        if (mode == MODE_MID) return hipErrorInvalidValue;
+        if (mode == MODE_MID || mode == MODE_MID_ADD) return hipErrorInvalidValue;
         return logt == 8 ? launch_mode<8, 4, true>(mode, a, st) : launch_mode<9, 4, true>(mode, a, st);
     }
     if (pair) {

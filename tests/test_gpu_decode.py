@@ -141,6 +141,52 @@ def test_headline_size_round_trip(torch_cuda, fe, lost_fraction):
         assert bool((damaged.view(-1) == data).all())
 
 
+@pytest.mark.parametrize("logn,S", [(18, 8), (18, 7), (19, 4), (18, 66)])
+def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S):
+    """(2k,k) codes with k >= 2^18 decode through two half-size transforms (option "decode_split", default on): the data half and the few
+    parity block groups in use each go through the first DIF tile with per-block factors, the parity half's coefficients join the data half's
+    between the two halves of the MID tile.  Same bits as the single 2k-point transform and as the original stripe; patterns that need
+    fewer parity groups than the one before (the zeroing of the groups no longer written), ragged and odd block sizes, repair."""
+    torch = torch_cuda
+    N = 1 << logn
+    g = torch.Generator(device="cuda:0").manual_seed(logn * 100 + S)
+    data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty_like(data)
+    rng = np.random.default_rng(S)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(data, parity)
+        for count in (N // 2, 300, N, 2 * N // 50, 257):  # many parity groups in use, then few, then all of them, ...
+            lost = rng.permutation(2 * N)[:count]
+            if count == N:
+                lost = np.concatenate([np.arange(N // 2), N + rng.permutation(N)[: N // 2]])  # half of the data, half of the parity
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            results = []
+            for split in (1, 0):
+                enc.set_option("decode_split", split)
+                enc.decode_prepare(dp, pp)
+                damaged, dpar = data.clone(), parity.clone()
+                damaged.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+                dpar.view(N, S)[torch.from_numpy(pp == 0).to("cuda:0")] = 0x5A5A5A5A
+                enc.profile(True)
+                enc.profile_reset()
+                enc.decode(damaged, dpar)
+                torch.cuda.synchronize()
+                prof = enc.profile_read()
+                enc.profile(False)
+                assert ("decode_split_transform" in prof) == (split == 1) and ("decode_transform_2k" in prof) == (split == 0), prof  # which path ran
+                results.append(damaged)
+                assert bool((damaged == data).all()), (count, split)
+                enc.repair(damaged, dpar)
+                torch.cuda.synchronize()
+                assert bool((damaged == data).all()) and bool((dpar == parity).all()), (count, split)
+            assert torch.equal(results[0], results[1])
+        enc.set_option("decode_split", 1)
+        with pytest.raises(fe.FastEccError):
+            enc.set_option("decode_split", 2)
+
+
 def test_sector_pipeline_pack_encode_lose_decode_unpack(torch_cuda, fe):
     """README.md:160-163 end to end: arbitrary 4096-byte sectors -> 4100-byte blocks -> parity; lose 30 % of the
     codeword; decode; unpack; the sectors come back bit for bit."""
