@@ -286,6 +286,14 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             ok = bool(torch.equal(dv[di], saved_d)) and bool(torch.equal(pv[pi], saved_p))
             ms = event_ms(lambda: enc.repair(data, parity, stream=stream), 5)
             out[name] = {"prepare_ms": round(prep, 2), "repair_ms": round(ms, 3), "restored": ok}
+            if name == "repair_2_percent_of_the_codeword_lost":
+                # fastecc_decode alone (the lost data blocks, not the lost parity): the split transform of the (2k,k) layout
+                dv[di] = -1
+                enc.decode(data, parity, stream=stream)
+                ok_d = bool(torch.equal(dv[di], saved_d))
+                ms_d = event_ms(lambda: enc.decode(data, parity, stream=stream), 5)
+                out["decode_2_percent_of_the_codeword_lost"] = {"decode_ms": round(ms_d, 3), "restored": ok_d,
+                                                                "codeword_GBps": round(2.0 * k * block_bytes / ms_d / 1e6, 1)}
     except Exception as e:  # noqa: BLE001
         out["decode_error"] = repr(e)
     # --- a code with 4 parity blocks: direct evaluation against the transform pipeline of the same context

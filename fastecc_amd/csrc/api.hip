@@ -144,6 +144,10 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.row_factor = cb.rows_factor;
                 a.groups = cb.groups;
             }
+            if (cb.rows_out_factor && last && p.mode == MODE_DIT) {  // split decoder: its scatter
+                mode = MODE_DIT_ROWS;
+                a.row_factor = cb.rows_out_factor;
+            }
             if (cb.addend && p.mode == MODE_MID) {
                 mode = MODE_MID_ADD;
                 a.addend = cb.addend + col0;
@@ -178,7 +182,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.in_odd = cb.gather_odd;
                 a.row_factor = cb.gather_factor;
             }
-            if ((cb.rows_factor && src == in) || (cb.addend && p.mode == MODE_MID)) return FASTECC_E_UNSUPPORTED;  // tile passes only
+            if ((cb.rows_factor && src == in) || (cb.addend && p.mode == MODE_MID) || (cb.rows_out_factor && last)) return FASTECC_E_UNSUPPORTED;  // tile passes only
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
         return FASTECC_OK;
@@ -1045,7 +1049,8 @@ uint32_t split_decode_groups(const fastecc_ctx* c) { return 1u << c->encode_plan
 uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_plan[0].logr; }  // blocks per group: i = group + (t << s)
 
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
-                     uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, hipStream_t st)
+                     uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
+                     uint32_t* out, hipStream_t st)
 {
     if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
@@ -1061,6 +1066,10 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
     cr.groups = parity_groups;
     cm.addend = r2;
     cm.addend_factor = parity_pos_factor;
+    if (out_rows_factor) {  // the last pass scatters: block i of the result, times its factor, goes to out[i] where that factor is not zero
+        cm.rows_out_factor = out_rows_factor;
+        cm.final_out = out;
+    }
     int rc = run_passes(c, first, data, q, twd, twu, st, 0, 0, nullptr, 1, cq);            // q~ : top levels of the data half
     if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use
     if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st);                              // r~ : low levels (r1 is zero outside those groups)

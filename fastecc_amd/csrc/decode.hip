@@ -59,6 +59,7 @@ struct DecodeState {
     uint32_t* split_order = nullptr;        // k words: the block each slot of its first pass holds (gather_tile_order)
     uint32_t* split_rows_data = nullptr;    // k words, that order: l(w^2i) of the surviving data blocks (0: lost)
     uint32_t* split_rows_parity = nullptr;  // k words, that order: l(w^(2i+1)) of the parity blocks in use (0: lost or unused)
+    uint32_t* split_rows_out = nullptr;     // k words, that order: gout of the block (0: not lost)
     uint32_t* split_pos_parity = nullptr;   // k words by position: -w^(-m) / 2 at position bitrev(m)
     uint32_t* split_r1 = nullptr;           // k blocks: the parity half after its first pass (zero outside the groups in use)
     uint32_t* split_r2 = nullptr;           // k blocks: ... after all DIF levels
@@ -105,7 +106,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
     if (d->split) fastecc_destroy(d->split);
-    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_pos_parity, d->split_r1, d->split_r2})
+    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_r1, d->split_r2})
         if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
@@ -260,14 +261,16 @@ __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __re
 }
 
 // split transform: the per-block factors of the two half stripes in the order the first pass reads them, from fin (by codeword position)
-__global__ __launch_bounds__(256) void split_rows_kernel(const uint32_t* __restrict__ fin, const uint32_t* __restrict__ order, uint32_t* __restrict__ rows_data,
-                                                         uint32_t* __restrict__ rows_parity, uint32_t k)
+__global__ __launch_bounds__(256) void split_rows_kernel(const uint32_t* __restrict__ fin, const uint32_t* __restrict__ gout, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ rows_data, uint32_t* __restrict__ rows_parity, uint32_t* __restrict__ rows_out,
+                                                         uint32_t k)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= k) return;
     const uint32_t i = order[slot];
     rows_data[slot] = fin[2u * i];
     rows_parity[slot] = fin[2u * i + 1u];
+    rows_out[slot] = gout[i];  // the last pass has the first one's tile shape, so its blocks come in the same order
 }
 // ... and the factor of the parity half's coefficients, by position: -w^(-m) / 2 (Montgomery) at position bitrev(m); wpow[u] = w^u, w of order 2k
 __global__ __launch_bounds__(256) void split_pos_kernel(const uint32_t* __restrict__ wpow, uint32_t* __restrict__ pos, uint32_t k, int lg, uint32_t neg_half)
@@ -729,7 +732,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             if (rc != FASTECC_OK) return rc;
             std::vector<uint32_t> order;
             if (!split_decode_supported(d->split) || split_decode_groups(d->split) != 1024u || !gather_tile_order(d->split, order)) return FASTECC_E_UNSUPPORTED;
-            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_pos_parity}) DEC_TRY(hipMalloc((void**)b, N * 4));
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity}) DEC_TRY(hipMalloc((void**)b, N * 4));
             DEC_TRY(hipMemcpy(d->split_order, order.data(), N * 4, hipMemcpyHostToDevice));
             DEC_TRY(hipMalloc((void**)&d->split_r1, N * ci.words * 4));
             DEC_TRY(hipMalloc((void**)&d->split_r2, N * ci.words * 4));
@@ -745,7 +748,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             (void)hipGetLastError();
             if (d->split) fastecc_destroy(d->split);
             d->split = nullptr;
-            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_pos_parity, &d->split_r1, &d->split_r2}) {
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_r1, &d->split_r2}) {
                 if (*b) (void)hipFree(*b);
                 *b = nullptr;
             }
@@ -816,7 +819,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipGetLastError());
     }
     if (split_groups != 0 && d->split) {
-        hipLaunchKernelGGL(split_rows_kernel, grid(N), dim3(256), 0, st, d->fin, d->split_order, d->split_rows_data, d->split_rows_parity, (uint32_t)N);
+        hipLaunchKernelGGL(split_rows_kernel, grid(N), dim3(256), 0, st, d->fin, d->gout, d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out,
+                           (uint32_t)N);
         DEC_TRY(hipGetLastError());
         if (d->split_dirty > split_groups) {
             // rows of groups this pattern does not write any more: group g = blocks g + (t << 10)
@@ -975,13 +979,15 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     // The other codes do not hold every position in memory: they take the table-driven gather, which never touches a
     // position whose factor is zero, instead of a tile that reads first and multiplies by zero afterwards.
     int rc = FASTECC_E_UNSUPPORTED;
+    bool scattered = false;
     if (d->split_ready) {
         // two half-size transforms instead of one of size 2k (see "even / odd split")
         void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
         rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
-                              d->split_r2, st);
+                              d->split_r2, d->split_rows_out, ddata, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
         profile_scope_end(scope);
         if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
+        scattered = rc == FASTECC_OK;
     }
     if (rc == FASTECC_E_UNSUPPORTED && d->standard) {
         void* scope = profile_scope_begin(c, st, "decode_transform_2k", 3 * N * block);
@@ -991,7 +997,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     const bool fused = rc == FASTECC_OK;
     if (!fused && rc != FASTECC_E_UNSUPPORTED) return rc;
     uint32_t* work = d->recovered;
-    if (!d->mixed) {
+    if (!d->mixed && !fused) {  // (the transform context's scratch stripe: only the unfused form gathers into it)
         rc = scratch_of(d->transform, &work);
         if (rc != FASTECC_OK) return rc;
     }
@@ -1008,7 +1014,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         rc = fastecc_encode(d->transform, work, d->mixed ? work : d->recovered, FASTECC_MEM_DEVICE, st);
         if (rc != FASTECC_OK) return rc;
     }
-    {
+    if (!scattered) {
         const uint64_t items = N * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
         if (v4) hipLaunchKernelGGL(decode_scatter_kernel<4>, grid, dim3(256), 0, st, d->recovered, ddata, d->gout, S, ld_rec, S, col_chunks, items);

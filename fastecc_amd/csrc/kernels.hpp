@@ -8,8 +8,9 @@ namespace fastecc {
 
 // MODE_DIF_ROWS / MODE_MID_ADD: tile passes of the decoder's split transform (tile_kernels.hip; decode.hip "even / odd split"):
 // a DIF tile whose input blocks are multiplied by per-block factors (TileArgs::row_factor, tile order), and a MID tile that adds
-// addend[p] * addend_factor[p] to block p between its two halves.
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4 };
+// addend[p] * addend_factor[p] to block p between its two halves; MODE_DIT_ROWS: a DIT tile that stores only the blocks with a non-zero
+// factor (row_factor, tile order), times that factor — the decoder's scatter in its last pass.
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4, MODE_DIT_ROWS = 5 };
 
 // Arguments of one register pass (kernels.hip: ntt_pass_kernel).
 struct PassArgs {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
     constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD;
     static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
-    static_assert(MODE != MODE_DIF_ROWS || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
+    static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
     static_assert(MODE != MODE_MID_ADD || PAIR, "addend: pair tiles");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
     static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
@@ -416,7 +416,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
             if (round + 1 < SPLIT) lds_barrier();  // the buffer is reused by the next column group
         }
     };
-    constexpr bool LOAD_A = MODE != MODE_DIT;  // DIF and MID start in layout A, DIT in layout B
+    constexpr bool LOAD_A = MODE != MODE_DIT && MODE != MODE_DIT_ROWS;  // DIF and MID start in layout A, DIT in layout B
     auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
         if constexpr (LOAD_A && PAIR) load_paired(r, v);
         else if constexpr (LOAD_A)    load_rows(r, v, lane_a, qa_u, G);
@@ -546,7 +546,24 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
             else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
             exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
             dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
-            if constexpr (PAIR) {
+            if constexpr (MODE == MODE_DIT_ROWS) {
+                // the decoder's scatter: only the blocks being rebuilt leave the tile, each times its factor; the others' stores get an
+                // offset beyond the descriptor and are dropped.  Factors in tile order (as MODE_DIF_ROWS), paired layout as store_paired.
+                pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
+                const_u32_ptr f = as_constant(a.row_factor) + (((size_t)(v.hi << s) + v.lo) * G + g) * (2 * R);
+                const uint32_t voff = lane_p | v.dead_mask;
+                uint32_t soff = g * row_bytes;
+                const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+#pragma unroll
+                for (int j = 0; j < R; j += 2) {
+                    const uint32_t f0 = pair_twiddle<LOGR>(f[2 * j + 0], f[2 * j + 1], upper_mask);
+                    const uint32_t f1 = pair_twiddle<LOGR>(f[2 * j + 2], f[2 * j + 3], upper_mask);
+                    __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j][0], f0), v.out, f0 ? voff : 0xFFFFFFFFu, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j + 1][0], f1), v.out, f1 ? voff : 0xFFFFFFFFu, soff + far, 0);
+                    soff += step;
+                    asm volatile("" : "+s"(soff));
+                }
+            } else if constexpr (PAIR) {
                 pair_level_dit<LOGR>(x, a.tw_dit, off, sl, upper_mask);
                 store_paired(x, v);
             } else {
@@ -639,7 +656,7 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
                 case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2>(a, st);
                 case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
                 case MODE_MID_ADD: return launch_one<LOGT, LOGR, PAIR, MODE_MID_ADD, 2>(a, st);
-                case MODE_DIF_ROWS: return hipErrorInvalidValue;
+                case MODE_DIF_ROWS: case MODE_DIT_ROWS: return hipErrorInvalidValue;
                 default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
             }
         }
@@ -648,6 +665,10 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     if (mode == MODE_MID_ADD) return hipErrorInvalidValue;
     if (mode == MODE_DIF_ROWS) {
         if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
+        else return hipErrorInvalidValue;
+    }
+    if (mode == MODE_DIT_ROWS) {
+        if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS>(a, st);
         else return hipErrorInvalidValue;
     }
     switch (mode) {

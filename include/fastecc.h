@@ -341,6 +341,9 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  stop at 32;
  *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
  *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96;
+ *   "decode_split" = 0 / 1 (default 1; (2k,k) codes over GF(0xFFF00001) with k >= 2^18, next decode_prepare): the decoder's 2k-point
+ *                  transform as two transforms of k points — the data half, and the parity half of which only as many block groups as there
+ *                  are lost data blocks are read (7.1 -> 4.6 ms at k = 2^19 x 4 KB); 0 = one transform of 2k points.  Same bits;
  *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),
  *                  2 = MFMA (i8 digits; falls back to 1 where it cannot run).  Same bits either way;
  *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;
