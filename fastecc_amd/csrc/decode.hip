@@ -744,7 +744,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             return FASTECC_OK;
         }();
         if (rc_split != FASTECC_OK) {
-            if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
+            // nothing half-built stays behind: a later call either builds all of it or none
             (void)hipGetLastError();
             if (d->split) fastecc_destroy(d->split);
             d->split = nullptr;
@@ -752,6 +752,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                 if (*b) (void)hipFree(*b);
                 *b = nullptr;
             }
+            if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
             d->split_unavailable = true;
         }
     }
