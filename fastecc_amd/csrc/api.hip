@@ -144,6 +144,11 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.row_factor = cb.rows_factor;
                 a.groups = cb.groups;
             }
+            if (cb.impulse_table && src == in && p.mode == MODE_DIF && p.s == 0) {  // split decoder: the parity half's low levels, few groups in use
+                mode = MODE_DIF_IMPULSE;
+                a.row_factor = cb.impulse_table;
+                a.impulse_rows = cb.impulse_rows;
+            }
             if (cb.rows_out_factor && last && p.mode == MODE_DIT) {  // split decoder: its scatter
                 mode = MODE_DIT_ROWS;
                 a.row_factor = cb.rows_out_factor;
@@ -182,7 +187,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.in_odd = cb.gather_odd;
                 a.row_factor = cb.gather_factor;
             }
-            if ((cb.rows_factor && src == in) || (cb.addend && p.mode == MODE_MID) || (cb.rows_out_factor && last)) return FASTECC_E_UNSUPPORTED;  // tile passes only
+            if ((cb.rows_factor && src == in) || (cb.addend && p.mode == MODE_MID) || (cb.rows_out_factor && last) || cb.impulse_table) return FASTECC_E_UNSUPPORTED;  // tile passes only
             HIP_TRY(launch_pass(p.logr, vec, p.mode, a, st));
         }
         return FASTECC_OK;
@@ -1045,12 +1050,13 @@ bool split_decode_supported(const fastecc_ctx* c)
            p2.mode == MODE_DIT && p2.tile;
 }
 
+int split_impulse_max() { return IMPULSE_MAX; }
 uint32_t split_decode_groups(const fastecc_ctx* c) { return 1u << c->encode_plan[0].s; }       // block groups of the first pass
 uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_plan[0].logr; }  // blocks per group: i = group + (t << s)
 
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, hipStream_t st)
+                     uint32_t* out, const uint32_t* impulse_table, hipStream_t st)
 {
     if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
@@ -1072,7 +1078,12 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
     }
     int rc = run_passes(c, first, data, q, twd, twu, st, 0, 0, nullptr, 1, cq);            // q~ : top levels of the data half
     if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use
-    if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st);                              // r~ : low levels (r1 is zero outside those groups)
+    CallBounds cl;
+    if (impulse_table && parity_groups <= 16u * IMPULSE_MAX) {  // few groups: six of the ten low levels as a multiply-add per block in use (MODE_DIF_IMPULSE)
+        cl.impulse_table = impulse_table;
+        cl.impulse_rows = parity_groups;
+    }
+    if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st, 0, 0, nullptr, 1, cl);       // r~ : low levels (r1 is zero outside those groups)
     if (rc == FASTECC_OK) rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, cm);         // g = fq q~ + fr r~, and the transform back up
     return rc;
 }

@@ -61,6 +61,7 @@ struct DecodeState {
     uint32_t* split_rows_parity = nullptr;  // k words, that order: l(w^(2i+1)) of the parity blocks in use (0: lost or unused)
     uint32_t* split_rows_out = nullptr;     // k words, that order: gout of the block (0: not lost)
     uint32_t* split_pos_parity = nullptr;   // k words by position: -w^(-m) / 2 at position bitrev(m)
+    uint32_t* split_impulse = nullptr;      // [IMPULSE_MAX][16][64]: what six DIF levels make of a lone block of a 1024-block tile (run_split_decode)
     uint32_t* split_r1 = nullptr;           // k blocks: the parity half after its first pass (zero outside the groups in use)
     uint32_t* split_r2 = nullptr;           // k blocks: ... after all DIF levels
     uint32_t split_groups = 0;              // block groups of the parity stripe this pattern reads
@@ -106,7 +107,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
     if (d->split) fastecc_destroy(d->split);
-    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_r1, d->split_r2})
+    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2})
         if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
@@ -738,6 +739,34 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             DEC_TRY(hipMalloc((void**)&d->split_r2, N * ci.words * 4));
             DEC_TRY(hipMemsetAsync(d->split_r1, 0, N * ci.words * 4, st));
             d->split_dirty = 0;
+            {
+                // the parity half's low levels when few block groups are in use (run_split_decode): what the DIF levels with strides 512 ... 16
+                // make of a 1024-block tile in which block q0 alone is 1 — simulated here exactly as the tile does them, (a, b) -> (a + b,
+                // (a - b) w_2s^i) with the inverse roots; entry [t][g][c] = block g + 16 c for q0 = g + 16 t
+                const uint32_t w1024_inv = gf::h_pow(gf::h_inv(gf::h_mul(w, w)), N / 1024);
+                const uint32_t tables = (uint32_t)split_impulse_max();
+                std::vector<uint32_t> table((size_t)tables * 16 * 64), v(1024), tw(512);
+                for (uint32_t q0 = 0; q0 < 16u * tables; q0++) {
+                    std::fill(v.begin(), v.end(), 0u);
+                    v[q0] = 1;
+                    for (uint32_t sdist = 512; sdist >= 16; sdist >>= 1) {
+                        const uint32_t root = gf::h_pow(w1024_inv, 512 / sdist);  // order 2 * sdist
+                        tw[0] = 1;
+                        for (uint32_t i = 1; i < sdist; i++) tw[i] = gf::h_mul(tw[i - 1], root);
+                        for (uint32_t base = 0; base < 1024; base += 2 * sdist)
+                            for (uint32_t i = 0; i < sdist; i++) {
+                                const uint32_t lo = v[base + i], hi = v[base + i + sdist];
+                                if ((lo | hi) == 0) continue;
+                                v[base + i] = (uint32_t)(((uint64_t)lo + hi) % gf::P);
+                                v[base + i + sdist] = gf::h_mul((uint32_t)(((uint64_t)lo + gf::P - hi) % gf::P), tw[i]);
+                            }
+                    }
+                    const uint32_t t = q0 / 16, g0 = q0 % 16;
+                    for (uint32_t cc = 0; cc < 64; cc++) table[(t * 16 + g0) * 64 + cc] = gf::h_to_mont(v[g0 + 16 * cc]);
+                }
+                DEC_TRY(hipMalloc((void**)&d->split_impulse, table.size() * 4));
+                DEC_TRY(hipMemcpy(d->split_impulse, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+            }
             const uint32_t neg_half = (uint32_t)(gf::P - gf::h_inv(2u));
             hipLaunchKernelGGL(split_pos_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d->wpow, d->split_pos_parity, (uint32_t)N, ci.log2k, neg_half);
             DEC_TRY(hipGetLastError());
@@ -748,7 +777,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             (void)hipGetLastError();
             if (d->split) fastecc_destroy(d->split);
             d->split = nullptr;
-            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_r1, &d->split_r2}) {
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_impulse, &d->split_r1,
+                                 &d->split_r2}) {
                 if (*b) (void)hipFree(*b);
                 *b = nullptr;
             }
@@ -985,7 +1015,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         // two half-size transforms instead of one of size 2k (see "even / odd split")
         void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
         rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
-                              d->split_r2, d->split_rows_out, ddata, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
+                              d->split_r2, d->split_rows_out, ddata, d->split_impulse, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
         profile_scope_end(scope);
         if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
         scattered = rc == FASTECC_OK;

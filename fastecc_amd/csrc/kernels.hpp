@@ -9,8 +9,11 @@ namespace fastecc {
 // MODE_DIF_ROWS / MODE_MID_ADD: tile passes of the decoder's split transform (tile_kernels.hip; decode.hip "even / odd split"):
 // a DIF tile whose input blocks are multiplied by per-block factors (TileArgs::row_factor, tile order), and a MID tile that adds
 // addend[p] * addend_factor[p] to block p between its two halves; MODE_DIT_ROWS: a DIT tile that stores only the blocks with a non-zero
-// factor (row_factor, tile order), times that factor — the decoder's scatter in its last pass.
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4, MODE_DIT_ROWS = 5 };
+// factor (row_factor, tile order), times that factor — the decoder's scatter in its last pass; MODE_DIF_IMPULSE: a 1024-block DIF tile at s = 0
+// whose input is zero from block `impulse_rows` <= 16 IMPULSE_MAX on: what its first six levels make of each of the few blocks in use is a
+// fixed vector of factors (row_factor = those tables, [IMPULSE_MAX][16][64]), so a multiply-add per word and block replaces them.
+constexpr int IMPULSE_MAX = 3;
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4, MODE_DIT_ROWS = 5, MODE_DIF_IMPULSE = 6 };
 
 // Arguments of one register pass (kernels.hip: ntt_pass_kernel).
 struct PassArgs {
@@ -66,6 +69,7 @@ struct TileArgs {
     const uint32_t* addend;         // MODE_MID_ADD: a stripe in the position order MID's first half leaves (block p = coefficient bitrev(p))
     const uint32_t* addend_factor;  // ... and its per-position factors (Montgomery form), laid out like dscale
     uint32_t groups;                // > 0: only the first `groups` block groups of the pass are run (MODE_DIF_ROWS: the others are known to be zero)
+    uint32_t impulse_rows;          // MODE_DIF_IMPULSE: blocks [impulse_rows, T) of every tile are zero and not read (<= 16 IMPULSE_MAX)
 };
 
 // Arguments of the odd-radix pass of a transform of order q * 2^m (mixed_kernels.hip: radix_kernel).

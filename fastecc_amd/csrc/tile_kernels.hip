@@ -171,7 +171,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
     // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
-    constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD;
+    constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS || MODE == MODE_DIF_IMPULSE, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD;
+    static_assert(MODE != MODE_DIF_IMPULSE || (PAIR && NWIN == 1 && LOGT == 10 && LOGR == 5), "impulse form: the 1024-block pair tile");
     static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
     static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
     static_assert(MODE != MODE_MID_ADD || PAIR, "addend: pair tiles");
@@ -418,6 +419,33 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     };
     constexpr bool LOAD_A = MODE != MODE_DIT && MODE != MODE_DIT_ROWS;  // DIF and MID start in layout A, DIT in layout B
     auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
+        if constexpr (MODE == MODE_DIF_IMPULSE) {
+            // Blocks impulse_rows.. of the tile are zero, impulse_rows <= 16 IMPULSE_MAX: of this wave's 2R blocks g + 16 c only c < IMPULSE_MAX may
+            // be non-zero, and what the pair level and the LOGR in-thread levels (strides 512 ... 16) make of block g + 16 t alone is a fixed
+            // vector of 64 factors (row_factor[t][g][c]; t = 0: w_1024^(g * bitrev6(c)), a zero partner at every level) — by linearity the
+            // 2R words are sum_t block(g + 16 t) * factor_t: one multiply-add per word and block in use instead of six levels.  Both half-waves
+            // read the blocks; register j of half-wave h is c = 32 h + j (layout A).
+            const uint32_t m = (a.impulse_rows + 15u) / 16u;
+#pragma unroll
+            for (int j = 0; j < R; ++j) r[j][0] = 0;
+#pragma unroll
+            for (int t = 0; t < IMPULSE_MAX; ++t) {
+                if ((uint32_t)t >= m) break;  // uniform
+                uint32_t xt = 0;
+                if (g + 16u * t < a.impulse_rows) xt = __builtin_amdgcn_raw_buffer_load_b32(v.in, (c * 4u) | v.dead_mask, (g + 16u * t) * row_bytes, 0);
+                const_u32_ptr tab = as_constant(a.row_factor) + ((uint32_t)t * 16u + g) * 64u;
+                constexpr int CHI = 16;
+#pragma unroll
+                for (int j0 = 0; j0 < R; j0 += CHI) {
+                    uint32_t tl[CHI], th[CHI];
+#pragma unroll
+                    for (int i = 0; i < CHI; ++i) tl[i] = tab[j0 + i], th[i] = tab[R + j0 + i];
+#pragma unroll
+                    for (int i = 0; i < CHI; ++i) r[j0 + i][0] = gf::add(r[j0 + i][0], gf::mul_mont(xt, pair_twiddle<LOGR>(tl[i], th[i], upper_mask)));
+                }
+            }
+            return;
+        }
         if constexpr (LOAD_A && PAIR) load_paired(r, v);
         else if constexpr (LOAD_A)    load_rows(r, v, lane_a, qa_u, G);
         else                          load_rows(r, v, lane_b, qb_u, 1);
@@ -469,7 +497,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                     }
                 }
             }
-            if (compute) {
+            if (compute && MODE != MODE_DIF_IMPULSE) {  // (the impulse form's load has done these levels)
                 if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
                 dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
             }
@@ -657,12 +685,13 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
                 case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
                 case MODE_MID_ADD: return launch_one<LOGT, LOGR, PAIR, MODE_MID_ADD, 2>(a, st);
                 case MODE_DIF_ROWS: case MODE_DIT_ROWS: return hipErrorInvalidValue;
+                case MODE_DIF_IMPULSE: return a.s == 0 && a.impulse_rows <= 16u * IMPULSE_MAX ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_IMPULSE, 2>(a, st) : hipErrorInvalidValue;
                 default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
             }
         }
     }
     // the split decoder's shapes (tile_split_supported): slim outer pair tiles with per-block factors; the addend MID only as above
-    if (mode == MODE_MID_ADD) return hipErrorInvalidValue;
+    if (mode == MODE_MID_ADD || mode == MODE_DIF_IMPULSE) return hipErrorInvalidValue;
     if (mode == MODE_DIF_ROWS) {
         if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
         else return hipErrorInvalidValue;
