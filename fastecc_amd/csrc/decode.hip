@@ -155,6 +155,28 @@ __global__ __launch_bounds__(256) void wpow_kernel(uint32_t* __restrict__ wpow, 
     if (u < count) wpow[u] = dev_pow(w, u);
 }
 
+// (2k,k) layout: position u is data block u / 2 (u even) or parity block u / 2 (bit 31) — the block map of the table-driven gather, which
+// serves the plans whose first pass cannot read the two stripes itself
+__global__ __launch_bounds__(256) void standard_srcmap_kernel(const uint8_t* __restrict__ state, uint32_t NC, uint32_t* __restrict__ srcmap)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < NC) srcmap[u] = state[u] == ST_HELD ? ((u >> 1) | ((u & 1u) << 31)) : 0u;
+}
+
+// erased[] = the positions whose state is LOST or UNUSED, in any order; *counter (zero on entry) ends as their number.  One atomic per wave.
+__global__ __launch_bounds__(256) void erased_list_kernel(const uint8_t* __restrict__ state, uint32_t NC, uint32_t* __restrict__ erased, uint32_t* __restrict__ counter)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lost = u < NC && (state[u] == ST_LOST || state[u] == ST_UNUSED);
+    const uint64_t mask = __ballot(lost);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+    base = __shfl(base, __builtin_ctzll(mask));
+    if (lost) erased[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = u;
+}
+
 // roots[i] = w^erased[i] for i < n_erased, 0 for the padding up to T (a factor x: it only shifts the locator)
 __global__ __launch_bounds__(256) void roots_kernel(uint32_t* __restrict__ roots, const uint32_t* __restrict__ erased,
                                                     const uint32_t* __restrict__ wpow, uint32_t n_erased, uint32_t T)
@@ -548,53 +570,55 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     enum : uint8_t { LOST = ST_LOST, HELD = ST_HELD, ZERO = ST_ZERO };
     // (branch-free loops: on a random pattern every "if (present)" is a coin flip — 2^20 mispredictions were most of this call's time at 50 % loss)
     std::vector<uint8_t> state(NC, LOST);
-    std::vector<uint32_t> srcmap(NC, 0);
+    // the block map serves the table-driven gather only: the (2k,k) layout reads its two stripes by position
+    const bool standard_layout = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
+    std::vector<uint32_t> srcmap(standard_layout ? 0 : NC, 0);
     uint64_t erased_data = 0;
-    for (uint64_t i = 0; i < ci.user_k; i++) {
-        const uint64_t u = i << e;
-        const uint32_t held = data_present[i] != 0;
-        state[u] = held ? HELD : LOST;
-        srcmap[u] = (uint32_t)i & (0u - held);
-        erased_data += 1u - held;
-    }
-    for (uint64_t i = ci.user_k; i < N; i++) state[i << e] = ZERO;
-    for (uint64_t q = 0; q < ci.user_m; q++) {
-        const uint64_t u = parity_position(q);
-        const uint32_t held = parity_present[q] != 0;
-        state[u] = held ? HELD : LOST;
-        srcmap[u] = ((uint32_t)q | 0x80000000u) & (0u - held);
+    if (standard_layout) {
+        for (uint64_t i = 0; i < N; i++) {
+            const uint32_t held_d = data_present[i] != 0, held_p = parity_present[i] != 0;
+            state[2 * i] = held_d ? HELD : LOST;
+            state[2 * i + 1] = held_p ? HELD : LOST;
+            erased_data += 1u - held_d;
+        }
+    } else {
+        for (uint64_t i = 0; i < ci.user_k; i++) {
+            const uint64_t u = i << e;
+            const uint32_t held = data_present[i] != 0;
+            state[u] = held ? HELD : LOST;
+            srcmap[u] = (uint32_t)i & (0u - held);
+            erased_data += 1u - held;
+        }
+        for (uint64_t i = ci.user_k; i < N; i++) state[i << e] = ZERO;
+        for (uint64_t q = 0; q < ci.user_m; q++) {
+            const uint64_t u = parity_position(q);
+            const uint32_t held = parity_present[q] != 0;
+            state[u] = held ? HELD : LOST;
+            srcmap[u] = ((uint32_t)q | 0x80000000u) & (0u - held);
+        }
     }
     // (2k,k) layout, split transform: recovering e lost data blocks takes e parity blocks, not all of them — the surviving parity blocks of
     // the first few block groups of the parity stripe (group g = blocks g + (t << 10): what one tile of the first pass reads).  The others
     // are left unread: roots of the locator like the lost ones.
     uint32_t split_groups = 0;
-    const bool want_split = ci.decode_split && !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended && ci.log2k >= 18 && erased_data != 0;
+    const bool want_split = ci.decode_split && standard_layout && ci.log2k >= 18 && erased_data != 0;
     if (want_split) {
         constexpr uint32_t GROUPS = 1024;
         uint32_t held_in[GROUPS] = {};
-        for (uint64_t q = 0; q < N; q++) held_in[q & (GROUPS - 1u)] += state[2 * q + 1] == HELD;
+        for (uint64_t q = 0; q < N; q++) held_in[q & (GROUPS - 1u)] += parity_present[q] != 0;
         uint64_t have = 0;
         while (split_groups < GROUPS && have < erased_data) have += held_in[split_groups++];
         if (have >= erased_data) {
-            for (uint64_t q = 0; q < N; q++) {
-                const uint32_t drop = ((uint32_t)q & (GROUPS - 1u)) >= split_groups && state[2 * q + 1] == HELD;
-                state[2 * q + 1] = drop ? (uint8_t)ST_UNUSED : state[2 * q + 1];
-                srcmap[2 * q + 1] &= 0u - (1u - drop);
-            }
+            for (uint64_t q0 = 0; q0 < N; q0 += GROUPS)  // (the blocks of the groups in use keep their state)
+                for (uint64_t q = q0 + split_groups; q < q0 + GROUPS; q++) state[2 * q + 1] = state[2 * q + 1] == HELD ? (uint8_t)ST_UNUSED : state[2 * q + 1];
         } else {
             split_groups = 0;  // not decodable: refused below
         }
     }
-    std::vector<uint32_t> erased(NC + 1);
-    {
-        uint64_t count = 0;
-        for (uint64_t u = 0; u < NC; u++) {
-            erased[count] = (uint32_t)u;
-            count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
-        }
-        erased.resize(count);
-    }
-    if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
+    // the erased positions themselves are listed on the device (erased_list_kernel): the host needs their number only
+    uint64_t erased_count = 0;
+    for (uint64_t u = 0; u < NC; u++) erased_count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
+    if (erased_count > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
     pt.mark("pattern scan (host)");
 
     DeviceScope ds(ci.device);
@@ -608,7 +632,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     DecodeState* d = slot;
     d->ready = false;
     d->erased_data = erased_data;
-    d->erased_total = erased.size();
+    d->erased_total = erased_count;
     d->positions = NC;
     d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
     d->mixed = mixed;
@@ -637,7 +661,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     while (T < NC - N && T < (1ull << 20)) T <<= 1;
     int lgT = 0;
     while ((1ull << lgT) < T) lgT++;
-    if (erased.size() > T) return FASTECC_E_UNSUPPORTED;
+    if (erased_count > T) return FASTECC_E_UNSUPPORTED;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
@@ -687,7 +711,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipMalloc((void**)&d->tree_y, 2 * T * 4));
         DEC_TRY(hipMalloc((void**)&d->tree_p, 2 * T * 4));
         DEC_TRY(hipMalloc((void**)&d->roots, T * 4));
-        DEC_TRY(hipMalloc((void**)&d->dev_erased, T * 4));
+        DEC_TRY(hipMalloc((void**)&d->dev_erased, (T + 1) * 4));  // + the counter of erased_list_kernel
         d->tree_T = T;
     }
     pt.mark("tree contexts + buffers");
@@ -806,10 +830,13 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     pt.mark("tables, tile order");
     // ---- this pattern ----
     DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
-    DEC_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, st));
-    DEC_TRY(hipMemcpyAsync(d->dev_erased, erased.data(), erased.size() * 4, hipMemcpyHostToDevice, st));
     auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
-    hipLaunchKernelGGL(roots_kernel, grid(T), dim3(256), 0, st, d->roots, d->dev_erased, d->wpow, (uint32_t)erased.size(), (uint32_t)T);
+    if (!srcmap.empty()) DEC_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, st));
+    else hipLaunchKernelGGL(standard_srcmap_kernel, grid(NC), dim3(256), 0, st, (const uint8_t*)d->dev_state, (uint32_t)NC, d->srcmap);
+    // the list of erased positions (any order: the locator is their product); its counter sits behind the list
+    DEC_TRY(hipMemsetAsync(d->dev_erased + T, 0, 4, st));
+    hipLaunchKernelGGL(erased_list_kernel, grid(NC), dim3(256), 0, st, (const uint8_t*)d->dev_state, (uint32_t)NC, d->dev_erased, d->dev_erased + T);
+    hipLaunchKernelGGL(roots_kernel, grid(T), dim3(256), 0, st, d->roots, d->dev_erased, d->wpow, (uint32_t)erased_count, (uint32_t)T);
     // leaves: T / leaf polynomials of degree `leaf`, side by side ([coefficient][polynomial]); the upper half of the
     // 2*leaf rows the first product needs is zero
     DEC_TRY(hipMemsetAsync(d->tree_x, 0, 2 * T * 4, st));
@@ -842,7 +869,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         if (rc != FASTECC_OK) return rc;
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
-                       (uint32_t)(T - erased.size()), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc,
+                       (uint32_t)(T - erased_count), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc,
                        d->standard && d->erased_parity != 0 ? d->gout_par : nullptr);
     DEC_TRY(hipGetLastError());
     if (d->fin_first_pass != d->fin) {
