@@ -509,6 +509,21 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 }
                 if (stores) store_rows(x, v, lane_b, qb_u, 1);
             } else {
+                // MODE_MID_ADD: the first blocks of the addend are requested before the low levels, each further run of blocks before the
+                // arithmetic of the one before (two runs of CHA registers in flight)
+                constexpr int CHA = 8;
+                uint32_t ya[2][CHA];
+                auto fetch_addend = [&](uint32_t (&y)[CHA], int k0) {
+                    const uint32_t voff = lane_b | v.dead_mask;
+                    uint32_t soff = (qb_u + k0) * row_bytes;
+#pragma unroll
+                    for (int i = 0; i < CHA; ++i) {
+                        y[i] = __builtin_amdgcn_raw_buffer_load_b32(v.add, voff, soff, 2);
+                        soff += row_bytes;
+                        asm volatile("" : "+s"(soff));
+                    }
+                };
+                if constexpr (MODE == MODE_MID_ADD) fetch_addend(ya[0], 0);
                 dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
                 // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so
                 // the R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different
@@ -537,23 +552,15 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                     // qb_u + k (+ R in the high half-wave), the same run of positions as the factors above)
                     const_u32_ptr e = as_constant(a.addend_factor) + ((size_t)v.hi << LOGT) + qb_u;
 #pragma unroll
-                    for (int k0 = 0; k0 < R; k0 += CH) {
-                        uint32_t y[CH], el[CH], eh[CH];
-                        {
-                            const uint32_t voff = lane_b | v.dead_mask;
-                            uint32_t soff = (qb_u + k0) * row_bytes;
+                    for (int k0 = 0; k0 < R; k0 += CHA) {
+                        const int cur = (k0 / CHA) & 1;
+                        if (k0 + CHA < R) fetch_addend(ya[cur ^ 1], k0 + CHA);
+                        uint32_t el[CHA], eh[CHA];
 #pragma unroll
-                            for (int i = 0; i < CH; ++i) {
-                                y[i] = __builtin_amdgcn_raw_buffer_load_b32(v.add, voff, soff, 2);
-                                soff += row_bytes;
-                                asm volatile("" : "+s"(soff));
-                            }
-                        }
+                        for (int i = 0; i < CHA; ++i) el[i] = e[k0 + i], eh[i] = e[R + k0 + i];
 #pragma unroll
-                        for (int i = 0; i < CH; ++i) el[i] = e[k0 + i], eh[i] = e[R + k0 + i];
-#pragma unroll
-                        for (int i = 0; i < CH; ++i)
-                            x[k0 + i][0] = gf::add(x[k0 + i][0], gf::mul_mont(y[i], pair_twiddle<LOGR>(el[i], eh[i], upper_mask)));
+                        for (int i = 0; i < CHA; ++i)
+                            x[k0 + i][0] = gf::add(x[k0 + i][0], gf::mul_mont(ya[cur][i], pair_twiddle<LOGR>(el[i], eh[i], upper_mask)));
                     }
                 }
                 dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
