@@ -248,14 +248,16 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * GF(0xFFF00001) as described below; GF((2^61-1)^2) for its (2k,k) codes with the same scheme on 16-byte elements
  * (gf61_decode.hip).  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
- * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass.
+ * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass — for
+ * the (2k,k) codes with k >= 2^18 as two pipelines of size k, the data half and the few parity blocks a pattern needs
+ * (option "decode_split").
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity
  * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
  * as known, so exactly n - k losses are tolerated.  Mixed-radix codes (fastecc_create_ex) are decoded the same way on the
  * (2 q 2^m)-th roots of unity with mixed-radix transforms, for orders q 2^m <= 2^20.
  *   fastecc_decode_prepare : set the erasure pattern, k data flags and n - k parity flags (non-zero = block survives).
  *                            The host classifies the positions; the locator's product tree, its two size-NC transforms
- *                            and the inversions run on the device (2-8 ms at (2^20,2^19); the first call also builds the
+ *                            and the inversions run on the device (2.2-2.4 ms at (2^20,2^19); the first call also builds the
  *                            decoder's contexts).  Synchronous.  FASTECC_E_INVAL if fewer than k blocks survive.
  *                            Reusable for any number of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
@@ -265,7 +267,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
  * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.3-3.5 ms, no transform contexts) and decode
  * is one read of the data plus a few parity blocks — 0.4 ms for up to 16 lost blocks of a 2 GiB stripe, 0.7 ms for 64, 2.6 ms for 256 (matrix
- * cores; option "direct_kernel") against 7.7-9 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
+ * cores; option "direct_kernel") against 4.3-5.8 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
  * code, and the (2k,k) codes of GF((2^61-1)^2); identical results.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
