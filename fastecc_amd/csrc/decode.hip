@@ -480,9 +480,11 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     const uint64_t NC = N << e;
     const int lgc = ci.log2k + e;
     // the matrix-core kernel recomputes 256 blocks in a third of the transform path's time, the VALU kernel breaks even near 128
-    // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for
+    // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for — at 80
+    // where the split transform (4.3 ms instead of 7.2 at k = 2^19 x 4 KB) is the alternative
     int direct_limit = std::min(ci.direct_max, direct_cap());
-    if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, 96);
+    const bool split_layout = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended && ci.log2k >= 18;
+    if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, split_layout ? 80 : 96);
     {
         // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
         uint64_t T = 1;
