@@ -1056,7 +1056,7 @@ uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_
 
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, const uint32_t* impulse_table, hipStream_t st)
+                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st)
 {
     if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
@@ -1069,12 +1069,16 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
     CallBounds cq, cr, cm;
     cq.rows_factor = data_rows_factor;
     cr.rows_factor = parity_rows_factor;
+    // zero-extended codes: the stripes hold fewer than k blocks — the rest reads as zero (and a scattered block never lies beyond: its factor is 0)
+    cq.in_rows = data_blocks < c->N ? data_blocks : 0;
+    cr.in_rows = parity_blocks < c->N ? parity_blocks : 0;
     cr.groups = parity_groups;
     cm.addend = r2;
     cm.addend_factor = parity_pos_factor;
     if (out_rows_factor) {  // the last pass scatters: block i of the result, times its factor, goes to out[i] where that factor is not zero
         cm.rows_out_factor = out_rows_factor;
         cm.final_out = out;
+        cm.out_rows = data_blocks < c->N ? data_blocks : 0;
     }
     int rc = run_passes(c, first, data, q, twd, twu, st, 0, 0, nullptr, 1, cq);            // q~ : top levels of the data half
     if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use

@@ -483,8 +483,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for — at 80
     // where the split transform (4.3 ms instead of 7.2 at k = 2^19 x 4 KB) is the alternative
     int direct_limit = std::min(ci.direct_max, direct_cap());
-    const bool split_layout = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended && ci.log2k >= 18;
-    if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, split_layout ? 80 : 96);
+    const bool split_applies = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.fold == 0 && ci.log2k >= 18;
+    if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, split_applies ? 80 : 96);
     {
         // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
         uint64_t T = 1;
@@ -603,11 +603,13 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // the first few block groups of the parity stripe (group g = blocks g + (t << 10): what one tile of the first pass reads).  The others
     // are left unread: roots of the locator like the lost ones.
     uint32_t split_groups = 0;
-    const bool want_split = ci.decode_split && standard_layout && ci.log2k >= 18 && erased_data != 0;
+    // (also the zero-extended codes inside (2N,N): data block i at position 2i, parity block j at 2j + 1, fewer blocks than N in either stripe)
+    const bool split_layout = !mixed && ci.cosets == 1 && ci.fold == 0;
+    const bool want_split = ci.decode_split && split_layout && ci.log2k >= 18 && erased_data != 0;
     if (want_split) {
         constexpr uint32_t GROUPS = 1024;
         uint32_t held_in[GROUPS] = {};
-        for (uint64_t q = 0; q < N; q++) held_in[q & (GROUPS - 1u)] += parity_present[q] != 0;
+        for (uint64_t q = 0; q < ci.user_m; q++) held_in[q & (GROUPS - 1u)] += parity_present[q] != 0;
         uint64_t have = 0;
         while (split_groups < GROUPS && have < erased_data) have += held_in[split_groups++];
         if (have >= erased_data) {
@@ -617,6 +619,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             split_groups = 0;  // not decodable: refused below
         }
     }
+    if (split_groups != 0 && !srcmap.empty())
+        for (uint64_t u = 1; u < NC; u += 2) srcmap[u] &= 0u - (uint32_t)(state[u] != ST_UNUSED);
     // the erased positions themselves are listed on the device (erased_list_kernel): the host needs their number only
     uint64_t erased_count = 0;
     for (uint64_t u = 0; u < NC; u++) erased_count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
@@ -1044,7 +1048,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         // two half-size transforms instead of one of size 2k (see "even / odd split")
         void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
         rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
-                              d->split_r2, d->split_rows_out, ddata, d->split_impulse, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
+                              d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
         profile_scope_end(scope);
         if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
         scattered = rc == FASTECC_OK;

@@ -122,7 +122,8 @@ int split_impulse_max();  // IMPULSE_MAX of kernels.hpp
 // out_rows_factor != null: the DIT tile stores only the blocks with a non-zero factor (tile order), times it, to out[] (the decoder's scatter).
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, const uint32_t* impulse_table, hipStream_t st);
+                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st);
+// data_blocks / parity_blocks: the blocks the two stripes really hold (<= k: zero-extended codes; the rest counts as zero blocks)
 // impulse_table (optional): [IMPULSE_MAX][16][64] words (Montgomery form), entry [t][g][c] = block g + 16 c of a 1024-block tile after the DIF
 // levels with strides 512 ... 16 when block g + 16 t alone was 1 — with at most 16 IMPULSE_MAX parity groups in use those six of the parity
 // half's low levels are a multiply-add per word and block in use (MODE_DIF_IMPULSE)

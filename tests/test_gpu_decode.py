@@ -187,6 +187,43 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             enc.set_option("decode_split", 2)
 
 
+@pytest.mark.parametrize("n,k,S", [(600000, 300000, 4), (2 * 262145, 262145, 6), (300000 + 270000, 300000, 8)])
+def test_split_transform_of_zero_extended_codes(torch_cuda, fe, n, k, S):
+    """k and n - k between 2^18 and 2^19, no powers of two: the code lives inside the (2^20, 2^19) code (zero extension, fold 0), its stripes
+    hold fewer than 2^19 blocks — the split transform reads them with a bound, the blocks beyond count as zero (data) or lost (parity)."""
+    torch = torch_cuda
+    m = n - k
+    g = torch.Generator(device="cuda:0").manual_seed(k % 1000 + S)
+    data = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+    rng = np.random.default_rng(S)
+    with fe.Encoder(n, k, 4 * S) as enc:
+        enc.encode(data, parity)
+        for count in (n // 40, m, 1000):
+            lost = rng.permutation(n)[:count]
+            dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+            dp[lost[lost < k]] = 0
+            pp[lost[lost >= k] - k] = 0
+            for split in (1, 0):
+                enc.set_option("decode_split", split)
+                enc.decode_prepare(dp, pp)
+                damaged, dpar = data.clone(), parity.clone()
+                damaged.view(k, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+                dpar.view(m, S)[torch.from_numpy(pp == 0).to("cuda:0")] = 0x5A5A5A5A
+                enc.profile(True)
+                enc.profile_reset()
+                enc.decode(damaged, dpar)
+                torch.cuda.synchronize()
+                prof = enc.profile_read()
+                enc.profile(False)
+                assert ("decode_split_transform" in prof) == (split == 1), prof
+                assert bool((damaged == data).all()), (count, split)
+                enc.repair(damaged, dpar)
+                torch.cuda.synchronize()
+                assert bool((damaged == data).all()) and bool((dpar == parity).all()), (count, split)
+        enc.set_option("decode_split", 1)
+
+
 def test_sector_pipeline_pack_encode_lose_decode_unpack(torch_cuda, fe):
     """README.md:160-163 end to end: arbitrary 4096-byte sectors -> 4100-byte blocks -> parity; lose 30 % of the
     codeword; decode; unpack; the sectors come back bit for bit."""
