@@ -64,6 +64,7 @@ struct DecodeState {
     uint32_t* split_impulse = nullptr;      // [IMPULSE_MAX][16][64]: what six DIF levels make of a lone block of a 1024-block tile (run_split_decode)
     uint32_t* split_r1 = nullptr;           // k blocks: the parity half after its first pass (zero outside the groups in use)
     uint32_t* split_r2 = nullptr;           // k blocks: ... after all DIF levels
+    uint32_t* split_r0 = nullptr;           // codes with fewer parity blocks (fold > 0): parity block j copied to its place j << fold of a k-block stripe (lazy)
     uint32_t split_groups = 0;              // block groups of the parity stripe this pattern reads
     uint32_t split_dirty = 0;               // groups of split_r1 that may hold non-zero rows
     bool split_ready = false;               // this pattern decodes through the split transform
@@ -107,7 +108,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
     if (d->split) fastecc_destroy(d->split);
-    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2})
+    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2, d->split_r0})
         if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
@@ -368,6 +369,26 @@ __global__ __launch_bounds__(256) void decode_scatter_kernel(const uint32_t* __r
     store_vec<V>(data + (size_t)i * ld + col, x);
 }
 
+// split transform of a code with fewer parity blocks: stage[q << fold] = parity[q] for the parity blocks in use (fin != 0 at their position); the
+// rest of the stage is never read with a non-zero factor
+template <int V>
+__global__ __launch_bounds__(256) void split_stage_kernel(const uint32_t* __restrict__ parity, uint32_t* __restrict__ stage, const uint32_t* __restrict__ fin,
+                                                          uint32_t S, int fold, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t q = (uint32_t)(item / col_chunks);
+    if (as_constant(fin)[2u * (q << fold) + 1u] == 0) return;  // wave-uniform
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t x[V];
+    load_vec<V>(x, parity + (size_t)q * S + col);
+    store_vec<V>(stage + (size_t)(q << fold) * S + col, x);
+}
+
 // parity[q] = again[q] for the parity blocks that were lost (lost[q] != 0); the others are not touched
 template <int V>
 __global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __restrict__ again, uint32_t* __restrict__ parity,
@@ -483,7 +504,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for — at 80
     // where the split transform (4.3 ms instead of 7.2 at k = 2^19 x 4 KB) is the alternative
     int direct_limit = std::min(ci.direct_max, direct_cap());
-    const bool split_applies = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.fold == 0 && ci.log2k >= 18;
+    const bool split_applies = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.log2k >= 18;
     if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, split_applies ? 80 : 96);
     {
         // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
@@ -603,13 +624,14 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // the first few block groups of the parity stripe (group g = blocks g + (t << 10): what one tile of the first pass reads).  The others
     // are left unread: roots of the locator like the lost ones.
     uint32_t split_groups = 0;
-    // (also the zero-extended codes inside (2N,N): data block i at position 2i, parity block j at 2j + 1, fewer blocks than N in either stripe)
-    const bool split_layout = !mixed && ci.cosets == 1 && ci.fold == 0;
+    // (also the zero-extended codes inside (2N,N): data block i at position 2i, parity block j at 2j + 1, fewer blocks than N in either stripe;
+    // and the codes with fewer parity blocks: parity block j at position 2 (j << fold) + 1, i.e. block j << fold of the parity half)
+    const bool split_layout = !mixed && ci.cosets == 1;
     const bool want_split = ci.decode_split && split_layout && ci.log2k >= 18 && erased_data != 0;
     if (want_split) {
         constexpr uint32_t GROUPS = 1024;
         uint32_t held_in[GROUPS] = {};
-        for (uint64_t q = 0; q < ci.user_m; q++) held_in[q & (GROUPS - 1u)] += parity_present[q] != 0;
+        for (uint64_t q = 0; q < ci.user_m; q++) held_in[(q << ci.fold) & (GROUPS - 1u)] += parity_present[q] != 0;
         uint64_t have = 0;
         while (split_groups < GROUPS && have < erased_data) have += held_in[split_groups++];
         if (have >= erased_data) {
@@ -1046,9 +1068,30 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
     bool scattered = false;
     if (d->split_ready) {
         // two half-size transforms instead of one of size 2k (see "even / odd split")
-        void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
-        rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
-                              d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
+        const uint32_t* parity_half = dparity;
+        uint32_t parity_half_blocks = (uint32_t)ci.user_m;
+        bool staged_ok = true;
+        if (ci.fold > 0 && !d->split_r0 && hipMalloc((void**)&d->split_r0, N * block) != hipSuccess) {
+            (void)hipGetLastError();  // no room for the staging stripe: the 2k-point transform below
+            d->split_r0 = nullptr;
+            staged_ok = false;
+        }
+        void* scope = staged_ok ? profile_scope_begin(c, st, "decode_split_transform", (3 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block)
+                                : nullptr;
+        if (ci.fold > 0 && staged_ok) {
+            // fewer parity blocks than data blocks: block j belongs at j << fold of the parity half — the blocks in use are copied there
+            const uint32_t S0 = (uint32_t)ci.words;
+            const bool w4 = (S0 % 4) == 0 && ((((uintptr_t)dparity | (uintptr_t)d->split_r0) & 15u) == 0);
+            const uint32_t chunks = (S0 + (w4 ? 256 : 64) - 1) / (w4 ? 256 : 64);
+            const uint64_t items = ci.user_m * chunks;
+            const dim3 grid((unsigned)((items + 3) / 4));
+            if (w4) hipLaunchKernelGGL(split_stage_kernel<4>, grid, dim3(256), 0, st, dparity, d->split_r0, d->fin, S0, ci.fold, chunks, items);
+            else    hipLaunchKernelGGL(split_stage_kernel<1>, grid, dim3(256), 0, st, dparity, d->split_r0, d->fin, S0, ci.fold, chunks, items);
+            parity_half = d->split_r0;
+            parity_half_blocks = (uint32_t)N;
+        }
+        if (staged_ok) rc = run_split_decode(d->split, ddata, parity_half, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
+                              d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, parity_half_blocks, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
         profile_scope_end(scope);
         if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
         scattered = rc == FASTECC_OK;

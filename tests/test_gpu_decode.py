@@ -187,10 +187,13 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             enc.set_option("decode_split", 2)
 
 
-@pytest.mark.parametrize("n,k,S", [(600000, 300000, 4), (2 * 262145, 262145, 6), (300000 + 270000, 300000, 8)])
+@pytest.mark.parametrize("n,k,S", [(600000, 300000, 4), (2 * 262145, 262145, 6), (300000 + 270000, 300000, 8),
+                                   ((1 << 18) + (1 << 17), 1 << 18, 8), ((1 << 18) + 100000, 1 << 18, 5), (300000 + 140000, 300000, 4), ((1 << 18) + (1 << 14), 1 << 18, 16)])
 def test_split_transform_of_zero_extended_codes(torch_cuda, fe, n, k, S):
     """k and n - k between 2^18 and 2^19, no powers of two: the code lives inside the (2^20, 2^19) code (zero extension, fold 0), its stripes
-    hold fewer than 2^19 blocks — the split transform reads them with a bound, the blocks beyond count as zero (data) or lost (parity)."""
+    hold fewer than 2^19 blocks — the split transform reads them with a bound, the blocks beyond count as zero (data) or lost (parity).
+    Codes with fewer parity blocks (n - k <= N / 2: parity block j sits at block j << fold of the parity half, fold = 1 ... 4) have the parity
+    blocks in use copied to their places first."""
     torch = torch_cuda
     m = n - k
     g = torch.Generator(device="cuda:0").manual_seed(k % 1000 + S)
@@ -199,7 +202,7 @@ def test_split_transform_of_zero_extended_codes(torch_cuda, fe, n, k, S):
     rng = np.random.default_rng(S)
     with fe.Encoder(n, k, 4 * S) as enc:
         enc.encode(data, parity)
-        for count in (n // 40, m, 1000):
+        for count in (min(n // 40, m), m, 1000):
             lost = rng.permutation(n)[:count]
             dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
             dp[lost[lost < k]] = 0
