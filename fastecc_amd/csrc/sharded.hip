@@ -23,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.hpp"
@@ -304,10 +305,24 @@ int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, cons
 {
     Sharded* s = sharded_of(shell);
     std::lock_guard<std::mutex> lk(mutex_of(shell));
-    for (Shard& sh : s->shards) {  // the same pattern for every slab (each context keeps its own tables on its own device)
-        const int rc = fastecc_decode_prepare(sh.ctx, data_present, parity_present);
-        if (rc != FASTECC_OK) return rc;
+    // the same pattern for every slab (each context keeps its own tables on its own device): one host thread per slab, so the set-ups — a host
+    // scan and a few dozen small kernels each, synchronous — run side by side instead of n_slabs times 2.3 ms one after the other
+    std::vector<int> rcs(s->shards.size(), FASTECC_OK);
+    std::vector<std::thread> workers;
+    std::vector<char> started(s->shards.size(), 0);
+    for (size_t i = 1; i < s->shards.size(); i++) {
+        try {
+            workers.emplace_back([&, i] { rcs[i] = fastecc_decode_prepare(s->shards[i].ctx, data_present, parity_present); });
+            started[i] = 1;
+        } catch (...) {  // no thread to be had: that slab is set up on this one below (no exception crosses the ABI)
+        }
     }
+    rcs[0] = fastecc_decode_prepare(s->shards[0].ctx, data_present, parity_present);  // (this thread's error detail is the one the caller can read)
+    for (std::thread& t : workers) t.join();
+    for (size_t i = 1; i < s->shards.size(); i++)
+        if (!started[i]) rcs[i] = fastecc_decode_prepare(s->shards[i].ctx, data_present, parity_present);
+    for (int rc : rcs)
+        if (rc != FASTECC_OK) return rc;
     return FASTECC_OK;
 }
 
