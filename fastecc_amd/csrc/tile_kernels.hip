@@ -33,6 +33,14 @@
 //
 // With N = 2^19 the encode is 3 launches: DIF over levels 18..10, MID over 9..0 twice, DIT over 10..18
 // (the reference needs 2 x (3 sweeps + twiddle sweep), ntt.cpp:412-446).
+//
+// Decoder modes (the split transform of decode.hip; same tiles, same level code):
+//   DIF_ROWS     DIF whose input blocks are multiplied by per-block factors on the way in (zero = block not in use); optionally only the first
+//                block groups of the pass are launched
+//   DIF_IMPULSE  the 1024-block DIF tile at s = 0 when only its first few blocks are non-zero: the six levels before the exchange as one
+//                multiply-add per word and block in use
+//   MID_ADD      MID with "+ addend[p] * factor[p]" between its halves
+//   DIT_ROWS     DIT that stores only the blocks with a non-zero factor, times that factor (the scatter)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
