@@ -14,6 +14,15 @@
 // Around it: a gather (codeword blocks times l(w^u), zeros at erasures; fused into the transform's first pass for the
 // (2k,k) layout) and one pass that multiplies the recovered rows by 1 / (w^e l'(w^e)).
 //
+// Even / odd split (codes with n <= 2k on power-of-two orders, k >= 2^18; option "decode_split"): recovering e data blocks takes e parity
+// blocks, so the other surviving parity blocks may count as erased too (ST_UNUSED: roots of l like the lost ones).  With q~ = DIF_k(data * l)
+// and r~ = DIF_k(parity * l), unnormalised inverse transforms of k points over the even and the odd positions, the 2k coefficients are
+// P[m] = (q~[m] + w^-m r~[m]) / 2k and P[m+k] = (q~[m] - w^-m r~[m]) / 2k, and because w^(2j(m+k)) = w^(2jm) the values of x p'(x) at the data
+// positions are the k-point forward transform of  g[m] = m P[m] + (m+k) P[m+k] = (2m+k)/2k q~[m] - 1/2 w^-m r~[m].  So the 2k-point
+// pipeline becomes: the encoder's own three passes over the data half (blocks times l(w^2i) on the way in, g's second term added between
+// the halves of MID, only the rebuilt blocks stored on the way out) plus r~ — the first pass over the few parity block groups in use, and
+// the low levels over a stripe that is zero elsewhere (run_split_decode in api.hip; tile modes in tile_kernels.hip).
+//
 // The other codes are the same thing on the (k << e)-th roots of unity (fastecc_decode_prepare): positions that hold no
 // block of the code count as erased, zero-extended data blocks as known zeros, the transform has fold = e.
 //
