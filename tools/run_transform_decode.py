@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Minimal driver for the profilers: decode and repair of a 2 % loss pattern of the (2^20,2^19) x 4 KB code (the transform path). usage: [reps]"""
+"""Minimal driver for the profilers: decode and repair of a 2 % loss pattern of the (2^20,2^19) x 4 KB code (the transform path). usage: [reps] [decode: skip the repairs]"""
 import os
 import sys
 
@@ -24,6 +24,6 @@ with fe.Encoder(2 * k, k, 4 * S) as enc:
     enc.decode_prepare(dp, pp)
     for _ in range(reps):
         enc.decode(data, parity, stream=stream)
-    for _ in range(reps):
+    for _ in range(0 if len(sys.argv) > 2 and sys.argv[2] == "decode" else reps):
         enc.repair(data, parity, stream=stream)
 torch.cuda.synchronize()
