@@ -198,7 +198,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         bool first = true;
         for (const Pass& p : plan) {
             if (p.fused) continue;  // encode_mixed launches it
-            const int rc = run_one(p, src, out, c->dscale, &p == &plan.back());
+            const int rc = run_one(p, src, out, cb.dscale_override ? cb.dscale_override : c->dscale, &p == &plan.back());
             if (rc != FASTECC_OK) return rc;
             src = out;  // after the first pass everything is in place on `out`
             if (first && first_done) HIP_TRY(hipEventRecord(first_done, st));
@@ -1056,7 +1056,7 @@ uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_
 
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st)
+                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st, const SplitRepair* odd)
 {
     if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
@@ -1088,7 +1088,19 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
         cl.impulse_rows = parity_groups;
     }
     if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st, 0, 0, nullptr, 1, cl);       // r~ : low levels (r1 is zero outside those groups)
-    if (rc == FASTECC_OK) rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, cm);         // g = fq q~ + fr r~, and the transform back up
+    // g = fq q~ + fr r~, and the transform back up.  With the odd positions wanted as well the top-level result q stays: this chain writes q2.
+    if (rc == FASTECC_OK) rc = run_passes(c, rest, q, odd ? odd->q2 : q, twd, twu, st, 0, 0, nullptr, 1, cm);
+    if (rc == FASTECC_OK && odd) {
+        // x p'(x) at the ODD positions (the parity blocks): the k-point transform of h[m] = w^m (m P[m] - (m+k) P[m+k]) = -1/2 w^m q~[m] +
+        // (2m+k)/2k r~[m] — the same two halves with the factor tables exchanged (the context's own table now scales the addend)
+        CallBounds ch;
+        ch.addend = r2;
+        ch.addend_factor = c->dscale;
+        ch.dscale_override = odd->data_pos_factor;
+        ch.rows_out_factor = odd->out_rows_factor;
+        ch.final_out = odd->out;
+        rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, ch);
+    }
     return rc;
 }
 

@@ -73,6 +73,10 @@ struct DecodeState {
     uint32_t* split_impulse = nullptr;      // [IMPULSE_MAX][16][64]: what six DIF levels make of a lone block of a 1024-block tile (run_split_decode)
     uint32_t* split_r1 = nullptr;           // k blocks: the parity half after its first pass (zero outside the groups in use)
     uint32_t* split_r2 = nullptr;           // k blocks: ... after all DIF levels
+    uint32_t* split_q2 = nullptr;           // fastecc_repair: k blocks, the data chain's MID output while the top-level result serves the parity chain (lazy)
+    uint32_t* split_pos_data_odd = nullptr;   // k words by position: -w^m / 2 at position bitrev(m) (the parity chain's factor of the data half)
+    uint32_t* split_rows_out_parity = nullptr;  // k words, first-pass order: gout_par of the block (0: not lost)
+    bool split_repair_ready = false;        // this pattern's lost parity blocks can come from the split transform too
     uint32_t* split_r0 = nullptr;           // codes with fewer parity blocks (fold > 0): parity block j copied to its place j << fold of a k-block stripe (lazy)
     uint32_t split_groups = 0;              // block groups of the parity stripe this pattern reads
     uint32_t split_dirty = 0;               // groups of split_r1 that may hold non-zero rows
@@ -117,7 +121,8 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
     if (d->split) fastecc_destroy(d->split);
-    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2, d->split_r0})
+    for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2, d->split_r0, d->split_q2, d->split_pos_data_odd,
+                        d->split_rows_out_parity})
         if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __re
 // split transform: the per-block factors of the two half stripes in the order the first pass reads them, from fin (by codeword position)
 __global__ __launch_bounds__(256) void split_rows_kernel(const uint32_t* __restrict__ fin, const uint32_t* __restrict__ gout, const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ rows_data, uint32_t* __restrict__ rows_parity, uint32_t* __restrict__ rows_out,
-                                                         uint32_t k)
+                                                         uint32_t k, const uint32_t* __restrict__ gout_par = nullptr, uint32_t* __restrict__ rows_out_parity = nullptr)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= k) return;
@@ -304,13 +309,16 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const uint32_t* __restr
     rows_data[slot] = fin[2u * i];
     rows_parity[slot] = fin[2u * i + 1u];
     rows_out[slot] = gout[i];  // the last pass has the first one's tile shape, so its blocks come in the same order
+    if (rows_out_parity) rows_out_parity[slot] = gout_par[i];
 }
 // ... and the factor of the parity half's coefficients, by position: -w^(-m) / 2 (Montgomery) at position bitrev(m); wpow[u] = w^u, w of order 2k
-__global__ __launch_bounds__(256) void split_pos_kernel(const uint32_t* __restrict__ wpow, uint32_t* __restrict__ pos, uint32_t k, int lg, uint32_t neg_half)
+// (forward: w^m instead — the factor of the data half's coefficients in the parity chain of fastecc_repair)
+__global__ __launch_bounds__(256) void split_pos_kernel(const uint32_t* __restrict__ wpow, uint32_t* __restrict__ pos, uint32_t k, int lg, uint32_t neg_half,
+                                                        bool forward)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= k) return;
-    const uint32_t w = wpow[m == 0 ? 0 : 2u * k - m];
+    const uint32_t w = wpow[forward ? m : (m == 0 ? 0 : 2u * k - m)];
     pos[__brev(m) >> (32 - lg)] = gf::mul(gf::mul(w, neg_half), gf::MONT_ONE);
 }
 
@@ -785,6 +793,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // mixed radix: the work stripe of all NC positions, transformed in place; else the N recovered data positions
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, (mixed ? NC : N) * ci.words * 4));
     d->split_ready = false;
+    d->split_repair_ready = false;
     if (split_groups != 0 && !d->split_unavailable && !d->split) {
         // ---- the split transform's context and tables (once).  Anything missing — a plan without the tile shapes, no memory for the two extra
         // stripes — leaves the 2k-point transform in charge; the pattern's unused parity blocks are unused there as well. ----
@@ -794,7 +803,9 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             if (rc != FASTECC_OK) return rc;
             std::vector<uint32_t> order;
             if (!split_decode_supported(d->split) || split_decode_groups(d->split) != 1024u || !gather_tile_order(d->split, order)) return FASTECC_E_UNSUPPORTED;
-            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity}) DEC_TRY(hipMalloc((void**)b, N * 4));
+            for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_pos_data_odd,
+                                 &d->split_rows_out_parity})
+                DEC_TRY(hipMalloc((void**)b, N * 4));
             DEC_TRY(hipMemcpy(d->split_order, order.data(), N * 4, hipMemcpyHostToDevice));
             DEC_TRY(hipMalloc((void**)&d->split_r1, N * ci.words * 4));
             DEC_TRY(hipMalloc((void**)&d->split_r2, N * ci.words * 4));
@@ -829,7 +840,8 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                 DEC_TRY(hipMemcpy(d->split_impulse, table.data(), table.size() * 4, hipMemcpyHostToDevice));
             }
             const uint32_t neg_half = (uint32_t)(gf::P - gf::h_inv(2u));
-            hipLaunchKernelGGL(split_pos_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d->wpow, d->split_pos_parity, (uint32_t)N, ci.log2k, neg_half);
+            hipLaunchKernelGGL(split_pos_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d->wpow, d->split_pos_parity, (uint32_t)N, ci.log2k, neg_half, false);
+            hipLaunchKernelGGL(split_pos_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d->wpow, d->split_pos_data_odd, (uint32_t)N, ci.log2k, neg_half, true);
             DEC_TRY(hipGetLastError());
             return FASTECC_OK;
         }();
@@ -839,7 +851,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             if (d->split) fastecc_destroy(d->split);
             d->split = nullptr;
             for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_impulse, &d->split_r1,
-                                 &d->split_r2}) {
+                                 &d->split_r2, &d->split_pos_data_odd, &d->split_rows_out_parity}) {
                 if (*b) (void)hipFree(*b);
                 *b = nullptr;
             }
@@ -914,8 +926,11 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         DEC_TRY(hipGetLastError());
     }
     if (split_groups != 0 && d->split) {
+        // (fastecc_repair in the (2k,k) layout: the lost parity blocks' factors too — gout_par is filled above for such patterns)
+        const bool with_parity = d->standard && d->erased_parity != 0 && d->gout_par != nullptr;
         hipLaunchKernelGGL(split_rows_kernel, grid(N), dim3(256), 0, st, d->fin, d->gout, d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out,
-                           (uint32_t)N);
+                           (uint32_t)N, with_parity ? d->gout_par : nullptr, with_parity ? d->split_rows_out_parity : nullptr);
+        d->split_repair_ready = with_parity;
         DEC_TRY(hipGetLastError());
         if (d->split_dirty > split_groups) {
             // rows of groups this pattern does not write any more: group g = blocks g + (t << 10)
@@ -1044,7 +1059,30 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         }
     } else {
     bool repaired_in_one_pass = false;
-    if (rebuild && d->erased_data != 0 && d->standard && d->transform_full && d->full_ok && d->gout_par) {
+    if (rebuild && d->erased_data != 0 && d->split_ready && d->split_repair_ready) {
+        // fastecc_repair through the split transform: the data chain as in fastecc_decode, and a second MID + DIT over the same two halves for
+        // x p'(x) at the odd positions — the lost parity blocks, written straight into the parity stripe.  (No room for the extra k-block
+        // stripe: the forms below.)
+        hipError_t e_alloc = hipSuccess;
+        if (!d->split_q2) e_alloc = hipMalloc((void**)&d->split_q2, N * block);
+        if (e_alloc != hipSuccess) {
+            (void)hipGetLastError();
+            d->split_q2 = nullptr;
+        } else {
+            uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
+            const SplitRepair odd{d->split_q2, d->split_pos_data_odd, d->split_rows_out_parity, dpar_out};
+            void* scope = profile_scope_begin(c, st, "repair_split_transform", (5 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
+            const int rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered,
+                                            d->split_r1, d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, &odd);
+            profile_scope_end(scope);
+            if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+            if (rc == FASTECC_OK) {
+                d->split_dirty = std::max(d->split_dirty, d->split_groups);
+                repaired_in_one_pass = true;
+            }
+        }
+    }
+    if (!repaired_in_one_pass && rebuild && d->erased_data != 0 && d->standard && d->transform_full && d->full_ok && d->gout_par) {
         // fastecc_repair, (2k,k) layout: x p'(x) at all 2k positions — the even rows give the lost data, the odd rows the lost parity
         const uint32_t S = (uint32_t)ci.words;
         hipError_t e_alloc = hipSuccess;

@@ -119,10 +119,18 @@ bool split_decode_supported(const fastecc_ctx* c);
 uint32_t split_decode_groups(const fastecc_ctx* c);
 uint32_t split_decode_group_rows(const fastecc_ctx* c);
 int split_impulse_max();  // IMPULSE_MAX of kernels.hpp
+// odd != null (fastecc_repair, (2k,k) layout): x p'(x) at the odd positions as well — a second MID + DIT over the same two halves.
+struct SplitRepair {
+    uint32_t* q2;                      // k blocks: where the first chain's MID writes, so that q survives for the second
+    const uint32_t* data_pos_factor;   // k words by position: -w^m / 2 at position bitrev(m)
+    const uint32_t* out_rows_factor;   // k words, tile order: 1 / (w^(2j+1) l'(w^(2j+1))) of the lost parity blocks, 0 elsewhere
+    uint32_t* out;                     // the parity stripe
+};
 // out_rows_factor != null: the DIT tile stores only the blocks with a non-zero factor (tile order), times it, to out[] (the decoder's scatter).
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st);
+                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st,
+                     const SplitRepair* odd = nullptr);
 // data_blocks / parity_blocks: the blocks the two stripes really hold (<= k: zero-extended codes; the rest counts as zero blocks)
 // impulse_table (optional): [IMPULSE_MAX][16][64] words (Montgomery form), entry [t][g][c] = block g + 16 c of a 1024-block tile after the DIF
 // levels with strides 512 ... 16 when block g + 16 t alone was 1 — with at most 16 IMPULSE_MAX parity groups in use those six of the parity

@@ -178,9 +178,19 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
                 assert ("decode_split_transform" in prof) == (split == 1) and ("decode_transform_2k" in prof) == (split == 0), prof  # which path ran
                 results.append(damaged)
                 assert bool((damaged == data).all()), (count, split)
-                enc.repair(damaged, dpar)
+                # repair from the damaged stripes again: the lost parity blocks come from a second chain over the same two half transforms
+                damaged2, dpar2 = data.clone(), parity.clone()
+                damaged2.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -3
+                dpar2.view(N, S)[torch.from_numpy(pp == 0).to("cuda:0")] = 0x5A5A5A5A
+                enc.profile(True)
+                enc.profile_reset()
+                enc.repair(damaged2, dpar2)
                 torch.cuda.synchronize()
-                assert bool((damaged == data).all()) and bool((dpar == parity).all()), (count, split)
+                prof = enc.profile_read()
+                enc.profile(False)
+                if (pp == 0).any():
+                    assert ("repair_split_transform" in prof) == (split == 1), prof
+                assert bool((damaged2 == data).all()) and bool((dpar2 == parity).all()), (count, split)
             assert torch.equal(results[0], results[1])
         enc.set_option("decode_split", 1)
         with pytest.raises(fe.FastEccError):
