@@ -154,9 +154,10 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 a.row_factor = cb.rows_out_factor;
             }
             if (cb.addend && p.mode == MODE_MID) {
-                mode = MODE_MID_ADD;
+                mode = cb.mid_up ? MODE_MID_UP : MODE_MID_ADD;
                 a.addend = cb.addend + col0;
                 a.addend_factor = cb.addend_factor;
+                a.keep = cb.keep && !cb.mid_up ? cb.keep + col0 : nullptr;
             }
             a.persistent_cus = c->persistent ? c->cus : 0;
             a.split2 = c->split2;
@@ -1088,18 +1089,20 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
         cl.impulse_rows = parity_groups;
     }
     if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st, 0, 0, nullptr, 1, cl);       // r~ : low levels (r1 is zero outside those groups)
-    // g = fq q~ + fr r~, and the transform back up.  With the odd positions wanted as well the top-level result q stays: this chain writes q2.
-    if (rc == FASTECC_OK) rc = run_passes(c, rest, q, odd ? odd->q2 : q, twd, twu, st, 0, 0, nullptr, 1, cm);
+    // g = fq q~ + fr r~, and the transform back up.  With the odd positions wanted as well MID also stores q~ (its tiles after the first half).
+    if (odd) cm.keep = odd->q2;
+    if (rc == FASTECC_OK) rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, cm);
     if (rc == FASTECC_OK && odd) {
         // x p'(x) at the ODD positions (the parity blocks): the k-point transform of h[m] = w^m (m P[m] - (m+k) P[m+k]) = -1/2 w^m q~[m] +
-        // (2m+k)/2k r~[m] — the same two halves with the factor tables exchanged (the context's own table now scales the addend)
+        // (2m+k)/2k r~[m] — MID's second half alone on the stored q~, the factor tables exchanged (the context's own table now scales the addend)
         CallBounds ch;
         ch.addend = r2;
         ch.addend_factor = c->dscale;
+        ch.mid_up = true;
         ch.dscale_override = odd->data_pos_factor;
         ch.rows_out_factor = odd->out_rows_factor;
         ch.final_out = odd->out;
-        rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, ch);
+        rc = run_passes(c, rest, odd->q2, odd->q2, twd, twu, st, 0, 0, nullptr, 1, ch);
     }
     return rc;
 }

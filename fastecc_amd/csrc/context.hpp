@@ -58,6 +58,8 @@ struct CallBounds {
     const uint32_t* addend_factor = nullptr;
     const uint32_t* impulse_table = nullptr;    // a lone DIF tile at s = 0 whose input is zero from block impulse_rows on (MODE_DIF_IMPULSE)
     uint32_t impulse_rows = 0;
+    uint32_t* keep = nullptr;                   // MODE_MID_ADD also stores its tiles as they are after the first half (TileArgs::keep)
+    bool mid_up = false;                        // the plan's MID pass runs its second half only, on such stored tiles (MODE_MID_UP)
     const uint32_t* dscale_override = nullptr;  // MID's per-block factors from this table instead of the context's
     const uint32_t* rows_out_factor = nullptr;  // the plan's last pass, a DIT tile, stores only the blocks with a non-zero factor, times it, to final_out (MODE_DIT_ROWS)
 };

@@ -119,9 +119,9 @@ bool split_decode_supported(const fastecc_ctx* c);
 uint32_t split_decode_groups(const fastecc_ctx* c);
 uint32_t split_decode_group_rows(const fastecc_ctx* c);
 int split_impulse_max();  // IMPULSE_MAX of kernels.hpp
-// odd != null (fastecc_repair, (2k,k) layout): x p'(x) at the odd positions as well — a second MID + DIT over the same two halves.
+// odd != null (fastecc_repair, (2k,k) layout): x p'(x) at the odd positions as well — MID's second half and a DIT once more over the same two halves.
 struct SplitRepair {
-    uint32_t* q2;                      // k blocks: where the first chain's MID writes, so that q survives for the second
+    uint32_t* q2;                      // k blocks: the data half after ALL its DIF levels, stored by the first chain's MID on its way; the second chain works there
     const uint32_t* data_pos_factor;   // k words by position: -w^m / 2 at position bitrev(m)
     const uint32_t* out_rows_factor;   // k words, tile order: 1 / (w^(2j+1) l'(w^(2j+1))) of the lost parity blocks, 0 elsewhere
     uint32_t* out;                     // the parity stripe

@@ -13,7 +13,7 @@ namespace fastecc {
 // whose input is zero from block `impulse_rows` <= 16 IMPULSE_MAX on: what its first six levels make of each of the few blocks in use is a
 // fixed vector of factors (row_factor = those tables, [IMPULSE_MAX][16][64]), so a multiply-add per word and block replaces them.
 constexpr int IMPULSE_MAX = 3;
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4, MODE_DIT_ROWS = 5, MODE_DIF_IMPULSE = 6 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_DIF_ROWS = 3, MODE_MID_ADD = 4, MODE_DIT_ROWS = 5, MODE_DIF_IMPULSE = 6, MODE_MID_UP = 7 };
 
 // Arguments of one register pass (kernels.hip: ntt_pass_kernel).
 struct PassArgs {
@@ -69,6 +69,7 @@ struct TileArgs {
     const uint32_t* addend;         // MODE_MID_ADD: a stripe in the position order MID's first half leaves (block p = coefficient bitrev(p))
     const uint32_t* addend_factor;  // ... and its per-position factors (Montgomery form), laid out like dscale
     uint32_t groups;                // > 0: only the first `groups` block groups of the pass are run (MODE_DIF_ROWS: the others are known to be zero)
+    uint32_t* keep;                 // MODE_MID_ADD, optional: the tile after MID's first half (before any factor) is also stored here — MODE_MID_UP's input
     uint32_t impulse_rows;          // MODE_DIF_IMPULSE: blocks [impulse_rows, T) of every tile are zero and not read (<= 16 IMPULSE_MAX)
 };
 

@@ -39,7 +39,8 @@
 //                block groups of the pass are launched
 //   DIF_IMPULSE  the 1024-block DIF tile at s = 0 when only its first few blocks are non-zero: the six levels before the exchange as one
 //                multiply-add per word and block in use
-//   MID_ADD      MID with "+ addend[p] * factor[p]" between its halves
+//   MID_ADD      MID with "+ addend[p] * factor[p]" between its halves (optionally also storing the tile as it is after the first half)
+//   MID_UP       that second half alone, from such a stored tile (fastecc_repair's second chain)
 //   DIT_ROWS     DIT that stores only the blocks with a non-zero factor, times that factor (the scatter)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -153,7 +154,8 @@ struct TileView {
     uint32_t lo, hi;          // tile group: stripe block of tile block q is (hi << (s+LOGT)) + lo + (q << s)
     uint32_t dead_mask;       // all ones in lanes whose column does not exist
     __amdgpu_buffer_rsrc_t in, out;
-    __amdgpu_buffer_rsrc_t add;  // MODE_MID_ADD: the tile's blocks of TileArgs::addend
+    __amdgpu_buffer_rsrc_t add;  // MODE_MID_ADD / MODE_MID_UP: the tile's blocks of TileArgs::addend
+    __amdgpu_buffer_rsrc_t keep; // MODE_MID_ADD with TileArgs::keep: the tile's blocks there
     // WIDE tiles only: descriptors of the upper half of the tile's blocks (block T/2 onwards).  A tile whose blocks span
     // up to 2^33 bytes is then addressed as two windows of < 2^32 bytes each.
     __amdgpu_buffer_rsrc_t in_hi, out_hi;
@@ -179,11 +181,12 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
     // SGPRs, < 2^33), 4 / 8 / 16 = MULTI (descriptors built per window from the tile's base pointers, < 2^34 .. 2^36)
     constexpr bool WIDE = NWIN == 2, MULTI = NWIN > 2;
-    constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS || MODE == MODE_DIF_IMPULSE, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD;
+    constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS || MODE == MODE_DIF_IMPULSE, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
     static_assert(MODE != MODE_DIF_IMPULSE || (PAIR && NWIN == 1 && LOGT == 10 && LOGR == 5), "impulse form: the 1024-block pair tile");
     static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
     static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
-    static_assert(MODE != MODE_MID_ADD || PAIR, "addend: pair tiles");
+    constexpr bool ADDK = MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
+    static_assert(!ADDK || PAIR, "addend: pair tiles");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
     static_assert(!MULTI || (NWIN <= TileCfg<LOGT, LOGR, PAIR>::G && NWIN <= TileCfg<LOGT, LOGR, PAIR>::R), "a wave's blocks must fit one window");
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
@@ -253,7 +256,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const size_t out_block0 = fold ? (size_t)((v.hi << LOGT) >> fold) : block0;
         v.in = make_desc(a.in + origin, window(a.in_rows, block0));
         v.out = make_desc(a.out + (fold ? out_block0 * a.ld + cc * W : origin), window(a.out_rows, out_block0));
-        if constexpr (MODE == MODE_MID_ADD) v.add = make_desc(a.addend + origin);
+        if constexpr (ADDK) v.add = make_desc(a.addend + origin);
+        if constexpr (MODE == MODE_MID_ADD) v.keep = make_desc((a.keep ? a.keep : a.out) + origin);
         if constexpr (MULTI) {
             v.in_base = a.in + origin;
             v.out_base = a.out + origin;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
             if (round + 1 < SPLIT) lds_barrier();  // the buffer is reused by the next column group
         }
     };
-    constexpr bool LOAD_A = MODE != MODE_DIT && MODE != MODE_DIT_ROWS;  // DIF and MID start in layout A, DIT in layout B
+    constexpr bool LOAD_A = MODE != MODE_DIT && MODE != MODE_DIT_ROWS && MODE != MODE_MID_UP;  // DIF and MID start in layout A, DIT (and MID's second half alone) in layout B
     auto load_tile = [&](uint32_t (&r)[R][1], const View& v) {
         if constexpr (MODE == MODE_DIF_IMPULSE) {
             // Blocks impulse_rows.. of the tile are zero, impulse_rows <= 16 IMPULSE_MAX: of this wave's 2R blocks g + 16 c only c < IMPULSE_MAX may
@@ -505,11 +509,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                     }
                 }
             }
-            if (compute && MODE != MODE_DIF_IMPULSE) {  // (the impulse form's load has done these levels)
+            if (compute && MODE != MODE_DIF_IMPULSE && MODE != MODE_MID_UP) {  // (the impulse form's load has done these levels; MID_UP starts after them)
                 if constexpr (PAIR) pair_level_dif<LOGR>(x, a.tw_dif, off, sl, upper_mask);
                 dif_levels<LOGR, 1, false>(x, a.tw_dif, off, sl);
             }
-            exchange(x, lds_a, qa_u, G, lds_b, qb_u, 1);
+            if constexpr (MODE != MODE_MID_UP) exchange(x, lds_a, qa_u, G, lds_b, qb_u, 1);
             if constexpr (DIFK) {
                 if (compute) {
                     if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
@@ -531,8 +535,15 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                         asm volatile("" : "+s"(soff));
                     }
                 };
-                if constexpr (MODE == MODE_MID_ADD) fetch_addend(ya[0], 0);
-                dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                if constexpr (MODE == MODE_MID_ADD) fetch_addend(ya[0], 0);  // (MID_UP: the tile's own loads are still in flight here)
+                if constexpr (MODE != MODE_MID_UP) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                if constexpr (MODE == MODE_MID_ADD) {
+                    if (a.keep) {  // uniform: fastecc_repair's second chain starts from here (MODE_MID_UP)
+                        View vk = v;
+                        vk.out = v.keep;
+                        store_rows(x, vk, lane_b, qb_u, 1);
+                    }
+                }
                 // position p = hi*T + q holds coefficient bitrev_n(p); dscale is stored in position order, so
                 // the R factors of a lane are contiguous.  In a PAIR tile the two half-waves hold different
                 // blocks: both runs are fetched (scalar) and selected per lane like the pair-level twiddles.
@@ -555,10 +566,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                         x[k0 + i][0] = gf::mul_mont(x[k0 + i][0], f);
                     }
                 }
-                if constexpr (MODE == MODE_MID_ADD) {
+                if constexpr (ADDK) {
                     // + addend[p] * addend_factor[p]: the other half of the split decoder's coefficient vector (layout B: this lane's blocks
                     // qb_u + k (+ R in the high half-wave), the same run of positions as the factors above)
                     const_u32_ptr e = as_constant(a.addend_factor) + ((size_t)v.hi << LOGT) + qb_u;
+                    if constexpr (MODE == MODE_MID_UP) fetch_addend(ya[0], 0);
 #pragma unroll
                     for (int k0 = 0; k0 < R; k0 += CHA) {
                         const int cur = (k0 / CHA) & 1;
@@ -699,6 +711,7 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
                 case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2>(a, st);
                 case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
                 case MODE_MID_ADD: return launch_one<LOGT, LOGR, PAIR, MODE_MID_ADD, 2>(a, st);
+                case MODE_MID_UP: return launch_one<LOGT, LOGR, PAIR, MODE_MID_UP, 2>(a, st);
                 case MODE_DIF_ROWS: case MODE_DIT_ROWS: return hipErrorInvalidValue;
                 case MODE_DIF_IMPULSE: return a.s == 0 && a.impulse_rows <= 16u * IMPULSE_MAX ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_IMPULSE, 2>(a, st) : hipErrorInvalidValue;
                 default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
@@ -706,7 +719,7 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
         }
     }
     // the split decoder's shapes (tile_split_supported): slim outer pair tiles with per-block factors; the addend MID only as above
-    if (mode == MODE_MID_ADD || mode == MODE_DIF_IMPULSE) return hipErrorInvalidValue;
+    if (mode == MODE_MID_ADD || mode == MODE_MID_UP || mode == MODE_DIF_IMPULSE) return hipErrorInvalidValue;
     if (mode == MODE_DIF_ROWS) {
         if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
         else return hipErrorInvalidValue;
@@ -753,7 +766,7 @@ hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& 
     if (!tile_supported(logt, pair, logr) || a.n < logt) return hipErrorInvalidValue;
     if (a.fold < 0 || (a.fold > 0 && (mode != MODE_MID || a.fold > tile_max_fold(logt, pair, logr)))) return hipErrorInvalidValue;
     if (logr == 4) {
-        if (mode == MODE_MID || mode == MODE_MID_ADD) return hipErrorInvalidValue;
+        if (mode == MODE_MID || mode == MODE_MID_ADD || mode == MODE_MID_UP) return hipErrorInvalidValue;
         return logt == 8 ? launch_mode<8, 4, true>(mode, a, st) : launch_mode<9, 4, true>(mode, a, st);
     }
     if (pair) {
