@@ -1102,6 +1102,7 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
         ch.dscale_override = odd->data_pos_factor;
         ch.rows_out_factor = odd->out_rows_factor;
         ch.final_out = odd->out;
+        ch.out_rows = parity_blocks < c->N ? parity_blocks : 0;  // (positions beyond a shorter parity stripe count as lost: nothing is stored there)
         rc = run_passes(c, rest, odd->q2, odd->q2, twd, twu, st, 0, 0, nullptr, 1, ch);
     }
     return rc;

@@ -777,9 +777,12 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     if (!d->fin) DEC_TRY(hipMalloc((void**)&d->fin, NC * 4));
     if (!d->srcmap) DEC_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
     if (!d->gout) DEC_TRY(hipMalloc((void**)&d->gout, N * 4));
+    // parity block j at position 2j + 1 (the (2k,k) layout and its zero-extended relatives with fold 0): a pattern that loses data AND parity
+    // gets the factors of its lost parity blocks too — fastecc_repair then needs no second encode
+    const bool parity_factors = d->erased_parity != 0 && (d->standard || (split_groups != 0 && ci.fold == 0));
+    if (parity_factors && !d->gout_par) DEC_TRY(hipMalloc((void**)&d->gout_par, N * 4));
     if (d->standard && d->erased_parity != 0) {
-        // repair in one transform (see DecodeState::transform_full): built when a pattern first loses data AND parity
-        if (!d->gout_par) DEC_TRY(hipMalloc((void**)&d->gout_par, N * 4));
+        // repair in one transform (see DecodeState::transform_full): the form for patterns or plans the split transform does not take
         if (!d->transform_full) {
             const int rc = create_ramp_transform_ctx(&d->transform_full, lgc, ci.words * 4, 0, gf::h_inv((uint32_t)NC), ci.device);
             if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM) return rc;
@@ -919,7 +922,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
                        (uint32_t)(T - erased_count), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc,
-                       d->standard && d->erased_parity != 0 ? d->gout_par : nullptr);
+                       parity_factors ? d->gout_par : nullptr);
     DEC_TRY(hipGetLastError());
     if (d->fin_first_pass != d->fin) {
         hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);
@@ -927,7 +930,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     }
     if (split_groups != 0 && d->split) {
         // (fastecc_repair in the (2k,k) layout: the lost parity blocks' factors too — gout_par is filled above for such patterns)
-        const bool with_parity = d->standard && d->erased_parity != 0 && d->gout_par != nullptr;
+        const bool with_parity = parity_factors && d->gout_par != nullptr;
         hipLaunchKernelGGL(split_rows_kernel, grid(N), dim3(256), 0, st, d->fin, d->gout, d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out,
                            (uint32_t)N, with_parity ? d->gout_par : nullptr, with_parity ? d->split_rows_out_parity : nullptr);
         d->split_repair_ready = with_parity;

@@ -231,9 +231,18 @@ def test_split_transform_of_zero_extended_codes(torch_cuda, fe, n, k, S):
                 enc.profile(False)
                 assert ("decode_split_transform" in prof) == (split == 1), prof
                 assert bool((damaged == data).all()), (count, split)
+                damaged.view(k, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -7   # repair from the damaged stripes
+                enc.profile(True)
+                enc.profile_reset()
                 enc.repair(damaged, dpar)
                 torch.cuda.synchronize()
+                prof = enc.profile_read()
+                enc.profile(False)
                 assert bool((damaged == data).all()) and bool((dpar == parity).all()), (count, split)
+                # fold 0 (n - k > N / 2): the lost parity blocks come from the split transform's second chain; fewer parity blocks: a second encode
+                n_pow = 1 << (k - 1).bit_length()
+                if (pp == 0).any():
+                    assert ("repair_split_transform" in prof) == (split == 1 and 2 * m > n_pow), prof
         enc.set_option("decode_split", 1)
 
 
