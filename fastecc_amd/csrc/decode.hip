@@ -781,18 +781,6 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // gets the factors of its lost parity blocks too — fastecc_repair then needs no second encode
     const bool parity_factors = d->erased_parity != 0 && (d->standard || (split_groups != 0 && ci.fold == 0));
     if (parity_factors && !d->gout_par) DEC_TRY(hipMalloc((void**)&d->gout_par, N * 4));
-    if (d->standard && d->erased_parity != 0) {
-        // repair in one transform (see DecodeState::transform_full): the form for patterns or plans the split transform does not take
-        if (!d->transform_full) {
-            const int rc = create_ramp_transform_ctx(&d->transform_full, lgc, ci.words * 4, 0, gf::h_inv((uint32_t)NC), ci.device);
-            if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM) return rc;
-            std::vector<uint32_t> o1, o2;
-            d->full_ok = d->transform_full && gather_tile_order(d->transform, o1) == gather_tile_order(d->transform_full, o2) && o1 == o2;
-            if (getenv("FASTECC_TRACE_PREPARE"))
-                fprintf(stderr, "[fastecc prepare] one-transform repair: context %s, same first-pass order %d (%s | %s)\n", d->transform_full ? "built" : "none",
-                        (int)d->full_ok, fastecc_plan_string(d->transform), d->transform_full ? fastecc_plan_string(d->transform_full) : "");
-        }
-    }
     // mixed radix: the work stripe of all NC positions, transformed in place; else the N recovered data positions
     if (!d->recovered) DEC_TRY(hipMalloc((void**)&d->recovered, (mixed ? NC : N) * ci.words * 4));
     d->split_ready = false;
@@ -860,6 +848,18 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
             }
             if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
             d->split_unavailable = true;
+        }
+    }
+    if (d->standard && d->erased_parity != 0 && !(split_groups != 0 && d->split)) {
+        // repair in one transform (see DecodeState::transform_full): the form for patterns or plans the split transform does not take
+        if (!d->transform_full) {
+            const int rc = create_ramp_transform_ctx(&d->transform_full, lgc, ci.words * 4, 0, gf::h_inv((uint32_t)NC), ci.device);
+            if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM) return rc;
+            std::vector<uint32_t> o1, o2;
+            d->full_ok = d->transform_full && gather_tile_order(d->transform, o1) == gather_tile_order(d->transform_full, o2) && o1 == o2;
+            if (getenv("FASTECC_TRACE_PREPARE"))
+                fprintf(stderr, "[fastecc prepare] one-transform repair: context %s, same first-pass order %d (%s | %s)\n", d->transform_full ? "built" : "none",
+                        (int)d->full_ok, fastecc_plan_string(d->transform), d->transform_full ? fastecc_plan_string(d->transform_full) : "");
         }
     }
     if (d->standard && !d->tile_order_valid) {
