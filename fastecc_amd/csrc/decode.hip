@@ -521,7 +521,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // (profiles/r03/direct_bench.jsonl); stripes the MFMA kernel cannot take (odd or short rows) stop at 96 unless a kernel was asked for — at 80
     // where the split transform (4.3 ms instead of 7.2 at k = 2^19 x 4 KB) is the alternative
     int direct_limit = std::min(ci.direct_max, direct_cap());
-    const bool split_applies = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.log2k >= 18;
+    const bool split_applies = ci.decode_split && ci.q <= 1 && ci.cosets == 1 && ci.log2k >= 17;
     if (ci.direct_kernel == 0 && !direct_mfma_applies(nullptr, nullptr, ci.words)) direct_limit = std::min(direct_limit, split_applies ? 80 : 96);
     {
         // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
@@ -644,7 +644,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     // (also the zero-extended codes inside (2N,N): data block i at position 2i, parity block j at 2j + 1, fewer blocks than N in either stripe;
     // and the codes with fewer parity blocks: parity block j at position 2 (j << fold) + 1, i.e. block j << fold of the parity half)
     const bool split_layout = !mixed && ci.cosets == 1;
-    const bool want_split = ci.decode_split && split_layout && ci.log2k >= 18 && erased_data != 0;
+    const bool want_split = ci.decode_split && split_layout && ci.log2k >= 17 && erased_data != 0;
     if (want_split) {
         constexpr uint32_t GROUPS = 1024;
         uint32_t held_in[GROUPS] = {};

@@ -720,12 +720,13 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     }
     // the split decoder's shapes (tile_split_supported): slim outer pair tiles with per-block factors; the addend MID only as above
     if (mode == MODE_MID_ADD || mode == MODE_MID_UP || mode == MODE_DIF_IMPULSE) return hipErrorInvalidValue;
+    constexpr bool ROWS_SHAPE = PAIR && (LOGR == 4 || LOGT == 7);  // the outer tiles of the default plans at k = 2^19, 2^18 (slim) and 2^17
     if (mode == MODE_DIF_ROWS) {
-        if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
+        if constexpr (ROWS_SHAPE) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS>(a, st);
         else return hipErrorInvalidValue;
     }
     if (mode == MODE_DIT_ROWS) {
-        if constexpr (LOGR == 4 && PAIR) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS>(a, st);
+        if constexpr (ROWS_SHAPE) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS>(a, st);
         else return hipErrorInvalidValue;
     }
     switch (mode) {

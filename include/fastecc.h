@@ -249,7 +249,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * (gf61_decode.hip).  The reference describes the algorithm (README.md:102-119 "Fastest", RS.md:42-79: erasure locator l,
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass — for
- * the codes with n <= 2k and k >= 2^18 as two pipelines of size k, the data half and the few parity blocks a pattern needs
+ * the codes with n <= 2k and k >= 2^17 as two pipelines of size k, the data half and the few parity blocks a pattern needs
  * (option "decode_split").
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity
  * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
@@ -343,7 +343,7 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  stop at 32;
  *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
  *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96;
- *   "decode_split" = 0 / 1 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^18 (power-of-two orders), next decode_prepare): the decoder's 2k-point
+ *   "decode_split" = 0 / 1 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^17 (power-of-two orders), next decode_prepare): the decoder's 2k-point
  *                  transform as two transforms of k points — the data half, and the parity half of which only as many block groups as there
  *                  are lost data blocks are read (7.1 -> 4.6 ms at k = 2^19 x 4 KB); 0 = one transform of 2k points.  Same bits;
  *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),

@@ -141,9 +141,9 @@ def test_headline_size_round_trip(torch_cuda, fe, lost_fraction):
         assert bool((damaged.view(-1) == data).all())
 
 
-@pytest.mark.parametrize("logn,S", [(18, 8), (18, 7), (19, 4), (18, 66)])
+@pytest.mark.parametrize("logn,S", [(18, 8), (18, 7), (19, 4), (18, 66), (17, 16), (17, 5)])
 def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S):
-    """(2k,k) codes with k >= 2^18 decode through two half-size transforms (option "decode_split", default on): the data half and the few
+    """(2k,k) codes with k >= 2^17 decode through two half-size transforms (option "decode_split", default on): the data half and the few
     parity block groups in use each go through the first DIF tile with per-block factors, the parity half's coefficients join the data half's
     between the two halves of the MID tile.  Same bits as the single 2k-point transform and as the original stripe; patterns that need
     fewer parity groups than the one before (the zeroing of the groups no longer written), ragged and odd block sizes, repair."""
