@@ -362,6 +362,36 @@ def test_a_failure_half_way_leaves_the_context_usable(torch_cuda, fe, oracle, fa
         assert np.array_equal(to_host(dd).reshape(N, S), x) and np.array_equal(to_host(dq).reshape(N, S), want)
 
 
+def test_sharded_decode_at_2_17_blocks_takes_the_split_transform(torch_cuda, fe):
+    """k = 2^17 in four column slabs on one device: every slab's decoder is set up on its own host thread (the same pattern), decodes through
+    the split transform (two half-size transforms, tests/test_gpu_decode.py) and repairs; compared on the device with the original stripes."""
+    torch = torch_cuda
+    N, S, G = 1 << 17, 64, 4
+    g = torch.Generator(device="cuda:0").manual_seed(99)
+    data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty_like(data)
+    rng = np.random.default_rng(17)
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        senc.encode(data, parity)
+        torch.cuda.synchronize()
+        for count in (N // 3, 500):
+            lost = rng.permutation(2 * N)[:count]
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            senc.decode_prepare(dp, pp)
+            damaged, dpar = data.clone(), parity.clone()
+            damaged.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+            dpar.view(N, S)[torch.from_numpy(pp == 0).to("cuda:0")] = -2
+            senc.decode(damaged, dpar)
+            torch.cuda.synchronize()
+            assert bool((damaged == data).all())
+            damaged.view(N, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -3
+            senc.repair(damaged, dpar)
+            torch.cuda.synchronize()
+            assert bool((damaged == data).all()) and bool((dpar == parity).all())
+
+
 def test_sharded_in_place_needs_room_for_the_parity(torch_cuda, fe):
     """parity == data with n - k > k would write past the data stripe: rejected like on one device."""
     torch = torch_cuda
