@@ -1,13 +1,15 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for one plan, one counter group per run (gpurun refuses --pmc with tracing).
-# usage: tools/prof_pmc.sh <plan> <outdir>
+# usage: tools/prof_pmc.sh <plan> <outdir> [command ...]      (default command: tools/run_encode.py --plan <plan> --steps 2)
 set -u
 PLAN=${1:-0}; OUT=${2:-gpurun_out/pmc}
+shift; shift
 REPO=$(pwd); export TMPDIR=/tmp
 mkdir -p "$OUT"
+if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python "$REPO/tools/run_encode.py" --plan "$PLAN" --steps 2); fi
 run() { # name counters...
   local name=$1; shift
-  ( cd /tmp && rocprofv3 --pmc "$@" -d "$REPO/$OUT/$name" -o pmc --output-format csv -- python "$REPO/tools/run_encode.py" --plan "$PLAN" --steps 2 ) > "$OUT/$name.log" 2>&1
+  ( cd /tmp && rocprofv3 --pmc "$@" -d "$REPO/$OUT/$name" -o pmc --output-format csv -- "${CMD[@]}" ) > "$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM
