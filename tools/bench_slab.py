@@ -1,6 +1,15 @@
-import sys, time, json
-sys.path.insert(0, '/root/repo')
-import torch, fastecc_amd as fe
+#!/usr/bin/env python3
+"""Encode time of the headline code with narrow blocks (512 B ... 4 KB): what one column slab of a sharded stripe costs on its GPU."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import fastecc_amd as fe  # noqa: E402
+
 P = 0xFFF00001
 k = 1 << 19
 out = {}
