@@ -184,7 +184,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS || MODE == MODE_DIF_IMPULSE, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
     static_assert(MODE != MODE_DIF_IMPULSE || (PAIR && NWIN == 1 && LOGT == 10 && LOGR == 5), "impulse form: the 1024-block pair tile");
     static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
-    static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN == 1), "per-block factors: single-window pair tiles");
+    static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN <= 2), "per-block factors: pair tiles of one or two windows");
     constexpr bool ADDK = MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
     static_assert(!ADDK || PAIR, "addend: pair tiles");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
@@ -614,7 +614,8 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                     const uint32_t f0 = pair_twiddle<LOGR>(f[2 * j + 0], f[2 * j + 1], upper_mask);
                     const uint32_t f1 = pair_twiddle<LOGR>(f[2 * j + 2], f[2 * j + 3], upper_mask);
                     __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j][0], f0), v.out, f0 ? voff : 0xFFFFFFFFu, soff, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j + 1][0], f1), v.out, f1 ? voff : 0xFFFFFFFFu, soff + far, 0);
+                    if constexpr (WIDE) __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j + 1][0], f1), v.out_hi, f1 ? voff : 0xFFFFFFFFu, soff, 0);
+                    else                __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j + 1][0], f1), v.out, f1 ? voff : 0xFFFFFFFFu, soff + far, 0);
                     soff += step;
                     asm volatile("" : "+s"(soff));
                 }
@@ -686,6 +687,9 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2>(a, st);
             if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2>(a, st);
         } else if constexpr (LOGR == 4) {
+            // (the split decoder's first and last pass on two-window tiles: 8 KB blocks at k = 2^19, 16 KB at 2^18)
+            if (mode == MODE_DIF_ROWS && a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 2>(a, st);
+            if (mode == MODE_DIT_ROWS && a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 2>(a, st);
             if (mode == MODE_DIF) {
                 if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 2>(a, st);
                 if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 4>(a, st);

@@ -197,6 +197,44 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             enc.set_option("decode_split", 2)
 
 
+def test_split_transform_on_two_window_tiles(torch_cuda, fe):
+    """16 KB blocks at k = 2^18: the outer tiles of the plan address their blocks through two windows (a tile spans 4 GiB); the per-block-factor
+    modes of the split transform exist for those tiles too.  One 2 % pattern, decode and repair, both forms of the transform."""
+    torch = torch_cuda
+    N, S = 1 << 18, 4096
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    data = torch.randint(0, 2**31 - 1, (N * S,), dtype=torch.int32, device="cuda:0", generator=g)   # (words below 2^31 < p: no 64-bit detour for 4 GiB)
+    parity = torch.empty_like(data)
+    rng = np.random.default_rng(5)
+    lost = rng.permutation(2 * N)[: 2 * N // 50]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    di, pi = torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0"), torch.from_numpy(np.flatnonzero(pp == 0)).to("cuda:0")
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        assert "SW32" in enc.plan()
+        enc.encode(data, parity)
+        saved_d, saved_p = data.view(N, S)[di].clone(), parity.view(N, S)[pi].clone()
+        for split in (1, 0):
+            enc.set_option("decode_split", split)
+            enc.decode_prepare(dp, pp)
+            data.view(N, S)[di] = -1
+            parity.view(N, S)[pi] = -2
+            enc.profile(True)
+            enc.profile_reset()
+            enc.decode(data, parity)
+            torch.cuda.synchronize()
+            prof = enc.profile_read()
+            enc.profile(False)
+            assert ("decode_split_transform" in prof) == (split == 1), prof
+            assert torch.equal(data.view(N, S)[di], saved_d)
+            data.view(N, S)[di] = -3
+            enc.repair(data, parity)
+            torch.cuda.synchronize()
+            assert torch.equal(data.view(N, S)[di], saved_d) and torch.equal(parity.view(N, S)[pi], saved_p)
+        enc.set_option("decode_split", 1)
+
+
 @pytest.mark.parametrize("n,k,S", [(600000, 300000, 4), (2 * 262145, 262145, 6), (300000 + 270000, 300000, 8),
                                    ((1 << 18) + (1 << 17), 1 << 18, 8), ((1 << 18) + 100000, 1 << 18, 5), (300000 + 140000, 300000, 4), ((1 << 18) + (1 << 14), 1 << 18, 16)])
 def test_split_transform_of_zero_extended_codes(torch_cuda, fe, n, k, S):
