@@ -279,3 +279,45 @@ def test_random_large_mixed_radix_configuration(torch_cuda, fe, oracle, seed):
         torch.cuda.synchronize()
         assert np.array_equal(dd.cpu().numpy().view(np.uint32).reshape(k, S), x), what
         assert np.array_equal(dq.cpu().numpy().view(np.uint32).reshape(m, S), want), what
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_split_decoder_configuration(torch_cuda, fe, seed):
+    """The decoder's split transform (k from 2^17 up, n <= 2k on power-of-two orders): random k around 2^17 and 2^18 (powers of two and
+    not), random parity counts from a few thousand to k (fold 0 ... 4, zero extension), tiny ragged blocks, random patterns from a few hundred
+    losses to all the code tolerates — decode and repair against the original stripes (no oracle at these sizes: the encoder is pinned elsewhere),
+    and the 2k-point form of the same pattern against both."""
+    torch = torch_cuda
+    rng = np.random.default_rng(7000 + seed)
+    base = 1 << int(rng.integers(17, 19))
+    k = int(base if rng.random() < 0.4 else rng.integers(base // 2 + 1, base + 1))
+    N = 1 << (k - 1).bit_length()
+    m = int(N if rng.random() < 0.3 else rng.integers(3000, N + 1))
+    if k < N and m < N and rng.random() < 0.5:
+        m = int(rng.integers(N // 2 + 1, N + 1))  # zero-extended data with fold 0 more often
+    S = int(rng.integers(1, 24))
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    data = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
+    count = int(rng.choice([300, 1000, m // 50 + 300, m // 3, m]))
+    count = min(count, m)
+    lost = rng.permutation(k + m)[:count]
+    dp, pp = np.ones(k, np.uint8), np.ones(m, np.uint8)
+    dp[lost[lost < k]] = 0
+    pp[lost[lost >= k] - k] = 0
+    with fe.Encoder(k + m, k, 4 * S) as enc:
+        enc.encode(data, parity)
+        for split in (1, 0):
+            enc.set_option("decode_split", split)
+            enc.decode_prepare(dp, pp)
+            d, q = data.clone(), parity.clone()
+            d.view(k, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+            q.view(m, S)[torch.from_numpy(pp == 0).to("cuda:0")] = -2
+            damaged_q = q.clone()
+            enc.decode(d, q)
+            torch.cuda.synchronize()
+            assert torch.equal(d, data) and torch.equal(q, damaged_q), (k, m, S, count, split)
+            d.view(k, S)[torch.from_numpy(dp == 0).to("cuda:0")] = -5
+            enc.repair(d, q)
+            torch.cuda.synchronize()
+            assert torch.equal(d, data) and torch.equal(q, parity), (k, m, S, count, split)
