@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""More seeds for tests/test_gpu_fuzz.py than the suite runs (2000 + 400 + 400 random configurations, about 100 s on an MI355X).
+"""More seeds for tests/test_gpu_fuzz.py than the suite runs (2000 + 400 + 400 + 400 random configurations, about 110 s on an MI355X).
 Last run at the end of round 3: 0 failures."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -21,5 +21,11 @@ for seed in range(1000, 1400):
         t.test_random_sharded_batched_and_column_calls(torch, fe, orc, seed)
     except Exception as e:
         bad += 1; print("p61/sharded seed", seed, repr(e)[:300])
+        if bad > 5: break
+for seed in range(1000, 1400):
+    try:
+        t.test_random_split_decoder_configuration(torch, fe, seed)
+    except Exception as e:
+        bad += 1; print("split decoder seed", seed, repr(e)[:300])
         if bad > 5: break
 print("done, failures:", bad)
