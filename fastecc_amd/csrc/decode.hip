@@ -1074,15 +1074,13 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         } else {
             uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
             const SplitRepair odd{d->split_q2, d->split_pos_data_odd, d->split_rows_out_parity, dpar_out};
+            d->split_dirty = std::max(d->split_dirty, d->split_groups);  // (before the launches: a failure half way must not hide written groups)
             void* scope = profile_scope_begin(c, st, "repair_split_transform", (5 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
             const int rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered,
                                             d->split_r1, d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, &odd);
             profile_scope_end(scope);
             if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
-            if (rc == FASTECC_OK) {
-                d->split_dirty = std::max(d->split_dirty, d->split_groups);
-                repaired_in_one_pass = true;
-            }
+            if (rc == FASTECC_OK) repaired_in_one_pass = true;
         }
     }
     if (!repaired_in_one_pass && rebuild && d->erased_data != 0 && d->standard && d->transform_full && d->full_ok && d->gout_par) {
@@ -1140,10 +1138,10 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
             parity_half = d->split_r0;
             parity_half_blocks = (uint32_t)N;
         }
+        if (staged_ok) d->split_dirty = std::max(d->split_dirty, d->split_groups);  // (before the launches, as above)
         if (staged_ok) rc = run_split_decode(d->split, ddata, parity_half, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered, d->split_r1,
                               d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, parity_half_blocks, st);  // ... whose last pass writes the rebuilt blocks straight into the data stripe
         profile_scope_end(scope);
-        if (rc == FASTECC_OK) d->split_dirty = std::max(d->split_dirty, d->split_groups);
         scattered = rc == FASTECC_OK;
     }
     if (rc == FASTECC_E_UNSUPPORTED && d->standard) {
