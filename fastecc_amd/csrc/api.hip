@@ -1047,7 +1047,7 @@ bool split_decode_supported(const fastecc_ctx* c)
     if (c->p61 || c->q > 1 || c->fold != 0 || c->cosets != 1 || c->encode_plan.size() != 3 || !c->dscale || c->ld != c->S) return false;
     const Pass &p0 = c->encode_plan[0], &p1 = c->encode_plan[1], &p2 = c->encode_plan[2];
     // a pair tile down (slim, or the 128-block one), the split 1024-block MID tile, the same tile up: k = 2^17, 2^18, 2^19 with the default plan
-    return p0.mode == MODE_DIF && p0.tile && p0.pair && (p0.wide == 0 ? (p0.rlog == 4 || p0.logr == 7) : (p0.wide == 2 && p0.rlog == 4)) && p1.mode == MODE_MID && p1.tile && p1.pair && p1.logr == 10 && c->split2 &&
+    return p0.mode == MODE_DIF && p0.tile && p0.pair && (p0.wide == 0 ? (p0.rlog == 4 || p0.logr == 7) : p0.rlog == 4) && p1.mode == MODE_MID && p1.tile && p1.pair && p1.logr == 10 && c->split2 &&
            p2.mode == MODE_DIT && p2.tile && p2.wide == p0.wide && p2.rlog == p0.rlog && p2.logr == p0.logr;
 }
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
     constexpr bool DIFK = MODE == MODE_DIF || MODE == MODE_DIF_ROWS || MODE == MODE_DIF_IMPULSE, MIDK = MODE == MODE_MID || MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
     static_assert(MODE != MODE_DIF_IMPULSE || (PAIR && NWIN == 1 && LOGT == 10 && LOGR == 5), "impulse form: the 1024-block pair tile");
     static_assert(NWIN == 1 || (PAIR && !MIDK), "windows: outer pair tiles only");
-    static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || (PAIR && NWIN <= 2), "per-block factors: pair tiles of one or two windows");
+    static_assert((MODE != MODE_DIF_ROWS && MODE != MODE_DIT_ROWS) || PAIR, "per-block factors: pair tiles");
     constexpr bool ADDK = MODE == MODE_MID_ADD || MODE == MODE_MID_UP;
     static_assert(!ADDK || PAIR, "addend: pair tiles");
     static_assert(NWIN == 1 || NWIN == 2 || NWIN == 4 || NWIN == 8 || NWIN == 16, "1, 2, 4, 8 or 16 windows");
@@ -609,6 +609,22 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 const uint32_t voff = lane_p | v.dead_mask;
                 uint32_t soff = g * row_bytes;
                 const uint32_t far = (T / 2) * row_bytes, step = 2 * G * row_bytes;
+                if constexpr (MULTI) {  // windows as in store_paired: register j's factor is the pair (f[2j], f[2j + 1]) of the two half-waves
+                    constexpr int PER = R / NWIN;
+#pragma unroll
+                    for (int w = 0; w < NWIN; ++w) {
+                        const __amdgpu_buffer_rsrc_t dsc = window_desc(v.out_base, a.out_rows, v, w);
+                        uint32_t so = g * row_bytes;
+#pragma unroll
+                        for (int ii = 0; ii < PER; ++ii) {
+                            const int j = 2 * ((w % (NWIN / 2)) * PER + ii) + w / (NWIN / 2);
+                            const uint32_t fj = pair_twiddle<LOGR>(f[2 * j], f[2 * j + 1], upper_mask);
+                            __builtin_amdgcn_raw_buffer_store_b32(gf::mul_mont(x[j][0], fj), dsc, fj ? voff : 0xFFFFFFFFu, so, 0);
+                            so += step;
+                            asm volatile("" : "+s"(so));
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < R; j += 2) {
                     const uint32_t f0 = pair_twiddle<LOGR>(f[2 * j + 0], f[2 * j + 1], upper_mask);
@@ -687,9 +703,17 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2>(a, st);
             if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2>(a, st);
         } else if constexpr (LOGR == 4) {
-            // (the split decoder's first and last pass on two-window tiles: 8 KB blocks at k = 2^19, 16 KB at 2^18)
-            if (mode == MODE_DIF_ROWS && a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 2>(a, st);
-            if (mode == MODE_DIT_ROWS && a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 2>(a, st);
+            // (the split decoder's first and last pass on tiles of several windows: 8 ... 64 KB blocks at k = 2^19)
+            if (mode == MODE_DIF_ROWS || mode == MODE_DIT_ROWS) {
+                const bool down = mode == MODE_DIF_ROWS;
+                if (a.wide == 2) return down ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 2>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 2>(a, st);
+                if (a.wide == 4) return down ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 4>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 4>(a, st);
+                if (a.wide == 8) return down ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 8>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 8>(a, st);
+                if constexpr (LOGT == 9) {
+                    if (a.wide == 16) return down ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_ROWS, 1, 16>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS, 1, 16>(a, st);
+                }
+                return hipErrorInvalidValue;
+            }
             if (mode == MODE_DIF) {
                 if (a.wide == 2) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 2>(a, st);
                 if (a.wide == 4) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 4>(a, st);

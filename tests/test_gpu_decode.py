@@ -197,11 +197,12 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             enc.set_option("decode_split", 2)
 
 
-def test_split_transform_on_two_window_tiles(torch_cuda, fe):
-    """16 KB blocks at k = 2^18: the outer tiles of the plan address their blocks through two windows (a tile spans 4 GiB); the per-block-factor
-    modes of the split transform exist for those tiles too.  One 2 % pattern, decode and repair, both forms of the transform."""
+@pytest.mark.parametrize("logn,tag", [(18, "SW32:"), (19, "SW4x32:")])
+def test_split_transform_on_tiles_of_several_windows(torch_cuda, fe, logn, tag):
+    """16 KB blocks at k = 2^18 / 2^19: the outer tiles of the plan address their blocks through two / four windows (a tile spans 4 / 8 GiB);
+    the per-block-factor modes of the split transform exist for those tiles too.  One 2 % pattern, decode and repair, both forms of the transform."""
     torch = torch_cuda
-    N, S = 1 << 18, 4096
+    N, S = 1 << logn, 4096
     g = torch.Generator(device="cuda:0").manual_seed(5)
     data = torch.randint(0, 2**31 - 1, (N * S,), dtype=torch.int32, device="cuda:0", generator=g)   # (words below 2^31 < p: no 64-bit detour for 4 GiB)
     parity = torch.empty_like(data)
@@ -212,7 +213,7 @@ def test_split_transform_on_two_window_tiles(torch_cuda, fe):
     pp[lost[lost >= N] - N] = 0
     di, pi = torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0"), torch.from_numpy(np.flatnonzero(pp == 0)).to("cuda:0")
     with fe.Encoder(2 * N, N, 4 * S) as enc:
-        assert "SW32" in enc.plan()
+        assert tag in enc.plan(), enc.plan()
         enc.encode(data, parity)
         saved_d, saved_p = data.view(N, S)[di].clone(), parity.view(N, S)[pi].clone()
         for split in (1, 0):
