@@ -165,10 +165,12 @@ __global__ __launch_bounds__(256) void k_locator_columns(const uint64_t* __restr
     st(lv + 4ull * m + 2, v1);
 }
 
-// fin[u] = l(w^u) on surviving positions (0 elsewhere); gout[i] = 1 / (w^2i l'(w^2i)) for erased data block i (0 elsewhere);
+// fin[u] = l(w^u) on surviving positions (0 elsewhere); gout[i] = 1 / (w^2i l'(w^2i)) for erased data block i (0 elsewhere), gout_all[u] the
+// same by position for every lost block (optional);
 // l = L w^(-u pad) on the points (the padding), see decode.hip finish_tables_kernel
 __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv, const uint8_t* __restrict__ state, const uint64_t* __restrict__ wpow,
-                                                uint64_t* __restrict__ fin, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad)
+                                                uint64_t* __restrict__ fin, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad,
+                                                uint64_t* __restrict__ gout_all)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
@@ -177,7 +179,11 @@ __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv,
     const Elem corr = ld(wpow + 2ull * (back == 0 ? 0 : NC - back));
     const bool held = state[u] == ST_HELD;
     st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * u), corr, k) : Elem{0, 0});
-    if ((u & 1u) == 0) st(gout + 2ull * (u >> 1), held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * u + 2), corr, k), k));
+    if ((u & 1u) == 0 || gout_all) {
+        const Elem g = held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * u + 2), corr, k), k);
+        if ((u & 1u) == 0) st(gout + 2ull * (u >> 1), g);
+        if (gout_all) st(gout_all + 2ull * u, g);  // every lost position, parity too: fastecc_repair in one transform
+    }
 }
 
 // One wave per (row, 64-element column chunk); the row's factor is wave-uniform.
@@ -456,6 +462,8 @@ struct Decoder {
     std::vector<Path*> tree;           // level k >= LEAF_LOG: size 2^(k+1), T >> k columns
     uint64_t *tree_x = nullptr, *tree_y = nullptr, *tree_f = nullptr;  // 2T elements each
     uint64_t *wpow = nullptr, *roots = nullptr, *lv = nullptr, *fin = nullptr, *gout = nullptr;
+    uint64_t* gout_all = nullptr;      // 2k factors by position (lazy: patterns that lose data AND parity), valid for the current pattern if gout_all_valid
+    bool gout_all_valid = false;
     uint32_t* erased = nullptr;
     uint8_t* state = nullptr;
     uint64_t* work = nullptr;          // 2k blocks (lazy)
@@ -488,7 +496,7 @@ void destroy_decoder(Decoder* d)
     destroy(d->pattern);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
-                    (void*)d->gout, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->rec, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
+                    (void*)d->gout, (void*)d->gout_all, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->rec, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
                     (void*)d->direct_inv, (void*)d->direct_pos, (void*)d->direct_partial, (void*)d->direct_wpow, (void*)d->direct_state})
         if (b) (void)hipFree(b);
     delete d;
@@ -693,7 +701,16 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         const int rc = ntt(d->pattern, d->lv, false, s0, nullptr);
         if (rc != FASTECC_OK) return rc;
     }
-    hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()));
+    d->gout_all_valid = false;
+    if (erased_data != 0 && erased_parity != 0) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
+        if (!d->gout_all && hipMalloc((void**)&d->gout_all, NC * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            d->gout_all = nullptr;
+        }
+        d->gout_all_valid = d->gout_all != nullptr;
+    }
+    hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()),
+                       d->gout_all_valid ? d->gout_all : nullptr);
     D61_TRY(hipGetLastError());
     D61_TRY(hipStreamSynchronize(s0));
     d->ready = true;
@@ -730,6 +747,14 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
                            d->direct_pad, d->direct, rebuild);
         D61_TRY(hipGetLastError());
         return FASTECC_OK;
+    }
+    if (d->erased_data != 0 && rebuild && d->gout_all_valid) {
+        // fastecc_repair in ONE transform: x p'(x) at all 2k positions, the gather in its first tile, the scatter — lost data AND lost parity
+        // blocks, each times its factor — in its last; no fold, no second encode
+        if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
+        const int rc = encode_ends(d->transform, data, parity, d->fin, d->work, d->gout_all, data, parity, s0, hooks);
+        if (rc == FASTECC_OK) return FASTECC_OK;
+        if (rc != FASTECC_E_UNSUPPORTED) return rc;
     }
     if (d->erased_data != 0) {
         if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));

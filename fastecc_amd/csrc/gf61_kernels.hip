@@ -56,6 +56,7 @@ struct PassArgs {
     // only where side[u] != 0; row i of the output is stored, times side[i], only where side[i] != 0
     const uint64_t* in2;
     const uint64_t* side;
+    uint64_t* out2;  // MODE_DIT_SCATTER, optional: the output rows are codeword positions — row i goes to (i even ? out : out2)[i / 2]
 };
 
 using gf61::Elem;
@@ -462,7 +463,8 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
             for (int j = 0; j < R; ++j) {
                 const uint64_t i = block0 + ((uint64_t)row_a(j) << s);
                 const uint64_t fre = as_constant(a.side)[2 * i], fim = as_constant(a.side)[2 * i + 1];
-                if ((fre | fim) != 0) store_elem(a.out + i * row_words + 2u * col, gf61::canon(gf61::mul(x[j], gf61::make_twiddle(fre, fim), k)));
+                uint64_t* dst = a.out2 ? ((i & 1u) ? a.out2 : a.out) + (i >> 1) * row_words : a.out + i * row_words;  // (uniform)
+                if ((fre | fim) != 0) store_elem(dst + 2u * col, gf61::canon(gf61::mul(x[j], gf61::make_twiddle(fre, fim), k)));
                 __builtin_amdgcn_sched_barrier(0);  // one row at a time: the products of all R rows at once do not fit the registers
             }
         } else {
@@ -870,6 +872,7 @@ struct FusedEnds {
     const uint64_t* first_side = nullptr;  // set: plan[0] must be a DIF tile
     const uint64_t* last_side = nullptr;   // set: plan.back() must be a canonical DIT tile; it then writes to last_out
     uint64_t* last_out = nullptr;
+    uint64_t* last_out2 = nullptr;         // set: the rows are codeword positions, even ones go to last_out, odd ones here (PassArgs::out2)
 };
 
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
@@ -898,6 +901,7 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
             mode = MODE_DIT_SCATTER;
             a.side = ends->last_side;
             a.out = ends->last_out;
+            a.out2 = ends->last_out2;
         }
         a.tw_dif = tw_dif;
         a.tw_dit = tw_dit;
@@ -1018,6 +1022,24 @@ int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint6
         fe.last_out = ends->data_out;
     }
     return run_passes(half, up, out, out, half->tw_inv, half->tw_fwd, true, st, hooks, 0, 0, &fe);
+}
+
+// The whole transform of `p` with the decoder's ends fused in (fastecc_repair in one transform): input position u = (u even ? data : parity)[u / 2]
+// times fin[u] (read where fin[u] != 0), output position u times gout_all[u] written to (u even ? data_out : parity_out)[u / 2] where that
+// factor is not zero.  work: the path's 2^n-block stripe.  FASTECC_E_UNSUPPORTED when the plan does not start with a DIF tile and end on a DIT tile.
+int encode_ends(Path* p, const uint64_t* data, const uint64_t* parity, const uint64_t* fin, uint64_t* work, const uint64_t* gout_all, uint64_t* data_out,
+                uint64_t* parity_out, hipStream_t st, const LaunchHooks* hooks)
+{
+    if (!p || p->enc.size() < 2) return FASTECC_E_UNSUPPORTED;
+    const Pass &first = p->enc.front(), &last = p->enc.back();
+    if (!first.tile || first.mode != MODE_DIF || !last.tile || last.mode != MODE_DIT || !last.canon) return FASTECC_E_UNSUPPORTED;
+    FusedEnds fe;
+    fe.first_in2 = parity;
+    fe.first_side = fin;
+    fe.last_side = gout_all;
+    fe.last_out = data_out;
+    fe.last_out2 = parity_out;
+    return run_passes(p, p->enc, data, work, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, &fe);
 }
 
 int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int force_mid, char* detail, size_t cap)

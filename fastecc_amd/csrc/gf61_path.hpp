@@ -46,6 +46,9 @@ enum { FOLD_PAIRS = 1, FOLD_GATHERS = 2, FOLD_SCATTERS = 4 };
 int fold_caps(Path* big, Path* half);  // what encode_fold can do with these two paths
 int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint64_t* out, hipStream_t st, const LaunchHooks* hooks,
                 const FoldEnds* ends = nullptr);
+// fastecc_repair in ONE transform (a path made by create_transform with FACTOR_INDEX, size 2k): see gf61_kernels.hip
+int encode_ends(Path* p, const uint64_t* data, const uint64_t* parity, const uint64_t* fin, uint64_t* work, const uint64_t* gout_all, uint64_t* data_out,
+                uint64_t* parity_out, hipStream_t st, const LaunchHooks* hooks);
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);

@@ -340,9 +340,19 @@ def test_decode_transform_is_folded(torch_cuda, fe, logn, elems):
             # the transform starts with a DIF tile and ends with a DIT tile there: the gather and the scatter ride in them (6- and 7-level forms)
             assert any(name.endswith("_gather") for name in prof) and any(name.endswith("_scatter") for name in prof), prof
         assert torch.equal(d, x)
-        enc.repair(d.clone(), q)
+        d2 = x.clone()
+        d2.view(N, 2 * elems)[torch.from_numpy(dp == 0).to("cuda:0")] = -1
+        enc.profile(True)
+        enc.profile_reset()
+        enc.repair(d2, q)
         torch.cuda.synchronize()
-        assert torch.equal(q, par)
+        prof = enc.profile_read()
+        enc.profile(False)
+        assert torch.equal(d2, x) and torch.equal(q, par)
+        if logn in (12, 13, 18):
+            # data AND parity lost: ONE transform over all 2k positions (no fold, no second encode), gather and scatter in its end tiles
+            assert "p61_tile_mid7_fold" not in prof and any(name.endswith("_gather") for name in prof) and any(name.endswith("_scatter") for name in prof), prof
+            assert not any(name.startswith("p61_tile_mid6") for name in prof), prof  # (that would be the encoder's MID: a re-encode)
 
 
 @pytest.mark.parametrize("N,elems", [(2, 3), (16, 70), (1024, 9), (1 << 14, 4)])
