@@ -623,11 +623,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
     uint32_t chunks;
     int pad;
     if (use_mfma) {
-        int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
-        if (const char* ev = getenv("FASTECC_DIRECT_MT")) {  // experiments only
-            const int v = atoi(ev);
-            if (v == 2 || v == 4 || v == 8) mt = v;
-        }
+        const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;  // M-tiles per workgroup (measured: profiles/r03/direct_bench.jsonl)
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
         const uint32_t steps_alloc = bulk / 8u + MFMA_G;  // zero steps at the end: the prefetch of a stage never leaves the table
