@@ -83,6 +83,14 @@ struct DecodeState {
     bool split_ready = false;               // this pattern decodes through the split transform
     bool split_unavailable = false;         // it could not be built on this context (plan shape, memory): the 2k-point transform serves
     uint32_t* parity_dev = nullptr;    // staging for FASTECC_MEM_HOST calls (lazy)
+    // FASTECC_MEM_HOST: only the rebuilt blocks travel back — their row numbers (host, and a device copy), valid for pattern `host_lists_of`
+    std::vector<uint32_t> host_lost_data, host_lost_parity;
+    std::vector<uint32_t> host_parity_used;  // few losses: the parity blocks the direct path reads (all it needs staged of a host parity stripe)
+    uint64_t pattern_serial = 0, host_lists_of = ~0ull;
+    uint32_t* lost_rows_dev = nullptr;  // the two lists back to back
+    uint64_t lost_rows_cap = 0;
+    uint32_t* pack_dev = nullptr;       // the rebuilt blocks, packed
+    uint64_t pack_words = 0;
     // fastecc_decode_prepare's device state (lazy): the product tree of the locator
     uint64_t tree_T = 0;                   // padded number of roots: the smallest power of two >= the most losses a code tolerates
     std::vector<fastecc_ctx*> tree_ctx;    // level k (polynomials of degree d = 2^k): transforms of length 2d, T/d columns
@@ -134,6 +142,8 @@ void destroy_decode_state(DecodeState* d)
     if (d->gout) (void)hipFree(d->gout);
     if (d->recovered) (void)hipFree(d->recovered);
     if (d->parity_dev) (void)hipFree(d->parity_dev);
+    if (d->lost_rows_dev) (void)hipFree(d->lost_rows_dev);
+    if (d->pack_dev) (void)hipFree(d->pack_dev);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
     direct_pass_free(d->direct_data);
@@ -406,6 +416,24 @@ __global__ __launch_bounds__(256) void split_stage_kernel(const uint32_t* __rest
     store_vec<V>(stage + (size_t)(q << fold) * S + col, x);
 }
 
+// packed[r] = stripe[rows[r]]: the rebuilt blocks side by side, for one copy to the host
+template <int V>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uint32_t* __restrict__ stripe, const uint32_t* __restrict__ rows, uint32_t* __restrict__ packed,
+                                                        uint32_t S, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t r = (uint32_t)(item / col_chunks);
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t x[V];
+    load_vec<V>(x, stripe + (size_t)as_constant(rows)[r] * S + col);
+    store_vec<V>(packed + (size_t)r * S + col, x);
+}
+
 // parity[q] = again[q] for the parity blocks that were lost (lost[q] != 0); the others are not touched
 template <int V>
 __global__ __launch_bounds__(256) void restore_parity_kernel(const uint32_t* __restrict__ again, uint32_t* __restrict__ parity,
@@ -599,6 +627,10 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
                 d->sub = true;
                 d->sub_lost_data = ed;
                 d->sub_lost_parity = ep;
+                d->host_lost_data = R;  // (FASTECC_MEM_HOST calls: the rows that travel back)
+                d->host_lost_parity = Pl;
+                d->host_parity_used = A;
+                d->host_lists_of = ++d->pattern_serial;
                 d->ready = true;
                 return FASTECC_OK;
             }
@@ -693,6 +725,7 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
     }
     pt.mark("lost-parity flags");
     d->sub = false;
+    ++d->pattern_serial;  // (the lists of rebuilt rows for FASTECC_MEM_HOST calls are made when such a call comes: decode_impl)
     if (erased_data == 0) {  // no data block to recover
         d->ready = true;
         return FASTECC_OK;
@@ -1039,10 +1072,42 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
 
     uint32_t* ddata = (uint32_t*)data;
     const uint32_t* dparity = (const uint32_t*)parity;
+    bool host_rows_only = false;  // FASTECC_MEM_HOST: only the rebuilt blocks are copied back (few enough of them, their rows known)
     if (mem_kind == FASTECC_MEM_HOST) {
-        // stage both parts of the codeword
+        // stage the codeword — of the parity stripe only what the decoder will read where that is known to be a few block groups (the split
+        // transform of the (2k,k) layout: groups g < split_groups = blocks g + 1024 t, one strided copy)
         if (!d->parity_dev) DEC_TRY(hipMalloc((void**)&d->parity_dev, parity_bytes + data_bytes));
-        DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, parity_bytes, hipMemcpyHostToDevice, st));
+        // the rows that will travel back: known from the set-up (few losses), else read off the decoder's tables once per pattern
+        if (d->host_lists_of != d->pattern_serial) {
+            d->host_lost_data.clear();
+            d->host_lost_parity.clear();
+            if (d->erased_data + d->erased_parity <= (ci.user_k + ci.user_m) / 8 && d->parity_lost && (d->erased_data == 0 || d->gout)) {
+                std::vector<uint32_t> flags(std::max(ci.user_k, ci.user_m));
+                if (d->erased_data != 0) {
+                    DEC_TRY(hipMemcpy(flags.data(), d->gout, ci.user_k * 4, hipMemcpyDeviceToHost));
+                    for (uint64_t i = 0; i < ci.user_k; i++)
+                        if (flags[i] != 0) d->host_lost_data.push_back((uint32_t)i);
+                }
+                DEC_TRY(hipMemcpy(flags.data(), d->parity_lost, ci.user_m * 4, hipMemcpyDeviceToHost));
+                for (uint64_t q = 0; q < ci.user_m; q++)
+                    if (flags[q] != 0) d->host_lost_parity.push_back((uint32_t)q);
+                if (d->host_lost_data.size() != d->erased_data) d->host_lost_data.clear(), d->host_lost_parity.clear();  // (tables of another shape: whole stripes back)
+            }
+            d->host_lists_of = d->pattern_serial;
+        }
+        const uint64_t back = (d->erased_data != 0 ? d->host_lost_data.size() : 0) + (rebuild ? d->host_lost_parity.size() : 0);
+        host_rows_only = back != 0 && (d->erased_data == 0 || d->host_lost_data.size() == d->erased_data) &&
+                         (!rebuild || d->host_lost_parity.size() == d->erased_parity) && back <= (ci.user_k + ci.user_m) / 8;
+        // (a repair that copies the whole parity stripe back must have staged all of it)
+        if (!d->sub && d->split_ready && d->standard && d->erased_data != 0 && d->split_groups < 512 && (!rebuild || host_rows_only)) {
+            DEC_TRY(hipMemcpy2DAsync(d->parity_dev, 1024 * block, parity, 1024 * block, (size_t)d->split_groups * block, ci.user_m / 1024, hipMemcpyHostToDevice, st));
+        } else if (d->sub && (!rebuild || host_rows_only)) {
+            // few losses: the direct path reads as many parity blocks as data blocks are lost (at most 256 copies of a block)
+            for (uint32_t q : d->host_parity_used)
+                DEC_TRY(hipMemcpyAsync(d->parity_dev + (size_t)q * ci.words, (const char*)parity + (size_t)q * block, block, hipMemcpyHostToDevice, st));
+        } else {
+            DEC_TRY(hipMemcpyAsync(d->parity_dev, parity, parity_bytes, hipMemcpyHostToDevice, st));
+        }
         DEC_TRY(hipMemcpyAsync(d->parity_dev + ci.user_m * ci.words, data, data_bytes, hipMemcpyHostToDevice, st));
         dparity = d->parity_dev;
         ddata = d->parity_dev + ci.user_m * ci.words;
@@ -1194,7 +1259,43 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         DEC_TRY(hipGetLastError());
     }
     }  // transform path
-    if (mem_kind == FASTECC_MEM_HOST) {
+    if (mem_kind == FASTECC_MEM_HOST && host_rows_only) {
+        // the rebuilt blocks packed side by side on the device, one copy, and a memcpy per block on the host
+        const uint32_t S = (uint32_t)ci.words;
+        const uint64_t nd = d->erased_data != 0 ? d->host_lost_data.size() : 0, np = rebuild ? d->host_lost_parity.size() : 0;
+        if (d->lost_rows_cap < nd + np) {
+            if (d->lost_rows_dev) (void)hipFree(d->lost_rows_dev);
+            d->lost_rows_dev = nullptr;
+            d->lost_rows_cap = 0;
+            DEC_TRY(hipMalloc((void**)&d->lost_rows_dev, (nd + np) * 4));
+            d->lost_rows_cap = nd + np;
+        }
+        if (d->pack_words < (nd + np) * S) {
+            if (d->pack_dev) (void)hipFree(d->pack_dev);
+            d->pack_dev = nullptr;
+            d->pack_words = 0;
+            DEC_TRY(hipMalloc((void**)&d->pack_dev, (nd + np) * S * 4));
+            d->pack_words = (nd + np) * S;
+        }
+        if (nd) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev, d->host_lost_data.data(), nd * 4, hipMemcpyHostToDevice, st));
+        if (np) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev + nd, d->host_lost_parity.data(), np * 4, hipMemcpyHostToDevice, st));
+        const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)d->parity_dev | (uintptr_t)d->pack_dev) & 15u) == 0);
+        const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+        auto pack = [&](const uint32_t* stripe, const uint32_t* rows, uint32_t* out, uint64_t count) {
+            const uint64_t items = count * col_chunks;
+            const dim3 grid((unsigned)((items + 3) / 4));
+            if (v4) hipLaunchKernelGGL(pack_rows_kernel<4>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
+            else    hipLaunchKernelGGL(pack_rows_kernel<1>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
+        };
+        if (nd) pack(ddata, d->lost_rows_dev, d->pack_dev, nd);
+        if (np) pack(d->parity_dev, d->lost_rows_dev + nd, d->pack_dev + nd * S, np);
+        DEC_TRY(hipGetLastError());
+        std::vector<uint32_t> packed((nd + np) * (size_t)S);
+        DEC_TRY(hipMemcpyAsync(packed.data(), d->pack_dev, packed.size() * 4, hipMemcpyDeviceToHost, st));
+        DEC_TRY(hipStreamSynchronize(st));
+        for (uint64_t r = 0; r < nd; r++) memcpy((char*)data + (size_t)d->host_lost_data[r] * block, packed.data() + r * S, block);
+        for (uint64_t r = 0; r < np; r++) memcpy((char*)parity_out + (size_t)d->host_lost_parity[r] * block, packed.data() + (nd + r) * S, block);
+    } else if (mem_kind == FASTECC_MEM_HOST) {
         if (d->erased_data != 0) DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
         if (rebuild) DEC_TRY(hipMemcpyAsync(parity_out, d->parity_dev, parity_bytes, hipMemcpyDeviceToHost, st));
         DEC_TRY(hipStreamSynchronize(st));

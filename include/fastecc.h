@@ -262,7 +262,9 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            Reusable for any number of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
- *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous.
+ *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous — the data
+ *                            stripe and the parity blocks the decoder reads travel up, the rebuilt blocks back (whole stripes
+ *                            when more than an eighth of the codeword is lost).
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
  * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
  * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.3-3.5 ms, no transform contexts) and decode

@@ -197,6 +197,50 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             enc.set_option("decode_split", 2)
 
 
+@pytest.mark.parametrize("count", [3, 200, 5000, 1 << 16])
+def test_host_stripes_only_the_rebuilt_blocks_travel_back(torch_cuda, fe, count):
+    """FASTECC_MEM_HOST decode / repair at k = 2^17: the stripes are staged through HBM (of the parity stripe only the block groups the split
+    transform reads), and with few enough lost blocks only those come back — packed on the device, one copy, a memcpy per block.  The surviving
+    blocks of the host stripes must be untouched (they hold a marker the device never saw changed), the lost ones restored."""
+    torch = torch_cuda
+    N, S = 1 << 17, 24
+    g = torch.Generator(device="cuda:0").manual_seed(count)
+    data = torch.randint(0, P, (N * S,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+    parity = torch.empty_like(data)
+    rng = np.random.default_rng(count)
+    lost = rng.permutation(2 * N)[:count]
+    dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+    dp[lost[lost < N]] = 0
+    pp[lost[lost >= N] - N] = 0
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.encode(data, parity)
+        torch.cuda.synchronize()
+        x, par = to_host(data, (N, S)).copy(), to_host(parity, (N, S)).copy()
+        enc.decode_prepare(dp, pp)
+        for repair in (False, True, True):  # (the second repair: lists and staging buffers of the first are reused)
+            hd, hq = x.copy(), par.copy()
+            hd[dp == 0] = 0xABABABAB
+            hq[pp == 0] = 0xCDCDCDCD
+            if repair:
+                enc.repair(hd, hq, mem=fe.MEM_HOST)
+                assert np.array_equal(hd, x) and np.array_equal(hq, par), (count, repair)
+            else:
+                enc.decode(hd, hq, mem=fe.MEM_HOST)
+                want_q = par.copy()
+                want_q[pp == 0] = 0xCDCDCDCD
+                assert np.array_equal(hd, x) and np.array_equal(hq, want_q), (count, repair)
+        # another pattern on the same context: the row lists follow it
+        dp2, pp2 = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        dp2[[5, 77, N - 1]] = 0
+        pp2[[0]] = 0
+        enc.decode_prepare(dp2, pp2)
+        hd, hq = x.copy(), par.copy()
+        hd[dp2 == 0] = 1
+        hq[pp2 == 0] = 2
+        enc.repair(hd, hq, mem=fe.MEM_HOST)
+        assert np.array_equal(hd, x) and np.array_equal(hq, par)
+
+
 @pytest.mark.parametrize("logn,tag", [(18, "SW32:"), (19, "SW4x32:")])
 def test_split_transform_on_tiles_of_several_windows(torch_cuda, fe, logn, tag):
     """16 KB blocks at k = 2^18 / 2^19: the outer tiles of the plan address their blocks through two / four windows (a tile spans 4 / 8 GiB);
