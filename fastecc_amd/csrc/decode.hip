@@ -1001,6 +1001,7 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
 {
     if (!c || !data || !parity || (((uintptr_t)data | (uintptr_t)parity) & 3u)) return FASTECC_E_INVAL;
     if (sharded_of(c)) return sharded_decode_stripe(c, data, const_cast<void*>(parity), mem_kind, parity_out != nullptr, (hipStream_t)stream);
+    if (mem_kind == FASTECC_MEM_HOST_PINNED) mem_kind = FASTECC_MEM_HOST;  // the same staging; the copies are simply faster from pinned memory
     if (mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_DEVICE) return FASTECC_E_INVAL;
     CallScope call(c);
     if (info_of(c).field == FASTECC_FIELD_GF_P61_SQUARED) {

@@ -262,7 +262,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            Reusable for any number of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
- *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST: staged, synchronous — the data
+ *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST / HOST_PINNED: staged, synchronous — the data
  *                            stripe and the parity blocks the decoder reads travel up, the rebuilt blocks back (whole stripes
  *                            when more than an eighth of the codeword is lost).
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.

@@ -239,6 +239,12 @@ def test_host_stripes_only_the_rebuilt_blocks_travel_back(torch_cuda, fe, count)
         hq[pp2 == 0] = 2
         enc.repair(hd, hq, mem=fe.MEM_HOST)
         assert np.array_equal(hd, x) and np.array_equal(hq, par)
+        # pinned host memory is accepted as well (the same staging)
+        td, tq = torch.from_numpy(x.view(np.int32).copy()).pin_memory(), torch.from_numpy(par.view(np.int32).copy()).pin_memory()
+        td.view(N, S)[torch.from_numpy(dp2 == 0)] = 3
+        tq.view(N, S)[torch.from_numpy(pp2 == 0)] = 4
+        enc.repair(td, tq, mem=fe.MEM_HOST_PINNED)
+        assert np.array_equal(td.numpy().view(np.uint32).reshape(N, S), x) and np.array_equal(tq.numpy().view(np.uint32).reshape(N, S), par)
 
 
 @pytest.mark.parametrize("logn,tag", [(18, "SW32:"), (19, "SW4x32:")])
