@@ -9,7 +9,10 @@ The encode has no exchange step: the S word columns of a stripe are independent 
     gathered over xGMI into full 4 KB parity blocks on one rank: `encode_sub_slabs_and_gather` (slab resident as contiguous
     column sub-slabs: no pack, the root's own part never moves, one re-interleaving kernel per sub-slab, transfers and
     re-interleave on a side stream under the next sub-slab's encode) or `encode_slab_and_gather` (slab resident as one
-    [k, w] array: fastecc_encode_columns per sub-slab, a pack per sub-slab, a copy per received piece).
+    [k, w] array: fastecc_encode_columns per sub-slab, a pack per sub-slab, a copy per received piece).  Gather-to-root is
+    bound by the root's links ((G-1)/G of the stripe enters one GPU); `encode_all_to_all` leaves the result BLOCK-DISTRIBUTED
+    instead — rank g ends with parity blocks [g*M/G, (g+1)*M/G) whole, every link carries 1/G^2 of the stripe — and can take
+    block-distributed data as well (the mirror transpose in front of the encode).
 
 The single-process form of the same thing (one host thread driving all GPUs, peer copies instead of RCCL) is
 fastecc_create_sharded / fastecc_encode_sharded in the C ABI (csrc/sharded.hip).
@@ -241,6 +244,137 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
     if on_gpu:
         main.wait_stream(side)  # the call behaves as one operation on the caller's stream
     return mine, (parity_full if root else None)
+
+
+def rows_for_rank(rows, rank, world):
+    """Block range [lo, hi) that `rank` holds WHOLE in the block-distributed layout; the blocks must split evenly."""
+    if rows % world:
+        raise ValueError("%d blocks do not divide over %d ranks" % (rows, world))
+    return rank * (rows // world), (rank + 1) * (rows // world)
+
+
+def encode_all_to_all(data, encode_fn, parity_rows, data_is_blocks=False, sub_slabs=2, parity_blocks=None, group=None, collective_on_host=False,
+                      workspace=None):
+    """ONE stripe over the ranks with a BLOCK-DISTRIBUTED result (and, optionally, input): the N data and M parity blocks of RS.md:13-33 are
+    separately stored units, so after the encode rank g holds parity blocks [g*M/G, (g+1)*M/G) WHOLE — what a host that disperses blocks to
+    devices wants — instead of everything converging on one root.
+
+    The compute is the column-slab encode (no exchange inside the transform); the exchange is an all-to-all in which every rank sends 1/G of its
+    slab to every other rank, so every xGMI link carries 1/G^2 of the stripe per direction and no rank is a hot spot (gather-to-root puts
+    (G-1)/G of the stripe into ONE rank's links):
+
+        parity sub-slab h of rank g, [M, ws]      rows are block indices: the G row chunks are contiguous, so all_to_all_single sends them as
+                                                  they lie — no pack
+        recv [G, M/G, ws]                         chunk j = rank j's columns of MY parity blocks
+        parity_blocks[:, j, h, :] <- recv[j]      one strided kernel per sub-slab (on the side stream, under the next sub-slab's encode)
+
+    data_is_blocks: the input is block-distributed as well — `data` = this rank's whole data blocks [k/G, S] (blocks [g*k/G, (g+1)*k/G)).  The
+    mirror transpose runs first, per sub-slab: pack [k/G, G, ws] -> [G, k/G, ws] (one strided kernel), all_to_all_single, and what arrives,
+    [G, k/G, ws], IS the contiguous [k, ws] data sub-slab (no unpack).  Sub-slab h+1 is transposed while sub-slab h is encoded.
+    Otherwise `data` is [H, k, ws]: the slab resident as H contiguous column sub-slabs (encode_sub_slabs_and_gather's residency).
+
+    encode_fn(data_sub_slab [k, ws], out [M, ws]) as in encode_sub_slabs_and_gather.  Returns (parity sub-slabs [H, M, ws] of this rank's
+    columns, parity_blocks [M/G, G*H*ws] = this rank's whole parity blocks).  The call behaves as one operation on the caller's stream.
+    """
+    import torch.distributed as dist
+    ranked = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if ranked else 1
+    rank = dist.get_rank(group) if ranked else 0
+    dev = data.device
+    if data_is_blocks:
+        kg, S = data.shape
+        k = kg * world
+        if S % world:
+            raise ValueError("block of %d words does not split over %d ranks" % (S, world))
+        w = S // world
+        H = sub_slab_count(w, sub_slabs, data.element_size() // 4)
+        ws = w // H
+    else:
+        H, k, ws = data.shape
+        w = H * ws
+        if k % world:
+            raise ValueError("%d data blocks do not divide over %d ranks" % (k, world))
+        kg = k // world
+    if parity_rows % world:
+        raise ValueError("%d parity blocks do not divide over %d ranks" % (parity_rows, world))
+    mg = parity_rows // world
+    ws_ = workspace if workspace is not None else {}
+    key = ("a2a", k, parity_rows, ws, H, world, str(dev), collective_on_host, bool(data_is_blocks))
+    if ws_.get("key") != key:
+        ws_.clear()
+        ws_["key"] = key
+
+    def buf(name, shape):
+        t = ws_.get(name)
+        if t is None:
+            t = ws_[name] = torch.empty(shape, dtype=data.dtype, device=dev)
+        return t
+
+    mine = buf("parity_sub", (H, parity_rows, ws))
+    recv = buf("recv", (H, world, mg, ws))
+    if parity_blocks is None:
+        parity_blocks = buf("parity_blocks", (mg, world * w))
+    out4 = parity_blocks.view(mg, world, H, ws)
+    if data_is_blocks:
+        data_sub = buf("data_sub", (H, k, ws))
+        send_in = buf("send_in", (H, world, kg, ws))
+        in4 = data.view(kg, world, H, ws)
+    else:
+        data_sub = data
+    on_gpu = dev.type == "cuda" and not collective_on_host
+
+    def exchange(dst, src):
+        """dst[j] <- rank j's src[rank] (dst, src: [world, rows, ws] contiguous)."""
+        if world == 1:
+            dst.copy_(src)
+        elif collective_on_host:
+            got = torch.empty(src.shape, dtype=src.dtype)
+            dist.all_to_all_single(got, src.cpu(), group=group)
+            dst.copy_(got)
+        else:
+            dist.all_to_all_single(dst, src, group=group)
+
+    def transpose_in(h):
+        send_in[h].copy_(in4[:, :, h, :].permute(1, 0, 2))                          # pack: [kg, G, ws] -> [G, kg, ws]
+        exchange(data_sub[h].view(world, kg, ws), send_in[h])                       # arrives as the contiguous [k, ws] sub-slab
+
+    def transpose_out(h):
+        exchange(recv[h], mine[h].view(world, mg, ws))                              # row chunks of the parity sub-slab travel as they lie
+        out4[:, :, h, :].copy_(recv[h].permute(1, 0, 2))                            # re-interleave into whole blocks
+
+    if on_gpu:
+        side_in, side_out = ws_.get("side_in"), ws_.get("side_out")
+        if side_in is None:
+            side_in = ws_["side_in"] = torch.cuda.Stream(device=dev)
+            side_out = ws_["side_out"] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        arrived = [None] * H
+        if data_is_blocks:
+            side_in.wait_stream(main)
+            with torch.cuda.stream(side_in):
+                transpose_in(0)
+                arrived[0] = side_in.record_event()
+        for h in range(H):
+            if data_is_blocks:
+                if h + 1 < H:                                                       # the next sub-slab's input travels under this encode
+                    with torch.cuda.stream(side_in):
+                        transpose_in(h + 1)
+                        arrived[h + 1] = side_in.record_event()
+                main.wait_event(arrived[h])
+            encode_fn(data_sub[h], mine[h])
+            side_out.wait_stream(main)
+            with torch.cuda.stream(side_out):
+                transpose_out(h)
+        main.wait_stream(side_out)
+        if data_is_blocks:
+            main.wait_stream(side_in)
+    else:
+        for h in range(H):
+            if data_is_blocks:
+                transpose_in(h)
+            encode_fn(data_sub[h], mine[h])
+            transpose_out(h)
+    return mine, parity_blocks
 
 
 def encode_column_sharded(stripe, encode_fn, group=None):
