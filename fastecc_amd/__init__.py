@@ -73,6 +73,8 @@ def lib():
     L.fastecc_create_sharded.argtypes = [ctypes.POINTER(vp), u64, u64, u64, i32, ctypes.POINTER(i32), i32]
     L.fastecc_create_sharded.restype = i32
     L.fastecc_encode_sharded.argtypes, L.fastecc_encode_sharded.restype = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp], i32
+    L.fastecc_encode_sharded_blocks.argtypes = [vp, ctypes.POINTER(vp), i32, ctypes.POINTER(vp), vp]
+    L.fastecc_encode_sharded_blocks.restype = i32
     L.fastecc_shard_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(u64), ctypes.POINTER(i32), i32]
     L.fastecc_shard_info.restype = i32
     L.fastecc_plan_describe.argtypes, L.fastecc_plan_describe.restype = [u64, u64, i32, ctypes.c_char_p, ctypes.c_size_t], i32
@@ -314,6 +316,15 @@ class ShardedEncoder(Encoder):
         p = (ctypes.c_void_p * g)(*[_addr(x) for x in parity_slabs]) if parity_slabs is not None else None
         _check(lib().fastecc_encode_sharded(self._h, d, p, _addr(parity), stream or None), "fastecc_encode_sharded")
         return parity if parity is not None else parity_slabs
+
+    def encode_sharded_blocks(self, data, parity_blocks, data_is_blocks=False, stream=0):
+        """Block-distributed result: parity_blocks[g] receives parity blocks [g*M/G, (g+1)*M/G) whole on GPU g (all-to-all over the peers).
+        data[g]: column slab g, or with data_is_blocks the data blocks [g*k/G, (g+1)*k/G) whole."""
+        g = len(self.gpu_ids)
+        d = (ctypes.c_void_p * g)(*[_addr(x) for x in data])
+        p = (ctypes.c_void_p * g)(*[_addr(x) for x in parity_blocks])
+        _check(lib().fastecc_encode_sharded_blocks(self._h, d, 1 if data_is_blocks else 0, p, stream or None), "fastecc_encode_sharded_blocks")
+        return parity_blocks
 
 
 def mixed_radix_order(k):

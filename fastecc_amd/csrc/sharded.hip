@@ -15,6 +15,12 @@
 // only waits.  Copies are issued by the GPU that owns the slab (it needs peer access to the root's memory, not the
 // other way round), either on the copy engines (hipMemcpy2DAsync) or as a kernel that stores straight through the
 // peer mapping ("gather_mode" 2).  All of it is wave-agnostic plumbing: no arithmetic happens here.
+//
+// A gather to one root is bound by the root's links ((G-1)/G of the stripe enters ONE GPU: 1.88 GB over 7 links at G = 8, four times
+// the per-GPU compute).  fastecc_encode_sharded_blocks is the form that can scale: the result stays BLOCK-DISTRIBUTED — GPU g ends with
+// parity blocks [g*M/G, (g+1)*M/G) whole (RS.md:13-33: the N data and M parity blocks are separately stored units) — so the exchange is an
+// all-to-all in which every GPU sends 1/G of its slab to every peer: 1/G^2 of the stripe per link and direction, no hot spot.  The mirror
+// transpose in front of the encode takes block-distributed DATA (GPU g holds data blocks [g*k/G, (g+1)*k/G) whole) to column slabs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,6 +49,8 @@ struct Shard {
     bool used = false;
     char* data_slab = nullptr;    // lazy: [k][slab_bytes], for callers that hand over full stripes
     char* parity_slab = nullptr;  // lazy: [n-k][slab_bytes], when the caller keeps no parity slabs
+    std::vector<hipStream_t> s_peer;              // lazy, all-to-all on the copy engines: one stream per destination, so the G links work side by side
+    std::vector<hipEvent_t> ev_peer;
 };
 
 int fail(const char* what, hipError_t e)
@@ -82,6 +90,27 @@ __global__ __launch_bounds__(256) void copy_window_kernel(const T* __restrict__ 
     }
 }
 
+// One launch of an all-to-all: piece d (rows x width) of this GPU goes to destination d,
+//     dst.p[d][r * dpitch + c] = src[d * sstride + r * spitch + c],
+// stored through the peer mappings — the G - 1 remote destinations sit behind G - 1 different xGMI links, which therefore all carry
+// traffic at once; consecutive threads = consecutive addresses of a row segment on both sides.
+struct PeerPtrs {
+    void* p[64];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void all_to_all_kernel(const T* __restrict__ src, PeerPtrs dst, uint32_t width, uint32_t rows, uint64_t spitch,
+                                                         uint64_t sstride, uint64_t dpitch, uint64_t total)
+{
+    const uint64_t piece = (uint64_t)rows * width;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = (uint32_t)(i / piece);
+        const uint64_t rem = i - d * piece;
+        const uint64_t r = rem / width;
+        const uint32_t c = (uint32_t)(rem - r * width);
+        ((T*)dst.p[d])[r * dpitch + c] = src[d * sstride + r * spitch + c];
+    }
+}
+
 }  // namespace
 
 struct Sharded {
@@ -93,6 +122,7 @@ struct Sharded {
     int sub_slabs = 2;
     int gather_mode = 1;  // 1 = hipMemcpy2DAsync (copy engines), 2 = copy kernel on the slab's GPU
     bool copy_engine_refused = false;  // mode 2 was forced by an error return of hipMemcpy2DAsync
+    int all_pairs = 0;   // fastecc_encode_sharded_blocks: 0 = not tried, 1 = every slab device can access every other one, -1 = it cannot
     hipEvent_t fork = nullptr;
     int fault_at = 0;    // tests only (option "inject_fault"): the fault_at-th slab step of the next call fails after its work has been enqueued
     int fault_step = 0;
@@ -147,6 +177,8 @@ void settle_after_failure(Sharded* s)
     for (Shard& sh : s->shards) {
         if (hipSetDevice(sh.device) != hipSuccess) continue;
         for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down})
+            if (q) (void)hipStreamSynchronize(q);
+        for (hipStream_t q : sh.s_peer)
             if (q) (void)hipStreamSynchronize(q);
         sh.used = false;  // nothing of this shard is in flight any more
     }
@@ -238,6 +270,167 @@ int run(fastecc_ctx* shell, const void* const* data_slabs, const void* data_stri
     const int rc = run_body(shell, data_slabs, data_stripe, parity_slabs, parity_stripe, stripe_on_host, st);
     if (rc != FASTECC_OK) settle_after_failure(sharded_of(shell));
     return rc;
+}
+
+// every slab device must reach every other one's memory (the gather only needs slab device -> root)
+int enable_all_pairs(Sharded* s)
+{
+    if (s->all_pairs) return s->all_pairs > 0 ? FASTECC_OK : FASTECC_E_UNSUPPORTED;
+    for (Shard& a : s->shards)
+        for (Shard& b : s->shards) {
+            if (a.device == b.device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a.device, b.device) != hipSuccess || !can) {
+                set_error_detail("hipDeviceCanAccessPeer(slab device -> slab device)", hipErrorPeerAccessUnsupported);
+                s->all_pairs = -1;
+                return FASTECC_E_UNSUPPORTED;
+            }
+            SH_TRY(hipSetDevice(a.device));
+            const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail("hipDeviceEnablePeerAccess", e);
+            (void)hipGetLastError();
+        }
+    s->all_pairs = 1;
+    return FASTECC_OK;
+}
+
+// piece d = rows x width bytes at src + d * sstride (row pitch spitch) -> dst[d] (row pitch dpitch), all G pieces of the current device.
+// gather_mode 2: ONE kernel storing through the peer mappings on `st`.  gather_mode 1: G pitched copies on the copy engines, each on the
+// stream of its destination (after `after`, joined into `st` again), so the transfers to different peers run side by side.
+int all_to_all_step(Sharded* s, Shard& sh, void* const* dst, size_t dpitch, const char* src, size_t spitch, size_t sstride, size_t width, size_t rows,
+                    hipStream_t st, hipEvent_t after)
+{
+    const int G = (int)s->shards.size();
+    if (rows == 0 || width == 0) return FASTECC_OK;
+    if (s->gather_mode != 2) {
+        if (sh.s_peer.empty()) {
+            sh.s_peer.assign(G, nullptr);
+            sh.ev_peer.assign(G, nullptr);
+            for (int d = 0; d < G; d++) {
+                SH_TRY(hipStreamCreateWithFlags(&sh.s_peer[d], hipStreamNonBlocking));
+                SH_TRY(hipEventCreateWithFlags(&sh.ev_peer[d], hipEventDisableTiming));
+            }
+        }
+        bool refused = false;
+        for (int d = 0; d < G && !refused; d++) {
+            SH_TRY(hipStreamWaitEvent(sh.s_peer[d], after, 0));
+            const hipError_t e = hipMemcpy2DAsync(dst[d], dpitch, src + (size_t)d * sstride, spitch, width, rows, hipMemcpyDefault, sh.s_peer[d]);
+            if (e != hipSuccess) {  // a runtime that refuses pitched peer copies: the copy kernel takes over for good (as in copy_window)
+                (void)hipGetLastError();
+                s->gather_mode = 2;
+                s->copy_engine_refused = true;
+                refused = true;
+                for (int f = 0; f < d; f++) SH_TRY(hipStreamSynchronize(sh.s_peer[f]));  // what was enqueued is simply repeated below
+                break;
+            }
+            SH_TRY(hipEventRecord(sh.ev_peer[d], sh.s_peer[d]));
+            SH_TRY(hipStreamWaitEvent(st, sh.ev_peer[d], 0));
+        }
+        if (!refused) return FASTECC_OK;
+    }
+    PeerPtrs pp;
+    uintptr_t align = width | dpitch | spitch | sstride | (uintptr_t)src;
+    for (int d = 0; d < G; d++) {
+        pp.p[d] = dst[d];
+        align |= (uintptr_t)dst[d];
+    }
+    const bool v16 = (align & 15u) == 0;
+    const size_t unit = v16 ? 16 : 4;
+    const uint64_t total = (uint64_t)G * rows * (width / unit);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 8192);
+    if (v16)
+        hipLaunchKernelGGL(all_to_all_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, pp, (uint32_t)(width / 16), (uint32_t)rows,
+                           (uint64_t)(spitch / 16), (uint64_t)(sstride / 16), (uint64_t)(dpitch / 16), total);
+    else
+        hipLaunchKernelGGL(all_to_all_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, pp, (uint32_t)(width / 4), (uint32_t)rows,
+                           (uint64_t)(spitch / 4), (uint64_t)(sstride / 4), (uint64_t)(dpitch / 4), total);
+    SH_TRY(hipGetLastError());
+    return FASTECC_OK;
+}
+
+// fastecc_encode_sharded_blocks.  data_blocks: GPU g holds data blocks [g*K/G, (g+1)*K/G) whole, else data[g] is slab g.
+// Per column sub-slab h (every GPU, its own streams):
+//   s_up    (block-distributed data) push columns [d*slab + h*wb, +wb) of my K/G blocks into rows [g*K/G, ...) of GPU d's data slab, all d
+//   s_comp  after the pushes of ALL GPUs for sub-slab h: encode the sub-slab
+//   s_down  rows [d*M/G, (d+1)*M/G) of my parity sub-slab into columns [g*slab + h*wb, +wb) of GPU d's whole parity blocks, all d
+// so sub-slab h+1 is transposed in and sub-slab h-1 transposed out while sub-slab h is in the kernels.
+int run_blocks_body(fastecc_ctx* shell, const void* const* data, bool data_blocks, void* const* parity_blocks, hipStream_t st)
+{
+    Sharded* s = sharded_of(shell);
+    const int G = (int)s->shards.size();
+    const size_t slab = s->slab_bytes, full = s->block_bytes;
+    const uint64_t kg = s->K / G, mg = s->M / G;
+    DeviceSwitch restore;
+    {
+        const int rc = enable_all_pairs(s);
+        if (rc != FASTECC_OK) return rc;
+    }
+    int H = std::max(1, std::min(s->sub_slabs, MAX_SUB));
+    const uint64_t slab_words = slab / 4;
+    while (H > 1 && (!columns_supported(s->shards[0].ctx) || (slab_words % (32u * H)) != 0)) H >>= 1;
+    const size_t wbytes = slab / H;
+
+    SH_TRY(hipSetDevice(s->root));
+    SH_TRY(hipEventRecord(s->fork, st));
+    // buffers, and the start of this call on every stream: after prior work on the caller's stream and after EVERY shard's previous call
+    // (the pushes write into other shards' slab buffers, the transposes out into other shards' result blocks)
+    for (int g = 0; g < G; g++) {
+        Shard& sh = s->shards[g];
+        SH_TRY(hipSetDevice(sh.device));
+        if (data_blocks && !sh.data_slab) SH_TRY(hipMalloc((void**)&sh.data_slab, s->K * slab));
+        if (!sh.parity_slab) SH_TRY(hipMalloc((void**)&sh.parity_slab, s->M * slab));
+        for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down}) {
+            SH_TRY(hipStreamWaitEvent(q, s->fork, 0));
+            for (int o = 0; o < G; o++)
+                if (s->shards[o].used) SH_TRY(hipStreamWaitEvent(q, s->shards[o].ev_all, 0));
+        }
+    }
+    std::vector<void*> dst(G);
+    for (int h = 0; h < H; h++) {
+        const size_t col = (size_t)h * wbytes;
+        if (data_blocks) {
+            for (int g = 0; g < G; g++) {  // GPU g pushes sub-slab h of its blocks to everyone
+                Shard& sh = s->shards[g];
+                SH_TRY(hipSetDevice(sh.device));
+                for (int d = 0; d < G; d++) dst[d] = s->shards[d].data_slab + (size_t)g * kg * slab + col;
+                SH_TRY(hipEventRecord(sh.ev_up[h], sh.s_up));  // the point the copy-engine form forks from; recorded again after the step
+                const int rc = all_to_all_step(s, sh, dst.data(), slab, (const char*)data[g] + col, full, slab, wbytes, kg, sh.s_up, sh.ev_up[h]);
+                if (rc != FASTECC_OK) return rc;
+                SH_TRY(hipEventRecord(sh.ev_up[h], sh.s_up));
+            }
+        }
+        for (int g = 0; g < G; g++) {
+            Shard& sh = s->shards[g];
+            SH_TRY(hipSetDevice(sh.device));
+            if (data_blocks)
+                for (int o = 0; o < G; o++) SH_TRY(hipStreamWaitEvent(sh.s_comp, s->shards[o].ev_up[h], 0));
+            const char* din = data_blocks ? sh.data_slab : (const char*)data[g];
+            const int rc = H > 1 ? fastecc_encode_columns(sh.ctx, din, sh.parity_slab, col / 4, wbytes / 4, sh.s_comp)
+                                 : fastecc_encode(sh.ctx, din, sh.parity_slab, FASTECC_MEM_DEVICE, sh.s_comp);
+            if (rc != FASTECC_OK) return rc;
+            if (injected_fault(s)) return FASTECC_E_DEVICE;
+            SH_TRY(hipSetDevice(sh.device));
+            SH_TRY(hipEventRecord(sh.ev_comp[h], sh.s_comp));
+            SH_TRY(hipStreamWaitEvent(sh.s_down, sh.ev_comp[h], 0));
+            for (int d = 0; d < G; d++) dst[d] = (char*)parity_blocks[d] + (size_t)g * slab + col;
+            const int rc2 = all_to_all_step(s, sh, dst.data(), full, sh.parity_slab + col, slab, (size_t)mg * slab, wbytes, mg, sh.s_down, sh.ev_comp[h]);
+            if (rc2 != FASTECC_OK) return rc2;
+        }
+    }
+    for (int g = 0; g < G; g++) {
+        Shard& sh = s->shards[g];
+        SH_TRY(hipSetDevice(sh.device));
+        if (data_blocks) {  // the slab buffers are free again once the last push AND the last read of them are done
+            SH_TRY(hipEventRecord(sh.ev_up[0], sh.s_up));
+            SH_TRY(hipStreamWaitEvent(sh.s_down, sh.ev_up[0], 0));
+        }
+        SH_TRY(hipEventRecord(sh.ev_all, sh.s_down));
+        sh.used = true;
+    }
+    SH_TRY(hipSetDevice(s->root));
+    for (int g = 0; g < G; g++) SH_TRY(hipStreamWaitEvent(st, s->shards[g].ev_all, 0));
+    if (s->copy_engine_refused) describe(shell);
+    return FASTECC_OK;
 }
 
 // Decoding on a sharded context: erasures hit whole blocks, so every slab sees the same pattern and repairs its own columns
@@ -354,6 +547,13 @@ void destroy_sharded(Sharded* s)
         if (sh.ev_all) (void)hipEventDestroy(sh.ev_all);
         for (hipStream_t q : {sh.s_up, sh.s_comp, sh.s_down})
             if (q) (void)hipStreamDestroy(q);
+        for (hipStream_t q : sh.s_peer)
+            if (q) {
+                (void)hipStreamSynchronize(q);
+                (void)hipStreamDestroy(q);
+            }
+        for (hipEvent_t e : sh.ev_peer)
+            if (e) (void)hipEventDestroy(e);
         if (sh.data_slab) (void)hipFree(sh.data_slab);
         if (sh.parity_slab) (void)hipFree(sh.parity_slab);
     }
@@ -512,6 +712,23 @@ int fastecc_encode_sharded(fastecc_ctx* c, const void* const* data_slabs, void* 
     }
     std::lock_guard<std::mutex> lk(mutex_of(c));
     return run(c, data_slabs, nullptr, parity_slabs, parity, false, (hipStream_t)stream);
+}
+
+int fastecc_encode_sharded_blocks(fastecc_ctx* c, const void* const* data, int data_layout, void* const* parity_blocks, void* stream)
+{
+    if (!c || !sharded_of(c) || !data || !parity_blocks) return FASTECC_E_INVAL;
+    if (data_layout != FASTECC_SHARD_SLABS && data_layout != FASTECC_SHARD_BLOCKS) return FASTECC_E_INVAL;
+    Sharded* s = sharded_of(c);
+    const size_t G = s->shards.size();
+    if (s->M % G || (data_layout == FASTECC_SHARD_BLOCKS && s->K % G)) return FASTECC_E_INVAL;  // whole blocks per GPU
+    const uintptr_t mask = s->field == FASTECC_FIELD_GF_P61_SQUARED ? 15u : 3u;
+    for (size_t g = 0; g < G; g++)
+        if (!data[g] || ((uintptr_t)data[g] & mask) || !parity_blocks[g] || ((uintptr_t)parity_blocks[g] & mask)) return FASTECC_E_INVAL;
+    std::lock_guard<std::mutex> lk(mutex_of(c));
+    DeviceSwitch restore;
+    const int rc = run_blocks_body(c, data, data_layout == FASTECC_SHARD_BLOCKS, parity_blocks, (hipStream_t)stream);
+    if (rc != FASTECC_OK) settle_after_failure(s);
+    return rc;
 }
 
 int fastecc_shard_info(const fastecc_ctx* c, int* n_slabs, uint64_t* slab_block_bytes, int* devices, int cap)

@@ -193,6 +193,25 @@ int fastecc_encode_columns(fastecc_ctx *ctx, const void *data, void *parity, uin
 int fastecc_create_sharded(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_bytes, int field, const int *gpu_ids,
                            int n_gpus);
 int fastecc_encode_sharded(fastecc_ctx *ctx, const void *const *data_slabs, void *const *parity_slabs, void *parity, void *stream);
+/*
+ * The block-distributed form of the same encode — the one that scales.  A gather to one root pushes (G-1)/G of the stripe through ONE
+ * GPU's links; here the result stays distributed the way RS.md:13-33 thinks of a codeword (N data and M parity blocks, separately stored
+ * units): GPU g ends with parity blocks [g*M/G, (g+1)*M/G) WHOLE in parity_blocks[g] ([M/G][block_bytes], device memory of GPU g).  The
+ * exchange is an all-to-all — every GPU sends rows [d*M/G, (d+1)*M/G) of its parity slab into its columns of GPU d's blocks — so each
+ * xGMI link carries 1/G^2 of the stripe per direction and no GPU is a hot spot.
+ *   data_layout FASTECC_SHARD_SLABS  : data[g] = column slab g on GPU g, as for fastecc_encode_sharded;
+ *               FASTECC_SHARD_BLOCKS : the data is block-distributed too — data[g] = data blocks [g*k/G, (g+1)*k/G) whole on GPU g
+ *                                      ([k/G][block_bytes]); the mirror all-to-all (whole blocks -> column slabs) runs in front of the
+ *                                      encode, sub-slab h+1 travelling while sub-slab h is in the kernels.
+ * Needs n - k (and, for FASTECC_SHARD_BLOCKS, k) divisible by the number of GPUs (FASTECC_E_INVAL otherwise) and peer access between every
+ * pair of the context's devices (FASTECC_E_UNSUPPORTED otherwise; checked and enabled at the first call).  parity_blocks must not overlap
+ * data.  "sub_slabs" and "gather_mode" apply: 2 = one kernel per GPU and sub-slab storing through all peer mappings at once, 1 = G pitched
+ * copies on the copy engines, one stream per destination.  Enqueued on internal streams; the call behaves as one operation on `stream`
+ * (a stream of the root device) and does not synchronise.
+ */
+#define FASTECC_SHARD_SLABS 0
+#define FASTECC_SHARD_BLOCKS 1
+int fastecc_encode_sharded_blocks(fastecc_ctx *ctx, const void *const *data, int data_layout, void *const *parity_blocks, void *stream);
 /* Geometry of a sharded context: slabs (= n_gpus given at creation), bytes of a block that one slab holds, and the
  * device of slab g (any pointer may be NULL).  FASTECC_E_INVAL on an ordinary context. */
 int fastecc_shard_info(const fastecc_ctx *ctx, int *n_slabs, uint64_t *slab_block_bytes, int *devices, int cap);

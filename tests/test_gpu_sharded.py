@@ -362,6 +362,121 @@ def test_a_failure_half_way_leaves_the_context_usable(torch_cuda, fe, oracle, fa
         assert np.array_equal(to_host(dd).reshape(N, S), x) and np.array_equal(to_host(dq).reshape(N, S), want)
 
 
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+@pytest.mark.parametrize("sub_slabs,gather_mode", [(1, 1), (2, 1), (2, 2), (4, 2)])
+def test_block_distributed_all_to_all_equals_the_single_device_encode(torch_cuda, fe, oracle, G, sub_slabs, gather_mode):
+    """fastecc_encode_sharded_blocks: 'GPU' g ends with parity blocks [g*M/G, (g+1)*M/G) whole; the data either in column slabs or
+    block-distributed as well (the mirror transpose in front of the encode)."""
+    torch = torch_cuda
+    N, S = 1 << 10, 1024
+    x = rand_stripe(70 + G, N, S)
+    want = oracle.encode_fast(x)
+    w, rows = S // G, N // G
+    slabs = [to_dev(torch, x[:, g * w:(g + 1) * w]) for g in range(G)]
+    blocks = [to_dev(torch, x[g * rows:(g + 1) * rows]) for g in range(G)]
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        senc.set_option("sub_slabs", sub_slabs)
+        senc.set_option("gather_mode", gather_mode)
+        for data, as_blocks in ((slabs, False), (blocks, True), (slabs, False)):
+            out = [torch.full((rows * S,), 0x33333333, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+            senc.encode_sharded_blocks(data, out, data_is_blocks=as_blocks, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            for g in range(G):
+                assert np.array_equal(to_host(out[g]).reshape(rows, S), want[g * rows:(g + 1) * rows]), (g, as_blocks)
+        # the gather-to-root form still works on the same context afterwards (shared slab buffers and events)
+        parity = torch.empty(N * S, dtype=torch.int32, device="cuda:0")
+        senc.encode_sharded(slabs, None, parity)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(parity).reshape(N, S), want)
+
+
+def test_block_distributed_other_codes_and_arguments(torch_cuda, fe, oracle):
+    torch = torch_cuda
+    # a folded code (k/4 parity blocks) and the 64-bit field: every slab is an ordinary context, only the row counts differ
+    N, S, G = 1 << 9, 256, 4
+    x = rand_stripe(5, N, S)
+    want = oracle.encode_fast(x)[::4]
+    M = N // 4
+    blocks = [to_dev(torch, x[g * (N // G):(g + 1) * (N // G)]) for g in range(G)]
+    out = [torch.empty((M // G) * S, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+    with fe.ShardedEncoder(N + M, N, 4 * S, [0] * G) as senc:
+        senc.encode_sharded_blocks(blocks, out, data_is_blocks=True)
+        torch.cuda.synchronize()
+        for g in range(G):
+            assert np.array_equal(to_host(out[g]).reshape(M // G, S), want[g * (M // G):(g + 1) * (M // G)])
+    from oracle import OracleP61
+    o61 = OracleP61()
+    N, elems, G = 256, 64, 2
+    h = o61.fill_splitmix(N, elems, 0x77)
+    want61 = o61.encode(h)
+    hv = h.reshape(N, 2 * elems)
+    blocks = [torch.from_numpy(np.ascontiguousarray(hv[g * (N // G):(g + 1) * (N // G)]).view(np.int64)).to("cuda:0") for g in range(G)]
+    out = [torch.empty((N // G) * 2 * elems, dtype=torch.int64, device="cuda:0") for _ in range(G)]
+    with fe.ShardedEncoder(2 * N, N, 16 * elems, [0] * G, field=fe.FIELD_GF_P61_SQUARED) as senc:
+        senc.encode_sharded_blocks(blocks, out, data_is_blocks=True)
+        torch.cuda.synchronize()
+        got = np.concatenate([t.cpu().numpy().view(np.uint64).reshape(N // G, 2 * elems) for t in out])
+        assert np.array_equal(got, want61.reshape(N, 2 * elems))
+    # blocks that do not divide over the GPUs are refused, as is an unknown layout
+    buf = torch.zeros(96 * 96, dtype=torch.int32, device="cuda:0")
+    with fe.ShardedEncoder(64 + 6, 64, 4 * 96, [0] * 4) as senc:  # 6 parity blocks over 4 GPUs
+        with pytest.raises(fe.FastEccError) as ei:
+            senc.encode_sharded_blocks([buf] * 4, [buf] * 4)
+        assert ei.value.code == fe.E_INVAL
+    with fe.ShardedEncoder(128, 64, 4 * 96, [0] * 3) as senc:
+        with pytest.raises(fe.FastEccError) as ei:  # 64 data blocks over 3 GPUs
+            senc.encode_sharded_blocks([buf] * 3, [buf] * 3, data_is_blocks=True)
+        assert ei.value.code == fe.E_INVAL
+        assert fe.lib().fastecc_encode_sharded_blocks(senc._h, None, 0, None, None) == fe.E_INVAL
+
+
+def test_headline_stripe_block_distributed_reproduces_the_reference_hash(torch_cuda, fe, oracle, golden_hashes):
+    """(2^20, 2^19) x 4 KB, data AND parity block-distributed over 8 'GPUs' (BASELINE configs[3] "block-sharded"): the eight result pieces put
+    together have the reference's parity hash (2896482084)."""
+    torch = torch_cuda
+    N, S, G = 1 << 19, 1024, 8
+    c = [g for g in golden_hashes["survey_appendix_b"] if g["input"] == "splitmix"][0]
+    x = oracle.fill_splitmix(N, S, golden_hashes["splitmix_seed"])
+    rows = N // G
+    blocks = [to_dev(torch, x[g * rows:(g + 1) * rows]) for g in range(G)]
+    out = [torch.empty(rows * S, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        for mode in (2, 1):
+            for t in out:
+                t.zero_()
+            senc.set_option("gather_mode", mode)
+            senc.encode_sharded_blocks(blocks, out, data_is_blocks=True)
+            torch.cuda.synchronize()
+            got = np.concatenate([to_host(t).reshape(rows, S) for t in out])
+            assert oracle.hash(got) == c["hash_parity"], mode
+
+
+@pytest.mark.parametrize("fault_at", [1, 2, 5, 8])
+def test_a_failure_half_way_through_the_all_to_all_leaves_the_context_usable(torch_cuda, fe, oracle, fault_at):
+    torch = torch_cuda
+    N, S, G = 1 << 10, 512, 4
+    x = rand_stripe(40 + fault_at, N, S)
+    want = oracle.encode_fast(x)
+    rows = N // G
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        senc.set_option("sub_slabs", 2)
+        for mode in (2, 1):
+            senc.set_option("gather_mode", mode)
+            blocks = [to_dev(torch, x[g * rows:(g + 1) * rows]) for g in range(G)]
+            out = [torch.full((rows * S,), 0x11111111, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+            senc.set_option("inject_fault", fault_at)
+            with pytest.raises(fe.FastEccError) as ei:
+                senc.encode_sharded_blocks(blocks, out, data_is_blocks=True)
+            assert ei.value.code == fe.E_DEVICE
+            del out  # nothing of the failed call is still in flight
+            torch.cuda.synchronize()
+            out = [torch.empty(rows * S, dtype=torch.int32, device="cuda:0") for _ in range(G)]
+            senc.encode_sharded_blocks(blocks, out, data_is_blocks=True)
+            torch.cuda.synchronize()
+            for g in range(G):
+                assert np.array_equal(to_host(out[g]).reshape(rows, S), want[g * rows:(g + 1) * rows]), (mode, g)
+
+
 def test_sharded_decode_at_2_17_blocks_takes_the_split_transform(torch_cuda, fe):
     """k = 2^17 in four column slabs on one device: every slab's decoder is set up on its own host thread (the same pattern), decodes through
     the split transform (two half-size transforms, tests/test_gpu_decode.py) and repairs; compared on the device with the original stripes."""
