@@ -6,12 +6,13 @@
 
 A step = one fastecc_encode of one stripe (k = 2^19 data blocks of 4 KB -> 2^19 parity blocks), inputs
 already resident in HBM, called through the C ABI (include/fastecc.h) exactly as a C++ host would.
-Multi-GPU: one process per GPU.  `value` is the replica mode — every rank encodes its own independent stripe (the
-path has no exchange step: word columns and stripes are independent — DESIGN.md §7), scaling "weak", no collective
-inside the timed region.  The same JSON line also carries `sharded_one_stripe`: BASELINE.json configs[3], ONE stripe
-in column slabs over the ranks (strong scaling), timed compute-only and with the RCCL gather of the parity into full
-blocks on rank 0 (fastecc_amd/sharding.py).  A single-process run that sees several GPUs additionally times the
-C-ABI form of that mode (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
+Multi-GPU: one process per GPU.  At N > 1 `value` is BASELINE.json configs[3]: ONE stripe sharded over the N GPUs in column
+slabs (word columns are independent transforms: no exchange inside the encode), the parity handed over block-distributed by
+an RCCL all-to-all (rank g ends with parity blocks [g*M/N, (g+1)*M/N) whole) — scaling "strong".  `one_stripe` carries that
+mode next to compute-only, gather-to-root, the block-distributed-input form and the bare exchange, each with the bytes its
+busiest rank receives and the fraction of the xGMI link roofline; `replicas` carries the weak-scaling mode (every rank
+encodes its own independent stripe, no collective).  A single-process run that sees several GPUs additionally times the
+C-ABI form (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
 
 At N = 1 the line additionally carries `other_paths`: short, checked timings of the rows around the headline path (few-loss repair
 and a 2 % loss pattern, a code with 4 parity blocks, a mixed-radix order) and BASELINE configs[4] (the 64-bit field, 32 + 32 GiB),
@@ -57,8 +58,9 @@ P = 0xFFF00001
 P61 = (1 << 61) - 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 # Secondary (informational) bound: the path is integer-VALU bound once fused.  Chip-wide rate of
-# the radix-2 GF(p) butterfly measured in isolation (tools/microbench.hip, profiles/r01/microbench_bfly_variants.jsonl).
-VALU_PEAK_GBFLY = 3700.0
+# the radix-2 GF(p) butterfly measured in isolation (tools/microbench.hip radix: 3796 radix-2 / 3826-3829 radix-4 form,
+# profiles/r03/microbench_radix4_vs_radix2.jsonl).
+VALU_PEAK_GBFLY = 3830.0
 
 
 def parse():
@@ -78,10 +80,10 @@ def parse():
     ap.add_argument("--plan", type=int, default=0, help="kernel plan (0 = library default); see DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2k", type=int, default=None, help="sample size for the CPU baseline (default: same as --log2k)")
-    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded_one_stripe modes")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the one_stripe modes")
     ap.add_argument("--sharded-timeout", type=int, default=300,
-                    help="N > 1: seconds the sharded_one_stripe measurement may take before the line is printed without it (0 = wait forever)")
-    ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the gather pipeline (sharded_one_stripe)")
+                    help="N > 1: seconds the one_stripe measurements may take before the line is printed without it (0 = wait forever)")
+    ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the exchange pipelines (one_stripe)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the short timings of the widened rows (other_paths)")
     ap.add_argument("--cabi-sharded-child", action="store_true", help=argparse.SUPPRESS)
@@ -101,6 +103,35 @@ def random_stripe(n_words, device, seed):
         m = min(chunk, n_words - i)
         r = torch.randint(0, P, (m,), dtype=torch.int64, device=device, generator=g)
         out[i:i + m] = r.to(torch.int32)  # keeps the low 32 bits
+    return out
+
+
+def _s64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
+
+
+def splitmix_window(device, S, row0, rows, col0, width, seed=0x1234):
+    """Rows [row0, row0 + rows) x word columns [col0, col0 + width) of the splitmix64(seed) stripe of S-word blocks (SURVEY.md Appendix B
+    "rand": word i = splitmix64 output i reduced mod p, filled in linear order — output i depends on i alone, so every rank generates its own
+    window on its device).  Returns [rows, width] int32 (the bit patterns of the uint32 words).  64-bit unsigned arithmetic on int64 tensors:
+    products wrap as they must, right shifts are masked to logical ones, and z mod p goes through z = hi * 2^32 + lo with 2^32 = 2^20 - 1 (mod p)."""
+    out = torch.empty((rows, width), dtype=torch.int32, device=device)
+    cols = torch.arange(col0 + 1, col0 + width + 1, dtype=torch.int64, device=device)
+
+    def lsr(z, n):
+        return (z >> n) & ((1 << (64 - n)) - 1)
+
+    step = max(1, (1 << 24) // max(width, 1))
+    for r in range(0, rows, step):
+        m = min(step, rows - r)
+        i = (torch.arange(row0 + r, row0 + r + m, dtype=torch.int64, device=device) * S).unsqueeze(1) + cols  # linear index + 1
+        z = i * _s64(0x9E3779B97F4A7C15) + _s64(seed)
+        z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        v = (lsr(z, 32) * ((1 << 20) - 1) + (z & 0xFFFFFFFF)) % P
+        out[r:r + m] = v.to(torch.int32)  # keeps the low 32 bits
     return out
 
 
@@ -274,8 +305,12 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             pi = torch.from_numpy(np.flatnonzero(pp == 0)).to(device)
             saved_d, saved_p = dv[di].clone(), pv[pi].clone()
             t0 = time.perf_counter()
-            enc.decode_prepare(dp, pp)
-            prep = (time.perf_counter() - t0) * 1e3
+            enc.decode_prepare(dp, pp)   # the first set-up of this kind of pattern on the context also builds that path's tables / contexts
+            prep_first = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            for _ in range(3):
+                enc.decode_prepare(dp, pp)
+            prep = (time.perf_counter() - t0) / 3 * 1e3
 
             def once():
                 dv[di] = -1
@@ -285,7 +320,7 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             once()
             ok = bool(torch.equal(dv[di], saved_d)) and bool(torch.equal(pv[pi], saved_p))
             ms = event_ms(lambda: enc.repair(data, parity, stream=stream), 5)
-            out[name] = {"prepare_ms": round(prep, 2), "repair_ms": round(ms, 3), "restored": ok}
+            out[name] = {"prepare_first_ms": round(prep_first, 2), "prepare_steady_ms": round(prep, 2), "repair_ms": round(ms, 3), "restored": ok}
             if name == "repair_2_percent_of_the_codeword_lost":
                 # fastecc_decode alone (the lost data blocks, not the lost parity): the split transform of the (2k,k) layout
                 dv[di] = -1
@@ -340,9 +375,40 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
         for _ in range(3):
             host_once()
         hms = (time.perf_counter() - t0) / 3 * 1e3
+        # what this box's host link allows, measured in the same process on the same pinned buffers: 2 GiB up, 2 GiB down, and both at once
+        # (two streams) — the end-to-end call cannot beat the duplex time
+        s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+        scratch = torch.empty_like(data)
+
+        def wall(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        def up():
+            with torch.cuda.stream(s_up):
+                scratch.copy_(hx, non_blocking=True)
+
+        def down():
+            with torch.cuda.stream(s_dn):
+                hp.copy_(ref, non_blocking=True)
+
+        nbytes = float(k * block_bytes)
+        up_ms, dn_ms = wall(up), wall(down)
+        both_ms = wall(lambda: (up(), down()))
+        probe = {"h2d_GBps": round(nbytes / up_ms / 1e6, 1), "d2h_GBps": round(nbytes / dn_ms / 1e6, 1),
+                 "duplex_GBps": round(2 * nbytes / both_ms / 1e6, 1), "duplex_ms": round(both_ms, 2),
+                 "what": "2 GiB pinned copies on this box in this process: up, down, and both directions at once on two streams (wall clock, 3 each)"}
         out["host_pinned_end_to_end"] = {"ms": round(hms, 2), "GBps": round(2.0 * k * block_bytes / hms / 1e6, 1), "same_parity_as_the_device_encode": ok,
+                                         "link_probe": probe, "frac_of_duplex": round(both_ms / hms, 3),
                                          "what": "fastecc_encode(FASTECC_MEM_HOST_PINNED): 2 GiB of data up and 2 GiB of parity down over the host link "
-                                                 "inside the timed region (wall clock, 3 calls); the regime RS.cpp:25-38 measures"}
+                                                 "inside the timed region (wall clock, 3 calls); the regime RS.cpp:25-38 measures.  frac_of_duplex = "
+                                                 "the time both copies alone need side by side / the time of the call"}
+        del scratch
         del hx, hp, ref
     except Exception as e:  # noqa: BLE001
         out["host_pinned_error"] = repr(e)
@@ -363,8 +429,10 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
     return out
 
 
-def other_field_p61(fastecc_amd, device, stream, steps=3):
-    """BASELINE.json configs[4] in the same run: (2^20, 2^19) x 64 KB over GF((2^61-1)^2), 32 + 32 GiB, HBM-resident."""
+def other_field_p61(fastecc_amd, device, stream, steps=10):
+    """BASELINE.json configs[4] in the same run: (2^20, 2^19) x 64 KB over GF((2^61-1)^2), 32 + 32 GiB, HBM-resident.
+    Timed with HIP events on the launch stream over `steps` encodes (the wall clock around a host-side synchronise is reported next to it:
+    rounds 2-3 timed 3 steps that way and every run came out as 200.0 ms / 3), then `steps` more with the per-kernel events on."""
     k, bb = 1 << 19, 65536
     free, _ = torch.cuda.mem_get_info(device)
     if free < 70 * 2**30:
@@ -372,16 +440,39 @@ def other_field_p61(fastecc_amd, device, stream, steps=3):
     data = random_stripe_p61(k * (bb // 8), device, seed=0x61)
     parity = torch.empty_like(data)
     with fastecc_amd.Encoder(2 * k, k, bb, device=device.index or 0, field=fastecc_amd.FIELD_GF_P61_SQUARED) as enc:
-        enc.encode(data, parity, stream=stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(2):
             enc.encode(data, parity, stream=stream)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            enc.encode(data, parity, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) / steps * 1e3
+        ms = e0.elapsed_time(e1) / steps
+        enc.profile(True)
+        enc.profile_reset()
+        for _ in range(steps):
+            enc.encode(data, parity, stream=stream)
+        kernels = enc.profile_read()
+        enc.profile(False)
+        per_kernel = {kn: {"avg_ms": round(v[0] / v[1], 3), "alg_GB_per_launch": round(v[2] / v[1] / 1e9, 2),
+                           "TBps": round(v[2] / v[0] / 1e9, 3), "frac_of_hbm_peak": round(v[2] / v[0] / 1e6 / HBM_PEAK_GBPS, 4)}
+                      for kn, v in sorted(kernels.items())}
+        dom = max(kernels.items(), key=lambda kv: kv[1][0]) if kernels else None
+        roof = None
+        if dom:
+            name, (ms_total, launches, nbytes) = dom
+            ach = nbytes / ms_total / 1e6
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "avg_kernel_ms": round(ms_total / launches, 3), "alg_bytes_per_launch": nbytes / launches,
+                    "encode": {"achieved": round(2.0 * k * bb / ms / 1e6, 1), "frac": round(2.0 * k * bb / ms / 1e6 / HBM_PEAK_GBPS, 4), "hbm_trips": len(kernels)}}
         check = parity_check_p61(data, parity, k, bb)
         return {"workload": "RS encode k=2^19 -> 2^19 parity blocks, 65536 B blocks, GF((2^61-1)^2), 32 GiB stripe", "ms_per_step": round(ms, 3),
-                "GBps": round(2.0 * k * bb / ms / 1e6, 1), "steps": steps, "plan": enc.plan(), "parity_check": check,
+                "GBps": round(2.0 * k * bb / ms / 1e6, 1), "steps": steps, "timing": "HIP events on the launch stream around %d encodes" % steps,
+                "wall_clock_ms_per_step": round(wall_ms, 3), "plan": enc.plan(), "per_kernel": per_kernel, "roofline": roof, "parity_check": check,
                 "parity_pin": "no upstream code exists for this field: pinned to this repository's oracle and Python big-integer goldens"}
 
 
@@ -488,6 +579,34 @@ def cabi_sharded_child(args):
             progress()
     checks = [v.get("gather_check") for kname, v in out.items() if kname.startswith("with_gather_") and "gather_check" in v]
     out["gather_check"] = "ok" if checks and all(c == "ok" for c in checks) else "FAILED"
+    # the block-distributed form (fastecc_encode_sharded_blocks): GPU g ends with parity blocks [g*k/G, (g+1)*k/G) whole — an all-to-all over
+    # the peers instead of a gather into the root — from data in slabs, and from block-distributed data (mirror transpose in front)
+    if k % G == 0:
+        rows = k // G
+        pblocks = [torch.empty(rows * S, dtype=torch.int32, device="cuda:%d" % g) for g in ids]
+        dblocks = [hx.view(k, S)[g * rows:(g + 1) * rows].to("cuda:%d" % g).reshape(-1) for g in ids]
+
+        def blocks_ok():
+            return all(torch.equal(pblocks[j].view(rows, S)[:, g * w:(g + 1) * w].cpu(), pslabs[g].view(k, w)[j * rows:(j + 1) * rows].cpu())
+                       for g in ids for j in ids)
+
+        enc.encode_sharded(slabs, pslabs, None, stream=stream)
+        sync_all()
+        for mode, name in ((2, "kernel"), (1, "copy_engine")):
+            enc.set_option("gather_mode", mode)
+            for sub in (1, 2, 4):
+                enc.set_option("sub_slabs", sub)
+                for as_blocks, tag in ((False, "all_to_all"), (True, "all_to_all_in_out")):
+                    key = "%s_%s_sub%d" % (tag, name, sub)
+                    try:
+                        for t in pblocks:
+                            t.zero_()
+                        out[key] = timed(lambda: enc.encode_sharded_blocks(dblocks if as_blocks else slabs, pblocks, data_is_blocks=as_blocks, stream=stream))
+                        out[key]["check"] = "ok" if blocks_ok() else "FAILED"
+                    except Exception as e:  # noqa: BLE001
+                        out[key] = {"error": repr(e)}
+                    progress()
+        del pblocks, dblocks
     enc.set_option("gather_mode", 1)
     enc.set_option("sub_slabs", 2)
     try:
@@ -499,6 +618,151 @@ def cabi_sharded_child(args):
     out["complete"] = True
     progress()
     enc.close()
+
+
+LINK_GBPS_PER_DIRECTION = 76.8  # one xGMI link: ~153.6 GB/s both directions together ("7 links x ~153 GB/s")
+
+
+def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61):
+    """BASELINE configs[3]: ONE (n,k) stripe over the ranks.  The compute is always the column-slab encode (rank r holds words
+    [r*S/G, (r+1)*S/G) of every block: no exchange inside the transform); the modes differ in what happens to the parity:
+
+        compute_only        it stays in slabs (no exchange at all)
+        gather_to_root      full blocks on rank 0 (RCCL gather; bound by the root's links: (G-1)/G of the stripe enters one GPU)
+        all_to_all          block-distributed: rank g ends with parity blocks [g*M/G, (g+1)*M/G) whole (RCCL all-to-all: 1/G^2 of the
+                            stripe per link and direction, no hot spot)
+        all_to_all_in_out   the data arrives block-distributed as well (whole data blocks per rank): the mirror transpose in front
+        exchange_only       all_to_all's exchange without the encode (what the links alone allow)
+
+    Every mode: W warm-up calls, then exactly K calls between barriers, max over ranks.  The stripe is the splitmix64(0x1234) one, so what
+    was timed is checked against the unmodified reference's parity hash (main.cpp:202-212) where a golden value exists."""
+    import torch.distributed as dist
+    from fastecc_amd import sharding
+    unit = 8 if p61 else 4
+    words = args.block_bytes // unit
+    S32 = args.block_bytes // 4
+    w = words // world
+    sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
+    wsub = w // sub
+    kg = k // world
+    gloo = backend != "nccl"
+    senc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
+    tune(senc)
+    # this rank's slab, resident as `sub` contiguous column sub-slabs [sub][k][wsub] (what a scatter delivers), and its whole data blocks
+    if p61:
+        slab = random_stripe_p61(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
+        blocks = None  # (the block-distributed input needs every rank to derive the same stripe: GF(0xFFF00001) only)
+    else:
+        slab = torch.stack([splitmix_window(device, S32, 0, k, rank * w + h * wsub, wsub) for h in range(sub)])
+        blocks = splitmix_window(device, S32, rank * kg, kg, 0, S32)
+    pslab = torch.empty_like(slab)
+    wsp_g, wsp_a, wsp_b, wsp_x = {}, {}, {}, {}
+    # gather_to_root: the root keeps its slab at the full block pitch ([k][world*w] arrays, its own columns filled): with "row_pitch_words"
+    # its encoder reads the sub-slab there and writes the parity straight into the full parity blocks, so the root's part is neither sent
+    # nor re-interleaved (GF(0xFFF00001) contexts; the 64-bit field keeps the contiguous form).
+    in_place = rank == 0 and not p61
+    penc = None
+    gslab = slab
+    if in_place:
+        penc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
+        tune(penc)
+        penc.set_option("row_pitch_words", words)
+        full_data = torch.zeros((k, world, sub, wsub), dtype=slab.dtype, device=device)
+        full_data[:, 0] = slab.permute(1, 0, 2)
+        gslab = full_data[:, 0].permute(1, 0, 2)  # [sub, k, wsub] views, row stride = the full block
+
+    def enc_fn(d, o):
+        (senc if d.is_contiguous() else penc).encode(d, o, stream=torch.cuda.current_stream().cuda_stream)
+
+    def encode_all():
+        for h in range(sub):
+            senc.encode(slab[h], pslab[h], stream=stream)
+
+    modes = [("compute_only", encode_all),
+             ("gather_to_root", lambda: sharding.encode_sub_slabs_and_gather(gslab, enc_fn, k, dst=0, workspace=wsp_g, collective_on_host=gloo,
+                                                                             root_in_place=in_place)),
+             ("all_to_all", lambda: sharding.encode_all_to_all(slab, enc_fn, k, workspace=wsp_a, collective_on_host=gloo))]
+    if blocks is not None:
+        modes.append(("all_to_all_in_out", lambda: sharding.encode_all_to_all(blocks, enc_fn, k, data_is_blocks=True, sub_slabs=sub, workspace=wsp_b,
+                                                                              collective_on_host=gloo)))
+    modes.append(("exchange_only", lambda: sharding.encode_all_to_all(slab, lambda d, o: None, k, workspace=wsp_x, collective_on_host=gloo)))
+    stripe_bytes = float(k) * args.block_bytes  # data = parity bytes of the (2k,k) stripe
+    G = world
+    link_in = {"compute_only": 0.0, "gather_to_root": (G - 1) / G * stripe_bytes, "all_to_all": (G - 1) / G**2 * stripe_bytes,
+               "all_to_all_in_out": 2 * (G - 1) / G**2 * stripe_bytes, "exchange_only": (G - 1) / G**2 * stripe_bytes}
+    link_peak = min(G - 1, 7) * LINK_GBPS_PER_DIRECTION
+    out = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d contiguous sub-slab(s) "
+                   "(the exchange of one sub-slab runs on side streams under the next sub-slab's encode).  compute_only: the parity stays in slabs; "
+                   "gather_to_root: RCCL gather into full blocks on rank 0 (no pack, the root encodes straight into the full blocks); all_to_all: "
+                   "block-distributed result, rank g holds parity blocks [g*M/G, (g+1)*M/G) whole; all_to_all_in_out: the data block-distributed as "
+                   "well (mirror transpose in front); exchange_only: all_to_all without the encode"
+                   % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+           "scaling": "strong", "sub_slabs": sub, "plan": senc.plan(),
+           "link_model": "link_bytes_in_max_rank = bytes entering the busiest rank per stripe; link_roofline_frac = that / ms_per_stripe / "
+                         "(min(G-1,7) links x %.1f GB/s per direction, an assumed figure: half of ~153.6 GB/s per link)" % LINK_GBPS_PER_DIRECTION}
+    for name, fn in modes:
+        try:
+            for _ in range(max(1, args.warmup)):
+                fn()
+            ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
+            rec = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * stripe_bytes / (ms * 1e-3) / 1e9, 2), "link_bytes_in_max_rank": int(link_in[name])}
+            if world > 1 and link_in[name]:
+                rate = link_in[name] / (ms * 1e-3) / 1e9
+                rec.update({"link_GBps_in_max_rank": round(rate, 1), "link_peak_GBps": round(link_peak, 1), "link_roofline_frac": round(rate / link_peak, 4)})
+            out[name] = rec
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+            if world > 1:  # a failed collective leaves the communicator unusable: stop here and report what exists
+                out["aborted_after"] = name
+                return out
+    # ---- what was timed is also right ----
+    checks = {}
+    encode_all()
+    torch.cuda.synchronize()
+    mine_a = wsp_a.get("parity_sub")
+    ok_local = mine_a is not None and bool(torch.equal(mine_a, pslab))
+    full = wsp_g.get("parity_full")
+    if rank == 0 and full is not None:  # the root's own columns of the gathered blocks = its slab
+        ok_local = ok_local and bool(torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w)))
+    flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    checks["slabs_equal_compute_only_on_every_rank"] = bool(flag.item() == 1.0)
+    for key, wsp in (("all_to_all", wsp_a), ("all_to_all_in_out", wsp_b)):
+        mineb = wsp.get("parity_blocks")
+        if mineb is None:
+            continue
+        if world > 1:
+            piece = mineb.cpu() if gloo else mineb
+            got = [torch.empty_like(piece) for _ in range(world)] if rank == 0 else None
+            dist.gather(piece, gather_list=got, dst=0)
+        else:
+            got = [mineb]
+        if rank == 0:
+            whole = torch.cat([g.to(device) for g in got], dim=0)  # [M, S]: every rank's whole parity blocks in block order
+            res = {"equals_gather_to_root": bool(torch.equal(whole, full)) if full is not None else None}
+            if not p61:
+                try:
+                    from oracle import Oracle
+                    with open(os.path.join(ROOT, "tests", "golden", "golden_hashes.json")) as f:
+                        gold = json.load(f)
+                    want = [c for c in gold.get("survey_appendix_b", []) + gold.get("cases", [])
+                            if c.get("input") == "splitmix" and c.get("log2N") == args.log2k and c.get("block_bytes") == args.block_bytes]
+                    if want:
+                        import numpy as np
+                        h = Oracle().hash(whole.cpu().numpy().view(np.uint32))
+                        res.update({"reference_parity_hash": h, "expected": want[0]["hash_parity"], "status": "ok" if h == want[0]["hash_parity"] else "FAILED"})
+                except Exception as e:  # noqa: BLE001
+                    res["hash_error"] = repr(e)
+            if "status" not in res:
+                res["status"] = "ok" if res["equals_gather_to_root"] else "FAILED"
+            checks[key] = res
+            del whole
+    out["checks"] = checks
+    senc.close()
+    if penc is not None:
+        penc.close()
+    return out
 
 
 def main():
@@ -675,26 +939,44 @@ def main():
     emitted = threading.Event()
     other_paths_result = {}
 
-    def emit(sharded, cabi=None, cpu=None):
+    def emit(one, cabi=None, cpu=None):
         if rank != 0 or emitted.is_set():
             return
         emitted.set()
+        code = ("(n,k)=(2^%d,2^%d), %d-byte blocks" % (args.log2k + 1, args.log2k, args.block_bytes)) if m_blocks == k else \
+               ("k=2^%d data + %d parity blocks, %d-byte blocks" % (args.log2k, m_blocks, args.block_bytes))
+        fieldname = "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)"
+        replicas = {"value": round(value, 2), "unit": "GB/s", "ms_per_step": round(ms_per_step, 4), "scaling": "weak",
+                    "what": "%d independent stripe(s), one per GPU, no collective in the timed region (the mode for many stripes: "
+                            "different stripes are independent jobs)" % world}
+        # N > 1: `value` is BASELINE configs[3] — ONE stripe over all GPUs, the parity handed over block-distributed (all-to-all); the
+        # replica figure stays in the line as `replicas`.  If that mode did not complete, the line says so and falls back to the replicas.
+        a2a = (one or {}).get("all_to_all") if world > 1 else None
+        if a2a and "ms_per_stripe" in a2a:
+            v, ms, scaling = a2a["GBps"], a2a["ms_per_stripe"], "strong"
+            which = ("ONE stripe over %d GPUs: column-slab encode + RCCL all-to-all into block-distributed parity (one_stripe.all_to_all)" % world)
+            workload = ("RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, ONE %.0f MiB stripe sharded over %d GPUs in column slabs "
+                        "(HBM-resident), parity block-distributed by an all-to-all over xGMI" % (args.log2k, m_blocks, args.block_bytes, fieldname,
+                                                                                               k * args.block_bytes / 2**20, world))
+            par = "one stripe, %d column slabs, all-to-all of the parity (strong scaling)" % world
+        else:
+            v, ms, scaling = value, ms_per_step, "weak"
+            which = "one stripe per GPU" if world == 1 else "REPLICAS (one independent stripe per GPU): the one-stripe all-to-all mode did not complete, see one_stripe"
+            workload = ("RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
+                        % (args.log2k, m_blocks, args.block_bytes, fieldname, k * args.block_bytes / 2**20))
+            par = "%d independent stripe(s), one per GPU, no collective" % world
         line = {
-            "metric": ("encode GB/s at (n,k)=(2^%d,2^%d), %d-byte blocks (data+parity bytes / s)" % (args.log2k + 1, args.log2k, args.block_bytes))
-                      if m_blocks == k else
-                      ("encode GB/s at k=2^%d data + %d parity blocks, %d-byte blocks (data+parity bytes / s)" % (args.log2k, m_blocks, args.block_bytes)),
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "ms_per_step_instrumented": round(ms_per_step_prof, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "encode GB/s at %s (data+parity bytes / s); value = %s" % (code, which),
+            "value": round(v, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "ms_per_step_instrumented": round(ms_per_step_prof, 4),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
-            "config": {"workload": "RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
-                                   % (args.log2k, m_blocks, args.block_bytes, "GF((2^61-1)^2)" if p61 else "GF(0xFFF00001)",
-                                      k * args.block_bytes / 2**20),
-                       "stripes_per_step": args.batch, "plan": enc.plan(), "parallelism": "%d independent stripe(s), one per GPU, no collective" % world},
-            "data_only_GBps": round(value / 2, 2),
+            "config": {"workload": workload, "stripes_per_step": args.batch, "plan": enc.plan(), "parallelism": par},
+            "data_only_GBps": round(v / 2, 2),
+            "replicas": replicas,
             "parity_check": check,
             "roofline": roof, "cpu_baseline": cpu,
-            "sharded_one_stripe": sharded,
+            "one_stripe": one,
             "devices": devices, "distributed": dist_info,
         }
         if other_paths_result:
@@ -703,14 +985,14 @@ def main():
             line["parity_pin"] = ("no upstream code exists for this field: the HIP path is pinned to this repository's own oracle and "
                                   "Python big-integer goldens (tests/test_gpu_p61.py), not to the reference")
         if cabi is not None:
-            line["sharded_one_stripe_c_abi"] = cabi
+            line["one_stripe_c_abi"] = cabi
         print(json.dumps(line), flush=True)
 
     # N > 1: the sharded mode below is the first thing in this file that needs every rank to make progress together inside
     # RCCL transfers of whole parity slabs.  If it stalls, the replica number measured above must still reach the driver:
     # after --sharded-timeout seconds rank 0 prints the line without it and every rank leaves.
     def give_up():
-        emit({"error": "sharded_one_stripe did not finish within %d s; the line carries the replica measurement only" % args.sharded_timeout})
+        emit({"error": "the one_stripe modes did not finish within %d s; the line carries the replica measurement only" % args.sharded_timeout})
         sys.stdout.flush()
         if rank != 0:
             time.sleep(3)  # let rank 0 print before its collectives see a peer disappear
@@ -722,86 +1004,19 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- BASELINE configs[3]: ONE stripe in column slabs over the ranks, gathered on rank 0 (strong scaling) ----
-    sharded = None
+    # ---- BASELINE configs[3]: ONE stripe over the ranks (strong scaling) — column-slab compute, three ways to hand over the parity ----
+    one = None
     unit = 8 if p61 else 4  # bytes per tensor word
     words = args.block_bytes // unit
     shardable = (not args.no_sharded and args.batch == 1 and m_blocks == k and words % world == 0 and (not p61 or world > 1)
-                 and (args.block_bytes // world) % (16 if p61 else 4) == 0)
+                 and (args.block_bytes // world) % (16 if p61 else 4) == 0 and k % world == 0)
     if shardable:
         try:
-            from fastecc_amd import sharding
             if os.environ.get("FASTECC_BENCH_TEST_STALL") and rank == world - 1:
                 time.sleep(1e6)  # test hook for the watchdog above: one rank never reaches the collectives
-            w = words // world
-            # this rank's slab: words [rank*w, (rank+1)*w) of every block of ONE stripe, resident in its HBM as `sub` contiguous
-            # column sub-slabs [sub][k][w/sub] (what a scatter delivers); each sub-slab is an ordinary stripe of narrower blocks
-            sub = sharding.sub_slab_count(w, args.sub_slabs, unit // 4)
-            wsub = w // sub
-            senc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
-            tune(senc)
-            slab = (random_stripe_p61 if p61 else random_stripe)(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
-            pslab = torch.empty_like(slab)
-            wsp = {}
-            # The root keeps its slab at the full block pitch ([k][world*w] arrays, its own columns filled): with "row_pitch_words" its encoder
-            # reads the sub-slab there and writes the parity straight into the full parity blocks, so the root's part is neither sent nor
-            # re-interleaved (GF(0xFFF00001) contexts; the 64-bit field keeps the contiguous form).
-            in_place = rank == 0 and not p61
-            penc = None
-            gslab = slab
-            if in_place:
-                penc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
-                tune(penc)
-                penc.set_option("row_pitch_words", words)
-                full_data = torch.zeros((k, world, sub, wsub), dtype=slab.dtype, device=device)
-                full_data[:, 0] = slab.permute(1, 0, 2)
-                gslab = full_data[:, 0].permute(1, 0, 2)  # [sub, k, wsub] views, row stride = the full block
-
-            def gather_encode(d, o):
-                (senc if d.is_contiguous() else penc).encode(d, o, stream=torch.cuda.current_stream().cuda_stream)
-
-            def encode_all():
-                for h in range(sub):
-                    senc.encode(slab[h], pslab[h], stream=stream)
-
-            modes = {"compute_only": encode_all,
-                     "with_gather": lambda: sharding.encode_sub_slabs_and_gather(gslab, gather_encode, k, dst=0, workspace=wsp,
-                                                                                collective_on_host=backend != "nccl", root_in_place=in_place)}
-            sharded = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d "
-                               "contiguous sub-slab(s); with_gather adds the RCCL gather of the parity into full blocks on rank 0: no pack, "
-                               "the root encodes its own part straight into the full blocks (row pitch = the block), the other ranks' parts travel "
-                               "and are re-interleaved by one kernel per sub-slab on a side stream under the next sub-slab's encode" % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
-                       "scaling": "strong", "sub_slabs": sub, "plan": senc.plan()}
-            for name, fn in modes.items():
-                for _ in range(max(1, args.warmup)):
-                    fn()
-                ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
-                sharded[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * k * args.block_bytes / (ms * 1e-3) / 1e9, 2)}
-            # what was timed is also right: the gathered blocks on rank 0 hold every rank's slab where it belongs
-            full = wsp.get("parity_full")
-            mine = (full[:, :w].view(k, sub, wsub).permute(1, 0, 2) if rank == 0 else wsp["send"]).permute(1, 0, 2).reshape(k, w).to(torch.int64)
-            sums = torch.stack([mine.sum(), (mine * torch.arange(1, w + 1, device=device)).sum()])  # wraps mod 2^64: fine for a checksum
-            if world > 1:
-                sums = sums.to(device if backend == "nccl" else "cpu")
-                every = [torch.empty_like(sums) for _ in range(world)]
-                dist.all_gather(every, sums)
-            else:
-                every = [sums]
-            if rank == 0 and full is not None:
-                encode_all()  # the same slab through the plain calls: compute_only's result
-                torch.cuda.synchronize()
-                ok = torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w))
-                for g in range(world):  # every rank's slab arrived in its columns of the full blocks
-                    part = full[:, g * w:(g + 1) * w].to(torch.int64)
-                    want = every[g].to(part.device)
-                    ok = ok and int(part.sum()) == int(want[0]) and int((part * torch.arange(1, w + 1, device=part.device)).sum()) == int(want[1])
-                sharded["gather_check"] = "ok" if ok else "FAILED"
-            senc.close()
-            if penc is not None:
-                penc.close()
-            del wsp, slab, pslab
-        except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of this mode
-            sharded = {"error": repr(e)}
+            one = one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61)
+        except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of these modes
+            one = {"error": repr(e)}
 
     if watchdog is not None:
         watchdog.cancel()
@@ -851,7 +1066,7 @@ def main():
             other_paths_result.update(json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]})
         except Exception as e:  # noqa: BLE001
             other_paths_result.update({"error": repr(e)})
-    emit(sharded, cabi, cpu)
+    emit(one, cabi, cpu)
     enc.close()
     if world > 1:
         dist.barrier()
