@@ -202,12 +202,12 @@ def pmc_traffic(kernel):
         return None
 
 
-ROCPROF_STATS = os.path.join("profiles", "r03", "rocprofv3_kernel_stats_bench_default.csv")
+ROCPROF_STATS = os.path.join("profiles", "r04", "rocprofv3_kernel_stats_bench_default.csv")
 
 
 def rocprof_avg_ms(kernel):
     """Average duration of `kernel` (the library's profile name, e.g. tile_mid10_w32) in the committed rocprofv3 --kernel-trace --stats
-    summary of this command (captured in the same GPU session as profiles/r03/bench_n1_default.json), or None.
+    summary of this command (captured in the same GPU session as profiles/r04/bench_n1_default.json), or None.
     tile_<mode><levels>_w32[_r16] <-> ntt_tile_kernel<levels, 5 or 4, true, 0/1/2, ...>."""
     import csv
     import re
@@ -882,7 +882,7 @@ def main():
             # figures the contract asks for, the VALU figures are in `valu`.
             roof = {"bound": "valu" if "_mid" in name else "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
+                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json = profiles/r04/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
                                                                    "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)",
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
                     "frac_rocprof": None if not prof_ms else round(per_launch / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

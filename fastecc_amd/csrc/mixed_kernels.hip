@@ -240,10 +240,8 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
 #pragma unroll
         for (int j = 0; j < R; ++j) y[j][0] = my_lds[row_of(to, j) * 64u];
     };
-    // the q-point transforms of register row j (tile row r): twiddles w_N^(+-i2*j1) before (way up) or after (way down)
-    auto radix = [&](int j, uint32_t r) {
-        const uint32_t i2 = row0 + (r << s);
-        const_u32_ptr tw = as_constant(a.tw) + (size_t)i2 * (Q - 1);
+    // the q-point transforms of register row j: twiddles w_N^(+-i2*j1) (tw, wave-uniform) before (way up) or after (way down)
+    auto radix = [&](int j, const uint32_t (&tw)[Q - 1]) {
         uint32_t(*p[Q])[1];
 #pragma unroll
         for (int i = 0; i < Q; ++i) p[i] = &x[i][j];
@@ -255,6 +253,29 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
         if constexpr (!DIT) {
 #pragma unroll
             for (int i = 1; i < Q; ++i) x[out_slot<Q>(i)][j][0] = gf::mul_mont(x[out_slot<Q>(i)][j][0], tw[i - 1]);
+        }
+    };
+    // All R rows, one at a time, the Q - 1 twiddles of row j + 1 requested while row j is in the arithmetic: two small SGPR sets instead of
+    // R (Q - 1) scalars fetched at the top (which spilled: up to 246 SGPRs in round 3) and instead of all rows' temporaries live at once.
+    // The empty asm pins the set that is about to be used (its s_waitcnt lands there, BEFORE the next set is requested — scalar loads return
+    // out of order, so a wait issued after the next request would wait for both).
+    auto radix_rows = [&]() {
+        uint32_t tw[2][Q - 1];
+        auto fetch = [&](uint32_t (&t)[Q - 1], int j) {
+            const uint32_t i2 = row0 + (row_of(0, j) << s);
+            const_u32_ptr src = as_constant(a.tw) + (size_t)i2 * (Q - 1);
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i) t[i] = src[i];
+        };
+        fetch(tw[0], 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i) asm volatile("" : "+s"(tw[j & 1][i]));
+            if (j + 1 < R) fetch(tw[(j + 1) & 1], j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            radix(j, tw[j & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // the levels of run p on one stripe
@@ -277,8 +298,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
                 const uint32_t row = (uint32_t)i * a.M + row0 + (row_of(0, j) << s);
                 x[i][j][0] = (a.in_rows == 0 || row < a.in_rows) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
             }
-#pragma unroll
-        for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
+        radix_rows();
 #pragma unroll
         for (int j1 = 0; j1 < Q; ++j1) {
             uint32_t(&y)[R][1] = x[out_slot<Q>(j1)];  // stripe j1
@@ -310,8 +330,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
                 if (p > 0) exchange(y, p, p - 1);
             }
         }
-#pragma unroll
-        for (int j = 0; j < R; ++j) radix(j, row_of(0, j));
+        radix_rows();
 #pragma unroll
         for (int t = 0; t < Q; ++t)
 #pragma unroll
