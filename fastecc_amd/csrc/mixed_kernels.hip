@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "gf.hpp"
@@ -196,8 +197,35 @@ __global__ __launch_bounds__(256) void radix_kernel(const RadixArgs a)
 // load A -> q-point transforms + twiddles -> per stripe: high levels, A=>B, low levels -> store B.  Way up: the mirror image.
 // Reads happen before the first barrier and writes after it, so the pass may run in place.
 // ------------------------------------------------------------------------------------------------
+// Workgroup barrier for the LDS exchanges: __syncthreads() also waits for global memory (vmcnt(0)), which would drain the tile's loads
+// and stores at every exchange; the exchange only needs this wave's LDS traffic to have completed (as in tile_kernels.hip).
+__device__ __forceinline__ void lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// f(integral_constant<int, I>) for I = BEGIN .. END-1, as straight-line code: the stripe loops of the fused kernel are too large for
+// "#pragma unroll" (its size threshold) — a loop left rolled indexes the register array dynamically and sends it to scratch memory.
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+// Waves per SIMD the register allocator should aim for: a lane holds Q * 2^RLOG values plus ~24 temporaries.  Without the upper bound a
+// 512-lane workgroup is compiled for 8 waves per SIMD (64 VGPRs) and the 80 values of q = 5 go to scratch.
+constexpr int fused_max_waves(int q, int rlog)
+{
+    const int regs = ((q * (1 << rlog) + 24 + 7) / 8) * 8;
+    const int w = 512 / regs;
+    return w < 1 ? 1 : w > 8 ? 8 : w;
+}
+
 template <int Q, int A, int RLOG, bool DIT>
-__global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const FusedArgs a)
+__global__ __launch_bounds__(64 << (A - RLOG)) __attribute__((amdgpu_waves_per_eu(1, fused_max_waves(Q, RLOG)))) void fused_radix_kernel(const FusedArgs a)
 {
     // The A levels run in NRUNS register runs, counted from the top: run p < NRUNS-1 covers the RLOG levels [A - (p+1) RLOG, A - p RLOG),
     // the last one the remaining LAST levels [0, LAST).  In the layout of run p a lane's register j is bits [B, B + RLOG) of the tile row
@@ -231,14 +259,23 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
     auto off_of = [&](int p) -> uint32_t { return ((g & ((1u << run_base(p)) - 1u)) << s) + lo; };
     uint32_t x[Q][R][1];
 
-    // one stripe's registers from the layout of run `from` to that of run `to`
+    // one stripe's registers from the layout of run `from` to that of run `to`.  The LDS address of register j in a layout is
+    // (one VGPR per layout: lane + the wave's share of the row number) + (j << B) rows — a compile-time immediate of the ds instruction
+    // (< 64 KiB), not 2 R separately computed addresses that would stay in VGPRs across all q stripes.
+    auto lds_of = [&](int p) -> uint32_t* {
+        const int B = run_base(p);
+        return my_lds + ((((g >> B) << (B + RLOG)) | (g & ((1u << B) - 1u))) * 64u);
+    };
     auto exchange = [&](uint32_t (&y)[R][1], int from, int to) {
-        __syncthreads();  // the previous exchange's reads are done
+        uint32_t* const wr = lds_of(from);
+        uint32_t* const rd = lds_of(to);
+        const int Bf = run_base(from), Bt = run_base(to);
+        lds_sync();  // the previous exchange's reads are done
 #pragma unroll
-        for (int j = 0; j < R; ++j) my_lds[row_of(from, j) * 64u] = y[j][0];
-        __syncthreads();
+        for (int j = 0; j < R; ++j) wr[((uint32_t)j << Bf) * 64u] = y[j][0];
+        lds_sync();
 #pragma unroll
-        for (int j = 0; j < R; ++j) y[j][0] = my_lds[row_of(to, j) * 64u];
+        for (int j = 0; j < R; ++j) y[j][0] = rd[((uint32_t)j << Bt) * 64u];
     };
     // the q-point transforms of register row j: twiddles w_N^(+-i2*j1) (tw, wave-uniform) before (way up) or after (way down)
     auto radix = [&](int j, const uint32_t (&tw)[Q - 1]) {
@@ -275,69 +312,110 @@ __global__ __launch_bounds__(64 << (A - RLOG)) void fused_radix_kernel(const Fus
             if (j + 1 < R) fetch(tw[(j + 1) & 1], j + 1);
             __builtin_amdgcn_sched_barrier(0);
             radix(j, tw[j & 1]);
+            // (a scheduling barrier alone orders nothing here: instruction selection places pure arithmetic wherever it likes inside the
+            //  kernel's one basic block — it sank all R rows' transforms below the last barrier; pinning the results ties them to this point)
+#pragma unroll
+            for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(x[i][j][0]));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // the levels of run p on one stripe
+    // the levels of run p on one stripe, one level at a time: without the scheduling barriers the whole kernel is ONE basic block, and the
+    // scheduler interleaves the butterflies of several levels (and their products' temporaries) until nothing fits the registers
     auto levels = [&](uint32_t (&y)[R][1], int p) {
         const int B = run_base(p);
-        if (p == NRUNS - 1) {
-            if constexpr (DIT) dit_levels<RLOG, 1, false, LAST>(y, a.twl, off_of(p), s + B);
-            else               dif_levels<RLOG, 1, false, LAST>(y, a.twl, off_of(p), s + B);
+        const int n = p == NRUNS - 1 ? LAST : RLOG;
+        const uint32_t off = off_of(p);
+        auto pin = [&]() {
+#pragma unroll
+            for (int j = 0; j < R; ++j) asm volatile("" : "+v"(y[j][0]));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (DIT) {
+            if (n >= 1) { dit_one_level<RLOG, 1, false, 0>(y, a.twl, off, s + B); pin(); }
+            if constexpr (RLOG >= 2) if (n >= 2) { dit_one_level<RLOG, 1, false, 1>(y, a.twl, off, s + B); pin(); }
+            if constexpr (RLOG >= 3) if (n >= 3) { dit_one_level<RLOG, 1, false, 2>(y, a.twl, off, s + B); pin(); }
+            if constexpr (RLOG >= 4) if (n >= 4) { dit_one_level<RLOG, 1, false, 3>(y, a.twl, off, s + B); pin(); }
         } else {
-            if constexpr (DIT) dit_levels<RLOG, 1, false, RLOG>(y, a.twl, off_of(p), s + B);
-            else               dif_levels<RLOG, 1, false, RLOG>(y, a.twl, off_of(p), s + B);
+            if constexpr (RLOG >= 4) if (n >= 4) { dif_one_level<RLOG, 1, false, 3>(y, a.twl, off, s + B); pin(); }
+            if constexpr (RLOG >= 3) if (n >= 3) { dif_one_level<RLOG, 1, false, 2>(y, a.twl, off, s + B); pin(); }
+            if constexpr (RLOG >= 2) if (n >= 2) { dif_one_level<RLOG, 1, false, 1>(y, a.twl, off, s + B); pin(); }
+            if (n >= 1) { dif_one_level<RLOG, 1, false, 0>(y, a.twl, off, s + B); pin(); }
         }
     };
 
+    // Addresses: raw buffer ops, one descriptor per stripe (built from wave-uniform values, used for that stripe's R accesses and dropped),
+    // the lane's column in voffset, and the tile row as ONE running scalar byte offset whose updates are pinned by an empty asm — left
+    // alone, the compiler materialises all Q * R row addresses up front (160 SGPRs for q = 5: they spilled to VGPR lanes), and a pinned
+    // POINTER loses its address space (flat_load instead of global_load).  The descriptor of a stripe ends after the last block the batch
+    // really holds (in_rows / out_rows: zero-extended data, truncated parity), so the hardware bounds check replaces the branches.  The
+    // host only plans this kernel when a stripe spans < 2^32 bytes (plan.hip).  Layout of run 0: register j <-> tile row j * G + g;
+    // last run: tile row g * R + j.
+    constexpr uint32_t G = 1u << (A - RLOG);
+    const uint32_t row_bytes = a.ld * 4u;
+    const uint32_t voff = col * 4u;
+    const uint32_t step0 = (G << s) * row_bytes, step_last = row_bytes << s;
+    const uint32_t first0 = (g << s) * row_bytes, first_last = ((g * (uint32_t)R) << s) * row_bytes;  // register 0 of the two layouts
+    auto stripe_desc = [&](const uint32_t* base, uint32_t stripe, uint32_t rows) {
+        const uint32_t first = stripe * a.M + row0;  // batch row of the tile's row 0 in this stripe (q * M < 2^32)
+        // bytes of the stripe from there on that exist: all of it (rows == 0: no bound), or up to batch row `rows`; 32-bit selects only
+        // (a stripe spans < 2^32 bytes), so that no branch splits the kernel's straight-line code
+        const uint32_t live = rows == 0 ? a.M : (first >= rows ? 0u : min(rows - first, a.M));
+        const uint32_t nrec = rows == 0 ? 0xFFFFFFFFu : live * row_bytes;
+        const uint64_t v = reinterpret_cast<uint64_t>(base + (size_t)first * a.ld);
+        const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+    };
+    auto load_stripe = [&](uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
+        const __amdgpu_buffer_rsrc_t d = stripe_desc(a.in, stripe, a.in_rows);
+        uint32_t soff = first;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            y[j][0] = __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 2);  // non-temporal: every word is touched once per pass
+            soff += step;
+            asm volatile("" : "+s"(soff));
+        }
+    };
+    auto store_stripe = [&](const uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
+        const __amdgpu_buffer_rsrc_t d = stripe_desc(a.out, stripe, a.out_rows);
+        uint32_t soff = first;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            __builtin_amdgcn_raw_buffer_store_b32(y[j][0], d, voff, soff, 2);
+            soff += step;
+            asm volatile("" : "+s"(soff));
+        }
+    };
     if constexpr (!DIT) {
-#pragma unroll
-        for (int i = 0; i < Q; ++i)
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const uint32_t row = (uint32_t)i * a.M + row0 + (row_of(0, j) << s);
-                x[i][j][0] = (a.in_rows == 0 || row < a.in_rows) ? __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col) : 0u;
-            }
+        static_for<0, Q>([&](auto I) { load_stripe(x[I.value], (uint32_t)I.value, first0, step0); });
+        __builtin_amdgcn_sched_barrier(0);
         radix_rows();
-#pragma unroll
-        for (int j1 = 0; j1 < Q; ++j1) {
-            uint32_t(&y)[R][1] = x[out_slot<Q>(j1)];  // stripe j1
-#pragma unroll
-            for (int p = 0; p < NRUNS; ++p) {
-                if (p > 0) exchange(y, p - 1, p);
-                levels(y, p);
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
-                __builtin_nontemporal_store(y[k][0], a.out + (size_t)row * a.ld + col);
-            }
-        }
+        static_for<0, Q>([&](auto J1) {
+            uint32_t(&y)[R][1] = x[out_slot<Q>(J1.value)];  // stripe j1
+            static_for<0, NRUNS>([&](auto P) {
+                if constexpr (P.value > 0) exchange(y, P.value - 1, P.value);
+                levels(y, P.value);
+            });
+            store_stripe(y, (uint32_t)J1.value, NRUNS > 1 ? first_last : first0, NRUNS > 1 ? step_last : step0);
+            __builtin_amdgcn_sched_barrier(0);  // one stripe at a time: interleaving the stripes' levels costs registers, not time
+        });
     } else {
-#pragma unroll
-        for (int j1 = 0; j1 < Q; ++j1)  // every load of the tile is in flight before the first barrier
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const uint32_t row = (uint32_t)j1 * a.M + row0 + (row_of(NRUNS - 1, k) << s);
-                x[j1][k][0] = __builtin_nontemporal_load(a.in + (size_t)row * a.ld + col);
-            }
-#pragma unroll
-        for (int j1 = 0; j1 < Q; ++j1) {
-            uint32_t(&y)[R][1] = x[j1];
-#pragma unroll
-            for (int p = NRUNS - 1; p >= 0; --p) {
+        // every load of the tile is in flight before the first barrier
+        static_for<0, Q>([&](auto J1) { load_stripe(x[J1.value], (uint32_t)J1.value, NRUNS > 1 ? first_last : first0, NRUNS > 1 ? step_last : step0); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, Q>([&](auto J1) {
+            uint32_t(&y)[R][1] = x[J1.value];
+            static_for<0, NRUNS>([&](auto PP) {
+                constexpr int p = NRUNS - 1 - PP.value;
                 levels(y, p);
-                if (p > 0) exchange(y, p, p - 1);
-            }
-        }
+                if constexpr (p > 0) exchange(y, p, p - 1);
+            });
+            __builtin_amdgcn_sched_barrier(0);  // one stripe at a time
+        });
         radix_rows();
-#pragma unroll
-        for (int t = 0; t < Q; ++t)
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const uint32_t row = (uint32_t)t * a.M + row0 + (row_of(0, j) << s);
-                if (a.out_rows == 0 || row < a.out_rows) __builtin_nontemporal_store(x[out_slot<Q>(t)][j][0], a.out + (size_t)row * a.ld + col);
-            }
+        static_for<0, Q>([&](auto T) {
+            store_stripe(x[out_slot<Q>(T.value)], (uint32_t)T.value, first0, step0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 }
 
