@@ -85,12 +85,12 @@ def build_host(force=False, verbose=False):
 
 def build_microbench(force=False, verbose=False):
     """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
-    for name in ("microbench", "microbench_valu2"):
+    for name in ("microbench", "microbench_valu2", "microbench_p61"):
         src = os.path.join(ROOT, "tools", name + ".hip")
         out = os.path.join(LIB_DIR, name)
         if not os.path.exists(src):
             continue
-        if not (force or _newer(out, [src, os.path.join(CSRC, "gf.hpp")])):
+        if not (force or _newer(out, [src, os.path.join(CSRC, "gf.hpp"), os.path.join(CSRC, "gf61.hpp")])):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", out]
         if verbose:
