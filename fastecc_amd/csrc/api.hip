@@ -113,7 +113,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
         }
         const bool above_mid = folded && p.mode == MODE_DIT;
         const int n_eff = above_mid ? c->n - c->fold : c->n, s_eff = above_mid ? p.s - c->fold : p.s;
-        const uint32_t* twd = above_mid ? twiddle_table(c, TW_FOLD_DIT) : tw_dit;
+        const uint32_t* twd = above_mid ? twiddle_table(c, TW_FOLD_DIT, st) : tw_dit;
         if (!twd) return FASTECC_E_DEVICE;
         const uint64_t rows_moved = !folded ? 2 * c->N : p.mode == MODE_DIF ? 2 * c->N : p.mode == MODE_MID ? c->N + c->M : 2 * c->M;
         ProfScope ps(c, st, pass_name(p, vec, name, sizeof name), rows_moved * width * 4ull * batch);
@@ -296,7 +296,7 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
             f.out = work;
             f.dft = c->q_dft_inv;
             f.tw = c->q_tw_dif;
-            f.twl = twiddle_table(c, TW_ENC_DIF);
+            f.twl = twiddle_table(c, TW_ENC_DIF, st);
             if (!f.twl) return FASTECC_E_DEVICE;
             f.s = pd.s;
             f.in_rows = c->K != N1 ? (uint32_t)c->K : 0;
@@ -306,14 +306,14 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
         }
         CallBounds cbm;
         cbm.dscale_whole = true;
-        const int rcm = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, (uint32_t)c->q, cbm);
+        const int rcm = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st, 0, 0, nullptr, (uint32_t)c->q, cbm);
         if (rcm != FASTECC_OK) return rcm;
         {
             f.in = work;
             f.out = parity;
             f.dft = c->q_dft_fwd;
             f.tw = c->q_tw_dit;
-            f.twl = twiddle_table(c, TW_ENC_DIT);
+            f.twl = twiddle_table(c, TW_ENC_DIT, st);
             if (!f.twl) return FASTECC_E_DEVICE;
             f.s = pu.s;
             f.in_rows = 0;
@@ -341,7 +341,7 @@ int encode_mixed(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStre
     }
     CallBounds cb;
     cb.dscale_whole = true;
-    const int rc = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, (uint32_t)c->q, cb);
+    const int rc = run_passes(c, c->encode_plan, work, work, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st, 0, 0, nullptr, (uint32_t)c->q, cb);
     if (rc != FASTECC_OK) return rc;
     {
         a.in = work;
@@ -427,7 +427,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
     const int H = c->slabs;
     const bool slabbed = c->fold == 0 && c->cosets == 1 && H > 1 && H <= fastecc_ctx::MAX_SLABS && plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2 &&
                          (c->S % (32u * H)) == 0;
-    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, 1, cb);
+    if (!slabbed) return run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st, 0, 0, nullptr, 1, cb);
 
     // Column slabs are independent transforms.  Slab h runs on its own stream and starts when slab h-1 has
     // finished its first pass, so that at any time the GPU holds one slab in each kind of pass: the
@@ -437,7 +437,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
         // one slab after the other on the caller's stream: a slab's three passes follow each other closely enough for the
         // second and third to find it in the memory-side cache (256 MB) when the slab is small enough
         for (int h = 0; h < H; h++) {
-            const int rc1 = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, h * width, width, nullptr, 1, cb);
+            const int rc1 = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st, h * width, width, nullptr, 1, cb);
             if (rc1 != FASTECC_OK) return rc1;
         }
         return FASTECC_OK;
@@ -449,7 +449,7 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
         hipStream_t sh = c->slab_stream[h];
         HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
         if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));
-        rc = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), sh, h * width, width, c->slab_first_done[h], 1, cb);
+        rc = run_passes(c, c->encode_plan, data, parity, twiddle_table(c, TW_ENC_DIF, sh), twiddle_table(c, TW_ENC_DIT, sh), sh, h * width, width, c->slab_first_done[h], 1, cb);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipEventRecord(c->slab_done[h], sh));
         HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
@@ -473,7 +473,7 @@ int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, h
     const size_t pitch = (size_t)c->S * 4;
     if (H == 1) {
         HIP_TRY(hipMemcpyAsync(c->dbuf, data, c->stripe_bytes, hipMemcpyHostToDevice, st));
-        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st);
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpyAsync(parity, c->dbuf, c->stripe_bytes, hipMemcpyDeviceToHost, st));
         return FASTECC_OK;
@@ -489,7 +489,7 @@ int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, h
         HIP_TRY(hipMemcpy2DAsync(c->dbuf + (size_t)h * width, pitch, data + (size_t)h * width, pitch, (size_t)width * 4, c->N,
                                  hipMemcpyHostToDevice, sh));
         HIP_TRY(hipEventRecord(c->slab_first_done[h], sh));
-        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), sh, h * width, width);
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF, sh), twiddle_table(c, TW_ENC_DIT, sh), sh, h * width, width);
         if (rc != FASTECC_OK) return rc;
         HIP_TRY(hipMemcpy2DAsync(parity + (size_t)h * width, pitch, c->dbuf + (size_t)h * width, pitch, (size_t)width * 4, c->N,
                                  hipMemcpyDeviceToHost, sh));
@@ -505,7 +505,7 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
         P61Hooks hk(c);
         return p61::ntt(c->p61, (uint64_t*)data, inverse, st, c->profiling ? &hk.h : nullptr);
     }
-    const uint32_t* tw = inverse ? twiddle_table(c, TW_NTT_INV) : twiddle_table(c, TW_NTT_FWD);
+    const uint32_t* tw = inverse ? twiddle_table(c, TW_NTT_INV, st) : twiddle_table(c, TW_NTT_FWD, st);
     int rc = run_passes(c, c->ntt_plan, data, data, tw, tw, st);
     if (rc != FASTECC_OK) return rc;
     if (c->n >= 2) {
@@ -902,6 +902,7 @@ int columns_supported(const fastecc_ctx* c)
     return !c->sharded && c->q == 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
 }
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
+void set_error_text(const char* text) { snprintf(g_detail, sizeof g_detail, "%s", text ? text : ""); }
 
 int create_transform_ctx(fastecc_ctx** out, int log2k, uint64_t block_bytes, int fold, const uint32_t* factor, int device)
 {
@@ -985,7 +986,7 @@ int mixed_dif(fastecc_ctx* c, const uint32_t* in, uint32_t* out, hipStream_t st)
     a.dft = c->q_dft_inv;
     a.tw = c->q_tw_dif;
     HIP_TRY(launch_radix(c->q, false, vec, a, st));
-    return run_passes(c, c->ntt_plan, out, out, twiddle_table(c, TW_NTT_INV), twiddle_table(c, TW_NTT_INV), st, 0, 0, nullptr, (uint32_t)c->q);
+    return run_passes(c, c->ntt_plan, out, out, twiddle_table(c, TW_NTT_INV, st), twiddle_table(c, TW_NTT_INV, st), st, 0, 0, nullptr, (uint32_t)c->q);
 }
 
 int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit, bool inverse_roots, uint32_t width, hipStream_t st)
@@ -993,7 +994,7 @@ int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit
     if (c->p61 || c->sharded || c->q > 1 || c->ntt_plan.empty() || width == 0 || width > c->S) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
-    const uint32_t* tw = inverse_roots ? twiddle_table(c, TW_NTT_INV) : twiddle_table(c, TW_NTT_FWD);
+    const uint32_t* tw = inverse_roots ? twiddle_table(c, TW_NTT_INV, st) : twiddle_table(c, TW_NTT_FWD, st);
     if (!dit) return run_passes(c, c->ntt_plan, in, out, tw, tw, st, 0, width);
     // the stand-alone plan mirrored: the same chunks bottom up as DIT passes; level for level the same register runs, so
     // the level-packed tables of the DIF plan serve both
@@ -1016,7 +1017,7 @@ int run_gathered(fastecc_ctx* c, const uint32_t* even_blocks, const uint32_t* od
     CallBounds cb;
     cb.gather_odd = odd_blocks;
     cb.gather_factor = row_factor;
-    return run_passes(c, c->encode_plan, even_blocks, out, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), st, 0, 0, nullptr, 1, cb);
+    return run_passes(c, c->encode_plan, even_blocks, out, twiddle_table(c, TW_ENC_DIF, st), twiddle_table(c, TW_ENC_DIT, st), st, 0, 0, nullptr, 1, cb);
 }
 
 bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
@@ -1062,7 +1063,7 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
     if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
-    const uint32_t *twd = twiddle_table(c, TW_ENC_DIF), *twu = twiddle_table(c, TW_ENC_DIT);
+    const uint32_t *twd = twiddle_table(c, TW_ENC_DIF, st), *twu = twiddle_table(c, TW_ENC_DIT, st);
     const std::vector<Pass> first{c->encode_plan[0]};
     // the levels MID takes on its way down, as a DIF tile of their own (the level tables are packed by level: the same table serves)
     const std::vector<Pass> low{Pass{MODE_DIF, c->encode_plan[1].logr, 0, true, true, 5}};
@@ -1175,6 +1176,8 @@ void fastecc_destroy(fastecc_ctx* c)
     }
     if (c->buf_event) (void)hipEventDestroy(c->buf_event);
     p61::destroy(c->p61);
+    for (hipEvent_t e : c->tw_event)
+        if (e) (void)hipEventDestroy(e);
     if (c->tw_enc_dif) (void)hipFree(c->tw_enc_dif);
     if (c->tw_enc_dit) (void)hipFree(c->tw_enc_dit);
     if (c->tw_ntt_fwd) (void)hipFree(c->tw_ntt_fwd);
@@ -1249,7 +1252,7 @@ int fastecc_encode_columns(fastecc_ctx* c, const void* data, void* parity, uint6
         return p61::encode_columns(c->p61, (const uint64_t*)data, (uint64_t*)parity, col0 / 4, width / 4, (hipStream_t)stream,
                                    c->profiling ? &hk.h : nullptr);
     }
-    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), (hipStream_t)stream,
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF, (hipStream_t)stream), twiddle_table(c, TW_ENC_DIT, (hipStream_t)stream), (hipStream_t)stream,
                       (uint32_t)col0, (uint32_t)width);
 }
 
@@ -1263,7 +1266,7 @@ int fastecc_encode_batch(fastecc_ctx* c, const void* data, void* parity, uint64_
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     CallLock lk(c->mu);
-    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF), twiddle_table(c, TW_ENC_DIT), (hipStream_t)stream, 0, 0,
+    return run_passes(c, c->encode_plan, (const uint32_t*)data, (uint32_t*)parity, twiddle_table(c, TW_ENC_DIF, (hipStream_t)stream), twiddle_table(c, TW_ENC_DIT, (hipStream_t)stream), (hipStream_t)stream, 0, 0,
                       nullptr, (uint32_t)count);
 }
 

@@ -123,6 +123,9 @@ struct fastecc_ctx {
     uint32_t* tw_ntt_fwd = nullptr;  // forward roots, ordered for the stand-alone transform's passes
     uint32_t* tw_ntt_inv = nullptr;  // inverse roots, same ordering
     unsigned tw_ready = 0;           // which of the five tables hold the current plan's values (bit TW_*): each is built on the device at first use
+    unsigned tw_pending = 0;         // built by a kernel that may still be running: tw_event[i] marks its end, tw_stream[i] the stream it ran on
+    hipEvent_t tw_event[5] = {};
+    hipStream_t tw_stream[5] = {};
     uint32_t* dscale = nullptr;  // position p -> w_2N^i / N with i = bitrev_n(p)     (RS.cpp:51-54)
     uint32_t* factor = nullptr;  // scratch for fastecc_scale_blocks, N words
     uint32_t* dbuf = nullptr;    // staging stripe for FASTECC_MEM_HOST calls (lazy)
@@ -187,7 +190,9 @@ int upload_twiddles(fastecc_ctx* c);  // the plans changed: every twiddle table 
 // The table `which` for the current plans, built on the context's device (the current device) at first use: a context that only ever encodes
 // never builds the stand-alone transform's tables and vice versa (the decoder's ~19 internal contexts each use one kind).  nullptr on failure.
 enum { TW_ENC_DIF = 0, TW_ENC_DIT = 1, TW_NTT_FWD = 2, TW_NTT_INV = 3, TW_FOLD_DIT = 4 };
-const uint32_t* twiddle_table(fastecc_ctx* c, int which);
+// The table is written by a kernel enqueued on `st` — the stream that is about to use it — with NO host synchronisation: the first call on a
+// context stays asynchronous (and may run under stream capture).  A later use on another stream waits for the build's event on the device.
+const uint32_t* twiddle_table(fastecc_ctx* c, int which, hipStream_t st);
 
 using CallLock = std::lock_guard<std::mutex>;
 

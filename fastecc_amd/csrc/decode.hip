@@ -91,6 +91,8 @@ struct DecodeState {
     uint64_t lost_rows_cap = 0;
     uint32_t* pack_dev = nullptr;       // the rebuilt blocks, packed
     uint64_t pack_words = 0;
+    uint32_t* pack_host = nullptr;      // pinned landing buffer of that copy (kept between calls; the blocks go to their places from here)
+    uint64_t pack_host_words = 0;
     // fastecc_decode_prepare's device state (lazy): the product tree of the locator
     uint64_t tree_T = 0;                   // padded number of roots: the smallest power of two >= the most losses a code tolerates
     std::vector<fastecc_ctx*> tree_ctx;    // level k (polynomials of degree d = 2^k): transforms of length 2d, T/d columns
@@ -144,6 +146,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->parity_dev) (void)hipFree(d->parity_dev);
     if (d->lost_rows_dev) (void)hipFree(d->lost_rows_dev);
     if (d->pack_dev) (void)hipFree(d->pack_dev);
+    if (d->pack_host) (void)hipHostFree(d->pack_host);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
     direct_pass_free(d->direct_data);
@@ -500,7 +503,22 @@ using namespace fastecc;
 
 extern "C" {
 
+static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present);
+
+// No exception crosses the ABI: the set-up and the host staging use std::vector; an allocation failure there is FASTECC_E_NOMEM (the call
+// locks of the context are scoped objects, so they are released on the way out).
 int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
+{
+    try {
+        return decode_prepare_impl(c, data_present, parity_present);
+    } catch (const std::bad_alloc&) {
+        return FASTECC_E_NOMEM;
+    } catch (...) {
+        return FASTECC_E_DEVICE;
+    }
+}
+
+static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, const uint8_t* parity_present)
 {
     if (!c || !data_present || !parity_present) return FASTECC_E_INVAL;
     if (sharded_of(c)) return sharded_decode_prepare(c, data_present, parity_present);
@@ -555,7 +573,9 @@ int fastecc_decode_prepare(fastecc_ctx* c, const uint8_t* data_present, const ui
         // orders above 2^20 (mixed radix): the locator tree is padded to 2^20 roots whatever the pattern
         uint64_t T = 1;
         while (T < NC - N) T <<= 1;
-        if (T > (1ull << 20) && ci.direct_max > 0) direct_limit = std::max(direct_limit, 256);  // their tree costs a 2^20-point product: the direct path first
+        // their tree costs a 2^20-point product: the direct path first, up to the caller's "decode_direct_max" (the 80 / 96 cap of rows the
+        // matrix-core kernel cannot take is a speed trade-off against a transform path that is much dearer here, so it does not apply)
+        if (T > (1ull << 20) && ci.direct_max > 0) direct_limit = std::max(direct_limit, std::min(ci.direct_max, direct_cap()));
     }
     auto parity_position = [&](uint64_t q) -> uint64_t {
         if (ci.cosets > 1) {
@@ -988,12 +1008,24 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
 
 int fastecc_decode(fastecc_ctx* c, void* data, const void* parity, int mem_kind, void* stream)
 {
-    return decode_impl(c, data, parity, mem_kind, stream, nullptr);
+    try {
+        return decode_impl(c, data, parity, mem_kind, stream, nullptr);
+    } catch (const std::bad_alloc&) {
+        return FASTECC_E_NOMEM;
+    } catch (...) {
+        return FASTECC_E_DEVICE;
+    }
 }
 
 int fastecc_repair(fastecc_ctx* c, void* data, void* parity, int mem_kind, void* stream)
 {
-    return decode_impl(c, data, parity, mem_kind, stream, parity);
+    try {
+        return decode_impl(c, data, parity, mem_kind, stream, parity);
+    } catch (const std::bad_alloc&) {
+        return FASTECC_E_NOMEM;
+    } catch (...) {
+        return FASTECC_E_DEVICE;
+    }
 }
 
 // parity_out != null (== parity): also rebuild the lost parity blocks from the repaired data
@@ -1260,43 +1292,58 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         DEC_TRY(hipGetLastError());
     }
     }  // transform path
+    bool rows_copied = false;
     if (mem_kind == FASTECC_MEM_HOST && host_rows_only) {
-        // the rebuilt blocks packed side by side on the device, one copy, and a memcpy per block on the host
+        // the rebuilt blocks packed side by side on the device, one copy into a pinned landing buffer, and a memcpy per block on the host.
+        // The repair has already run: if one of the buffers of this shortcut cannot be had, the whole-stripe copy below still delivers it.
         const uint32_t S = (uint32_t)ci.words;
         const uint64_t nd = d->erased_data != 0 ? d->host_lost_data.size() : 0, np = rebuild ? d->host_lost_parity.size() : 0;
+        bool have = true;
         if (d->lost_rows_cap < nd + np) {
             if (d->lost_rows_dev) (void)hipFree(d->lost_rows_dev);
             d->lost_rows_dev = nullptr;
             d->lost_rows_cap = 0;
-            DEC_TRY(hipMalloc((void**)&d->lost_rows_dev, (nd + np) * 4));
-            d->lost_rows_cap = nd + np;
+            if (hipMalloc((void**)&d->lost_rows_dev, (nd + np) * 4) == hipSuccess) d->lost_rows_cap = nd + np;
+            else have = false;
         }
-        if (d->pack_words < (nd + np) * S) {
+        if (have && d->pack_words < (nd + np) * S) {
             if (d->pack_dev) (void)hipFree(d->pack_dev);
             d->pack_dev = nullptr;
             d->pack_words = 0;
-            DEC_TRY(hipMalloc((void**)&d->pack_dev, (nd + np) * S * 4));
-            d->pack_words = (nd + np) * S;
+            if (hipMalloc((void**)&d->pack_dev, (nd + np) * S * 4) == hipSuccess) d->pack_words = (nd + np) * S;
+            else have = false;
         }
-        if (nd) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev, d->host_lost_data.data(), nd * 4, hipMemcpyHostToDevice, st));
-        if (np) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev + nd, d->host_lost_parity.data(), np * 4, hipMemcpyHostToDevice, st));
-        const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)d->parity_dev | (uintptr_t)d->pack_dev) & 15u) == 0);
-        const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
-        auto pack = [&](const uint32_t* stripe, const uint32_t* rows, uint32_t* out, uint64_t count) {
-            const uint64_t items = count * col_chunks;
-            const dim3 grid((unsigned)((items + 3) / 4));
-            if (v4) hipLaunchKernelGGL(pack_rows_kernel<4>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
-            else    hipLaunchKernelGGL(pack_rows_kernel<1>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
-        };
-        if (nd) pack(ddata, d->lost_rows_dev, d->pack_dev, nd);
-        if (np) pack(d->parity_dev, d->lost_rows_dev + nd, d->pack_dev + nd * S, np);
-        DEC_TRY(hipGetLastError());
-        std::vector<uint32_t> packed((nd + np) * (size_t)S);
-        DEC_TRY(hipMemcpyAsync(packed.data(), d->pack_dev, packed.size() * 4, hipMemcpyDeviceToHost, st));
-        DEC_TRY(hipStreamSynchronize(st));
-        for (uint64_t r = 0; r < nd; r++) memcpy((char*)data + (size_t)d->host_lost_data[r] * block, packed.data() + r * S, block);
-        for (uint64_t r = 0; r < np; r++) memcpy((char*)parity_out + (size_t)d->host_lost_parity[r] * block, packed.data() + (nd + r) * S, block);
-    } else if (mem_kind == FASTECC_MEM_HOST) {
+        if (have && d->pack_host_words < (nd + np) * S) {
+            if (d->pack_host) (void)hipHostFree(d->pack_host);
+            d->pack_host = nullptr;
+            d->pack_host_words = 0;
+            if (hipHostMalloc((void**)&d->pack_host, (nd + np) * S * 4, hipHostMallocDefault) == hipSuccess) d->pack_host_words = (nd + np) * S;
+            else have = false;
+        }
+        if (!have) {
+            (void)hipGetLastError();  // out of memory for the shortcut only
+        } else {
+            if (nd) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev, d->host_lost_data.data(), nd * 4, hipMemcpyHostToDevice, st));
+            if (np) DEC_TRY(hipMemcpyAsync(d->lost_rows_dev + nd, d->host_lost_parity.data(), np * 4, hipMemcpyHostToDevice, st));
+            const bool v4 = (S % 4) == 0 && ((((uintptr_t)ddata | (uintptr_t)d->parity_dev | (uintptr_t)d->pack_dev) & 15u) == 0);
+            const uint32_t col_chunks = (S + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+            auto pack = [&](const uint32_t* stripe, const uint32_t* rows, uint32_t* out, uint64_t count) {
+                const uint64_t items = count * col_chunks;
+                const dim3 grid((unsigned)((items + 3) / 4));
+                if (v4) hipLaunchKernelGGL(pack_rows_kernel<4>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
+                else    hipLaunchKernelGGL(pack_rows_kernel<1>, grid, dim3(256), 0, st, stripe, rows, out, S, col_chunks, items);
+            };
+            if (nd) pack(ddata, d->lost_rows_dev, d->pack_dev, nd);
+            if (np) pack(d->parity_dev, d->lost_rows_dev + nd, d->pack_dev + nd * S, np);
+            DEC_TRY(hipGetLastError());
+            DEC_TRY(hipMemcpyAsync(d->pack_host, d->pack_dev, (nd + np) * (size_t)S * 4, hipMemcpyDeviceToHost, st));
+            DEC_TRY(hipStreamSynchronize(st));
+            for (uint64_t r = 0; r < nd; r++) memcpy((char*)data + (size_t)d->host_lost_data[r] * block, d->pack_host + r * S, block);
+            for (uint64_t r = 0; r < np; r++) memcpy((char*)parity_out + (size_t)d->host_lost_parity[r] * block, d->pack_host + (nd + r) * S, block);
+            rows_copied = true;
+        }
+    }
+    if (mem_kind == FASTECC_MEM_HOST && !rows_copied) {
         if (d->erased_data != 0) DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
         if (rebuild) DEC_TRY(hipMemcpyAsync(parity_out, d->parity_dev, parity_bytes, hipMemcpyDeviceToHost, st));
         DEC_TRY(hipStreamSynchronize(st));

@@ -80,6 +80,7 @@ fastecc_ctx* new_shell_ctx(int root_device, int field, uint64_t k, uint64_t m, u
 void set_plan_text(fastecc_ctx* c, const std::string& t);
 int columns_supported(const fastecc_ctx* c);  // fastecc_encode_columns works on this context
 void set_error_detail(const char* what, hipError_t e);
+void set_error_text(const char* text);  // this thread's fastecc_last_error_detail, verbatim (a worker thread's text republished on the caller's)
 
 // A transform context (GF(0xFFF00001)): DIF over all log2k levels with inverse roots, the block holding coefficient m
 // multiplied by factor[m] (plain representatives, k entries), DIT back with forward roots keeping every 2^fold-th

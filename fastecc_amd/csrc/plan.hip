@@ -219,54 +219,81 @@ __global__ __launch_bounds__(256) void level_table_kernel(uint32_t* __restrict__
     tab[h + (((i & ((1u << s) - 1u)) << t) | (i >> s))] = gf::mul(r, gf::MONT_ONE);
 }
 
-int device_level_table(uint32_t** dst, int n, uint32_t root_of_order_N, const std::vector<int>& sl)
+int device_level_table(uint32_t** dst, int n, uint32_t root_of_order_N, const std::vector<int>& sl, hipStream_t stream)
 {
     const size_t entries = std::max<size_t>((size_t)1 << n, 2);
     if (!*dst) HIP_TRY(hipMalloc((void**)dst, entries * 4));
     if (n < 1) {
-        HIP_TRY(hipMemset(*dst, 0, entries * 4));
+        HIP_TRY(hipMemsetAsync(*dst, 0, entries * 4, stream));
         return FASTECC_OK;
     }
     LevelStrides st{};
     for (int l = 0; l < n && l < 32; l++) st.sl[l] = sl[l];
-    hipLaunchKernelGGL(level_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, nullptr, *dst, n, root_of_order_N, st);
+    hipLaunchKernelGGL(level_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, stream, *dst, n, root_of_order_N, st);
     HIP_TRY(hipGetLastError());
     return FASTECC_OK;
 }
 
 }  // namespace
 
-// The plans changed (or the context is new): the tables are rebuilt when they are next used.  The device must be idle w.r.t. this context.
+// The plans changed (or the context is new): the tables are rebuilt when they are next used.  Builds that may still be running (and
+// their readers, on the same streams) are waited for first, so the old tables are not overwritten under a kernel.
 int upload_twiddles(fastecc_ctx* c)
 {
+    for (int i = 0; i < 5; i++)
+        if ((c->tw_pending & (1u << i)) && c->tw_event[i]) (void)hipEventSynchronize(c->tw_event[i]);
+    c->tw_pending = 0;
     c->tw_ready = 0;
     return FASTECC_OK;
 }
 
-const uint32_t* twiddle_table(fastecc_ctx* c, int which)
+const uint32_t* twiddle_table(fastecc_ctx* c, int which, hipStream_t st)
 {
     uint32_t** slot = which == TW_ENC_DIF ? &c->tw_enc_dif : which == TW_ENC_DIT ? &c->tw_enc_dit : which == TW_NTT_FWD ? &c->tw_ntt_fwd
                     : which == TW_NTT_INV ? &c->tw_ntt_inv : &c->tw_fold_dit;
-    if (c->tw_ready & (1u << which)) return *slot;
+    const unsigned bit = 1u << which;
+    if (c->tw_ready & bit) {
+        // built earlier by a kernel on tw_stream: a use on another stream waits for that kernel on the device, until the event is seen complete
+        if ((c->tw_pending & bit) && st != c->tw_stream[which]) {
+            if (hipEventQuery(c->tw_event[which]) == hipSuccess) c->tw_pending &= ~bit;
+            else if (hipStreamWaitEvent(st, c->tw_event[which], 0) != hipSuccess) return nullptr;
+            (void)hipGetLastError();  // hipErrorNotReady of the query is not an error
+        }
+        return *slot;
+    }
     const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
     int rc = FASTECC_OK;
     switch (which) {
-    case TW_ENC_DIF: rc = device_level_table(slot, c->n, wNi, level_strides(c->encode_plan, c->n)); break;        // interpolate: inverse roots (RS.cpp:41)
-    case TW_ENC_DIT: rc = device_level_table(slot, c->n, wN, level_strides(c->encode_plan, c->n, true)); break;   // evaluate (RS.cpp:63)
-    case TW_NTT_FWD: rc = device_level_table(slot, c->n, wN, level_strides(c->ntt_plan, c->n)); break;
-    case TW_NTT_INV: rc = device_level_table(slot, c->n, wNi, level_strides(c->ntt_plan, c->n)); break;
+    case TW_ENC_DIF: rc = device_level_table(slot, c->n, wNi, level_strides(c->encode_plan, c->n), st); break;        // interpolate: inverse roots (RS.cpp:41)
+    case TW_ENC_DIT: rc = device_level_table(slot, c->n, wN, level_strides(c->encode_plan, c->n, true), st); break;   // evaluate (RS.cpp:63)
+    case TW_NTT_FWD: rc = device_level_table(slot, c->n, wN, level_strides(c->ntt_plan, c->n), st); break;
+    case TW_NTT_INV: rc = device_level_table(slot, c->n, wNi, level_strides(c->ntt_plan, c->n), st); break;
     default: {
         // level l' of the size-M transform is level l' + fold of the size-k one, on positions >> fold
         const std::vector<int> enc_up = level_strides(c->encode_plan, c->n, true);
         const int nf = c->n - c->fold;
         std::vector<int> sl(std::max(nf, 0), 0);
         for (int l = 0; l < nf; l++) sl[l] = std::max(enc_up[l + c->fold] - c->fold, 0);
-        rc = device_level_table(slot, nf, gf::h_root((uint32_t)c->M), sl);
+        rc = device_level_table(slot, nf, gf::h_root((uint32_t)c->M), sl, st);
     }
     }
-    if (rc == FASTECC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize(twiddle table)");
     if (rc != FASTECC_OK) return nullptr;
-    c->tw_ready |= 1u << which;
+    // no host synchronisation: the table's first reader follows on the same stream; other streams wait for this event (above)
+    hipError_t e = hipSuccess;
+    if (!c->tw_event[which]) e = hipEventCreateWithFlags(&c->tw_event[which], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(c->tw_event[which], st);
+    if (e != hipSuccess) {  // no event to be had: fall back to waiting here
+        (void)hipGetLastError();
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            (void)hip_fail(hipGetLastError(), "hipStreamSynchronize(twiddle table)");
+            return nullptr;
+        }
+        c->tw_pending &= ~bit;
+    } else {
+        c->tw_pending |= bit;
+        c->tw_stream[which] = st;
+    }
+    c->tw_ready |= bit;
     return *slot;
 }
 

@@ -499,23 +499,40 @@ int sharded_decode_prepare(fastecc_ctx* shell, const uint8_t* data_present, cons
     Sharded* s = sharded_of(shell);
     std::lock_guard<std::mutex> lk(mutex_of(shell));
     // the same pattern for every slab (each context keeps its own tables on its own device): one host thread per slab, so the set-ups — a host
-    // scan and a few dozen small kernels each, synchronous — run side by side instead of n_slabs times 2.3 ms one after the other
-    std::vector<int> rcs(s->shards.size(), FASTECC_OK);
-    std::vector<std::thread> workers;
-    std::vector<char> started(s->shards.size(), 0);
-    for (size_t i = 1; i < s->shards.size(); i++) {
+    // scan and a few dozen small kernels each, synchronous — run side by side instead of n_slabs times 2.3 ms one after the other.
+    // The error detail is thread-local and a worker must not throw: each worker maps exceptions to a code and hands its detail text back,
+    // and the first failing slab's text is republished on the calling thread.
+    const size_t G = s->shards.size();
+    std::vector<int> rcs(G, FASTECC_OK);
+    std::vector<std::string> details(G);
+    auto one = [&](size_t i) {
         try {
-            workers.emplace_back([&, i] { rcs[i] = fastecc_decode_prepare(s->shards[i].ctx, data_present, parity_present); });
+            rcs[i] = fastecc_decode_prepare(s->shards[i].ctx, data_present, parity_present);
+            if (rcs[i] != FASTECC_OK) details[i] = fastecc_last_error_detail();
+        } catch (const std::bad_alloc&) {
+            rcs[i] = FASTECC_E_NOMEM;
+        } catch (...) {
+            rcs[i] = FASTECC_E_DEVICE;
+        }
+    };
+    std::vector<std::thread> workers;
+    std::vector<char> started(G, 0);
+    for (size_t i = 1; i < G; i++) {
+        try {
+            workers.emplace_back(one, i);
             started[i] = 1;
         } catch (...) {  // no thread to be had: that slab is set up on this one below (no exception crosses the ABI)
         }
     }
-    rcs[0] = fastecc_decode_prepare(s->shards[0].ctx, data_present, parity_present);  // (this thread's error detail is the one the caller can read)
+    one(0);
     for (std::thread& t : workers) t.join();
-    for (size_t i = 1; i < s->shards.size(); i++)
-        if (!started[i]) rcs[i] = fastecc_decode_prepare(s->shards[i].ctx, data_present, parity_present);
-    for (int rc : rcs)
-        if (rc != FASTECC_OK) return rc;
+    for (size_t i = 1; i < G; i++)
+        if (!started[i]) one(i);
+    for (size_t i = 0; i < G; i++)
+        if (rcs[i] != FASTECC_OK) {
+            set_error_text(details[i].c_str());
+            return rcs[i];
+        }
     return FASTECC_OK;
 }
 
@@ -524,7 +541,9 @@ int sharded_decode_stripe(fastecc_ctx* shell, void* data, void* parity, int mem_
     if (mem_kind != FASTECC_MEM_DEVICE && mem_kind != FASTECC_MEM_HOST && mem_kind != FASTECC_MEM_HOST_PINNED) return FASTECC_E_INVAL;
     std::lock_guard<std::mutex> lk(mutex_of(shell));
     const int rc = run_decode(shell, data, parity, nullptr, nullptr, mem_kind != FASTECC_MEM_DEVICE, repair, st);
-    if (rc != FASTECC_OK || mem_kind != FASTECC_MEM_HOST) return rc;
+    // host stripes, pageable or pinned: synchronous, as include/fastecc.h says for fastecc_decode / fastecc_repair (the single-device path
+    // stages both kinds the same way)
+    if (rc != FASTECC_OK || mem_kind == FASTECC_MEM_DEVICE) return rc;
     DeviceSwitch restore;
     SH_TRY(hipSetDevice(sharded_of(shell)->root));
     SH_TRY(hipStreamSynchronize(st));

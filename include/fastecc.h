@@ -142,7 +142,8 @@ void fastecc_destroy(fastecc_ctx *ctx);
  *          and needs n - k <= k.  Codes with few parity blocks are evaluated directly (option "encode_direct_max"), same bits.
  * mem_kind FASTECC_MEM_DEVICE: both pointers are device memory on the context's device; the work is
  *          enqueued on `stream` (a hipStream_t, NULL = default stream) and the call does not
- *          synchronise.  FASTECC_MEM_HOST: pointers are host memory; the call stages through HBM and
+ *          synchronise — not even the first call on a context: its twiddle tables are written by a kernel on `stream` in front of the
+ *          first pass (a use on another stream later waits for that kernel on the device), so calls may be captured into a hipGraph.  FASTECC_MEM_HOST: pointers are host memory; the call stages through HBM and
  *          returns when `parity` is complete.
  */
 int fastecc_encode(fastecc_ctx *ctx, const void *data, void *parity, int mem_kind, void *stream);
@@ -281,7 +282,8 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            Reusable for any number of stripes.
  *   fastecc_decode         : data (k blocks; the erased ones are overwritten with the recovered content, the others
  *                            are not written) and parity (n - k blocks, read only; content of erased blocks is ignored).
- *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST / HOST_PINNED: staged, synchronous — the data
+ *                            DEVICE pointers: enqueued on `stream`, no synchronisation.  HOST / HOST_PINNED: staged, synchronous (on sharded contexts
+ *                            too) — the data
  *                            stripe and the parity blocks the decoder reads travel up, the rebuilt blocks back (whole stripes
  *                            when more than an eighth of the codeword is lost).
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
@@ -363,7 +365,8 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  pipeline (2.4 ms); same parity bits.  Rows the matrix-core kernel cannot take (odd length, < 64 words, not 8-byte aligned)
  *                  stop at 32;
  *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
- *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96;
+ *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96 (not for mixed-radix orders above 2^20, whose transform
+ *                  path is much dearer: there the option alone decides);
  *   "decode_split" = 0 / 1 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^17 (power-of-two orders), next decode_prepare): the decoder's 2k-point
  *                  transform as two transforms of k points — the data half, and the parity half of which only as many block groups as there
  *                  are lost data blocks are read (7.1 -> 4.6 ms at k = 2^19 x 4 KB); 0 = one transform of 2k points.  Same bits;

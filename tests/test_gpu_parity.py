@@ -549,3 +549,43 @@ def test_batched_stripes_equal_individual_encodes(torch_cuda, fe, oracle, log2n,
             with pytest.raises(fe.FastEccError) as ei:
                 enc.encode_batch(d, out, count)
             assert ei.value.code == fe.E_UNSUPPORTED
+
+
+def test_first_call_does_not_synchronise_and_tables_follow_the_streams(torch_cuda, fe, oracle):
+    """The twiddle tables of a context are written by a kernel on the stream of the first call, with no host synchronisation
+    (include/fastecc.h: DEVICE calls never synchronise): (a) a first call on a side stream followed at once by a call on another
+    stream — which must wait for that build on the device — gives the right parity both times; (b) the first call of a context can be
+    captured into a graph and replayed."""
+    torch = torch_cuda
+    N, S = 1 << 12, 256
+    x = np.random.default_rng(42).integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    want = oracle.encode_fast(x)
+    d = torch.from_numpy(x.view(np.int32)).to("cuda:0")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):  # fresh contexts: every round builds its tables again
+        with fe.Encoder(2 * N, N, 4 * S) as enc:
+            o1, o2 = torch.empty_like(d), torch.empty_like(d)
+            enc.encode(d, o1, stream=s1.cuda_stream)
+            enc.encode(d, o2, stream=s2.cuda_stream)
+            enc.ntt(o2.clone(), stream=s2.cuda_stream)  # another table kind, first built on s2 ...
+            t = d.clone()
+            enc.ntt(t, stream=s1.cuda_stream)            # ... and used on s1 right away
+            torch.cuda.synchronize()
+            assert np.array_equal(o1.cpu().numpy().view(np.uint32).reshape(N, S), want)
+            assert np.array_equal(o2.cpu().numpy().view(np.uint32).reshape(N, S), want)
+            assert np.array_equal(t.cpu().numpy().view(np.uint32).reshape(N, S), oracle.ntt_fast(x))
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        out = torch.zeros_like(d)
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        try:
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="relaxed"):
+                enc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+        except Exception as e:  # noqa: BLE001
+            pytest.fail("the first fastecc_encode of a context could not be captured: %r" % (e,))
+        torch.cuda.synchronize()
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(N, S), want)
