@@ -565,11 +565,11 @@ def test_first_call_does_not_synchronise_and_tables_follow_the_streams(torch_cud
     torch.cuda.synchronize()
     for _ in range(3):  # fresh contexts: every round builds its tables again
         with fe.Encoder(2 * N, N, 4 * S) as enc:
-            o1, o2 = torch.empty_like(d), torch.empty_like(d)
+            o1, o2, t0, t = torch.empty_like(d), torch.empty_like(d), d.clone(), d.clone()
+            torch.cuda.synchronize()                     # (the clones ran on torch's stream: the library's streams below do not wait for it)
             enc.encode(d, o1, stream=s1.cuda_stream)
             enc.encode(d, o2, stream=s2.cuda_stream)
-            enc.ntt(o2.clone(), stream=s2.cuda_stream)  # another table kind, first built on s2 ...
-            t = d.clone()
+            enc.ntt(t0, stream=s2.cuda_stream)           # another table kind, first built on s2 ...
             enc.ntt(t, stream=s1.cuda_stream)            # ... and used on s1 right away
             torch.cuda.synchronize()
             assert np.array_equal(o1.cpu().numpy().view(np.uint32).reshape(N, S), want)
