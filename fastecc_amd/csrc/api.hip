@@ -157,6 +157,7 @@ int run_passes(fastecc_ctx* c, const std::vector<Pass>& plan, const uint32_t* in
                 mode = cb.mid_up ? MODE_MID_UP : MODE_MID_ADD;
                 a.addend = cb.addend + col0;
                 a.addend_factor = cb.addend_factor;
+                a.addend_shift = cb.addend_shift;
                 a.keep = cb.keep && !cb.mid_up ? cb.keep + col0 : nullptr;
             }
             a.persistent_cus = c->persistent ? c->cus : 0;
@@ -1058,9 +1059,11 @@ uint32_t split_decode_group_rows(const fastecc_ctx* c) { return 1u << c->encode_
 
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
-                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st, const SplitRepair* odd)
+                     uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st, const SplitRepair* odd,
+                     const uint32_t* small_addend, uint32_t addend_shift)
 {
-    if (!split_decode_supported(c) || parity_groups < 1 || parity_groups > split_decode_groups(c)) return FASTECC_E_UNSUPPORTED;
+    if (!split_decode_supported(c)) return FASTECC_E_UNSUPPORTED;
+    if (small_addend ? (addend_shift < 1 || addend_shift > 5) : (parity_groups < 1 || parity_groups > split_decode_groups(c))) return FASTECC_E_UNSUPPORTED;
     DeviceGuard dg(c->device);
     if (!dg.ok) return FASTECC_E_DEVICE;
     const uint32_t *twd = twiddle_table(c, TW_ENC_DIF, st), *twu = twiddle_table(c, TW_ENC_DIT, st);
@@ -1075,7 +1078,10 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
     cq.in_rows = data_blocks < c->N ? data_blocks : 0;
     cr.in_rows = parity_blocks < c->N ? parity_blocks : 0;
     cr.groups = parity_groups;
-    cm.addend = r2;
+    // r~ after all its DIF levels: the k-block stripe r2 — or, when the parity blocks in use sit at multiples of 2^shift only, the (k >> shift)-
+    // block transform of those (the caller's small_addend), each of whose blocks stands for 2^shift consecutive positions
+    cm.addend = small_addend ? small_addend : r2;
+    cm.addend_shift = small_addend ? addend_shift : 0;
     cm.addend_factor = parity_pos_factor;
     if (out_rows_factor) {  // the last pass scatters: block i of the result, times its factor, goes to out[i] where that factor is not zero
         cm.rows_out_factor = out_rows_factor;
@@ -1083,13 +1089,15 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
         cm.out_rows = data_blocks < c->N ? data_blocks : 0;
     }
     int rc = run_passes(c, first, data, q, twd, twu, st, 0, 0, nullptr, 1, cq);            // q~ : top levels of the data half
-    if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use
-    CallBounds cl;
-    if (impulse_table && parity_groups <= 16u * IMPULSE_MAX) {  // few groups: six of the ten low levels as a multiply-add per block in use (MODE_DIF_IMPULSE)
-        cl.impulse_table = impulse_table;
-        cl.impulse_rows = parity_groups;
+    if (!small_addend) {
+        if (rc == FASTECC_OK) rc = run_passes(c, first, parity, r1, twd, twu, st, 0, 0, nullptr, 1, cr);  // r~ : top levels, the groups that hold parity blocks in use
+        CallBounds cl;
+        if (impulse_table && parity_groups <= 16u * IMPULSE_MAX) {  // few groups: six of the ten low levels as a multiply-add per block in use (MODE_DIF_IMPULSE)
+            cl.impulse_table = impulse_table;
+            cl.impulse_rows = parity_groups;
+        }
+        if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st, 0, 0, nullptr, 1, cl);       // r~ : low levels (r1 is zero outside those groups)
     }
-    if (rc == FASTECC_OK) rc = run_passes(c, low, r1, r2, twd, twu, st, 0, 0, nullptr, 1, cl);       // r~ : low levels (r1 is zero outside those groups)
     // g = fq q~ + fr r~, and the transform back up.  With the odd positions wanted as well MID also stores q~ (its tiles after the first half).
     if (odd) cm.keep = odd->q2;
     if (rc == FASTECC_OK) rc = run_passes(c, rest, q, q, twd, twu, st, 0, 0, nullptr, 1, cm);
@@ -1097,7 +1105,8 @@ int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parit
         // x p'(x) at the ODD positions (the parity blocks): the k-point transform of h[m] = w^m (m P[m] - (m+k) P[m+k]) = -1/2 w^m q~[m] +
         // (2m+k)/2k r~[m] — MID's second half alone on the stored q~, the factor tables exchanged (the context's own table now scales the addend)
         CallBounds ch;
-        ch.addend = r2;
+        ch.addend = cm.addend;
+        ch.addend_shift = cm.addend_shift;
         ch.addend_factor = c->dscale;
         ch.mid_up = true;
         ch.dscale_override = odd->data_pos_factor;

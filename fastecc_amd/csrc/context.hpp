@@ -56,6 +56,7 @@ struct CallBounds {
     uint32_t groups = 0;
     const uint32_t* addend = nullptr;
     const uint32_t* addend_factor = nullptr;
+    uint32_t addend_shift = 0;  // TileArgs::addend_shift
     const uint32_t* impulse_table = nullptr;    // a lone DIF tile at s = 0 whose input is zero from block impulse_rows on (MODE_DIF_IMPULSE)
     uint32_t impulse_rows = 0;
     uint32_t* keep = nullptr;                   // MODE_MID_ADD also stores its tiles as they are after the first half (TileArgs::keep)

@@ -79,6 +79,12 @@ struct DecodeState {
     bool split_repair_ready = false;        // this pattern's lost parity blocks can come from the split transform too
     uint32_t* split_r0 = nullptr;           // codes with fewer parity blocks (fold > 0): parity block j copied to its place j << fold of a k-block stripe (lazy)
     uint32_t split_groups = 0;              // block groups of the parity stripe this pattern reads
+    // "small" form of the parity half: the parity blocks in use are those at multiples of 2^split_shift of the parity half (1 <= shift <= 5), so r~
+    // is the transform of (k >> shift) rows, each result block standing for 2^shift positions: no k-block stripes r1 / r2, no impulse pass
+    uint32_t split_shift = 0;
+    fastecc_ctx* split_small[6] = {};       // stand-alone transform contexts of k >> shift blocks (lazy, by shift)
+    uint32_t* split_small_buf = nullptr;    // (k >> shift) blocks: those rows times l, then transformed in place
+    uint64_t split_small_blocks = 0;
     uint32_t split_dirty = 0;               // groups of split_r1 that may hold non-zero rows
     bool split_ready = false;               // this pattern decodes through the split transform
     bool split_unavailable = false;         // it could not be built on this context (plan shape, memory): the 2k-point transform serves
@@ -131,6 +137,9 @@ void destroy_decode_state(DecodeState* d)
     if (d->transform) fastecc_destroy(d->transform);
     if (d->transform_full) fastecc_destroy(d->transform_full);
     if (d->split) fastecc_destroy(d->split);
+    for (fastecc_ctx* sc : d->split_small)
+        if (sc) fastecc_destroy(sc);
+    if (d->split_small_buf) (void)hipFree(d->split_small_buf);
     for (uint32_t* b : {d->split_order, d->split_rows_data, d->split_rows_parity, d->split_rows_out, d->split_pos_parity, d->split_impulse, d->split_r1, d->split_r2, d->split_r0, d->split_q2, d->split_pos_data_odd,
                         d->split_rows_out_parity})
         if (b) (void)hipFree(b);
@@ -419,6 +428,33 @@ __global__ __launch_bounds__(256) void split_stage_kernel(const uint32_t* __rest
     store_vec<V>(stage + (size_t)(q << fold) * S + col, x);
 }
 
+// split transform, small form: row m of the work stripe = parity block at position m << shift of the parity half (block (m << shift) >> fold of
+// the parity stripe) times l at its codeword position — zero where that block is lost, not in use, or does not exist
+template <int V>
+__global__ __launch_bounds__(256) void split_small_gather_kernel(const uint32_t* __restrict__ parity, uint32_t* __restrict__ work, const uint32_t* __restrict__ fin,
+                                                                 uint32_t S, int shift, int fold, uint32_t parity_blocks, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t m = (uint32_t)(item / col_chunks);
+    const uint32_t h = m << shift, q = h >> fold;
+    const uint32_t f = ((h & ((1u << fold) - 1u)) == 0 && q < parity_blocks) ? as_constant(fin)[2u * h + 1u] : 0u;  // wave-uniform
+    const uint32_t col = (cc * 64u + lane) * V;
+    if (col >= S) return;
+    uint32_t x[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] = 0;
+    if (f != 0) {
+        load_vec<V>(x, parity + (size_t)q * S + col);
+#pragma unroll
+        for (int v = 0; v < V; ++v) x[v] = gf::mul_mont(x[v], f);
+    }
+    store_vec<V>(work + (size_t)m * S + col, x);
+}
+
 // packed[r] = stripe[rows[r]]: the rebuilt blocks side by side, for one copy to the host
 template <int V>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uint32_t* __restrict__ stripe, const uint32_t* __restrict__ rows, uint32_t* __restrict__ packed,
@@ -697,7 +733,24 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     // and the codes with fewer parity blocks: parity block j at position 2 (j << fold) + 1, i.e. block j << fold of the parity half)
     const bool split_layout = !mixed && ci.cosets == 1;
     const bool want_split = ci.decode_split && split_layout && ci.log2k >= 17 && erased_data != 0;
+    uint32_t split_shift = 0;
     if (want_split) {
+        // first choice: the surviving parity blocks at multiples of 2^h of the parity half, the largest h <= 5 that still leaves as many as there are
+        // lost data blocks (2 % of the codeword lost: h = 5) — r~ is then the transform of k >> h rows (see DecodeState::split_shift)
+        uint64_t at_multiple[6] = {};
+        for (uint64_t q = 0; q < ci.user_m; q++) {
+            if (!parity_present[q]) continue;
+            const uint64_t hpos = q << ci.fold;
+            for (int h = 1; h <= 5 && (hpos & ((1ull << h) - 1ull)) == 0; h++) at_multiple[h]++;
+        }
+        for (int h = 5; h >= 1 && split_shift == 0; h--)
+            if (at_multiple[h] >= erased_data && ci.decode_split != 2) split_shift = (uint32_t)h;
+        if (split_shift != 0) {
+            const uint64_t mask = (1ull << split_shift) - 1ull;
+            for (uint64_t q = 0; q < N; q++)
+                if ((q & mask) != 0 && state[2 * q + 1] == HELD) state[2 * q + 1] = (uint8_t)ST_UNUSED;
+            split_groups = 1;  // (non-zero: "this pattern goes through the split transform" for the code below)
+        } else {
         constexpr uint32_t GROUPS = 1024;
         uint32_t held_in[GROUPS] = {};
         for (uint64_t q = 0; q < ci.user_m; q++) held_in[(q << ci.fold) & (GROUPS - 1u)] += parity_present[q] != 0;
@@ -708,6 +761,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
                 for (uint64_t q = q0 + split_groups; q < q0 + GROUPS; q++) state[2 * q + 1] = state[2 * q + 1] == HELD ? (uint8_t)ST_UNUSED : state[2 * q + 1];
         } else {
             split_groups = 0;  // not decodable: refused below
+        }
         }
     }
     if (split_groups != 0 && !srcmap.empty())
@@ -851,10 +905,6 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
                                  &d->split_rows_out_parity})
                 DEC_TRY(hipMalloc((void**)b, N * 4));
             DEC_TRY(hipMemcpy(d->split_order, order.data(), N * 4, hipMemcpyHostToDevice));
-            DEC_TRY(hipMalloc((void**)&d->split_r1, N * ci.words * 4));
-            DEC_TRY(hipMalloc((void**)&d->split_r2, N * ci.words * 4));
-            DEC_TRY(hipMemsetAsync(d->split_r1, 0, N * ci.words * 4, st));
-            d->split_dirty = 0;
             {
                 // the parity half's low levels when few block groups are in use (run_split_decode): what the DIF levels with strides 512 ... 16
                 // make of a 1024-block tile in which block q0 alone is 1 — simulated here exactly as the tile does them, (a, b) -> (a + b,
@@ -889,6 +939,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
             DEC_TRY(hipGetLastError());
             return FASTECC_OK;
         }();
+        if (rc_split == FASTECC_OK) d->split_dirty = 0;
         if (rc_split != FASTECC_OK) {
             // nothing half-built stays behind: a later call either builds all of it or none
             (void)hipGetLastError();
@@ -901,6 +952,41 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
             }
             if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
             d->split_unavailable = true;
+        }
+    }
+    if (split_groups != 0 && d->split) {
+        // the parity half's work buffers, by form.  No memory for them: the 2k-point transform serves this pattern (as for a missing tile shape).
+        hipError_t e = hipSuccess;
+        if (split_shift != 0) {
+            const uint64_t rows = N >> split_shift;
+            if (!d->split_small[split_shift]) {
+                const int rc = create_ntt_ctx(&d->split_small[split_shift], ci.log2k - (int)split_shift, ci.words * 4, ci.device);
+                if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM && rc != FASTECC_E_UNSUPPORTED) return rc;
+                if (rc != FASTECC_OK) e = hipErrorOutOfMemory;
+            }
+            if (e == hipSuccess && d->split_small_blocks < rows) {
+                if (d->split_small_buf) (void)hipFree(d->split_small_buf);
+                d->split_small_buf = nullptr;
+                d->split_small_blocks = 0;
+                e = hipMalloc((void**)&d->split_small_buf, rows * ci.words * 4);
+                if (e == hipSuccess) d->split_small_blocks = rows;
+            }
+        } else if (!d->split_r1 || !d->split_r2) {
+            if (!d->split_r1) e = hipMalloc((void**)&d->split_r1, N * ci.words * 4);
+            if (e == hipSuccess && !d->split_r2) e = hipMalloc((void**)&d->split_r2, N * ci.words * 4);
+            if (e == hipSuccess) e = hipMemsetAsync(d->split_r1, 0, N * ci.words * 4, st);
+            d->split_dirty = 0;
+            if (e != hipSuccess) {
+                for (uint32_t** b : {&d->split_r1, &d->split_r2}) {
+                    if (*b) (void)hipFree(*b);
+                    *b = nullptr;
+                }
+            }
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            split_groups = 0;  // (the pattern's unused parity blocks stay unused: the 2k-point transform reads the same factors)
+            split_shift = 0;
         }
     }
     if (d->standard && d->erased_parity != 0 && !(split_groups != 0 && d->split)) {
@@ -988,14 +1074,15 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
                            (uint32_t)N, with_parity ? d->gout_par : nullptr, with_parity ? d->split_rows_out_parity : nullptr);
         d->split_repair_ready = with_parity;
         DEC_TRY(hipGetLastError());
-        if (d->split_dirty > split_groups) {
+        d->split_shift = split_shift;
+        if (split_shift == 0 && d->split_dirty > split_groups) {
             // rows of groups this pattern does not write any more: group g = blocks g + (t << 10)
             const size_t row = ci.words * 4;
             DEC_TRY(hipMemset2DAsync(d->split_r1 + (size_t)split_groups * ci.words, 1024 * row, 0, (d->split_dirty - split_groups) * row,
                                      split_decode_group_rows(d->split), st));
             d->split_dirty = split_groups;
         }
-        d->split_groups = split_groups;
+        d->split_groups = split_shift == 0 ? split_groups : 0;
         d->split_ready = true;
     }
     DEC_TRY(hipStreamSynchronize(st));
@@ -1132,7 +1219,11 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         host_rows_only = back != 0 && (d->erased_data == 0 || d->host_lost_data.size() == d->erased_data) &&
                          (!rebuild || d->host_lost_parity.size() == d->erased_parity) && back <= (ci.user_k + ci.user_m) / 8;
         // (a repair that copies the whole parity stripe back must have staged all of it)
-        if (!d->sub && d->split_ready && d->standard && d->erased_data != 0 && d->split_groups < 512 && (!rebuild || host_rows_only)) {
+        if (!d->sub && d->split_ready && d->split_shift != 0 && d->standard && d->erased_data != 0 && (!rebuild || host_rows_only)) {
+            // small form: the parity blocks at multiples of 2^shift are all the decoder reads — one strided copy of every 2^shift-th block
+            const size_t pitch = block << d->split_shift;
+            DEC_TRY(hipMemcpy2DAsync(d->parity_dev, pitch, parity, pitch, block, (ci.user_m + (1ull << d->split_shift) - 1) >> d->split_shift, hipMemcpyHostToDevice, st));
+        } else if (!d->sub && d->split_ready && d->split_shift == 0 && d->standard && d->erased_data != 0 && d->split_groups < 512 && (!rebuild || host_rows_only)) {
             DEC_TRY(hipMemcpy2DAsync(d->parity_dev, 1024 * block, parity, 1024 * block, (size_t)d->split_groups * block, ci.user_m / 1024, hipMemcpyHostToDevice, st));
         } else if (d->sub && (!rebuild || host_rows_only)) {
             // few losses: the direct path reads as many parity blocks as data blocks are lost (at most 256 copies of a block)
@@ -1160,6 +1251,18 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         }
     } else {
     bool repaired_in_one_pass = false;
+    // split transform, small form: the rows of the parity half in use (multiples of 2^shift), times l, and their stand-alone DIF — in place
+    auto small_parity_half = [&]() -> int {
+        const uint32_t S0 = (uint32_t)ci.words, rows = (uint32_t)(N >> d->split_shift);
+        const bool w4 = (S0 % 4) == 0 && ((((uintptr_t)dparity | (uintptr_t)d->split_small_buf) & 15u) == 0);
+        const uint32_t chunks = (S0 + (w4 ? 256 : 64) - 1) / (w4 ? 256 : 64);
+        const uint64_t items = (uint64_t)rows * chunks;
+        const dim3 grid((unsigned)((items + 3) / 4));
+        if (w4) hipLaunchKernelGGL(split_small_gather_kernel<4>, grid, dim3(256), 0, st, dparity, d->split_small_buf, d->fin, S0, (int)d->split_shift, ci.fold, (uint32_t)ci.user_m, chunks, items);
+        else    hipLaunchKernelGGL(split_small_gather_kernel<1>, grid, dim3(256), 0, st, dparity, d->split_small_buf, d->fin, S0, (int)d->split_shift, ci.fold, (uint32_t)ci.user_m, chunks, items);
+        DEC_TRY(hipGetLastError());
+        return transform_bitrev(d->split_small[d->split_shift], d->split_small_buf, d->split_small_buf, false, true, S0, st);
+    };
     if (rebuild && d->erased_data != 0 && d->split_ready && d->split_repair_ready) {
         // fastecc_repair through the split transform: the data chain as in fastecc_decode, and a second MID + DIT over the same two halves for
         // x p'(x) at the odd positions — the lost parity blocks, written straight into the parity stripe.  (No room for the extra k-block
@@ -1174,8 +1277,16 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
             const SplitRepair odd{d->split_q2, d->split_pos_data_odd, d->split_rows_out_parity, dpar_out};
             d->split_dirty = std::max(d->split_dirty, d->split_groups);  // (before the launches: a failure half way must not hide written groups)
             void* scope = profile_scope_begin(c, st, "repair_split_transform", (5 * N + (uint64_t)d->split_groups * split_decode_group_rows(d->split)) * block);
-            const int rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered,
-                                            d->split_r1, d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, &odd);
+            int rc;
+            if (d->split_shift != 0) {
+                rc = small_parity_half();
+                if (rc == FASTECC_OK)
+                    rc = run_split_decode(d->split, ddata, nullptr, d->split_rows_data, nullptr, 0, d->split_pos_parity, d->recovered, nullptr, nullptr, d->split_rows_out, ddata,
+                                          nullptr, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, &odd, d->split_small_buf, d->split_shift);
+            } else {
+                rc = run_split_decode(d->split, ddata, dparity, d->split_rows_data, d->split_rows_parity, d->split_groups, d->split_pos_parity, d->recovered,
+                                      d->split_r1, d->split_r2, d->split_rows_out, ddata, d->split_impulse, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, &odd);
+            }
             profile_scope_end(scope);
             if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
             if (rc == FASTECC_OK) repaired_in_one_pass = true;
@@ -1217,6 +1328,17 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         const uint32_t* parity_half = dparity;
         uint32_t parity_half_blocks = (uint32_t)ci.user_m;
         bool staged_ok = true;
+        if (d->split_shift != 0) {
+            // (the gather of the small form reads parity block (h >> fold) for position h itself: no staging stripe for codes with fewer parity blocks)
+            void* scope = profile_scope_begin(c, st, "decode_split_transform", (3 * N + 3 * (N >> d->split_shift)) * block);
+            rc = small_parity_half();
+            if (rc == FASTECC_OK)
+                rc = run_split_decode(d->split, ddata, nullptr, d->split_rows_data, nullptr, 0, d->split_pos_parity, d->recovered, nullptr, nullptr, d->split_rows_out, ddata,
+                                      nullptr, (uint32_t)ci.user_k, (uint32_t)ci.user_m, st, nullptr, d->split_small_buf, d->split_shift);
+            profile_scope_end(scope);
+            scattered = rc == FASTECC_OK;
+            staged_ok = false;  // (done, or unsupported: nothing more to try in this branch)
+        } else
         if (ci.fold > 0 && !d->split_r0 && hipMalloc((void**)&d->split_r0, N * block) != hipSuccess) {
             (void)hipGetLastError();  // no room for the staging stripe: the 2k-point transform below
             d->split_r0 = nullptr;

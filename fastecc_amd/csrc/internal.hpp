@@ -131,7 +131,11 @@ struct SplitRepair {
 int run_split_decode(fastecc_ctx* c, const uint32_t* data, const uint32_t* parity, const uint32_t* data_rows_factor, const uint32_t* parity_rows_factor,
                      uint32_t parity_groups, const uint32_t* parity_pos_factor, uint32_t* q, uint32_t* r1, uint32_t* r2, const uint32_t* out_rows_factor,
                      uint32_t* out, const uint32_t* impulse_table, uint32_t data_blocks, uint32_t parity_blocks, hipStream_t st,
-                     const SplitRepair* odd = nullptr);
+                     const SplitRepair* odd = nullptr, const uint32_t* small_addend = nullptr, uint32_t addend_shift = 0);
+// small_addend != null (1 <= addend_shift <= 5): the parity blocks in use sit at multiples of 2^shift of the parity half only.  The DIF of such a
+// stripe is the DIF of its (k >> shift) non-zero rows with every result block repeated 2^shift times (the last `shift` levels pair a value with a
+// zero under the twiddle 1), so the caller has transformed those rows alone — small_addend, (k >> shift) blocks in that transform's own bit-
+// reversed order — and parity, parity_rows_factor, parity_groups, r1, r2 and impulse_table are not used.
 // data_blocks / parity_blocks: the blocks the two stripes really hold (<= k: zero-extended codes; the rest counts as zero blocks)
 // impulse_table (optional): [IMPULSE_MAX][16][64] words (Montgomery form), entry [t][g][c] = block g + 16 c of a 1024-block tile after the DIF
 // levels with strides 512 ... 16 when block g + 16 t alone was 1 — with at most 16 IMPULSE_MAX parity groups in use those six of the parity

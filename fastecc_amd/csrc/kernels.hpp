@@ -68,6 +68,8 @@ struct TileArgs {
     uint32_t dscale_whole;  // as PassArgs::dscale_whole
     const uint32_t* addend;         // MODE_MID_ADD: a stripe in the position order MID's first half leaves (block p = coefficient bitrev(p))
     const uint32_t* addend_factor;  // ... and its per-position factors (Montgomery form), laid out like dscale
+    uint32_t addend_shift;          // 0..5: block p of the addend is block p >> addend_shift of the buffer (every 2^shift positions share one block:
+                                    // the transform of a stripe that is zero outside the multiples of 2^shift, stored once — decode.hip)
     uint32_t groups;                // > 0: only the first `groups` block groups of the pass are run (MODE_DIF_ROWS: the others are known to be zero)
     uint32_t* keep;                 // MODE_MID_ADD, optional: the tile after MID's first half (before any factor) is also stored here — MODE_MID_UP's input
     uint32_t impulse_rows;          // MODE_DIF_IMPULSE: blocks [impulse_rows, T) of every tile are zero and not read (<= 16 IMPULSE_MAX)

@@ -89,7 +89,7 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         return FASTECC_OK;
     }
     if (!strcmp(name, "decode_split")) {  // (2k,k) codes, from the next fastecc_decode_prepare: see context.hpp
-        if (value < 0 || value > 1) return FASTECC_E_INVAL;
+        if (value < 0 || value > 2) return FASTECC_E_INVAL;  // 2: the split transform in its block-group form only (A/B against the small form)
         c->decode_split = value;
         return FASTECC_OK;
     }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
         const size_t out_block0 = fold ? (size_t)((v.hi << LOGT) >> fold) : block0;
         v.in = make_desc(a.in + origin, window(a.in_rows, block0));
         v.out = make_desc(a.out + (fold ? out_block0 * a.ld + cc * W : origin), window(a.out_rows, out_block0));
-        if constexpr (ADDK) v.add = make_desc(a.addend + origin);
+        if constexpr (ADDK) v.add = make_desc(a.addend + (size_t)((v.hi << LOGT) >> a.addend_shift) * a.ld + cc * W);  // (MID: s = 0, lo = 0)
         if constexpr (MODE == MODE_MID_ADD) v.keep = make_desc((a.keep ? a.keep : a.out) + origin);
         if constexpr (MULTI) {
             v.in_base = a.in + origin;
@@ -525,13 +525,16 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 // arithmetic of the one before (two runs of CHA registers in flight)
                 constexpr int CHA = 8;
                 uint32_t ya[2][CHA];
+                // addend_shift = h > 0: tile block q is block q >> h of the addend buffer — 2^h consecutive registers read the same block (the
+                // repeats are cache hits; HBM sees 1 / 2^h of the stripe).  qb_u and the half-wave's R are multiples of 32 >= 2^h.
                 auto fetch_addend = [&](uint32_t (&y)[CHA], int k0) {
-                    const uint32_t voff = lane_b | v.dead_mask;
-                    uint32_t soff = (qb_u + k0) * row_bytes;
+                    const uint32_t h = a.addend_shift, hmask = (1u << h) - 1u;
+                    const uint32_t voff = (lane_b - ((qb_l - (qb_l >> h)) * a.ld) * 4u) | v.dead_mask;
+                    uint32_t soff = ((qb_u + k0) >> h) * row_bytes;
 #pragma unroll
                     for (int i = 0; i < CHA; ++i) {
                         y[i] = __builtin_amdgcn_raw_buffer_load_b32(v.add, voff, soff, 2);
-                        soff += row_bytes;
+                        soff += (((uint32_t)(k0 + i + 1) & hmask) == 0u) ? row_bytes : 0u;
                         asm volatile("" : "+s"(soff));
                     }
                 };

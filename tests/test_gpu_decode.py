@@ -163,7 +163,7 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
             dp[lost[lost < N]] = 0
             pp[lost[lost >= N] - N] = 0
             results = []
-            for split in (1, 0):
+            for split in (1, 2, 0):  # 1: the small form where the pattern allows it (else block groups), 2: block groups only, 0: one 2k-point transform
                 enc.set_option("decode_split", split)
                 enc.decode_prepare(dp, pp)
                 damaged, dpar = data.clone(), parity.clone()
@@ -175,7 +175,11 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
                 torch.cuda.synchronize()
                 prof = enc.profile_read()
                 enc.profile(False)
-                assert ("decode_split_transform" in prof) == (split == 1) and ("decode_transform_2k" in prof) == (split == 0), prof  # which path ran
+                assert ("decode_split_transform" in prof) == (split != 0) and ("decode_transform_2k" in prof) == (split == 0), prof  # which path ran
+                # the small form runs the parity half as a stand-alone transform of k >> shift rows (register / tile passes of an ntt context)
+                # instead of the first tile over block groups + the low-level tile: tell the two forms apart by the impulse / low-level pass
+                if split == 2:
+                    assert any(name.startswith("tile_dif10") for name in prof), prof
                 results.append(damaged)
                 assert bool((damaged == data).all()), (count, split)
                 # repair from the damaged stripes again: the lost parity blocks come from a second chain over the same two half transforms
@@ -189,12 +193,12 @@ def test_split_transform_matches_the_2k_point_transform(torch_cuda, fe, logn, S)
                 prof = enc.profile_read()
                 enc.profile(False)
                 if (pp == 0).any():
-                    assert ("repair_split_transform" in prof) == (split == 1), prof
+                    assert ("repair_split_transform" in prof) == (split != 0), prof
                 assert bool((damaged2 == data).all()) and bool((dpar2 == parity).all()), (count, split)
-            assert torch.equal(results[0], results[1])
+            assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
         enc.set_option("decode_split", 1)
         with pytest.raises(fe.FastEccError):
-            enc.set_option("decode_split", 2)
+            enc.set_option("decode_split", 3)
 
 
 @pytest.mark.parametrize("count", [3, 200, 5000, 1 << 16])
