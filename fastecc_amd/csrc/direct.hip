@@ -376,25 +376,74 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
 // L_i(y) = (y^N - 1) x_i / (N (y - x_i)), so coef[i][t] = c_t x_i / (y_t - x_i) with c_t = (y_t^N - 1) / N.
 // The `outputs` inversions of a row are one: prefix products are parked in the output row, then unwound.
 // params: [0, CAP) y_t, [CAP, 2 CAP) c_t
+// A row's weights are written and read in runs of 16 — one 64-byte piece of the table per row and run (coef_index), as four 16-byte
+// accesses per lane with the lanes' pieces back to back: a single word per lane and instruction touched a whole 64-byte segment for
+// 4 bytes of it, 15 GB of traffic for a 0.5 GB table (profiles/r03).  Tables of fewer than 16 outputs per row are one short run.
+__device__ __forceinline__ void coef_store_run(uint32_t* coef, uint32_t row, int t0, uint32_t rows, int pad, const uint32_t (&v)[16])
+{
+    uint32_t* p = coef + coef_index(row, (uint32_t)t0, rows, (uint32_t)pad);
+    if (pad >= 16) {
+        uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < pad) p[j] = v[j];
+    }
+}
+__device__ __forceinline__ void coef_load_run(const uint32_t* coef, uint32_t row, int t0, uint32_t rows, int pad, uint32_t (&v)[16])
+{
+    const uint32_t* p = coef + coef_index(row, (uint32_t)t0, rows, (uint32_t)pad);
+    if (pad >= 16) {
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 w = q[j];
+            v[4 * j] = w.x, v[4 * j + 1] = w.y, v[4 * j + 2] = w.z, v[4 * j + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = j < pad ? p[j] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void lagrange_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t wd, uint32_t K, int outputs, int pad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const uint32_t xi = dev_pow(wd, i);
-    auto at = [&](int t) -> uint32_t& { return coef[coef_index(i, (uint32_t)t, K, (uint32_t)pad)]; };
     uint32_t run = 1;
-    for (int t = 0; t < outputs; ++t) {
-        at(t) = run;
-        run = gf::mul(run, gf::sub(params[t], xi));  // never zero: a parity point is not a data point
+    for (int t0 = 0; t0 < pad; t0 += 16) {  // prefix products, parked in the output row
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = 0;
+            if (t0 + j < outputs) {
+                v[j] = run;
+                run = gf::mul(run, gf::sub(params[t0 + j], xi));  // never zero: a parity point is not a data point
+            }
+        }
+        coef_store_run(coef, i, t0, K, pad, v);
     }
     uint32_t inv = dev_pow(run, gf::P - 2u);
-    for (int t = outputs - 1; t >= 0; --t) {
-        const uint32_t d = gf::sub(params[t], xi);
-        const uint32_t invd = gf::mul(inv, at(t));  // 1 / (y_t - x_i)
-        inv = gf::mul(inv, d);
-        at(t) = gf::mul(gf::mul(gf::mul(params[DIRECT_CAP + t], xi), invd), gf::MONT_ONE);
+    for (int t0 = ((pad - 1) / 16) * 16; t0 >= 0; t0 -= 16) {
+        uint32_t v[16];
+        coef_load_run(coef, i, t0, K, pad, v);
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const int t = t0 + j;
+            if (t < outputs) {
+                const uint32_t d = gf::sub(params[t], xi);
+                const uint32_t invd = gf::mul(inv, v[j]);  // 1 / (y_t - x_i)
+                inv = gf::mul(inv, d);
+                v[j] = gf::mul(gf::mul(gf::mul(params[DIRECT_CAP + t], xi), invd), gf::MONT_ONE);
+            } else {
+                v[j] = 0;
+            }
+        }
+        coef_store_run(coef, i, t0, K, pad, v);
     }
-    for (int t = outputs; t < pad; ++t) at(t) = 0;
 }
 
 // Interpolation on the N nodes {x_i : i not lost} + {y_a}: R the lost data rows (points x_r), A as many surviving parity points y_a,
@@ -420,25 +469,39 @@ __global__ __launch_bounds__(256) void interp_coef_kernel(uint32_t* __restrict__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const uint32_t xi = dev_pow(wd, i);
-    auto at = [&](int t) -> uint32_t& { return coef[coef_index(i, (uint32_t)t, rows, (uint32_t)pad)]; };
     uint32_t A = 1, run = 1;
-    for (int t = 0; t < ed; ++t) {
-        A = gf::mul(A, gf::sub(xi, params[DIRECT_CAP + t]));
-        at(t) = run;  // prod_{s < t} (x_i - x_s)
-        run = gf::mul(run, gf::sub(xi, params[t]));
+    for (int t0 = 0; t0 < pad; t0 += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = 0;
+            if (t0 + j < ed) {
+                A = gf::mul(A, gf::sub(xi, params[DIRECT_CAP + t0 + j]));
+                v[j] = run;  // prod_{s < t} (x_i - x_s)
+                run = gf::mul(run, gf::sub(xi, params[t0 + j]));
+            }
+        }
+        coef_store_run(coef, i, t0, rows, pad, v);
     }
-    if (run == 0) {  // x_i is one of the lost points: the row is not a node
-        for (int t = 0; t < pad; ++t) at(t) = 0;
-        return;
-    }
-    const uint32_t base = gf::mul(xi, dev_pow(A, gf::P - 2u));  // x_i / A(x_i)
+    const bool node = run != 0;  // x_i is one of the lost points: the row is not a node, its weights are zero
+    const uint32_t base = node ? gf::mul(xi, dev_pow(A, gf::P - 2u)) : 0u;  // x_i / A(x_i)
     uint32_t suf = 1;
-    for (int r = ed - 1; r >= 0; --r) {
-        const uint32_t v = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + r], base), at(r)), suf);
-        suf = gf::mul(suf, gf::sub(xi, params[r]));
-        at(r) = gf::mul(v, gf::MONT_ONE);
+    for (int t0 = ((pad - 1) / 16) * 16; t0 >= 0; t0 -= 16) {
+        uint32_t v[16];
+        coef_load_run(coef, i, t0, rows, pad, v);
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const int r = t0 + j;
+            if (r < ed && node) {
+                const uint32_t w = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + r], base), v[j]), suf);
+                suf = gf::mul(suf, gf::sub(xi, params[r]));
+                v[j] = gf::mul(w, gf::MONT_ONE);
+            } else {
+                v[j] = 0;
+            }
+        }
+        coef_store_run(coef, i, t0, rows, pad, v);
     }
-    for (int t = ed; t < pad; ++t) at(t) = 0;
 }
 // thread (a, r): the weight of parity node a in lost row r -> coef[K + a][r]
 __global__ __launch_bounds__(256) void interp_node_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t K, uint32_t N, int ed, int pad)

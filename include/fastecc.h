@@ -270,7 +270,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * p = f*l known everywhere, f(e) = p'(e) / l'(e)) and does not implement it; the data-parallel part here is one
  * transform pipeline of size 2N (the encoder's kernels, N = 2^ceil(log2 k)) between a gather and a scale pass — for
  * the codes with n <= 2k and k >= 2^17 as two pipelines of size k, the data half and the few parity blocks a pattern needs
- * (option "decode_split", DESIGN.md section 12).
+ * (option "decode_split", DESIGN.md section 9).
  * Works for every GF(0xFFF00001) code fastecc_create accepts: a code is f on a subset of the (N << e)-th roots of unity
  * (e = 1, or 2 / 3 for n = 4k / 8k); positions that hold none of its blocks count as erased, zero-extended data blocks
  * as known, so exactly n - k losses are tolerated.  Mixed-radix codes (fastecc_create_ex) are decoded the same way on the
@@ -290,7 +290,7 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
  * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.3-3.5 ms, no transform contexts) and decode
  * is one read of the data plus a few parity blocks — 0.4 ms for up to 16 lost blocks of a 2 GiB stripe, 0.7 ms for 64, 2.6 ms for 256 (matrix
- * cores; option "direct_kernel") against 4.3-5.8 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
+ * cores; option "direct_kernel") against 3.8-5.7 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
  * code, and the (2k,k) codes of GF((2^61-1)^2); identical results.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
@@ -367,9 +367,11 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
  *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96 (not for mixed-radix orders above 2^20, whose transform
  *                  path is much dearer: there the option alone decides);
- *   "decode_split" = 0 / 1 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^17 (power-of-two orders), next decode_prepare): the decoder's 2k-point
- *                  transform as two transforms of k points — the data half, and the parity half of which only as many block groups as there
- *                  are lost data blocks are read (7.1 -> 4.6 ms at k = 2^19 x 4 KB); 0 = one transform of 2k points.  Same bits;
+ *   "decode_split" = 0 / 1 / 2 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^17 (power-of-two orders), next decode_prepare): the
+ *                  decoder's 2k-point transform as two transforms of k points — the data half, and of the parity half only the blocks needed: the
+ *                  survivors at multiples of 2^h of that half (largest h <= 5 that leaves as many as there are lost data blocks), whose transform is
+ *                  one of k >> h rows (2 % of the codeword lost: decode 7.1 -> 3.8 ms at k = 2^19 x 4 KB), else the surviving blocks of the first
+ *                  few block groups (what round 3 always did: 2 = that form only); 0 = one transform of 2k points.  Same bits;
  *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),
  *                  2 = MFMA (i8 digits; falls back to 1 where it cannot run).  Same bits either way;
  *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;
