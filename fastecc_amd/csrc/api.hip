@@ -460,10 +460,11 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
 
 int ensure_dbuf(fastecc_ctx* c);
 
-// FASTECC_MEM_HOST_PINNED: the stripe lives in pinned host memory.  Column slabs are independent transforms, so slab
-// h is uploaded (a strided 2-D copy on a copy engine: full link rate from 512-byte rows up), encoded in place in the
-// device staging stripe and downloaded on its own stream while the next slab is still arriving: the two directions of
-// the link and the kernels overlap.  Uploads are chained so that they run one after the other in slab order.
+// FASTECC_MEM_HOST_PINNED: the stripe lives in pinned host memory.  Column slabs are independent transforms, so the call is a
+// three-stage pipeline over the slabs — upload (a strided 2-D copy on a copy engine: full link rate from 512-byte rows up), encode in
+// place in the device staging stripe, download — on THREE streams, one per stage: every direction of the link then has exactly one
+// transfer in flight, in slab order, and the two directions and the kernels overlap.  (One stream per SLAB, as in rounds 1-3, let the
+// runtime map eight streams onto its few hardware queues: the rocprofv3 copy trace showed upload 3 waiting behind downloads 1 and 2.)
 int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
 {
     int rc = ensure_dbuf(c);
@@ -482,21 +483,22 @@ int encode_host_pinned(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, h
     rc = ensure_slab_streams(c);
     if (rc != FASTECC_OK) return rc;
     const uint32_t width = (uint32_t)(c->S / H);
+    hipStream_t s_up = c->slab_stream[0], s_cp = c->slab_stream[1], s_dn = c->slab_stream[2];
     HIP_TRY(hipEventRecord(c->slab_fork, st));
+    for (hipStream_t q : {s_up, s_cp, s_dn}) HIP_TRY(hipStreamWaitEvent(q, c->slab_fork, 0));
     for (int h = 0; h < H; h++) {
-        hipStream_t sh = c->slab_stream[h];
-        HIP_TRY(hipStreamWaitEvent(sh, c->slab_fork, 0));
-        if (h > 0) HIP_TRY(hipStreamWaitEvent(sh, c->slab_first_done[h - 1], 0));  // previous slab's upload
-        HIP_TRY(hipMemcpy2DAsync(c->dbuf + (size_t)h * width, pitch, data + (size_t)h * width, pitch, (size_t)width * 4, c->N,
-                                 hipMemcpyHostToDevice, sh));
-        HIP_TRY(hipEventRecord(c->slab_first_done[h], sh));
-        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF, sh), twiddle_table(c, TW_ENC_DIT, sh), sh, h * width, width);
+        HIP_TRY(hipMemcpy2DAsync(c->dbuf + (size_t)h * width, pitch, data + (size_t)h * width, pitch, (size_t)width * 4, c->N, hipMemcpyHostToDevice, s_up));
+        HIP_TRY(hipEventRecord(c->slab_first_done[h], s_up));
+        HIP_TRY(hipStreamWaitEvent(s_cp, c->slab_first_done[h], 0));
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF, s_cp), twiddle_table(c, TW_ENC_DIT, s_cp), s_cp, h * width, width);
         if (rc != FASTECC_OK) return rc;
-        HIP_TRY(hipMemcpy2DAsync(parity + (size_t)h * width, pitch, c->dbuf + (size_t)h * width, pitch, (size_t)width * 4, c->N,
-                                 hipMemcpyDeviceToHost, sh));
-        HIP_TRY(hipEventRecord(c->slab_done[h], sh));
-        HIP_TRY(hipStreamWaitEvent(st, c->slab_done[h], 0));
+        HIP_TRY(hipEventRecord(c->slab_done[h], s_cp));
+        HIP_TRY(hipStreamWaitEvent(s_dn, c->slab_done[h], 0));
+        HIP_TRY(hipMemcpy2DAsync(parity + (size_t)h * width, pitch, c->dbuf + (size_t)h * width, pitch, (size_t)width * 4, c->N, hipMemcpyDeviceToHost, s_dn));
     }
+    // the call behaves as one operation on `st`: it ends with the last download (which follows everything else)
+    HIP_TRY(hipEventRecord(c->slab_fork, s_dn));
+    HIP_TRY(hipStreamWaitEvent(st, c->slab_fork, 0));
     return FASTECC_OK;
 }
 
