@@ -63,20 +63,34 @@ __device__ __forceinline__ void sym_dft(const Slots& p, const_u32_ptr tab)
     }
 #pragma unroll
     for (int i = 0; i < H2; ++i) vadd<V>(*p[0], *p[0], u[i]);
+    // C and S are symmetric (C_ij = C_ji), so output j reads ROW j of the two tables: H2 consecutive constants each, one wide scalar load.
+    // Large q (13: 72 constants) fetch them row by row, pinned — all rows requested at the top would not fit the SGPRs.
 #pragma unroll
     for (int j = 0; j < H2; ++j) {
+        uint32_t cj[H2], sj[H2];
+#pragma unroll
+        for (int i = 0; i < H2; ++i) cj[i] = tab[j * H2 + i], sj[i] = tab[H2 * H2 + j * H2 + i];
+        if constexpr (Q >= 11) {
+#pragma unroll
+            for (int i = 0; i < H2; ++i) asm volatile("" : "+s"(cj[i]), "+s"(sj[i]));
+        }
         uint32_t a[V], b[V];
-        vmul<V>(b, d[0], tab[H2 * H2 + j]);
+        vmul<V>(b, d[0], sj[0]);
 #pragma unroll
         for (int v = 0; v < V; ++v) a[v] = x0[v];
-        vmadd<V>(a, u[0], tab[j]);
+        vmadd<V>(a, u[0], cj[0]);
 #pragma unroll
         for (int i = 1; i < H2; ++i) {
-            vmadd<V>(a, u[i], tab[i * H2 + j]);
-            vmadd<V>(b, d[i], tab[H2 * H2 + i * H2 + j]);
+            vmadd<V>(a, u[i], cj[i]);
+            vmadd<V>(b, d[i], sj[i]);
         }
         vadd<V>(*p[j + 1], a, b);
         vsub<V>(*p[Q - 1 - j], a, b);
+        if constexpr (Q >= 11) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) asm volatile("" : "+v"((*p[j + 1])[v]), "+v"((*p[Q - 1 - j])[v]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -366,6 +380,7 @@ __global__ __launch_bounds__(64 << (A - RLOG)) __attribute__((amdgpu_waves_per_e
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
     };
     auto load_stripe = [&](uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
+        asm volatile("" : "+s"(stripe));  // (as in store_stripe: one stripe's address arithmetic at a time)
         const __amdgpu_buffer_rsrc_t d = stripe_desc(a.in, stripe, a.in_rows);
         uint32_t soff = first;
 #pragma unroll
@@ -376,6 +391,9 @@ __global__ __launch_bounds__(64 << (A - RLOG)) __attribute__((amdgpu_waves_per_e
         }
     };
     auto store_stripe = [&](const uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
+        // (the stripe number goes through an empty asm: otherwise the address arithmetic of all Q output descriptors is shared with the input
+        //  descriptors', done in the kernel's prologue, and parked in spilled SGPRs until each stripe's stores — 3 spills per stripe)
+        asm volatile("" : "+s"(stripe));
         const __amdgpu_buffer_rsrc_t d = stripe_desc(a.out, stripe, a.out_rows);
         uint32_t soff = first;
 #pragma unroll
