@@ -9,7 +9,8 @@ path, key = sys.argv[1], sys.argv[2]
 s = open(path).read()
 m = re.search(r"^(\S*%s\S*):" % re.escape(key), s, re.M)
 start = m.end()
-body = s[start:s.index("s_endpgm", start)].splitlines()
+end = s.find(".Lfunc_end", start)  # (a kernel may hold several s_endpgm: early exits)
+body = s[start:end if end > 0 else s.index("s_endpgm", start)].splitlines()
 ins = []
 for l in body:
     t = l.strip()
