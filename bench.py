@@ -389,20 +389,25 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps * 1e3
 
+        # (the copies the library itself issues — hipMemcpy2DAsync, here with whole 4 KiB rows — through the runtime torch has loaded.  Both torch's
+        #  copy_ and plain hipMemcpyAsync of the two directions on two streams came out serialised on these boxes, "both at once" no faster
+        #  than one direction, while the pitched copies overlap: 57 GB/s against 97 GB/s on the box of profiles/r04/host_link_and_pipeline.jsonl.)
+        import ctypes
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipMemcpy2DAsync.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+
         def up():
-            with torch.cuda.stream(s_up):
-                scratch.copy_(hx, non_blocking=True)
+            hip.hipMemcpy2DAsync(scratch.data_ptr(), block_bytes, hx.data_ptr(), block_bytes, block_bytes, k, 1, s_up.cuda_stream)  # hipMemcpyHostToDevice
 
         def down():
-            with torch.cuda.stream(s_dn):
-                hp.copy_(ref, non_blocking=True)
+            hip.hipMemcpy2DAsync(hp.data_ptr(), block_bytes, ref.data_ptr(), block_bytes, block_bytes, k, 2, s_dn.cuda_stream)      # hipMemcpyDeviceToHost
 
         nbytes = float(k * block_bytes)
         up_ms, dn_ms = wall(up), wall(down)
         both_ms = wall(lambda: (up(), down()))
         probe = {"h2d_GBps": round(nbytes / up_ms / 1e6, 1), "d2h_GBps": round(nbytes / dn_ms / 1e6, 1),
                  "duplex_GBps": round(2 * nbytes / both_ms / 1e6, 1), "duplex_ms": round(both_ms, 2),
-                 "what": "2 GiB pinned copies on this box in this process: up, down, and both directions at once on two streams (wall clock, 3 each)"}
+                 "what": "2 GiB pinned copies on this box in this process (hipMemcpy2DAsync, whole rows): up, down, and both directions at once on two streams (wall clock, 3 each)"}
         out["host_pinned_end_to_end"] = {"ms": round(hms, 2), "GBps": round(2.0 * k * block_bytes / hms / 1e6, 1), "same_parity_as_the_device_encode": ok,
                                          "link_probe": probe, "frac_of_duplex": round(both_ms / hms, 3),
                                          "what": "fastecc_encode(FASTECC_MEM_HOST_PINNED): 2 GiB of data up and 2 GiB of parity down over the host link "
@@ -1060,8 +1065,11 @@ def main():
         # in a child process: a fault in one of these paths must not cost the line its headline number
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--other-paths-child", "--log2k", str(args.log2k), "--block-bytes", str(args.block_bytes)]
+        # (not this process's OpenMP settings: spinning worker threads — wanted for the CPU baseline above — eat the container's CPU quota, and the
+        #  HIP runtime's own threads then starve: the child's host-link copies ran at 40 instead of 57 GB/s and its pipeline timing jumped 80 <-> 100 ms)
+        child_env = dict(os.environ, OMP_WAIT_POLICY="passive", OMP_NUM_THREADS=str(min(8, usable_cpus())))
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=child_env)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             other_paths_result.update(json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]})
         except Exception as e:  # noqa: BLE001
