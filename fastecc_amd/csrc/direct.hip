@@ -318,8 +318,12 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
 #pragma unroll
                 for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], sw * G * step_bytes, 0);
                 const uint4* wcur = wl[s & 1u];
-                uint4 af[2];
-                af[0] = wcur[lane];
+                // A fragments: PF of them on their way from LDS ahead of the MFMAs that use them — with ONE wave per SIMD (MT = 8) nothing else
+                // runs while this wave sits in an s_waitcnt, and one fragment ahead (two MFMAs = 64 cycles) is about the latency of a ds_read_b128
+                constexpr int PF = 3, RING = 4;
+                uint4 af[RING];
+#pragma unroll
+                for (int t = 0; t < PF && t < G * MT; ++t) af[t] = wcur[t * 64 + lane];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     v4i bf[2];
@@ -334,9 +338,9 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int t = g * MT + mt;
-                        if (t + 1 < G * MT) af[(t + 1) & 1] = wcur[(t + 1) * 64 + lane];  // one fragment ahead of the MFMAs that use it
+                        if (t + PF < G * MT) af[(t + PF) % RING] = wcur[(t + PF) * 64 + lane];
                         v4i av;
-                        av[0] = (int)af[t & 1].x; av[1] = (int)af[t & 1].y; av[2] = (int)af[t & 1].z; av[3] = (int)af[t & 1].w;
+                        av[0] = (int)af[t % RING].x; av[1] = (int)af[t % RING].y; av[2] = (int)af[t % RING].z; av[3] = (int)af[t % RING].w;
                         acc[mt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[0], acc[mt][0], 0, 0, 0);
                         acc[mt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[1], acc[mt][1], 0, 0, 0);
                     }
@@ -686,7 +690,9 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
     uint32_t chunks;
     int pad;
     if (use_mfma) {
-        const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;  // M-tiles per workgroup (measured: profiles/r03/direct_bench.jsonl)
+        // M-tiles per workgroup (measured: profiles/r03/direct_bench.jsonl; round 4: 8 tiles at one wave per SIMD and 4 tiles at two waves per SIMD with
+        // twice the sweeps take the same time — 0.70 / 1.23 / 2.33 ms for 64 / 128 / 256 outputs — so latency is not what holds the kernel at ~45 % of the MFMA rate)
+        const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
         const uint32_t steps_alloc = bulk / 8u + MFMA_G;  // zero steps at the end: the prefetch of a stage never leaves the table
