@@ -285,3 +285,26 @@ def test_p61_oracle_decoder_round_trip():
         damaged = x.copy()
         damaged[dp == 0] = 12345
         assert np.array_equal(o.decode(damaged, par, dp, pp), x)
+
+
+def test_bench_generates_the_splitmix_stripe_window_by_window(oracle):
+    """bench.py's N > 1 line checks the exchanged parity against the reference's hash of the splitmix64(0x1234) stripe; every rank generates its
+    own window of that stripe on its device with 64-bit integer tensor arithmetic (bench.splitmix_window).  It must be the oracle's stripe."""
+    import importlib.util
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    N, S = 96, 40
+    want = oracle.fill_splitmix(N, S, 0x1234)
+    cpu = torch.device("cpu")
+    assert np.array_equal(bench.splitmix_window(cpu, S, 0, N, 0, S).numpy().view(np.uint32), want)
+    assert np.array_equal(bench.splitmix_window(cpu, S, 17, 30, 8, 16).numpy().view(np.uint32), want[17:47, 8:24])
+    assert np.array_equal(bench.splitmix_window(cpu, S, 0, N, 39, 1, seed=0x1234).numpy().view(np.uint32), want[:, 39:40])
