@@ -135,6 +135,11 @@ struct fastecc_ctx {
     uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
     void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
     size_t pinned_bytes = 0;
+    // FASTECC_MEM_HOST results go back to pageable memory through a ring of pinned slots emptied by helper threads (download_pageable, lazy)
+    static constexpr int STAGE_SLOTS = 4;
+    static constexpr size_t STAGE_SLOT_BYTES = (size_t)32 << 20;
+    char* stage_ring = nullptr;
+    hipEvent_t stage_event[STAGE_SLOTS] = {};
 
     int rmax = 5;            // levels per register pass
     int vec = 1;             // words per lane in register passes

@@ -1466,8 +1466,14 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         }
     }
     if (mem_kind == FASTECC_MEM_HOST && !rows_copied) {
-        if (d->erased_data != 0) DEC_TRY(hipMemcpyAsync(data, ddata, data_bytes, hipMemcpyDeviceToHost, st));
-        if (rebuild) DEC_TRY(hipMemcpyAsync(parity_out, d->parity_dev, parity_bytes, hipMemcpyDeviceToHost, st));
+        if (d->erased_data != 0) {
+            const int rc = download_pageable(c, data, ddata, data_bytes, st);
+            if (rc != FASTECC_OK) return rc;
+        }
+        if (rebuild) {
+            const int rc = download_pageable(c, parity_out, d->parity_dev, parity_bytes, st);
+            if (rc != FASTECC_OK) return rc;
+        }
         DEC_TRY(hipStreamSynchronize(st));
     }
     return FASTECC_OK;

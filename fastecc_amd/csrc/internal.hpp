@@ -81,6 +81,8 @@ void set_plan_text(fastecc_ctx* c, const std::string& t);
 int columns_supported(const fastecc_ctx* c);  // fastecc_encode_columns works on this context
 void set_error_detail(const char* what, hipError_t e);
 void set_error_text(const char* text);  // this thread's fastecc_last_error_detail, verbatim (a worker thread's text republished on the caller's)
+// device -> pageable host memory through a ring of pinned slots emptied by helper threads (api.hip); synchronous; c's call lock held by the caller
+int download_pageable(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
 
 // A transform context (GF(0xFFF00001)): DIF over all log2k levels with inverse roots, the block holding coefficient m
 // multiplied by factor[m] (plain representatives, k entries), DIT back with forward roots keeping every 2^fold-th

@@ -203,6 +203,22 @@ def test_host_memory_and_block_pointer_forms(torch_cuda, fe, oracle):
         assert np.array_equal(y, oracle.ntt_fast(x, True))
 
 
+def test_host_memory_results_through_the_staging_ring(torch_cuda, fe, oracle):
+    """Pageable results of 64 MiB and more leave HBM through the pinned ring that helper threads empty (api.hip stage_download): a
+    ragged size (no multiple of a slot, nor of the helpers' pieces), encode and transform, twice on one context (slots reused)."""
+    N, S = 1 << 12, 4099  # 67.2 MB per stripe
+    x = rand_stripe(np.random.default_rng(4242), N, S)
+    want = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        for _ in range(2):
+            out = np.full_like(x, 0xA5A5A5A5)
+            enc.encode_host(x, out)
+            assert np.array_equal(out, want)
+        y = x.copy()
+        enc.ntt(y, inverse=False, mem=fe.MEM_HOST)
+        assert np.array_equal(y, oracle.ntt_fast(x, False))
+
+
 def test_error_codes_on_device(torch_cuda, fe):
     torch = torch_cuda
     with fe.Encoder(16, 8, 16) as enc:
