@@ -20,6 +20,7 @@ FIELD_GF_FFF00001 = 0
 FIELD_GF_P61_SQUARED = 1  # GF((2^61-1)^2), 16-byte elements (re, im): include/fastecc.h
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 CODE_MIXED_RADIX = 1  # fastecc_create_ex flag: transform order q * 2^m, q in {1, 3, 5, 7, 9, 13, 15}
+CODE_MIXED_RADIX_PFA = 4  # ... and the composite q = 21, 35, 39, 45, 63, 65, 91, 105, 117 (prime-factor map)
 CODE_TOP_RADIX2 = 2  # fastecc_create_ex flag (A/B experiment): the top level of a power-of-two transform through the fused odd-radix kernel
 
 OK, E_INVAL, E_NOMEM, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -327,11 +328,15 @@ class ShardedEncoder(Encoder):
         return parity_blocks
 
 
-def mixed_radix_order(k):
+MIXED_RADIX_Q = (1, 3, 5, 7, 9, 13, 15)
+MIXED_RADIX_PFA_Q = MIXED_RADIX_Q + (21, 35, 39, 45, 63, 65, 91, 105, 117)
+
+
+def mixed_radix_order(k, pfa=False):
     """Transform order fastecc_create_ex(..., CODE_MIXED_RADIX) picks for k data blocks: the smallest q * 2^m >= k,
-    q in {1, 3, 5, 7, 9, 13, 15}, 1 <= m <= 19 (None if there is none)."""
+    q in {1, 3, 5, 7, 9, 13, 15} (pfa: CODE_MIXED_RADIX_PFA, also 21 ... 117), 1 <= m <= 19 (None if there is none)."""
     best = None
-    for q in (1, 3, 5, 7, 9, 13, 15):
+    for q in (MIXED_RADIX_PFA_Q if pfa else MIXED_RADIX_Q):
         for m in range(1, 20):
             if (q << m) >= k and (best is None or (q << m) < best):
                 best = q << m

@@ -818,7 +818,7 @@ int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_
 {
     if (!out) return FASTECC_E_INVAL;
     *out = nullptr;
-    if (flags & ~(unsigned)(FASTECC_CODE_MIXED_RADIX | FASTECC_CODE_TOP_RADIX2)) return FASTECC_E_INVAL;
+    if (flags & ~(unsigned)(FASTECC_CODE_MIXED_RADIX | FASTECC_CODE_TOP_RADIX2 | FASTECC_CODE_MIXED_RADIX_PFA)) return FASTECC_E_INVAL;
     if (flags & FASTECC_CODE_TOP_RADIX2) {
         if (flags != FASTECC_CODE_TOP_RADIX2 || field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
         int lg = 0;
@@ -834,18 +834,21 @@ int fastecc_create_ex(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_
         }
         return rc;
     }
-    if (!(flags & FASTECC_CODE_MIXED_RADIX)) return fastecc_create(out, n, k, block_bytes, field, device);
+    if (!(flags & (FASTECC_CODE_MIXED_RADIX | FASTECC_CODE_MIXED_RADIX_PFA))) return fastecc_create(out, n, k, block_bytes, field, device);
     if (field != FASTECC_FIELD_GF_FFF00001) return FASTECC_E_UNSUPPORTED;
     if (k < 1 || n <= k || block_bytes == 0 || (block_bytes % 4) != 0) return FASTECC_E_INVAL;
-    // transform order: the smallest q * 2^m >= k with q in {1, 3, 5, 7, 9, 13, 15}, m >= 1 (NTT.md:43-46: "the next divider of
-    // 0xFFF00000 is only a few percents larger than N itself"); w_(2 q 2^m) must exist: 2^(m+1) | 2^20
+    // transform order: the smallest q * 2^m >= k with q in {1, 3, 5, 7, 9, 13, 15} — with FASTECC_CODE_MIXED_RADIX_PFA also the products
+    // of coprime factors 21 ... 117 —, m >= 1 (NTT.md:43-46: "the next divider of 0xFFF00000 is only a few percents larger than N itself");
+    // w_(2 q 2^m) must exist: 2^(m+1) | 2^20
     uint64_t best = 0;
     int bq = 1, bm = 0;
-    for (int q : {1, 3, 5, 7, 9, 13, 15})
+    for (int q : {1, 3, 5, 7, 9, 13, 15, 21, 35, 39, 45, 63, 65, 91, 105, 117}) {
+        if (q > 15 && !(flags & FASTECC_CODE_MIXED_RADIX_PFA)) break;
         for (int m = 1; m <= 19; m++) {
             const uint64_t N1 = (uint64_t)q << m;
             if (N1 >= k && (best == 0 || N1 < best)) best = N1, bq = q, bm = m;
         }
+    }
     if (best == 0 || n - k > best) return FASTECC_E_UNSUPPORTED;
     if (bq == 1) return fastecc_create(out, n, k, block_bytes, field, device);
     if (block_bytes / 4 > 0xFFFFFFFFull / 2) return FASTECC_E_UNSUPPORTED;

@@ -128,6 +128,14 @@ int fastecc_create(fastecc_ctx **out, uint64_t n, uint64_t k, uint64_t block_byt
  * profiles/r02/mixed_radix_bench.jsonl: faster than zero extension for q <= 9.
  */
 #define FASTECC_CODE_MIXED_RADIX 1u
+/* The same with the composite odd factors of the prime-factor map as well (NTT.md:43-46 "PFA NTT as well as NTT kernels of orders
+ * 3,5,7,9,13"): q in {1, 3, 5, 7, 9, 13, 15, 21, 35, 39, 45, 63, 65, 91, 105, 117}, again the smallest q * 2^m >= k — the next order is
+ * then at most 8.4 % above k (20 % with the seven q of FASTECC_CODE_MIXED_RADIX).  The q-point transforms are prime-factor compositions of
+ * the 3-, 5-, 7-, 9- and 13-point ones, in registers (3 * 7, 5 * 7, 3 * 13, 9 * 5, 9 * 7, 5 * 13, 7 * 13, 15 * 7, 9 * 13: no twiddles
+ * between the two factors).  Three trips through HBM up to m = 10, and for q <= 63 up to m = 13 (q = 63), 14 (35, 39, 45) or 16 (21) (the fused outer tile);
+ * beyond that the odd-radix level has its own two passes.  A different code than FASTECC_CODE_MIXED_RADIX builds whenever the orders differ; the
+ * other 8 odd divisors of 4095 (195 ... 4095: that many blocks per lane do not fit the registers) are not offered. */
+#define FASTECC_CODE_MIXED_RADIX_PFA 4u
 /* A/B experiment (same code, same results as fastecc_create): for n = 2k, k = 2^m >= 2^12 the top level of the transform is handled
  * like an odd radix with q = 2 — fused with the next levels in mixed_kernels.hip's kernel instead of tile_kernels.hip's outer tile. */
 #define FASTECC_CODE_TOP_RADIX2 2u

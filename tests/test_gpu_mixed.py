@@ -120,7 +120,7 @@ def test_every_plan_and_block_pointers(torch_cuda, fe, oracle):
 
 def test_flags_validation(torch_cuda, fe):
     with pytest.raises(fe.FastEccError) as ei:
-        fe.Encoder(8, 4, 64, flags=4)
+        fe.Encoder(8, 4, 64, flags=8)
     assert ei.value.code == fe.E_INVAL
     with pytest.raises(fe.FastEccError) as ei:
         fe.Encoder(2 * 96, 96, 64, field=fe.FIELD_GF_P61_SQUARED, flags=fe.CODE_MIXED_RADIX)

@@ -231,7 +231,7 @@ def test_lagrange_decoder_recovers_what_the_encoder_wrote(oracle):
 # ------------------------------------------------------------------------------------------------
 # mixed-radix orders (NTT.md:43-46): the oracle's transforms of order q * 2^m against the reference
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N", [3, 6, 12, 5, 10, 40, 7, 28, 9, 18, 72, 96, 160, 13, 26, 104, 15, 30, 120])
+@pytest.mark.parametrize("N", [3, 6, 12, 5, 10, 40, 7, 28, 9, 18, 72, 96, 160, 13, 26, 104, 15, 30, 120, 42, 70, 156, 90, 252, 130, 182, 210, 468])
 def test_mixed_radix_transform_matches_the_definition(oracle, N):
     """orc_ntt_mixed (odd factor outermost + radix-2) == the O(N^2) definition orc_slow_ntt, both directions."""
     x = np.random.default_rng(N).integers(0, P, size=(N, 3), dtype=np.uint64).astype(np.uint32)
@@ -240,7 +240,7 @@ def test_mixed_radix_transform_matches_the_definition(oracle, N):
     assert np.array_equal(oracle.encode_mixed(x), oracle.encode_slow(x))
 
 
-@pytest.mark.parametrize("N", [3, 12, 24, 9, 36, 5, 20, 7, 14, 13, 52, 15, 60])
+@pytest.mark.parametrize("N", [3, 12, 24, 9, 36, 5, 20, 7, 14, 13, 52, 15, 60, 42, 70, 78, 90, 126, 130, 182, 210, 234])
 def test_mixed_radix_is_pinned_to_the_reference(oracle, reference, N):
     """Slow_NTT (ntt.cpp:451-483) is the one reference transform that accepts a non-power-of-two order; the encode is the
     RS.cpp:40-63 composition around it.  Both must agree with the oracle's fast mixed-radix path."""
