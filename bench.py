@@ -431,6 +431,20 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
                                                                      "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain))}
     except Exception as e:  # noqa: BLE001
         out["mixed_radix_error"] = repr(e)
+    # --- a composite odd factor of the prime-factor map (21 * 2^(log2k - 5) data blocks: the order the seven plain factors would round up to is 14 % larger)
+    try:
+        kp = 21 << max(log2k - 5, 1)
+        with fastecc_amd.Encoder(2 * kp, kp, block_bytes, device=device.index or 0, flags=fastecc_amd.CODE_MIXED_RADIX_PFA) as pfa:
+            src = data[: kp * S]
+            p_fused, p_plain = torch.empty(kp * S, dtype=torch.int32, device=device), torch.empty(kp * S, dtype=torch.int32, device=device)
+            plan = pfa.plan()
+            ms = event_ms(lambda: pfa.encode(src, p_fused, stream=stream), 10)
+            pfa.set_option("fuse_radix", 0)
+            pfa.encode(src, p_plain, stream=stream)
+            out["encode_mixed_radix_21x2^%d" % max(log2k - 5, 1)] = {"ms": round(ms, 3), "GBps": round(2.0 * kp * block_bytes / ms / 1e6, 1), "plan": plan,
+                                                                      "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain))}
+    except Exception as e:  # noqa: BLE001
+        out["mixed_radix_pfa_error"] = repr(e)
     return out
 
 
