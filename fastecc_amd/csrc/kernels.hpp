@@ -104,6 +104,7 @@ struct FusedArgs {
 // the register run length the fused kernel uses for (q, A levels), 0 if that shape is not instantiated
 int fused_rlog(int q, int levels);
 hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st);
+bool fused_batch_fits(uint64_t ld, uint64_t S, uint64_t rows);  // can the fused kernel address this batch (one descriptor, 32-bit offsets)?
 bool radix_supported(int q);
 std::vector<uint32_t> radix_dft_table(int q, uint32_t wq);  // host: wq = the primitive q-th root of the direction
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st);

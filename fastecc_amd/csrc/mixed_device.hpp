@@ -106,32 +106,61 @@ __device__ __forceinline__ void sym_dft(const Slots& p, const_u32_ptr tab)
 #pragma unroll
     for (int i = 0; i < H2; ++i) vadd<V>(*p[0], *p[0], u[i]);
     // C and S are symmetric (C_ij = C_ji), so output j reads ROW j of the two tables: H2 consecutive constants each, one wide scalar load.
-    // Large q (13: 72 constants) fetch them row by row, pinned — all rows requested at the top would not fit the SGPRs.
+    // Large q (13: 72 constants) fetch them row by row, two rows in flight: the row offset goes through an empty asm, which makes the
+    // address opaque — the loads of row j + 1 can be neither hoisted above that point nor merged with the neighbouring rows' (the compiler
+    // had fused the loads of C rows 0-2 into one early request and parked them in spilled SGPRs: 45 spills for q = 13) — and the set about
+    // to be used is pinned BEFORE the next request (scalar loads return out of order: a wait after a request waits for it too).
+    if constexpr (Q >= 11) {
+        uint32_t cs[2][2 * H2];  // (a third row in flight measured the same and costs 12 SGPRs)
+        auto fetch = [&](uint32_t (&t)[2 * H2], int j) {
+            uint32_t o = (uint32_t)(j * H2);
+            asm volatile("" : "+s"(o));
+            const_u32_ptr row = tab + o;  // (tab[o + i] would be 2 H2 separate loads, each with its own 64-bit address: o + i may wrap in 32 bits)
 #pragma unroll
-    for (int j = 0; j < H2; ++j) {
-        uint32_t cj[H2], sj[H2];
+            for (int i = 0; i < H2; ++i) t[i] = row[i], t[H2 + i] = row[H2 * H2 + i];
+        };
+        fetch(cs[0], 0);
 #pragma unroll
-        for (int i = 0; i < H2; ++i) cj[i] = tab[j * H2 + i], sj[i] = tab[H2 * H2 + j * H2 + i];
-        if constexpr (Q >= 11) {
+        for (int j = 0; j < H2; ++j) {
+            uint32_t(&c)[2 * H2] = cs[j & 1];
 #pragma unroll
-            for (int i = 0; i < H2; ++i) asm volatile("" : "+s"(cj[i]), "+s"(sj[i]));
-        }
-        uint32_t a[V], b[V];
-        vmul<V>(b, d[0], sj[0]);
+            for (int i = 0; i < 2 * H2; ++i) asm volatile("" : "+s"(c[i]));
+            if (j + 1 < H2) fetch(cs[(j + 1) & 1], j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t a[V], b[V];
+            vmul<V>(b, d[0], c[H2]);
 #pragma unroll
-        for (int v = 0; v < V; ++v) a[v] = x0[v];
-        vmadd<V>(a, u[0], cj[0]);
+            for (int v = 0; v < V; ++v) a[v] = x0[v];
+            vmadd<V>(a, u[0], c[0]);
 #pragma unroll
-        for (int i = 1; i < H2; ++i) {
-            vmadd<V>(a, u[i], cj[i]);
-            vmadd<V>(b, d[i], sj[i]);
-        }
-        vadd<V>(*p[j + 1], a, b);
-        vsub<V>(*p[Q - 1 - j], a, b);
-        if constexpr (Q >= 11) {
+            for (int i = 1; i < H2; ++i) {
+                vmadd<V>(a, u[i], c[i]);
+                vmadd<V>(b, d[i], c[H2 + i]);
+            }
+            vadd<V>(*p[j + 1], a, b);
+            vsub<V>(*p[Q - 1 - j], a, b);
 #pragma unroll
             for (int v = 0; v < V; ++v) asm volatile("" : "+v"((*p[j + 1])[v]), "+v"((*p[Q - 1 - j])[v]));
             __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < H2; ++j) {
+            uint32_t cj[H2], sj[H2];
+#pragma unroll
+            for (int i = 0; i < H2; ++i) cj[i] = tab[j * H2 + i], sj[i] = tab[H2 * H2 + j * H2 + i];
+            uint32_t a[V], b[V];
+            vmul<V>(b, d[0], sj[0]);
+#pragma unroll
+            for (int v = 0; v < V; ++v) a[v] = x0[v];
+            vmadd<V>(a, u[0], cj[0]);
+#pragma unroll
+            for (int i = 1; i < H2; ++i) {
+                vmadd<V>(a, u[i], cj[i]);
+                vmadd<V>(b, d[i], sj[i]);
+            }
+            vadd<V>(*p[j + 1], a, b);
+            vsub<V>(*p[Q - 1 - j], a, b);
         }
     }
 }
@@ -223,29 +252,95 @@ __global__ __launch_bounds__(256) void radix_kernel(const RadixArgs a)
     const_u32_ptr dft = as_constant(a.dft);                       // constants of the Q-point transform (radix_dft_table)
 
     uint32_t x[Q][V];
+    if constexpr (Q <= 15) {
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-        const uint32_t row = (uint32_t)i * a.M + i2;
-        if (a.in_rows == 0 || row < a.in_rows) {
-            load_vec<V>(x[i], a.in + (size_t)row * a.ld + col);
-        } else {  // zero-extended data: blocks from in_rows on do not exist
+        for (int i = 0; i < Q; ++i) {
+            const uint32_t row = (uint32_t)i * a.M + i2;
+            if (a.in_rows == 0 || row < a.in_rows) {
+                load_vec<V>(x[i], a.in + (size_t)row * a.ld + col);
+            } else {  // zero-extended data: blocks from in_rows on do not exist
 #pragma unroll
-            for (int v = 0; v < V; ++v) x[i][v] = 0;
+                for (int v = 0; v < V; ++v) x[i][v] = 0;
+            }
         }
-    }
-    if constexpr (DIT) {
+        if constexpr (DIT) {
 #pragma unroll
-        for (int j = 1; j < Q; ++j) vmul<V>(x[j], x[j], tw[j - 1]);
-    }
-    small_dft<Q, V>(x, dft);
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        uint32_t(&y)[V] = x[out_slot<Q>(j)];
-        if constexpr (!DIT) {
-            if (j > 0) vmul<V>(y, y, tw[j - 1]);
+            for (int j = 1; j < Q; ++j) vmul<V>(x[j], x[j], tw[j - 1]);
         }
-        const uint32_t row = (uint32_t)j * a.M + i2;
-        if (a.out_rows == 0 || row < a.out_rows) store_vec<V>(a.out + (size_t)row * a.ld + col, y);
+        small_dft<Q, V>(x, dft);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            uint32_t(&y)[V] = x[out_slot<Q>(j)];
+            if constexpr (!DIT) {
+                if (j > 0) vmul<V>(y, y, tw[j - 1]);
+            }
+            const uint32_t row = (uint32_t)j * a.M + i2;
+            if (a.out_rows == 0 || row < a.out_rows) store_vec<V>(a.out + (size_t)row * a.ld + col, y);
+        }
+    } else {
+        // The composite q (20 ... 116 twiddles, as many row addresses): the word offset of the row is ONE running scalar pinned by an empty
+        // asm (left alone, all Q 64-bit row addresses are formed in the prologue and parked in spilled SGPRs), and the twiddles come in
+        // pieces of at most 16 through an opaque offset, the next piece requested while this one is multiplied in (as in the fused kernel).
+        uint64_t off = (uint64_t)i2 * a.ld;  // wave-uniform: the lane's column is added at the access
+        const uint64_t pitch = (uint64_t)a.M * a.ld;
+        static_for<0, Q>([&](auto I) {
+            const uint32_t row = (uint32_t)I.value * a.M + i2;
+            if (a.in_rows == 0 || row < a.in_rows) {
+                load_vec<V>(x[I.value], a.in + off + col);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[I.value][v] = 0;
+            }
+            off += pitch;
+            asm volatile("" : "+s"(off));
+        });
+        auto twiddles = [&]() {
+            constexpr int NTW = Q - 1, NCH = (NTW + 15) / 16, CH = (NTW + NCH - 1) / NCH;
+            uint32_t t[2][CH];
+            auto fetch = [&](uint32_t (&w)[CH], auto C) {
+                uint32_t o = (uint32_t)(C.value * CH);
+                asm volatile("" : "+s"(o));
+                const_u32_ptr piece = tw + o;
+                static_for<0, CH>([&](auto I) {
+                    if constexpr (C.value * CH + I.value < NTW) w[I.value] = piece[I.value];
+                    else w[I.value] = 0;
+                });
+            };
+            fetch(t[0], std::integral_constant<int, 0>{});
+            static_for<0, NCH>([&](auto C) {
+                constexpr int c = C.value;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) asm volatile("" : "+s"(t[c & 1][i]));
+                if constexpr (c + 1 < NCH) fetch(t[(c + 1) & 1], std::integral_constant<int, c + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, CH>([&](auto I) {
+                    constexpr int idx = c * CH + I.value + 1;  // twiddle of stripe idx (way up) / of output idx (way down)
+                    if constexpr (idx < Q) {
+                        constexpr int slot = DIT ? idx : out_slot<Q>(idx);
+                        vmul<V>(x[slot], x[slot], t[c & 1][I.value]);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) asm volatile("" : "+v"(x[slot][v]));
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if constexpr (DIT) twiddles();
+        small_dft<Q, V>(x, dft);
+        static_for<0, Q>([&](auto I) {
+            uint32_t(&y)[V] = x[I.value];  // (a lambda does not capture a variable it names in asm operands only)
+#pragma unroll
+            for (int v = 0; v < V; ++v) asm volatile("" : "+v"(y[v]));
+        });
+        if constexpr (!DIT) twiddles();
+        off = (uint64_t)i2 * a.ld;
+        asm volatile("" : "+s"(off));
+        static_for<0, Q>([&](auto J) {
+            const uint32_t row = (uint32_t)J.value * a.M + i2;
+            if (a.out_rows == 0 || row < a.out_rows) store_vec<V>(a.out + off + col, x[out_slot<Q>(J.value)]);
+            off += pitch;
+            asm volatile("" : "+s"(off));
+        });
     }
 }
 
@@ -443,49 +538,49 @@ __global__ __launch_bounds__(64 << (A - RLOG)) __attribute__((amdgpu_waves_per_e
         }
     };
 
-    // Addresses: raw buffer ops, one descriptor per stripe (built from wave-uniform values, used for that stripe's R accesses and dropped),
-    // the lane's column in voffset, and the tile row as ONE running scalar byte offset whose updates are pinned by an empty asm — left
-    // alone, the compiler materialises all Q * R row addresses up front (160 SGPRs for q = 5: they spilled to VGPR lanes), and a pinned
-    // POINTER loses its address space (flat_load instead of global_load).  The descriptor of a stripe ends after the last block the batch
-    // really holds (in_rows / out_rows: zero-extended data, truncated parity), so the hardware bounds check replaces the branches.  The
-    // host only plans this kernel when a stripe spans < 2^32 bytes (plan.hip).  Layout of run 0: register j <-> tile row j * G + g;
-    // last run: tile row g * R + j.
+    // Addresses: raw buffer ops through ONE descriptor for the whole batch of q * M blocks (the host plans this kernel only for batches
+    // below 4 GiB: plan.hip), the lane's column in voffset, and the block as ONE running scalar byte offset whose updates are pinned by an
+    // empty asm — left alone, the compiler materialises all Q * R row offsets up front (160 SGPRs for q = 5), and a pinned POINTER loses
+    // its address space (flat_load instead of global_load).  The descriptor ends after the last block the batch really holds (in_rows /
+    // out_rows: zero-extended data, truncated parity), so the hardware bounds check replaces the branches.
+    // (Rounds 2-4 had a descriptor per stripe — a stripe, not the batch, had to stay below 4 GiB; with all Q stripes' loads issued at the
+    //  top, Q descriptors were alive at once: 16-58 SGPRs spilled to VGPR lanes for q = 13, up to 670 for q = 63.  Structured addressing
+    //  (stride = block pitch, block number as index) reaches any batch size with one descriptor as well, but measured 1.2-1.6x slower:
+    //  fused3_dif7 0.97 ms against 0.60.)
+    // Layout of run 0: register j <-> tile row j * G + g; last run: tile row g * R + j.
     constexpr uint32_t G = 1u << (A - RLOG);
-    const uint32_t row_bytes = a.ld * 4u;
     const uint32_t voff = col * 4u;
-    const uint32_t step0 = (G << s) * row_bytes, step_last = row_bytes << s;
-    const uint32_t first0 = (g << s) * row_bytes, first_last = ((g * (uint32_t)R) << s) * row_bytes;  // register 0 of the two layouts
-    auto stripe_desc = [&](const uint32_t* base, uint32_t stripe, uint32_t rows) {
-        const uint32_t first = stripe * a.M + row0;  // batch row of the tile's row 0 in this stripe (q * M < 2^32)
-        // bytes of the stripe from there on that exist: all of it (rows == 0: no bound), or up to batch row `rows`; 32-bit selects only
-        // (a stripe spans < 2^32 bytes), so that no branch splits the kernel's straight-line code
-        const uint32_t live = rows == 0 ? a.M : (first >= rows ? 0u : min(rows - first, a.M));
-        const uint32_t nrec = rows == 0 ? 0xFFFFFFFFu : live * row_bytes;
-        const uint64_t v = reinterpret_cast<uint64_t>(base + (size_t)first * a.ld);
+    const uint32_t step0 = G << s, step_last = 1u << s;                           // in blocks
+    const uint32_t first0 = row0 + (g << s), first_last = row0 + ((g * (uint32_t)R) << s);  // register 0 of the two layouts, inside a stripe
+    auto batch_desc = [&](const uint32_t* base, uint32_t rows) {
+        const uint64_t v = reinterpret_cast<uint64_t>(base);
         const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+        const uint32_t nbytes = rows == 0 ? 0xFFFFFFFFu : rows * (a.ld * 4u);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, __builtin_amdgcn_readfirstlane(nbytes), 0x00020000);
     };
+    const __amdgpu_buffer_rsrc_t d_in = batch_desc(a.in, a.in_rows), d_out = batch_desc(a.out, a.out_rows);
+    const uint32_t row_bytes = a.ld * 4u;
     auto load_stripe = [&](uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
-        asm volatile("" : "+s"(stripe));  // (as in store_stripe: one stripe's address arithmetic at a time)
-        const __amdgpu_buffer_rsrc_t d = stripe_desc(a.in, stripe, a.in_rows);
-        uint32_t soff = first;
+        asm volatile("" : "+s"(stripe));  // (as in store_stripe)
+        uint32_t soff = (stripe * a.M + first) * row_bytes;
+        asm volatile("" : "+s"(soff));
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            y[j][0] = __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 2);  // non-temporal: every word is touched once per pass
-            soff += step;
+            y[j][0] = __builtin_amdgcn_raw_buffer_load_b32(d_in, voff, soff, 2);  // non-temporal: every word is touched once per pass
+            soff += step * row_bytes;
             asm volatile("" : "+s"(soff));
         }
     };
     auto store_stripe = [&](const uint32_t (&y)[R][1], uint32_t stripe, uint32_t first, uint32_t step) {
-        // (the stripe number goes through an empty asm: otherwise the address arithmetic of all Q output descriptors is shared with the input
-        //  descriptors', done in the kernel's prologue, and parked in spilled SGPRs until each stripe's stores — 3 spills per stripe)
+        // (the stripe number goes through an empty asm: otherwise the offsets of all Q stripes' stores are computed in the kernel's prologue
+        //  and parked in spilled SGPRs until each stripe's turn)
         asm volatile("" : "+s"(stripe));
-        const __amdgpu_buffer_rsrc_t d = stripe_desc(a.out, stripe, a.out_rows);
-        uint32_t soff = first;
+        uint32_t soff = (stripe * a.M + first) * row_bytes;
+        asm volatile("" : "+s"(soff));
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            __builtin_amdgcn_raw_buffer_store_b32(y[j][0], d, voff, soff, 2);
-            soff += step;
+            __builtin_amdgcn_raw_buffer_store_b32(y[j][0], d_out, voff, soff, 2);
+            soff += step * row_bytes;
             asm volatile("" : "+s"(soff));
         }
     };

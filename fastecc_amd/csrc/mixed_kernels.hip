@@ -1,13 +1,18 @@
 // mixed_kernels.hip — the odd-radix passes for q in {2, 3, 5, 7, 9, 13, 15}: dispatch, and the host-side constant tables of every q.
+#include <algorithm>
 #include <functional>
 
 #include "mixed_device.hpp"
 
 namespace fastecc {
 
+// The fused kernel reaches the whole batch of `rows` blocks through one buffer descriptor with 32-bit byte offsets.
+bool fused_batch_fits(uint64_t ld, uint64_t S, uint64_t rows) { return rows * std::max(ld, S) * 4ull < 0xFFFF0000ull; }
+
 hipError_t launch_fused(int q, int levels, bool dit, FusedArgs a, hipStream_t st)
 {
     if (fused_rlog(q, levels) == 0 || a.M == 0 || (a.M >> levels) == 0) return hipErrorInvalidValue;
+    if (!fused_batch_fits(a.ld, a.S, (uint64_t)q * a.M)) return hipErrorInvalidValue;
     a.col_chunks = (a.S + 63u) / 64u;
     const uint64_t tiles = (uint64_t)(a.M >> levels) * a.col_chunks;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;

@@ -86,8 +86,8 @@ void build_plans(fastecc_ctx* c)
     const int max_chunk = c->tile_mid > 0 ? 10 : c->rmax;
     const std::vector<int> outer = split_levels(n - mid, max_chunk);
     // mixed radix: one outer chunk and a fused shape for it -> the odd-radix level rides on that pass (3 trips instead of 5)
-    // (the fused kernel addresses a stripe of 2^n blocks through one buffer descriptor: 32-bit offsets)
-    const bool stripe_fits = ((uint64_t)c->N * std::max<uint64_t>(c->ld, c->S) * 4ull) < 0xFFFF0000ull;
+    // (the fused kernel addresses the batch of q * 2^n blocks through one buffer descriptor: 32-bit offsets)
+    const bool stripe_fits = fused_batch_fits(c->ld, c->S, (uint64_t)std::max(c->q, 1) * c->N);
     const int fused_run = (c->q > 1 && c->fuse_radix && outer.size() == 1 && stripe_fits) ? fused_rlog(c->q, outer[0]) : 0;
     int s = n;
     for (int r : outer) {
