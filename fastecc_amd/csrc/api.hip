@@ -522,63 +522,112 @@ int ntt_device(fastecc_ctx* c, uint32_t* data, bool inverse, hipStream_t st)
     return FASTECC_OK;
 }
 
-// Device -> PAGEABLE host memory (what RS.cpp's malloc'ed buffers are).  The runtime's own pageable download stages through pinned memory with
-// one copying host thread: 2 GiB took 89 ms (24 GB/s) on a link that moves them in 37 ms.  Here: the copy engine fills a ring of pinned slots
-// (hipMemcpyAsync on `st`, an event per slot) and a few helper threads empty each slot into the caller's buffer side by side; a slot is
-// refilled once all of them are done with it.  Synchronous (the caller's memory is complete on return).  Any failure to set this up —
-// no pinned memory, no threads — falls back to the plain copy.
-int stage_download(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st)
+// PAGEABLE host memory (what RS.cpp's malloc'ed buffers are) <-> device.  The runtime's own pageable download stages through pinned memory
+// with one copying host thread: 2 GiB took 89 ms (24 GB/s) on a link that moves them in 37 ms.  Here a ring of pinned slots sits between the
+// two: the copy engine fills (or empties) a slot with one hipMemcpy2DAsync on `st`, an event per slot, and a few helper threads move the
+// slot's rows from / to the caller's buffer side by side; a slot is reused once all of them (download) or the copy engine (upload) are done
+// with it.  The transfer is a `rows x width` rectangle on both sides (pitches may differ: a column slab of a stripe), packed in the slots.
+// Synchronous on the host: returns when the caller's memory is complete (download) or every copy is on the stream (upload).  Any failure to
+// set this up — no pinned memory, no threads — falls back to the plain copy.
+struct StageJob {
+    bool to_device;
+    char* host;           // pageable
+    size_t host_pitch;
+    char* dev;
+    size_t dev_pitch;
+    size_t width, rows;   // bytes per row, rows
+};
+
+int stage_plain(const StageJob& j, hipStream_t st)
+{
+    if (j.to_device) HIP_TRY(hipMemcpy2DAsync(j.dev, j.dev_pitch, j.host, j.host_pitch, j.width, j.rows, hipMemcpyHostToDevice, st));
+    else HIP_TRY(hipMemcpy2DAsync(j.host, j.host_pitch, j.dev, j.dev_pitch, j.width, j.rows, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FASTECC_OK;
+}
+
+bool ensure_stage_ring(fastecc_ctx::StageRing& r)
+{
+    constexpr int NSLOT = fastecc_ctx::STAGE_SLOTS;
+    if (r.slots) return true;
+    if (hipHostMalloc((void**)&r.slots, NSLOT * fastecc_ctx::STAGE_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        r.slots = nullptr;
+        return false;
+    }
+    for (int i = 0; i < NSLOT; i++)
+        if (hipEventCreateWithFlags(&r.event[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int k = 0; k < i; k++) (void)hipEventDestroy(r.event[k]), r.event[k] = nullptr;
+            (void)hipHostFree(r.slots);
+            r.slots = nullptr;
+            return false;
+        }
+    return true;
+}
+
+int stage_transfer(fastecc_ctx* c, const StageJob& j, hipStream_t st, int threads = 0)
 {
     constexpr int NSLOT = fastecc_ctx::STAGE_SLOTS;
     constexpr size_t SLOT = fastecc_ctx::STAGE_SLOT_BYTES;
-    auto plain = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return FASTECC_OK;
-    };
-    if (bytes < 2 * SLOT) return plain();
-    if (!c->stage_ring) {
-        if (hipHostMalloc((void**)&c->stage_ring, NSLOT * SLOT, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            c->stage_ring = nullptr;
-            return plain();
-        }
-        for (int i = 0; i < NSLOT; i++)
-            if (hipEventCreateWithFlags(&c->stage_event[i], hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                for (int j = 0; j < i; j++) (void)hipEventDestroy(c->stage_event[j]), c->stage_event[j] = nullptr;
-                (void)hipHostFree(c->stage_ring);
-                c->stage_ring = nullptr;
-                return plain();
-            }
-    }
-    const size_t chunks = (bytes + SLOT - 1) / SLOT;
+    if (j.width == 0 || j.rows == 0) return FASTECC_OK;
+    fastecc_ctx::StageRing& ring = j.to_device ? c->stage_up : c->stage_down;
+    if (j.width * j.rows < 2 * SLOT || j.width > SLOT || !ensure_stage_ring(ring)) return stage_plain(j, st);
+    const size_t chunk_rows = SLOT / j.width, chunks = (j.rows + chunk_rows - 1) / chunk_rows;
     const unsigned hw = std::thread::hardware_concurrency();
-    const int T = (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
+    const int T = threads > 0 ? threads : (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
     std::mutex mu;
     std::condition_variable cv;
-    long issued = -1;                      // chunks [0, issued] have their copy and event on the stream
-    std::vector<int> done(chunks, 0);      // helper threads finished with chunk i
+    long issued = -1;                   // chunks [0, issued] have their copy and event on the stream
+    std::vector<int> done(chunks, 0);   // helper threads finished with chunk i (download: emptied the slot; upload: filled it)
     bool failed = false;
     const int device = c->device;
+    auto rows_of = [&](size_t i) { return std::min(chunk_rows, j.rows - i * chunk_rows); };
+    auto move_rows = [&](size_t i, int t) {  // thread t's share of chunk i between the slot (packed rows) and the caller's buffer
+        const size_t n = rows_of(i), r0 = i * chunk_rows;
+        char* slot = ring.slots + (i % NSLOT) * SLOT;
+        if (j.width == j.host_pitch) {  // contiguous on the host: one piece per thread
+            const size_t bytes = n * j.width, piece = ((bytes / T + 63) / 64) * 64;
+            const size_t lo = std::min(bytes, (size_t)t * piece), hi = std::min(bytes, lo + piece);
+            if (hi > lo) {
+                if (j.to_device) memcpy(slot + lo, j.host + r0 * j.host_pitch + lo, hi - lo);
+                else memcpy(j.host + r0 * j.host_pitch + lo, slot + lo, hi - lo);
+            }
+            return;
+        }
+        const size_t per = (n + T - 1) / T, lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+        if (hi <= lo) return;
+        if (j.to_device) host_copy_rows(slot + lo * j.width, j.width, j.host + (r0 + lo) * j.host_pitch, j.host_pitch, j.width, hi - lo);
+        else host_copy_rows(j.host + (r0 + lo) * j.host_pitch, j.host_pitch, slot + lo * j.width, j.width, j.width, hi - lo);
+    };
     auto worker = [&](int t) {
         (void)hipSetDevice(device);
         for (size_t i = 0; i < chunks; i++) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return issued >= (long)i || failed; });
-                if (failed) return;
-            }
-            const bool ok = hipEventSynchronize(c->stage_event[i % NSLOT]) == hipSuccess;
-            if (ok) {
-                const size_t n = std::min(SLOT, bytes - i * SLOT), piece = ((n / T + 63) / 64) * 64;
-                const size_t lo = std::min(n, (size_t)t * piece), hi = std::min(n, lo + piece);
-                if (hi > lo) memcpy((char*)dst + i * SLOT + lo, c->stage_ring + (i % NSLOT) * SLOT + lo, hi - lo);
+            bool ok = true;
+            if (j.to_device) {
+                // the slot's previous content has left for the device: chunk i - NSLOT of this call, or the tail of the previous call on this ring
+                // (an upload returns with its copies on the stream, not completed)
+                if (i >= (size_t)NSLOT) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return issued >= (long)(i - NSLOT) || failed; });
+                    if (failed) return;
+                }
+                ok = hipEventSynchronize(ring.event[i % NSLOT]) == hipSuccess;
+                if (ok) move_rows(i, t);
+            } else {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return issued >= (long)i || failed; });
+                    if (failed) return;
+                }
+                ok = hipEventSynchronize(ring.event[i % NSLOT]) == hipSuccess;
+                if (ok) move_rows(i, t);
             }
             std::lock_guard<std::mutex> lk(mu);
             if (!ok) failed = true;
             done[i]++;
             cv.notify_all();
+            if (!ok) return;
         }
     };
     std::vector<std::thread> pool;
@@ -591,27 +640,108 @@ int stage_download(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hip
         }
         cv.notify_all();
         for (std::thread& th : pool) th.join();
-        return plain();
+        return stage_plain(j, st);  // (helpers that had started have touched nothing the plain copy does not rewrite)
     }
     hipError_t err = hipSuccess;
     for (size_t i = 0; i < chunks && err == hipSuccess; i++) {
-        if (i >= (size_t)NSLOT) {  // the slot's previous content has been copied out by every helper
+        {
+            // download: the slot's previous content has been copied out by every helper; upload: every helper has filled its share
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return done[i - NSLOT] == T || failed; });
+            if (j.to_device) cv.wait(lk, [&] { return done[i] == T || failed; });
+            else if (i >= (size_t)NSLOT) cv.wait(lk, [&] { return done[i - NSLOT] == T || failed; });
             if (failed) break;
         }
-        const size_t n = std::min(SLOT, bytes - i * SLOT);
-        err = hipMemcpyAsync(c->stage_ring + (i % NSLOT) * SLOT, (const char*)src + i * SLOT, n, hipMemcpyDeviceToHost, st);
-        if (err == hipSuccess) err = hipEventRecord(c->stage_event[i % NSLOT], st);
+        const size_t n = rows_of(i), r0 = i * chunk_rows;
+        char* slot = ring.slots + (i % NSLOT) * SLOT;
+        if (j.to_device) err = hipMemcpy2DAsync(j.dev + r0 * j.dev_pitch, j.dev_pitch, slot, j.width, j.width, n, hipMemcpyHostToDevice, st);
+        else err = hipMemcpy2DAsync(slot, j.width, j.dev + r0 * j.dev_pitch, j.dev_pitch, j.width, n, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipEventRecord(ring.event[i % NSLOT], st);
         std::lock_guard<std::mutex> lk(mu);
         if (err != hipSuccess) failed = true;
         else issued = (long)i;
         cv.notify_all();
     }
     for (std::thread& th : pool) th.join();
-    if (err != hipSuccess) return hip_fail(err, "stage_download");
-    if (failed) return hip_fail(hipErrorUnknown, "stage_download (helper thread)");
+    if (err != hipSuccess) return hip_fail(err, "stage_transfer");
+    if (failed) return hip_fail(hipErrorUnknown, "stage_transfer (helper thread)");
     return FASTECC_OK;
+}
+
+int stage_download(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    // one "row" per slot-sized piece keeps the 2-D copies wide
+    const size_t width = std::min<size_t>(bytes, (size_t)1 << 20);
+    const size_t rows = bytes / width, rest = bytes - rows * width;
+    int rc = stage_transfer(c, StageJob{false, (char*)dst, width, (char*)const_cast<void*>(src), width, width, rows}, st);
+    if (rc == FASTECC_OK && rest) {
+        HIP_TRY(hipMemcpyAsync((char*)dst + rows * width, (const char*)src + rows * width, rest, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return rc;
+}
+
+// FASTECC_MEM_HOST on a code the column-slab pipeline takes (as encode_host_pinned: n = 2k = 2^m, all-tile plan), large stripes: slab h
+// goes up through the staging ring while slab h - 1 comes down through the other one — its own helper threads, driven by one more thread
+// — and the kernels of a slab run in between on a third stream.  Both directions of the link and 2 x T host cores are busy at once:
+// 2 + 2 GiB in 65-100 ms where upload, encode and download one after the other take a steady 81-86 (a 16-CPU quota of an EPYC 9575F
+// shared with other jobs: the twelve copying threads move 8 GiB through the cores in that time, which is what bounds it, not the link) —
+// hence an option ("host_pipeline"), off by default.  Returns FASTECC_E_UNSUPPORTED for what it does
+// not take (the caller then runs the plain sequence).
+int encode_host_pageable(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st)
+{
+    int H = c->host_slabs;
+    while (H > 1 && (c->S % (32u * H)) != 0) H >>= 1;
+    if (H <= 1 || c->stripe_bytes < ((size_t)256 << 20) || !(plan_is_all_tiles(c->encode_plan) && c->encode_plan.size() >= 2)) return FASTECC_E_UNSUPPORTED;
+    const uint32_t width = (uint32_t)(c->S / H);
+    const size_t pitch = (size_t)c->S * 4, wbytes = (size_t)width * 4;
+    if (wbytes * c->N < 2 * fastecc_ctx::STAGE_SLOT_BYTES) return FASTECC_E_UNSUPPORTED;
+    int rc = ensure_dbuf(c);
+    if (rc == FASTECC_OK) rc = ensure_slab_streams(c);
+    if (rc != FASTECC_OK) return rc;
+    if (!ensure_stage_ring(c->stage_up) || !ensure_stage_ring(c->stage_down)) return FASTECC_E_UNSUPPORTED;
+    hipStream_t s_up = c->slab_stream[0], s_cp = c->slab_stream[1], s_dn = c->slab_stream[2];
+    HIP_TRY(hipEventRecord(c->slab_fork, st));
+    for (hipStream_t q : {s_up, s_cp, s_dn}) HIP_TRY(hipStreamWaitEvent(q, c->slab_fork, 0));
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
+    std::thread down;
+    int down_rc = FASTECC_OK;
+    char down_text[256] = "";
+    auto join_down = [&]() -> int {
+        if (down.joinable()) down.join();
+        if (down_rc != FASTECC_OK) set_error_text(down_text);
+        return down_rc;
+    };
+    for (int h = 0; h < H && rc == FASTECC_OK; h++) {
+        rc = stage_transfer(c, StageJob{true, (char*)const_cast<uint32_t*>(data + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_up, T);
+        if (rc != FASTECC_OK) break;
+        hipError_t e = hipEventRecord(c->slab_first_done[h], s_up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_cp, c->slab_first_done[h], 0);
+        if (e != hipSuccess) { rc = hip_fail(e, "encode_host_pageable"); break; }
+        rc = run_passes(c, c->encode_plan, c->dbuf, c->dbuf, twiddle_table(c, TW_ENC_DIF, s_cp), twiddle_table(c, TW_ENC_DIT, s_cp), s_cp, h * width, width);
+        if (rc != FASTECC_OK) break;
+        e = hipEventRecord(c->slab_done[h], s_cp);
+        if (e != hipSuccess) { rc = hip_fail(e, "encode_host_pageable"); break; }
+        rc = join_down();  // slab h - 1 is home; its ring is free for slab h
+        if (rc != FASTECC_OK) break;
+        try {
+            down = std::thread([c, h, width, pitch, wbytes, parity, s_dn, T, &down_rc, &down_text] {
+                (void)hipSetDevice(c->device);
+                hipError_t w = hipStreamWaitEvent(s_dn, c->slab_done[h], 0);
+                down_rc = w != hipSuccess ? hip_fail(w, "encode_host_pageable")
+                                          : stage_transfer(c, StageJob{false, (char*)(parity + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_dn, T);
+                if (down_rc != FASTECC_OK) snprintf(down_text, sizeof down_text, "%s", fastecc_last_error_detail());
+            });
+        } catch (...) {  // no thread: this slab comes down on the calling thread
+            HIP_TRY(hipStreamWaitEvent(s_dn, c->slab_done[h], 0));
+            rc = stage_transfer(c, StageJob{false, (char*)(parity + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_dn, T);
+        }
+    }
+    const int rd = join_down();
+    if (rc == FASTECC_OK) rc = rd;
+    // settle the three streams on every path: the context's buffers are free when the call returns
+    for (hipStream_t q : {s_up, s_cp, s_dn}) (void)hipStreamSynchronize(q);
+    return rc;
 }
 
 int ensure_dbuf(fastecc_ctx* c)
@@ -1304,9 +1434,11 @@ void fastecc_destroy(fastecc_ctx* c)
     for (uint32_t* t : {c->q_tw_dif, c->q_tw_dit, c->q_dft_inv, c->q_dft_fwd, c->mixbuf})
         if (t) (void)hipFree(t);
     if (c->pinned) (void)hipHostFree(c->pinned);
-    if (c->stage_ring) (void)hipHostFree(c->stage_ring);
-    for (hipEvent_t e : c->stage_event)
-        if (e) (void)hipEventDestroy(e);
+    for (fastecc_ctx::StageRing* r : {&c->stage_up, &c->stage_down}) {
+        if (r->slots) (void)hipHostFree(r->slots);
+        for (hipEvent_t e : r->event)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete c;
 }
 
@@ -1334,6 +1466,10 @@ int fastecc_encode(fastecc_ctx* c, const void* data, void* parity, int mem_kind,
     if (mem_kind != FASTECC_MEM_HOST) return FASTECC_E_INVAL;
     if (c->ld != c->S) return FASTECC_E_UNSUPPORTED;  // host stripes are always contiguous
     return with_internal_buffers(c, st, [&]() -> int {
+        if (!c->p61 && c->q <= 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->host_pipeline) {
+            const int rp = encode_host_pageable(c, (const uint32_t*)data, (uint32_t*)parity, st);
+            if (rp != FASTECC_E_UNSUPPORTED) return rp;
+        }
         int rc = ensure_dbuf(c);
         if (rc != FASTECC_OK) return rc;
         const size_t block_bytes = (size_t)c->S * 4;

@@ -137,9 +137,12 @@ struct fastecc_ctx {
     size_t pinned_bytes = 0;
     // FASTECC_MEM_HOST results go back to pageable memory through a ring of pinned slots emptied by helper threads (download_pageable, lazy)
     static constexpr int STAGE_SLOTS = 4;
-    static constexpr size_t STAGE_SLOT_BYTES = (size_t)32 << 20;
-    char* stage_ring = nullptr;
-    hipEvent_t stage_event[STAGE_SLOTS] = {};
+    static constexpr size_t STAGE_SLOT_BYTES = (size_t)16 << 20;
+    struct StageRing {  // pinned slots between pageable host memory and the copy engine, one ring per direction (api.hip stage_transfer)
+        char* slots = nullptr;
+        hipEvent_t event[STAGE_SLOTS] = {};
+    };
+    StageRing stage_up, stage_down;
 
     int rmax = 5;            // levels per register pass
     int vec = 1;             // words per lane in register passes
@@ -149,6 +152,7 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
+    int host_pipeline = 0;   // 1: FASTECC_MEM_HOST encodes of large stripes run the column-slab pipeline through the staging rings (0: upload, encode, download in turn)
     DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
     int encode_direct_max = 160;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 32
     int decode_split = 1;         // (2k,k) codes: 1 = the decoder's transform as two half-size ones (decode.hip, "even / odd split"), 0 = one of size 2k

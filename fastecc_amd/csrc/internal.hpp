@@ -81,6 +81,8 @@ void set_plan_text(fastecc_ctx* c, const std::string& t);
 int columns_supported(const fastecc_ctx* c);  // fastecc_encode_columns works on this context
 void set_error_detail(const char* what, hipError_t e);
 void set_error_text(const char* text);  // this thread's fastecc_last_error_detail, verbatim (a worker thread's text republished on the caller's)
+// host_copy.hip: `rows` pieces of `width` bytes between two pitched host buffers (software prefetch + streaming stores)
+void host_copy_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t width, size_t rows);
 // device -> pageable host memory through a ring of pinned slots emptied by helper threads (api.hip); synchronous; c's call lock held by the caller
 int download_pageable(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
 

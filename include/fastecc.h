@@ -367,7 +367,12 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  HBM layout pad odd block sizes (2052, 4100 bytes) to a multiple of 128 bytes: +50 % throughput.
  *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
  *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
- *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline;
+ *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline (and of the FASTECC_MEM_HOST one);
+ *   "host_pipeline" = 0 / 1 (default 0): 1 = FASTECC_MEM_HOST encodes of (2k,k) stripes of 256 MiB and more move pageable memory through two
+ *                  rings of pinned slots (64 MiB each, allocated at the first such call) served by helper threads, slab h going up while
+ *                  slab h - 1 comes down; 0 = upload, encode, download one after the other (the download still through its ring).  The
+ *                  pipeline is bounded by what the host's cores copy, not by the link: 65-100 ms against a steady 81-86 for 2 + 2 GiB in
+ *                  a 16-CPU share of an EPYC 9575F (profiles/r04/host_pageable_pipeline.jsonl) — worth it on a host with cores to spare;
  *   "encode_direct_max" = 0..256 (default 160): codes with at most this many parity blocks (n - k) are encoded straight from the Lagrange
  *                  basis — one read of the data (0.4 ms up to 16 parity blocks ... 1.4 ms for 128 at k = 2^19 x 4 KB) instead of the transform
  *                  pipeline (2.4 ms); same parity bits.  Rows the matrix-core kernel cannot take (odd length, < 64 words, not 8-byte aligned)

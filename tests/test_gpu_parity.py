@@ -219,6 +219,28 @@ def test_host_memory_results_through_the_staging_ring(torch_cuda, fe, oracle):
         assert np.array_equal(y, oracle.ntt_fast(x, False))
 
 
+def test_host_memory_encode_pipelined_through_both_rings(torch_cuda, fe, oracle):
+    """A 256 MiB stripe in pageable memory: column slab h goes up through one ring of pinned slots while slab h - 1 comes down through the
+    other (api.hip encode_host_pageable).  Same parity as the oracle, as the one-after-the-other sequence (option host_pipeline = 0, the default) and as
+    other slab counts; the data is left alone."""
+    N, S = 1 << 16, 1024
+    x = rand_stripe(np.random.default_rng(99), N, S)
+    keep = x.copy()
+    want = oracle.encode_fast(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.set_option("host_pipeline", 1)
+        for slabs in (8, 2, 4):
+            enc.set_option("host_slabs", slabs)
+            out = np.full_like(x, 0x5A5A5A5A)
+            enc.encode_host(x, out)
+            assert np.array_equal(out, want), slabs
+        enc.set_option("host_pipeline", 0)
+        out = np.full_like(x, 0x5A5A5A5A)
+        enc.encode_host(x, out)
+        assert np.array_equal(out, want)
+    assert np.array_equal(x, keep)
+
+
 def test_error_codes_on_device(torch_cuda, fe):
     torch = torch_cuda
     with fe.Encoder(16, 8, 16) as enc:
