@@ -392,15 +392,29 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     auto row_a = [&](int j) { return (uint32_t)j * G + g; };
     auto row_b = [&](int j) { return g * R + (uint32_t)j; };
     Elem x[R];
+    // Rows of a layout are equidistant: the word offset of the row is ONE running scalar whose updates go through an empty asm — left
+    // alone, the 2 R row addresses (64 bits each) are all formed in the prologue and parked in spilled SGPRs (23-49 spills, round 3).
     auto load = [&](auto row_of) {
+        uint64_t off = (block0 + ((uint64_t)row_of(0) << s)) * row_words;
+        const uint64_t step = ((uint64_t)(row_of(1) - row_of(0)) << s) * row_words;
+        asm volatile("" : "+s"(off));
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            x[j] = load_elem(a.in + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col);
+        for (int j = 0; j < R; ++j) {
+            x[j] = load_elem(a.in + off + 2u * col);
+            off += step;
+            asm volatile("" : "+s"(off));
+        }
     };
     auto store = [&](auto row_of) {
+        uint64_t off = (block0 + ((uint64_t)row_of(0) << s)) * row_words;
+        const uint64_t step = ((uint64_t)(row_of(1) - row_of(0)) << s) * row_words;
+        asm volatile("" : "+s"(off));
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            store_elem(a.out + (block0 + ((uint64_t)row_of(j) << s)) * row_words + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);
+        for (int j = 0; j < R; ++j) {
+            store_elem(a.out + off + 2u * col, CANON ? gf61::canon(x[j]) : x[j]);
+            off += step;
+            asm volatile("" : "+s"(off));
+        }
     };
     // write the registers in one layout, read them back in the other; nobody may still be reading the buffer on entry
     auto exchange_of = [&](auto& v, auto wrow, auto rrow) {
