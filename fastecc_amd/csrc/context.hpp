@@ -133,9 +133,7 @@ struct fastecc_ctx {
     uint32_t* parbuf = nullptr;  // Mu < M: the M computed parity blocks, of which the first Mu are handed out (lazy)
     uint32_t* hostpar = nullptr; // device parity for FASTECC_MEM_HOST encodes with more parity than data blocks (lazy)
     uint32_t* rawbuf = nullptr;  // staging for the raw side of fastecc_pack_blocks / _unpack_blocks on host memory (lazy)
-    void* pinned = nullptr;      // pinned bounce buffer for fastecc_encode_blocks (lazy)
-    size_t pinned_bytes = 0;
-    // FASTECC_MEM_HOST results go back to pageable memory through a ring of pinned slots emptied by helper threads (download_pageable, lazy)
+    // pageable host memory (FASTECC_MEM_HOST results, fastecc_encode_blocks) moves through rings of pinned slots served by helper threads (lazy)
     static constexpr int STAGE_SLOTS = 4;
     static constexpr size_t STAGE_SLOT_BYTES = (size_t)16 << 20;
     struct StageRing {  // pinned slots between pageable host memory and the copy engine, one ring per direction (api.hip stage_transfer)
