@@ -414,6 +414,43 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
                                                  "inside the timed region (wall clock, 3 calls); the regime RS.cpp:25-38 measures.  frac_of_duplex = "
                                                  "the time both copies alone need side by side / the time of the call"}
         del scratch
+        # the drop-in calls themselves, on PAGEABLE memory as RS.cpp:25-33 holds it (malloc'ed buffers; numpy arrays here): the contiguous stripe
+        # (fastecc_encode, FASTECC_MEM_HOST) and the reference's T** table of block pointers, in place (fastecc_encode_blocks)
+        import numpy as np
+        px = hx.numpy().copy()
+        pp = np.empty_like(px)
+        want = ref.cpu().numpy()
+
+        def wall_host(fn, reps=3):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        pms = wall_host(lambda: enc.encode_host(px.reshape(k, S), pp.reshape(k, S)))
+        out["host_pageable_end_to_end"] = {"ms": round(pms, 2), "GBps": round(2.0 * k * block_bytes / pms / 1e6, 1), "same_parity_as_the_device_encode": bool(np.array_equal(pp, want)),
+                                           "what": "fastecc_encode(FASTECC_MEM_HOST) on pageable buffers, synchronous: upload, encode, parity back through a ring of pinned "
+                                                   "slots emptied by helper threads (wall clock, 3 calls)"}
+        table = (ctypes.c_void_p * k)(*(px.ctypes.data + np.arange(k, dtype=np.uint64) * np.uint64(block_bytes)).tolist())
+        keep = px.copy()
+
+        def blocks_once():
+            np.copyto(px, keep)  # (in place: the data is gone after a call; the refill is not timed below)
+
+        times = []
+        for _ in range(3):
+            blocks_once()
+            t0 = time.perf_counter()
+            rc = fastecc_amd.lib().fastecc_encode_blocks(enc._h, table)
+            times.append((time.perf_counter() - t0) * 1e3)
+            if rc != 0:
+                raise RuntimeError("fastecc_encode_blocks rc=%d" % rc)
+        bms = min(times[1:])
+        out["encode_blocks_end_to_end"] = {"ms": round(bms, 2), "GBps": round(2.0 * k * block_bytes / bms / 1e6, 1), "same_parity_as_the_device_encode": bool(np.array_equal(px, want)),
+                                           "what": "fastecc_encode_blocks: the reference's T** form (RS.cpp:31-33), k pointers to 4 KiB blocks in pageable memory, in place; "
+                                                   "blocks gathered / scattered through the staging rings (wall clock, best of 2 after a first call)"}
+        del px, pp, keep, want, table
         del hx, hp, ref
     except Exception as e:  # noqa: BLE001
         out["host_pinned_error"] = repr(e)

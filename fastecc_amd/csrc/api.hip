@@ -602,7 +602,7 @@ int stage_transfer(fastecc_ctx* c, const StageJob& j, hipStream_t st, int thread
     if (j.width * j.rows < 2 * SLOT || j.width > SLOT || !ensure_stage_ring(ring)) return stage_plain(j, st);
     const size_t chunk_rows = SLOT / j.width, chunks = (j.rows + chunk_rows - 1) / chunk_rows;
     const unsigned hw = std::thread::hardware_concurrency();
-    const int T = threads > 0 ? threads : (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
+    const int T = threads > 0 ? threads : c->stage_threads > 0 ? c->stage_threads : (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
     std::mutex mu;
     std::condition_variable cv;
     long issued = -1;                   // chunks [0, issued] have their copy and event on the stream

@@ -150,6 +150,7 @@ struct fastecc_ctx {
     int cache_policy = 15;   // tile kernels: bit 0/1 non-temporal loads/stores in the outer passes, bit 2/3 the same in MID
     int xcd_swizzle = 1;     // tile kernels: 1 = each XCD takes a contiguous run of column chunks, 2 = whole block groups
     int host_slabs = 8;      // column slabs of a FASTECC_MEM_HOST_PINNED encode (upload / kernels / download pipeline)
+    int stage_threads = 0;   // helper threads per staging ring (0: min(6, hardware threads / 4))
     int host_pipeline = 0;   // 1: FASTECC_MEM_HOST encodes of large stripes run the column-slab pipeline through the staging rings (0: upload, encode, download in turn)
     DirectEncode* direct_enc = nullptr;  // n - k <= encode_direct_max: the parity straight from the Lagrange basis (direct.hip), built on first use
     int encode_direct_max = 160;  // ... with the MFMA kernel; stripes it cannot take (odd or misaligned rows) stop at 32

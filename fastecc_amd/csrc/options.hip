@@ -78,6 +78,11 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         c->host_slabs = value;
         return FASTECC_OK;
     }
+    if (!strcmp(name, "stage_threads")) {  // helper threads that move pageable host memory to / from the pinned staging slots (0 = automatic)
+        if (value < 0 || value > 64) return FASTECC_E_INVAL;
+        c->stage_threads = value;
+        return FASTECC_OK;
+    }
     if (!strcmp(name, "host_pipeline")) {  // FASTECC_MEM_HOST encodes of large stripes: column-slab pipeline through the staging rings (1) or upload, encode, download in turn (0)
         if (value < 0 || value > 1) return FASTECC_E_INVAL;
         c->host_pipeline = value;

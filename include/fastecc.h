@@ -370,6 +370,8 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  fastecc_pack_blocks / _unpack_blocks follow the pitch on their packed side; the other entry
  *                  points return FASTECC_E_UNSUPPORTED while a pitch is set;
  *   "host_slabs" = 1 .. 32, a power of two (default 8): column slabs of the FASTECC_MEM_HOST_PINNED pipeline (and of the FASTECC_MEM_HOST one);
+ *   "stage_threads" = 0 .. 64 (default 0 = min(6, hardware threads / 4)): helper threads per staging ring (pageable host memory: FASTECC_MEM_HOST
+ *                  results, fastecc_encode_blocks); 4 to 12 measured the same on a 16-CPU share (profiles/r04/encode_blocks_bench.jsonl);
  *   "host_pipeline" = 0 / 1 (default 0): 1 = FASTECC_MEM_HOST encodes of (2k,k) stripes of 256 MiB and more move pageable memory through two
  *                  rings of pinned slots (64 MiB each, allocated at the first such call) served by helper threads, slab h going up while
  *                  slab h - 1 comes down; 0 = upload, encode, download one after the other (the download still through its ring).  The

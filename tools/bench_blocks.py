@@ -16,7 +16,16 @@ N, S = 1 << log2k, 1024
 x = (np.arange(N * S, dtype=np.uint64) % 0xFFF00001).astype(np.uint32).reshape(N, S)
 want = np.empty_like(x)
 with fe.Encoder(2 * N, N, 4 * S) as enc:
+    if len(sys.argv) > 2:
+        enc.set_option("stage_threads", int(sys.argv[2]))
     enc.encode_host(x, want)
+    ts = []
+    for rep in range(3):
+        out = np.empty_like(x)
+        t0 = time.perf_counter()
+        enc.encode_host(x, out)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"call": "fastecc_encode(FASTECC_MEM_HOST)", "stage_threads": int(sys.argv[2]) if len(sys.argv) > 2 else 0, "ms": [round(t, 1) for t in ts]}), flush=True)
     for layout in ("one_buffer_in_order", "one_buffer_shuffled"):
         ts = []
         for rep in range(3):
