@@ -175,7 +175,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p, u
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(num_records), 0x00020000);
 }
 
-template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1>
+// SZ: what the launcher knows about TileArgs::s — 1: it is zero, 0: it is not, -1: decided in the kernel (a uniform branch between the two
+// versions of the low levels: fine where registers are plentiful; in the 1024-block outer tiles, 32 values per lane under a cap of 64 VGPRs,
+// the allocator parked twelve of the values in scratch memory around that branch).
+template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1, int SZ = -1>
 __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 || SPLIT > 1 ? 8 : 4)) void ntt_tile_kernel(const TileArgs a)
 {
     // NWIN address windows per tile: 1 = one buffer descriptor (blocks span < 2^32 bytes), 2 = WIDE (two descriptors kept in
@@ -516,8 +519,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
             if constexpr (MODE != MODE_MID_UP) exchange(x, lds_a, qa_u, G, lds_b, qb_u, 1);
             if constexpr (DIFK) {
                 if (compute) {
-                    if (s == 0) dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
-                    else        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
+                    if constexpr (SZ == 1)      dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                    else if constexpr (SZ == 0) dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
+                    else if (s == 0)            dif_levels<LOGR, 1, true, L2>(x, a.tw_dif, 0u, 0);
+                    else                        dif_levels<LOGR, 1, false, L2>(x, a.tw_dif, v.lo, s);
                 }
                 if (stores) store_rows(x, v, lane_b, qb_u, 1);
             } else {
@@ -600,8 +605,10 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 }
             }
         } else {
-            if (s == 0) dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
-            else        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
+            if constexpr (SZ == 1)      dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
+            else if constexpr (SZ == 0) dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
+            else if (s == 0)            dit_levels<LOGR, 1, true, L2>(x, a.tw_dit, 0u, 0);
+            else                        dit_levels<LOGR, 1, false, L2>(x, a.tw_dit, v.lo, s);
             exchange(x, lds_b, qb_u, 1, lds_a, qa_u, G);
             dit_levels<LOGR, 1, false>(x, a.tw_dit, off, sl);
             if constexpr (MODE == MODE_DIT_ROWS) {
@@ -658,11 +665,11 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1>
+template <int LOGT, int LOGR, bool PAIR, int MODE, int SPLIT = 1, int NWIN = 1, int SZ = -1>
 static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
-    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, SPLIT, NWIN>;
+    auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, SPLIT, NWIN, SZ>;
     // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
     static bool configured[64] = {};
     int dev = 0;
@@ -703,8 +710,9 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     if (a.wide) {
         // several address windows per tile (blocks spanning up to 2^33 / 2^34 / 2^35 bytes): outer passes of the shapes the plans use
         if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
-            if (a.wide == 2 && mode == MODE_DIF) return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2>(a, st);
-            if (a.wide == 2 && mode == MODE_DIT) return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2>(a, st);
+            // (the two versions of the low levels — s = 0 or not — as two kernels: see SZ)
+            if (a.wide == 2 && mode == MODE_DIF) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 2, 0>(a, st);
+            if (a.wide == 2 && mode == MODE_DIT) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 2, 0>(a, st);
         } else if constexpr (LOGR == 4) {
             // (the split decoder's first and last pass on tiles of several windows: 8 ... 64 KB blocks at k = 2^19)
             if (mode == MODE_DIF_ROWS || mode == MODE_DIT_ROWS) {
@@ -739,12 +747,12 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
     if constexpr (LOGT == 10 && PAIR && LOGR == 5) {
         if (a.split2) {  // 1024-block tiles through a 64 KiB buffer: two workgroups per CU, never persistent
             switch (mode) {
-                case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2>(a, st);
-                case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2>(a, st);
+                case MODE_DIF: return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 1, 0>(a, st);
+                case MODE_DIT: return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 1, 0>(a, st);
                 case MODE_MID_ADD: return launch_one<LOGT, LOGR, PAIR, MODE_MID_ADD, 2>(a, st);
                 case MODE_MID_UP: return launch_one<LOGT, LOGR, PAIR, MODE_MID_UP, 2>(a, st);
                 case MODE_DIF_ROWS: case MODE_DIT_ROWS: return hipErrorInvalidValue;
-                case MODE_DIF_IMPULSE: return a.s == 0 && a.impulse_rows <= 16u * IMPULSE_MAX ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_IMPULSE, 2>(a, st) : hipErrorInvalidValue;
+                case MODE_DIF_IMPULSE: return a.s == 0 && a.impulse_rows <= 16u * IMPULSE_MAX ? launch_one<LOGT, LOGR, PAIR, MODE_DIF_IMPULSE, 2, 1, 1>(a, st) : hipErrorInvalidValue;
                 default:       return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
             }
         }
@@ -760,9 +768,15 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
         if constexpr (ROWS_SHAPE) return launch_one<LOGT, LOGR, PAIR, MODE_DIT_ROWS>(a, st);
         else return hipErrorInvalidValue;
     }
+    // (32 values per lane: the two versions of the low levels as two kernels where the single one spills — see SZ)
+    constexpr bool TWO = LOGR == 5 && ((LOGT == 10 && PAIR) || (LOGT == 9 && !PAIR));
     switch (mode) {
-        case MODE_DIF: return launch_one<LOGT, LOGR, PAIR, MODE_DIF>(a, st);
-        case MODE_DIT: return launch_one<LOGT, LOGR, PAIR, MODE_DIT>(a, st);
+        case MODE_DIF:
+            if constexpr (TWO) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, 1, 1, 0>(a, st);
+            else return launch_one<LOGT, LOGR, PAIR, MODE_DIF>(a, st);
+        case MODE_DIT:
+            if constexpr (TWO) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, 1, 1, 0>(a, st);
+            else return launch_one<LOGT, LOGR, PAIR, MODE_DIT>(a, st);
         default:
             if constexpr (LOGR == 5) return launch_one<LOGT, LOGR, PAIR, MODE_MID>(a, st);
             else return hipErrorInvalidValue;
