@@ -1064,6 +1064,7 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
         else (void)hipGetLastError();
     }
+    c->classic_plan = custom_factor != nullptr;  // the decoder's transform contexts (and the stand-alone transform's): see build_plans
     if (!f61) build_plans(c);
 
     DeviceGuard dg(device);

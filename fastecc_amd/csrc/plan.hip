@@ -64,7 +64,28 @@ void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastec
 
 }  // namespace
 
+static void build_plans_with(fastecc_ctx* c, int tile_mid);
+
+// The default plan (fastecc_set_plan 0) of the plain (2k,k) encoder gives MID fewer levels than it could take: MID is bound by VALU issue,
+// the outer passes by HBM with arithmetic to spare, so at k = 2^19 the split dif10 / mid9 / dit10 runs in 3.33 ms where dif9 / mid10 / dit9
+// takes 3.47 (profiles/r04/plan_sweep_mid_levels.jsonl: k = 2^16 ... 2^19; it needed the 1024-block outer tiles without scratch and the
+// 512-block MID tile at four workgroups per CU).  Contexts the decoder builds (their passes are the split transform's: MID10 between slim
+// outer tiles), other code shapes and explicit plan ids keep MID at `tile_mid` levels; so does any size whose outer chunk has no tile.
 void build_plans(fastecc_ctx* c)
+{
+    const bool plain = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && c->fold == 0 &&
+                       c->cosets == 1 && !c->p61;
+    const int shorter = c->n >= 17 ? 9 : c->n == 16 ? 8 : 0;
+    if (plain && shorter) {
+        build_plans_with(c, shorter);
+        bool tiles = c->encode_plan.size() == 3;
+        for (const Pass& p : c->encode_plan) tiles = tiles && p.tile && p.wide == 0;  // (tiles of several address windows: not measured in this split)
+        if (tiles) return;
+    }
+    build_plans_with(c, c->tile_mid);
+}
+
+static void build_plans_with(fastecc_ctx* c, int tile_mid)
 {
     const int n = c->n;
     c->encode_plan.clear();
@@ -73,7 +94,7 @@ void build_plans(fastecc_ctx* c)
     int mid = std::min(n, c->rmax);
     bool mid_tile = false, mid_pair = false;
     if (c->tile_mid > 0) {
-        const int want = std::min(n, c->tile_mid);
+        const int want = std::min(n, tile_mid);
         if (!tile_fits(c, want, 0)) {
             // blocks too large for 32-bit tile offsets: register passes handle the low levels
         } else if (tile_supported(want, !c->tile_mid_wide) && tile_max_fold(want, !c->tile_mid_wide) >= c->fold) {
@@ -336,6 +357,7 @@ static int apply_plan(fastecc_ctx* c, int plan)
     c->persistent = persistent;
     c->slim_outer = slim;
     c->split2 = split2;
+    c->plan_auto = plan == 0;
     build_plans(c);
     return FASTECC_OK;
 }

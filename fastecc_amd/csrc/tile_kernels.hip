@@ -757,6 +757,10 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             }
         }
     }
+    if constexpr (LOGT == 9 && PAIR && LOGR == 5) {
+        // 512-block MID tiles through a 32 KiB buffer (two column rounds): four workgroups of eight waves per CU instead of two
+        if (a.split2 && mode == MODE_MID) return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);
+    }
     // the split decoder's shapes (tile_split_supported): slim outer pair tiles with per-block factors; the addend MID only as above
     if (mode == MODE_MID_ADD || mode == MODE_MID_UP || mode == MODE_DIF_IMPULSE) return hipErrorInvalidValue;
     constexpr bool ROWS_SHAPE = PAIR && (LOGR == 4 || LOGT == 7);  // the outer tiles of the default plans at k = 2^19, 2^18 (slim) and 2^17

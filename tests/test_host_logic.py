@@ -42,6 +42,13 @@ def parse(text):
 def test_headline_plan_is_three_trips(hip_lib):
     rc, text = describe(hip_lib, 1 << 19, 4096)
     assert rc == 0
+    # the default gives MID one level fewer than it could take (VALU-bound) and the HBM-bound outer passes one more
+    assert parse(text) == [("T32", "dif", 10, 9), ("T32", "mid", 9, 0), ("T32", "dit", 10, 9)], text
+    assert parse(describe(hip_lib, 1 << 18, 4096)[1]) == [("S32", "dif", 9, 9), ("T32", "mid", 9, 0), ("S32", "dit", 9, 9)]
+    assert parse(describe(hip_lib, 1 << 17, 4096)[1]) == [("S32", "dif", 8, 9), ("T32", "mid", 9, 0), ("S32", "dit", 8, 9)]
+    assert parse(describe(hip_lib, 1 << 16, 4096)[1]) == [("S32", "dif", 8, 8), ("T32", "mid", 8, 0), ("S32", "dit", 8, 8)]
+    assert parse(describe(hip_lib, 1 << 15, 4096)[1])[1] == ("T32", "mid", 10, 0)
+    rc, text = describe(hip_lib, 1 << 19, 4096, 3100)  # the plan of rounds 1-4, also what the decoder's contexts run
     assert parse(text) == [("S32", "dif", 9, 10), ("T32", "mid", 10, 0), ("S32", "dit", 9, 10)], text
     rc, text = describe(hip_lib, 1 << 19, 4096, 1100)
     assert parse(text) == [("T32", "dif", 9, 10), ("T32", "mid", 10, 0), ("T32", "dit", 9, 10)], text
@@ -72,7 +79,7 @@ def test_blocks_too_large_for_tiles_use_register_passes(hip_lib):
     rc, text = describe(hip_lib, 64, (1 << 25) + 16)   # 2^31 < span < 2^32: still addressable with 32-bit offsets
     assert rc == 0 and "T64:mid6@0" in text
     rc, text = describe(hip_lib, 1 << 19, 4100)  # 4096 data bytes + the packing word (GF.md:72-104): still 3 tile trips
-    assert rc == 0 and parse(text) == [("S32", "dif", 9, 10), ("T32", "mid", 10, 0), ("S32", "dit", 9, 10)], text
+    assert rc == 0 and parse(text) == [("T32", "dif", 10, 9), ("T32", "mid", 9, 0), ("T32", "dit", 10, 9)], text
     rc, text = describe(hip_lib, 1 << 19, 65536)  # 64 KB blocks (BASELINE config 5's block size)
     assert rc == 0 and "T32:mid10@0" in text and "T32:dif" not in text, text
 
@@ -113,7 +120,8 @@ def test_level_tables_hold_the_reference_roots(hip_lib, oracle, log2k, plan):
 def test_tile_eligibility_follows_the_block_span(hip_lib):
     """32-bit buffer offsets: an outer tile must span < 2^32 bytes, or up to 2^36 with 2 … 16 address windows
     (W forms); beyond that the top levels fall back to register passes with 64-bit addressing."""
-    assert describe(hip_lib, 1 << 19, 4096)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")
+    assert describe(hip_lib, 1 << 19, 4096)[1].startswith("T32:dif10@9,T32:mid9@0,T32:dit10@9")
+    assert describe(hip_lib, 1 << 19, 4096, 3100)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")
     assert describe(hip_lib, 1 << 19, 8192)[1].startswith("SW32:dif9@10,T32:mid10@0,SW32:dit9@10")
     assert describe(hip_lib, 1 << 18, 16384)[1].startswith("SW32:dif8@10,T32:mid10@0,SW32:dit8@10")
     assert describe(hip_lib, 1 << 19, 16384)[1].startswith("SW4x32:dif9@10,T32:mid10@0,SW4x32:dit9@10")
