@@ -66,15 +66,16 @@ void push_chunk(std::vector<Pass>& plan, int mode, int bits, int s, const fastec
 
 static void build_plans_with(fastecc_ctx* c, int tile_mid);
 
-// The default plan (fastecc_set_plan 0) of the plain (2k,k) encoder gives MID fewer levels than it could take: MID is bound by VALU issue,
+// The default plan (fastecc_set_plan 0) of the power-of-two codes gives MID fewer levels than it could take: MID is bound by VALU issue,
 // the outer passes by HBM with arithmetic to spare, so at k = 2^19 the split dif10 / mid9 / dit10 runs in 3.33 ms where dif9 / mid10 / dit9
 // takes 3.47 (profiles/r04/plan_sweep_mid_levels.jsonl: k = 2^16 ... 2^19; it needed the 1024-block outer tiles without scratch and the
 // 512-block MID tile at four workgroups per CU).  Contexts the decoder builds (their passes are the split transform's: MID10 between slim
-// outer tiles), other code shapes and explicit plan ids keep MID at `tile_mid` levels; so does any size whose outer chunk has no tile.
+// outer tiles), the mixed-radix orders and explicit plan ids keep MID at `tile_mid` levels; so does any size whose outer chunk has no tile.
 void build_plans(fastecc_ctx* c)
 {
-    const bool plain = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && c->fold == 0 &&
-                       c->cosets == 1 && !c->p61;
+    // (codes with fewer parity blocks, n = 4k / 8k and zero extension gain as much or more: 2.86 -> 2.62 ms at 2^19 + 2^18, 2.25 -> 2.05 at 2^19 + 2^16,
+    //  2.48 -> 2.22 at 400000 + 100000; the mixed-radix orders do not — their fused outer passes are VALU-bound themselves: 13 x 2^15 3.25 -> 3.87)
+    const bool plain = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && !c->p61;
     const int shorter = c->n >= 17 ? 9 : c->n == 16 ? 8 : 0;
     if (plain && shorter) {
         build_plans_with(c, shorter);
