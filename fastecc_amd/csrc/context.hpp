@@ -145,6 +145,7 @@ struct fastecc_ctx {
     int rmax = 5;            // levels per register pass
     int vec = 1;             // words per lane in register passes
     int tile_mid = 10;       // > 0: LDS-tiled plan, MID covers min(n, tile_mid) levels
+    bool outer64 = false;    // plans 4000+: 9-level outer chunks as 64-word-row tiles with the two-round exchange
     bool plan_auto = true;   // plan id 0: the plain (2k,k) encoder may give MID fewer levels (plan.hip build_plans)
     bool classic_plan = false;  // contexts the decoder builds: MID keeps tile_mid levels (the split transform's shapes)
     bool tile_mid_wide = false;  // MID tile with 64-word rows instead of the 32-word pair form

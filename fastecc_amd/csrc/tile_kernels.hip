@@ -757,6 +757,11 @@ static hipError_t launch_mode(int mode, const TileArgs& a, hipStream_t st)
             }
         }
     }
+    if constexpr (LOGT == 9 && !PAIR && LOGR == 5) {
+        // 512 blocks x 64 words through a 64 KiB buffer (two rounds of 32 columns): 256-byte pieces of a block per request, two workgroups per CU
+        if (a.split2 && mode == MODE_DIF) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIF, 2, 1, 0>(a, st);
+        if (a.split2 && mode == MODE_DIT) return a.s == 0 ? launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 1, 1>(a, st) : launch_one<LOGT, LOGR, PAIR, MODE_DIT, 2, 1, 0>(a, st);
+    }
     if constexpr (LOGT == 9 && PAIR && LOGR == 5) {
         // 512-block MID tiles through a 32 KiB buffer (two column rounds): four workgroups of eight waves per CU instead of two
         if (a.split2 && mode == MODE_MID) return launch_one<LOGT, LOGR, PAIR, MODE_MID, 2>(a, st);

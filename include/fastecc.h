@@ -399,7 +399,9 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  */
 int fastecc_set_option(fastecc_ctx *ctx, const char *name, int value);
 
-/* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md §8. */
+/* Select the kernel plan (0 = default).  Exposed so bench.py can A/B plans; see DESIGN.md §5.  3100 is the split of rounds 1-4 (dif9 / mid10 / dit9
+ * at k = 2^19); the default gives MID one level fewer for the power-of-two codes from k = 2^16 up (3090: dif10 / mid9 / dit10; 4090 at 2^18:
+ * outer tiles of 64-word rows).  Every plan computes the same words. */
 int fastecc_set_plan(fastecc_ctx *ctx, int plan);
 
 /*

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 P = 0xFFF00001
 P61 = (1 << 61) - 1
-PLANS = (0, 51, 52, 54, 42, 34, 1100, 2080, 3100, 1090)
+PLANS = (0, 51, 52, 54, 42, 34, 1100, 2080, 3100, 1090, 3090, 4090)
 
 
 @pytest.fixture(scope="module")

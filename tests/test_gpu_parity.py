@@ -149,7 +149,7 @@ def test_encode_matches_oracle(torch_cuda, fe, oracle, log2n, S):
 
 
 @pytest.mark.parametrize("plan", [11, 14, 21, 22, 24, 31, 32, 34, 41, 42, 44, 51, 52, 54,
-                                  1060, 1061, 1070, 1071, 1080, 1081, 1090, 1091, 1094, 1100, 1104, 1105, 2080, 2090, 2100, 3090, 3100])
+                                  1060, 1061, 1070, 1071, 1080, 1081, 1090, 1091, 1094, 1100, 1104, 1105, 2080, 2090, 2100, 3080, 3090, 3100, 4080, 4090, 4100])
 def test_every_plan_is_bit_exact(torch_cuda, fe, oracle, plan):
     """Register plans (levels-per-pass * 10 + words-per-lane) and LDS-tiled plans (1000 + 10*mid_levels
     + wide flag, fastecc_set_plan): all must give identical parity."""

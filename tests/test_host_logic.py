@@ -44,7 +44,7 @@ def test_headline_plan_is_three_trips(hip_lib):
     assert rc == 0
     # the default gives MID one level fewer than it could take (VALU-bound) and the HBM-bound outer passes one more
     assert parse(text) == [("T32", "dif", 10, 9), ("T32", "mid", 9, 0), ("T32", "dit", 10, 9)], text
-    assert parse(describe(hip_lib, 1 << 18, 4096)[1]) == [("S32", "dif", 9, 9), ("T32", "mid", 9, 0), ("S32", "dit", 9, 9)]
+    assert parse(describe(hip_lib, 1 << 18, 4096)[1]) == [("T64", "dif", 9, 9), ("T32", "mid", 9, 0), ("T64", "dit", 9, 9)]
     assert parse(describe(hip_lib, 1 << 17, 4096)[1]) == [("S32", "dif", 8, 9), ("T32", "mid", 9, 0), ("S32", "dit", 8, 9)]
     assert parse(describe(hip_lib, 1 << 16, 4096)[1]) == [("S32", "dif", 8, 8), ("T32", "mid", 8, 0), ("S32", "dit", 8, 8)]
     assert parse(describe(hip_lib, 1 << 15, 4096)[1])[1] == ("T32", "mid", 10, 0)
@@ -55,7 +55,7 @@ def test_headline_plan_is_three_trips(hip_lib):
 
 
 @pytest.mark.parametrize("log2k", range(1, 20))
-@pytest.mark.parametrize("plan", [0, 31, 54, 1060, 1081, 1090, 1100, 2080, 2100])
+@pytest.mark.parametrize("plan", [0, 31, 54, 1060, 1081, 1090, 1100, 2080, 2100, 3090, 3100, 4090, 4100])
 def test_every_plan_covers_every_level_once(hip_lib, log2k, plan):
     rc, text = describe(hip_lib, 1 << log2k, 4096, plan)
     assert rc == 0, (log2k, plan)
