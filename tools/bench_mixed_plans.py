@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Mixed-radix orders q * 2^m x 4 KB under the default plan (MID10 between the fused outer passes) and with a shorter MID (plans 3090, 3080):
+ms per encode, plan text, same parity.  The shorter MID loses here — the fused outer passes carry the odd-radix transform and are VALU-bound."""
 import json, os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch
