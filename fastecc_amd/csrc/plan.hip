@@ -81,8 +81,9 @@ void build_plans(fastecc_ctx* c)
     if (plain && shorter) {
         // k = 2^18: both outer chunks have 9 levels, the shape that exists with 64-word rows (256-byte pieces of a block per request:
         // 0.435 ms per pass against 0.47 with 32-word rows; plan 4090) — at 2^19 the outer chunks need 10 levels, which only the 32-word tile has
+        // (only 9-level chunks are affected: the encoder's at 2^18, the stand-alone transform's second chunk at 2^19)
         const bool outer64 = c->outer64;
-        if (c->n == 18) c->outer64 = true;
+        c->outer64 = true;
         build_plans_with(c, shorter);
         c->outer64 = outer64;
         bool tiles = c->encode_plan.size() == 3;

@@ -367,6 +367,41 @@ def test_large_n_with_ragged_blocks(torch_cuda, fe, oracle, log2n, S):
     assert bool((guard == 0x5A5A5A5A).all())
 
 
+@pytest.mark.parametrize("k,m,S", [(1 << 18, 1 << 16, 6), (1 << 18, (1 << 17) + 3, 33), (200000, 50000, 5), (1 << 19, 1 << 17, 3), (400000, 100000, 4),
+                                   (1 << 17, 1 << 14, 40), (1 << 16, 1 << 15, 64), (1 << 17, 3 << 17, 9)])
+def test_default_plans_of_large_codes_with_other_shapes(torch_cuda, fe, oracle, k, m, S):
+    """The shorter MID and the 64-word-row outer tiles are the default from k = 2^16 up for every power-of-two code shape: fewer parity blocks
+    (the compact parity stripe of the passes above MID), zero extension (loads bounded by the descriptor), n = 4k (cosets), ragged rows."""
+    torch = torch_cuda
+    x = rand_stripe(np.random.default_rng(k % 1000 + m % 100 + S), k, S)
+    lg = int(np.ceil(np.log2(k)))
+    N = 1 << lg
+    padded = np.zeros((N, S), dtype=np.uint32)
+    padded[:k] = x
+    if m > N:  # n = 4k: the cosets w_2k, w_4k, w_4k^3 of the data points (k = N here): RS.cpp:40-63 with the coset's generator for root(2N)
+        coef = oracle.ntt_fast(x, inverse=True)
+        gens = [oracle.gf_root(2 * N)] + [oracle.gf_pow(oracle.gf_root(4 * N), c) for c in (1, 3)]
+        want = np.concatenate([oracle.ntt_fast(oracle.scale_blocks(coef, oracle.gf_inv(N), g)) for g in gens])
+    else:
+        fold = min(lg - (int(np.ceil(np.log2(m))) if m > 1 else 0), 4)
+        want = oracle.encode_fast(padded)[:: 1 << fold][:m]
+    d = to_dev(torch, x)
+    out = torch.full((m * S,), 0x66666666, dtype=torch.int32, device="cuda:0")
+    with fe.Encoder(k + m, k, 4 * S) as enc:
+        plan = enc.plan()
+        assert "mid9@0" in plan or "mid8@0" in plan, plan
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        got = to_host(out).reshape(m, S)
+        enc.set_plan(3100)
+        out2 = torch.empty_like(out)
+        enc.encode(d, out2)
+        torch.cuda.synchronize()
+        assert np.array_equal(got, to_host(out2).reshape(m, S)), (plan, enc.plan())
+    assert np.array_equal(got, want), plan
+    assert np.array_equal(to_host(d).reshape(k, S), x)
+
+
 def _big_block_case(torch, fe, oracle, N, S, expect_tiles):
     g = torch.Generator(device="cuda:0")
     g.manual_seed(7)
