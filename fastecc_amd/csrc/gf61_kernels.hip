@@ -585,8 +585,11 @@ struct Pass {
 // Tile shapes that are instantiated: 6 levels = 8 elements per lane, runs of 3 + 3 levels (8 waves, 64 KiB; no root of
 // order 16 inside a run, i.e. no general product besides the collected twiddles); 7 levels = 16 elements per lane, runs
 // of 4 + 3 (8 waves, 128 KiB or 2 x 64 KiB with the split exchange).
-constexpr int tile_logr(int levels) { return levels == 6 ? 3 : 4; }
+// MID alone also as 5 levels (runs of 3 + 2, 4 waves, 32 KiB): MID is the VALU-bound pass (12 levels + the factors at 6) while the outer
+// passes move the stripe at 5.5 TB/s with arithmetic to spare, so k = 2^19 runs dif7, dif7, mid5, dit7, dit7 rather than dif7, dif6, mid6, ...
+constexpr int tile_logr(int levels) { return levels <= 6 ? 3 : 4; }
 bool tile_shape(int levels) { return levels == 6 || levels == 7; }
+bool tile_shape_mid(int levels) { return levels == 5 || tile_shape(levels); }
 
 template <int LOGT, int MODE, bool CANON, int SPLIT, bool INV>
 hipError_t launch_tile_one(const PassArgs& a, unsigned tiles, hipStream_t st)
@@ -665,7 +668,7 @@ Chunking choose_chunks(int n, int L, bool tiles, int force_mid = 0)
 {
     Chunking best;
     auto consider = [&](int mid, const std::vector<int>& outer) {
-        int trips = (tiles && tile_shape(mid)) ? 1 : reg_passes(mid, L), reg = (tiles && tile_shape(mid)) ? 0 : 1;
+        int trips = (tiles && tile_shape_mid(mid)) ? 1 : reg_passes(mid, L), reg = (tiles && tile_shape_mid(mid)) ? 0 : 1;
         for (int c : outer) {
             const bool t = tiles && tile_shape(c);
             trips += 2 * (t ? 1 : reg_passes(c, L));
@@ -700,7 +703,7 @@ Chunking choose_chunks(int n, int L, bool tiles, int force_mid = 0)
 
 void push_chunk(std::vector<Pass>& plan, int mode, int levels, int s, int L, bool tiles)
 {
-    if (tiles && tile_shape(levels) && (mode == MODE_MID || s >= 1)) {
+    if (tiles && (mode == MODE_MID ? tile_shape_mid(levels) : tile_shape(levels) && s >= 1)) {
         Pass q{mode, levels, s, false};
         q.tile = true;
         plan.push_back(q);
@@ -733,7 +736,7 @@ void build_plans(Path* p)
     // a register MID pass covers at most L levels: the rest of a longer MID chunk becomes DIF / DIT passes around it
     int mid = ch.mid;
     std::vector<int> outer = ch.outer;
-    if (!(p->tiles && tile_shape(mid)) && mid > L) {
+    if (!(p->tiles && tile_shape_mid(mid)) && mid > L) {
         outer.push_back(mid - L);
         mid = L;
     }
@@ -935,7 +938,11 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         Scope sc(hooks, st, name, 2ull * p->N * width * 16ull);
         hipError_t e;
         if (q.tile) {
-            if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
+            if (q.logr == 5) {  // MID only (tile_shape_mid)
+                if (mode != MODE_MID) return FASTECC_E_UNSUPPORTED;
+                if (p->split == 2) e = q.canon ? launch_tile_one<5, MODE_MID, true, 2, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 2, true>(a, (unsigned)blocks, st);
+                else e = q.canon ? launch_tile_one<5, MODE_MID, true, 1, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 1, true>(a, (unsigned)blocks, st);
+            } else if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             else if (q.logr == 6) e = launch_tile_mode<6, 1>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             else if (p->split == 2) e = launch_tile_mode<7, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             else e = launch_tile_mode<7, 1>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
