@@ -606,7 +606,12 @@ int stage_transfer(fastecc_ctx* c, const StageJob& j, hipStream_t st, int thread
     std::mutex mu;
     std::condition_variable cv;
     long issued = -1;                   // chunks [0, issued] have their copy and event on the stream
-    std::vector<int> done(chunks, 0);   // helper threads finished with chunk i (download: emptied the slot; upload: filled it)
+    std::vector<int> done;              // helper threads finished with chunk i (download: emptied the slot; upload: filled it)
+    try {
+        done.assign(chunks, 0);
+    } catch (const std::bad_alloc&) {
+        return stage_plain(j, st);
+    }
     bool failed = false;
     const int device = c->device;
     auto rows_of = [&](size_t i) { return std::min(chunk_rows, j.rows - i * chunk_rows); };
