@@ -1577,11 +1577,18 @@ int fastecc_encode_blocks(fastecc_ctx* c, void* const* blocks)
     // between the caller's table of pointers and pinned slots that the copy engine moves): 2 + 2 GiB in ~85 ms.  (Rounds 1-4: one thread
     // and one synchronous copy per 64 MiB, 325-365 ms.)
     const size_t bb = (size_t)c->S * 4;
-    rc = stage_transfer(c, StageJob{true, nullptr, 0, (char*)c->dbuf, bb, bb, (size_t)c->K, blocks}, nullptr);
+    // RS.cpp's own table points into ONE buffer, block after block (RS.cpp:31-33): then the stripe goes up as one copy, like FASTECC_MEM_HOST
+    // (the runtime's pageable upload runs at the link rate; it is its download that needs the ring)
+    bool one_buffer = true;
+    for (uint64_t i = 1; i < c->K && one_buffer; i++) one_buffer = (const char*)blocks[i] == (const char*)blocks[i - 1] + bb;
+    if (one_buffer) HIP_TRY(hipMemcpyAsync(c->dbuf, blocks[0], c->K * bb, hipMemcpyHostToDevice, nullptr));
+    else rc = stage_transfer(c, StageJob{true, nullptr, 0, (char*)c->dbuf, bb, bb, (size_t)c->K, blocks}, nullptr);
     if (rc != FASTECC_OK) return rc;
     rc = encode_device(c, c->dbuf, c->dbuf, nullptr);
     if (rc != FASTECC_OK) return rc;
-    rc = stage_transfer(c, StageJob{false, nullptr, 0, (char*)c->dbuf, bb, bb, (size_t)c->Mu, blocks}, nullptr);  // the first n - k blocks receive the parity
+    // the first n - k blocks receive the parity
+    if (one_buffer) rc = stage_download(c, blocks[0], c->dbuf, c->Mu * bb, nullptr);
+    else rc = stage_transfer(c, StageJob{false, nullptr, 0, (char*)c->dbuf, bb, bb, (size_t)c->Mu, blocks}, nullptr);
     if (rc != FASTECC_OK) return rc;
     return mark_internal_buffers(c, nullptr);
 }

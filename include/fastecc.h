@@ -239,8 +239,9 @@ int fastecc_encode_batch(fastecc_ctx *ctx, const void *data, void *parity, uint6
  * (T** data of RS.cpp:31-33 / ntt.cpp:348-350).  On return blocks[j] holds parity block j (the
  * pointer array itself is left untouched, which is also what two MFA_NTT calls leave behind,
  * SURVEY.md §8 a1).  Synchronous.  The blocks travel through rings of pinned slots that helper threads fill from / empty into
- * the caller's blocks while the copy engine moves the previous slot: k = 2^19 blocks of 4 KB (2 GiB up, 2 GiB down) in 88-100 ms =
- * 45-49 GB/s of data + parity (profiles/r04/encode_blocks_bench.jsonl).
+ * the caller's blocks while the copy engine moves the previous slot: k = 2^19 blocks of 4 KB (2 GiB up, 2 GiB down) in 88-110 ms =
+ * 39-49 GB/s of data + parity; a table that points into one buffer, block after block (RS.cpp's own), goes up as one copy: 82-88 ms
+ * (profiles/r04/encode_blocks_bench.jsonl).
  */
 int fastecc_encode_blocks(fastecc_ctx *ctx, void *const *blocks);
 
