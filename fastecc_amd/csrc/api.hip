@@ -1176,6 +1176,10 @@ int columns_supported(const fastecc_ctx* c)
     return !c->sharded && c->q == 1 && c->fold == 0 && c->cosets == 1 && c->K == c->N && c->Mu == c->M && c->slabs <= 1;
 }
 int download_pageable(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) { return stage_download(c, dst, src, bytes, st); }
+int stage_rect(fastecc_ctx* c, bool to_device, void* host, size_t host_pitch, void* dev, size_t dev_pitch, size_t width, size_t rows, hipStream_t st, int threads)
+{
+    return stage_transfer(c, StageJob{to_device, (char*)host, host_pitch, (char*)dev, dev_pitch, width, rows}, st, threads);
+}
 void set_error_detail(const char* what, hipError_t e) { (void)hip_fail(e, what); }
 void set_error_text(const char* text) { snprintf(g_detail, sizeof g_detail, "%s", text ? text : ""); }
 

@@ -83,6 +83,9 @@ void set_error_detail(const char* what, hipError_t e);
 void set_error_text(const char* text);  // this thread's fastecc_last_error_detail, verbatim (a worker thread's text republished on the caller's)
 // host_copy.hip: `rows` pieces of `width` bytes between two pitched host buffers (software prefetch + streaming stores)
 void host_copy_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t width, size_t rows);
+// a rows x width rectangle between PAGEABLE host memory and the device through c's ring of pinned slots (api.hip stage_transfer); c's call lock is
+// the caller's business; threads = 0: the default number of helper threads
+int stage_rect(fastecc_ctx* c, bool to_device, void* host, size_t host_pitch, void* dev, size_t dev_pitch, size_t width, size_t rows, hipStream_t st, int threads);
 // device -> pageable host memory through a ring of pinned slots emptied by helper threads (api.hip); synchronous; c's call lock held by the caller
 int download_pageable(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
 

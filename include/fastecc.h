@@ -185,7 +185,8 @@ int fastecc_encode_columns(fastecc_ctx *ctx, const void *data, void *parity, uin
  *                                root device) and does not synchronise.
  *       FASTECC_MEM_HOST_PINNED  full stripes in pinned host memory: every GPU moves its own slab over its own host
  *                                link (strided copies), so G links work in parallel and no xGMI traffic exists.
- *       FASTECC_MEM_HOST         the same, synchronous.
+ *       FASTECC_MEM_HOST         the same for pageable memory, synchronous: every slab has a host thread that moves its columns through that
+ *                                slab's rings of pinned slots (128 MiB of pinned memory per GPU), all slabs side by side.
  *   fastecc_encode_sharded : the data is ALREADY sharded — data_slabs[g] is slab g ([k][block_bytes/G], contiguous)
  *       in GPU g's memory.  parity_slabs (optional): G device pointers, slab g of the parity stays on GPU g.
  *       parity (optional): full parity stripe in the ROOT's memory, gathered over xGMI ("a final gather").  At least
