@@ -111,6 +111,27 @@ def test_sharded_slabs_equal_the_single_device_encode(torch_cuda, fe, oracle, G,
             senc.encode_sharded(slabs, None, None)
 
 
+def test_pageable_host_stripes_go_through_every_slabs_staging_rings(torch_cuda, fe, oracle):
+    """FASTECC_MEM_HOST on a sharded context at a size whose slabs use the rings of pinned slots (32 MiB and more per slab): a host thread per slab,
+    rows gathered / scattered at a pitch, twice on one context (slots reused), and a fault injected in one slab surfaces as the call's error."""
+    N, S, G = 1 << 14, 1024, 2
+    x = rand_stripe(1234, N, S)
+    keep = x.copy()
+    want = oracle.encode_fast(x)
+    with fe.ShardedEncoder(2 * N, N, 4 * S, [0] * G) as senc:
+        for _ in range(2):
+            out = np.full_like(x, 0x3C3C3C3C)
+            senc.encode(x, out, mem=fe.MEM_HOST)
+            assert np.array_equal(out, want)
+        senc.set_option("inject_fault", 2)
+        with pytest.raises(fe.FastEccError):
+            senc.encode(x, out, mem=fe.MEM_HOST)
+        out = np.full_like(x, 0x3C3C3C3C)
+        senc.encode(x, out, mem=fe.MEM_HOST)  # the context is usable afterwards
+        assert np.array_equal(out, want)
+    assert np.array_equal(x, keep)
+
+
 @pytest.mark.parametrize("mem", ["device", "host", "pinned"])
 def test_sharded_context_takes_full_stripes_like_fastecc_encode(torch_cuda, fe, oracle, mem):
     torch = torch_cuda
