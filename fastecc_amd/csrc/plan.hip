@@ -75,8 +75,9 @@ static void build_plans_with(fastecc_ctx* c, int tile_mid);
 void build_plans(fastecc_ctx* c)
 {
     // (codes with fewer parity blocks, n = 4k / 8k and zero extension gain as much or more: 2.86 -> 2.62 ms at 2^19 + 2^18, 2.25 -> 2.05 at 2^19 + 2^16,
-    //  2.48 -> 2.22 at 400000 + 100000; the mixed-radix orders do not — their fused outer passes are VALU-bound themselves: 13 x 2^15 3.25 -> 3.87)
-    const bool plain = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && !c->p61;
+    //  2.48 -> 2.22 at 400000 + 100000; the mixed-radix orders do not — their fused outer passes are VALU-bound themselves: 13 x 2^15 3.25 -> 3.87;
+    //  blocks below 2 KB keep MID10 too: k = 2^19 x 1 KB measured 0.87 ms with it against 0.90; 2 KB, 2052 B, 4 KB, 4100 B gain 2-4 %)
+    const bool plain = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && !c->p61 && c->S >= 512;
     const int shorter = c->n >= 17 ? 9 : c->n == 16 ? 8 : 0;
     if (plain && shorter) {
         // k = 2^18: both outer chunks have 9 levels, the shape that exists with 64-word rows (256-byte pieces of a block per request:

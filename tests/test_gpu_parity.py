@@ -388,18 +388,34 @@ def test_default_plans_of_large_codes_with_other_shapes(torch_cuda, fe, oracle, 
     d = to_dev(torch, x)
     out = torch.full((m * S,), 0x66666666, dtype=torch.int32, device="cuda:0")
     with fe.Encoder(k + m, k, 4 * S) as enc:
-        plan = enc.plan()
-        assert "mid9@0" in plan or "mid8@0" in plan, plan
-        enc.encode(d, out)
-        torch.cuda.synchronize()
-        got = to_host(out).reshape(m, S)
-        enc.set_plan(3100)
-        out2 = torch.empty_like(out)
-        enc.encode(d, out2)
-        torch.cuda.synchronize()
-        assert np.array_equal(got, to_host(out2).reshape(m, S)), (plan, enc.plan())
-    assert np.array_equal(got, want), plan
+        # (these short rows keep the MID10 plan by default — the re-split is chosen from 2 KB blocks up —, so it is selected by id: 3090 / 3080 =
+        #  MID9 / MID8 with the 1024-block outer tiles where the levels ask for them, 4090 = 64-word rows for 9-level outer chunks)
+        for plan in (3090, 3080, 4090, 0):
+            enc.set_plan(plan)
+            out.fill_(0x66666666)
+            enc.encode(d, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(out).reshape(m, S), want), (plan, enc.plan())
     assert np.array_equal(to_host(d).reshape(k, S), x)
+
+
+def test_the_default_plan_of_large_stripes_is_the_shorter_mid(torch_cuda, fe):
+    """From 2 KB blocks and k = 2^16 up the default is the split with the shorter MID (plan.hip build_plans); it and plan 3100 give the same parity."""
+    torch = torch_cuda
+    for log2k, S, text in ((16, 512, "S32:dif8@8,T32:mid8@0,S32:dit8@8"), (17, 512, "S32:dif8@9,T32:mid9@0,S32:dit8@9"), (18, 513, "T64:dif9@9,T32:mid9@0,T64:dit9@9")):
+        k = 1 << log2k
+        d = torch.randint(0, P, (k * S,), dtype=torch.int64, device="cuda:0").to(torch.int32)
+        a, b = torch.empty_like(d), torch.empty_like(d)
+        with fe.Encoder(2 * k, k, 4 * S) as enc:
+            assert enc.plan().startswith(text), enc.plan()
+            enc.encode(d, a)
+            enc.set_plan(3100)
+            assert "mid10@0" in enc.plan()
+            enc.encode(d, b)
+            torch.cuda.synchronize()
+        assert bool(torch.equal(a, b)), log2k
+    with fe.Encoder(1 << 20, 1 << 19, 1024) as enc:  # 1 KB blocks: MID10 stays
+        assert "mid10@0" in enc.plan()
 
 
 def _big_block_case(torch, fe, oracle, N, S, expect_tiles):
