@@ -48,6 +48,11 @@ def test_headline_plan_is_three_trips(hip_lib):
     assert parse(describe(hip_lib, 1 << 17, 4096)[1]) == [("S32", "dif", 8, 9), ("T32", "mid", 9, 0), ("S32", "dit", 8, 9)]
     assert parse(describe(hip_lib, 1 << 16, 4096)[1]) == [("S32", "dif", 8, 8), ("T32", "mid", 8, 0), ("S32", "dit", 8, 8)]
     assert parse(describe(hip_lib, 1 << 15, 4096)[1])[1] == ("T32", "mid", 10, 0)
+    # ... from 2 KB blocks up (1 KB blocks measured slower with the shorter MID), and not where the outer tile would need address windows
+    assert parse(describe(hip_lib, 1 << 19, 2048)[1])[1] == ("T32", "mid", 9, 0)
+    assert parse(describe(hip_lib, 1 << 19, 2052)[1])[1] == ("T32", "mid", 9, 0)
+    assert parse(describe(hip_lib, 1 << 19, 1024)[1])[1] == ("T32", "mid", 10, 0)
+    assert parse(describe(hip_lib, 1 << 19, 8192)[1])[1] == ("T32", "mid", 10, 0)
     rc, text = describe(hip_lib, 1 << 19, 4096, 3100)  # the plan of rounds 1-4, also what the decoder's contexts run
     assert parse(text) == [("S32", "dif", 9, 10), ("T32", "mid", 10, 0), ("S32", "dit", 9, 10)], text
     rc, text = describe(hip_lib, 1 << 19, 4096, 1100)
