@@ -9,9 +9,10 @@ already resident in HBM, called through the C ABI (include/fastecc.h) exactly as
 Multi-GPU: one process per GPU.  At N > 1 `value` is BASELINE.json configs[3]: ONE stripe sharded over the N GPUs in column
 slabs (word columns are independent transforms: no exchange inside the encode), the parity handed over block-distributed by
 an RCCL all-to-all (rank g ends with parity blocks [g*M/N, (g+1)*M/N) whole) — scaling "strong".  `one_stripe` carries that
-mode next to compute-only, gather-to-root, the block-distributed-input form and the bare exchange, each with the bytes its
-busiest rank receives and the fraction of the xGMI link roofline; `replicas` carries the weak-scaling mode (every rank
-encodes its own independent stripe, no collective).  A single-process run that sees several GPUs additionally times the
+mode next to compute-only (also at the top level as `compute_only_GBps`: the same stripe with no exchange), the bare exchange, the
+block-distributed-input form and gather-to-root — in that order, `value` first, each under its own timer, a failing mode costing only
+itself — each with the bytes its busiest rank receives and the fraction of the link rate the bare exchange reached in the same run;
+`replicas` carries the weak-scaling mode (every rank encodes its own independent stripe, no collective).  A single-process run that sees several GPUs additionally times the
 C-ABI form (fastecc_create_sharded: peer copies instead of RCCL) in a child process.
 
 At N = 1 the line additionally carries `other_paths`: short, checked timings of the rows around the headline path (few-loss repair
@@ -83,6 +84,9 @@ def parse():
     ap.add_argument("--no-sharded", action="store_true", help="skip the one_stripe modes")
     ap.add_argument("--sharded-timeout", type=int, default=300,
                     help="N > 1: seconds the one_stripe measurements may take before the line is printed without it (0 = wait forever)")
+    ap.add_argument("--mode-timeout", type=int, default=90,
+                    help="N > 1: seconds ONE one_stripe mode (warm-up + K steps, incl. the first use of its communicator) may take; at expiry the line "
+                         "is printed with every mode measured so far and the job ends (0 = no per-mode timer)")
     ap.add_argument("--sub-slabs", type=int, default=2, help="column sub-slabs of the exchange pipelines (one_stripe)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-hash gate after the timed region")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the short timings of the widened rows (other_paths)")
@@ -677,22 +681,48 @@ def cabi_sharded_child(args):
     enc.close()
 
 
-LINK_GBPS_PER_DIRECTION = 76.8  # one xGMI link: ~153.6 GB/s both directions together ("7 links x ~153 GB/s")
+LINK_GBPS_PER_DIRECTION_ASSUMED = 76.8  # one xGMI link: ~153.6 GB/s both directions together ("7 links x ~153 GB/s"); an ASSUMPTION —
+#                                         the line prices the modes against the rate `exchange_only` measures in the same run and keeps this as link_peak_assumed
+
+# Order of the one-stripe modes = order of importance: `value` comes from all_to_all, so it runs right after the exchange-free baseline; the
+# gather-to-root (the mode DESIGN.md section 8 itself says cannot scale) runs last, where a failure or a stall in it can cost nothing else.
+ONE_STRIPE_MODES = ("compute_only", "all_to_all", "exchange_only", "all_to_all_in_out", "gather_to_root")
+OWN_GROUP_MODES = ("all_to_all_in_out", "gather_to_root")  # modes after `value`: each on its own communicator (dist.new_group)
 
 
-def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61):
+def injected_fault(mode, rank, world):
+    """Test hook FASTECC_BENCH_TEST_STALL=<mode>[:stall|:raise|:raise_all] — the LAST rank stalls (never enters the mode's collectives) or raises
+    inside `mode` (raise_all: every rank raises); "1" / "all" = the last rank never reaches the one-stripe modes at all.  tests/test_gpu_sharded.py drives it with gloo on one GPU."""
+    spec = os.environ.get("FASTECC_BENCH_TEST_STALL", "")
+    name, _, how = spec.partition(":")
+    if not spec or (rank != world - 1 and how != "raise_all"):
+        return
+    if name in ("1", "all"):
+        name = "before_the_modes"
+    if name != mode:
+        return
+    if how in ("raise", "raise_all"):
+        raise RuntimeError("FASTECC_BENCH_TEST_STALL: injected failure in %s on rank %d" % (mode, rank))
+    time.sleep(1e6)
+
+
+def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61, out, watch):
     """BASELINE configs[3]: ONE (n,k) stripe over the ranks.  The compute is always the column-slab encode (rank r holds words
     [r*S/G, (r+1)*S/G) of every block: no exchange inside the transform); the modes differ in what happens to the parity:
 
         compute_only        it stays in slabs (no exchange at all)
-        gather_to_root      full blocks on rank 0 (RCCL gather; bound by the root's links: (G-1)/G of the stripe enters one GPU)
         all_to_all          block-distributed: rank g ends with parity blocks [g*M/G, (g+1)*M/G) whole (RCCL all-to-all: 1/G^2 of the
-                            stripe per link and direction, no hot spot)
+                            stripe per link and direction, no hot spot) — the line's `value` at N > 1
+        exchange_only       all_to_all's exchange without the encode (what the links alone allow: the measured link roofline)
         all_to_all_in_out   the data arrives block-distributed as well (whole data blocks per rank): the mirror transpose in front
-        exchange_only       all_to_all's exchange without the encode (what the links alone allow)
+        gather_to_root      full blocks on rank 0 (RCCL gather; bound by the root's links: (G-1)/G of the stripe enters one GPU)
 
-    Every mode: W warm-up calls, then exactly K calls between barriers, max over ranks.  The stripe is the splitmix64(0x1234) one, so what
-    was timed is checked against the unmodified reference's parity hash (main.cpp:202-212) where a golden value exists."""
+    Every mode: W warm-up calls, then exactly K calls between barriers, max over ranks.  A mode that raises costs only itself: the error is
+    recorded and the next mode runs (the two modes after `value` on communicators of their own, so a broken one is not reused).  A mode that
+    STALLS cannot be cancelled from Python (a rank blocked inside a collective), so `watch(name)` arms a per-mode timer whose expiry prints the
+    line with everything measured so far and ends the job: by the order above a stall can only cost modes less important than its own.
+    `out` is filled as the modes finish (the timer reads it).  The stripe is the splitmix64(0x1234) one, so what was timed is checked
+    against the unmodified reference's parity hash (main.cpp:202-212) where a golden value exists."""
     import torch.distributed as dist
     from fastecc_amd import sharding
     unit = 8 if p61 else 4
@@ -703,16 +733,32 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
     wsub = w // sub
     kg = k // world
     gloo = backend != "nccl"
-    senc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
-    tune(senc)
-    # this rank's slab, resident as `sub` contiguous column sub-slabs [sub][k][wsub] (what a scatter delivers), and its whole data blocks
-    if p61:
-        slab = random_stripe_p61(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
-        blocks = None  # (the block-distributed input needs every rank to derive the same stripe: GF(0xFFF00001) only)
-    else:
-        slab = torch.stack([splitmix_window(device, S32, 0, k, rank * w + h * wsub, wsub) for h in range(sub)])
-        blocks = splitmix_window(device, S32, rank * kg, kg, 0, S32)
-    pslab = torch.empty_like(slab)
+    stripe_bytes = float(k) * args.block_bytes  # data = parity bytes of the (2k,k) stripe
+    G = world
+    out.update({"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d contiguous sub-slab(s) "
+                        "(the exchange of one sub-slab runs on side streams under the next sub-slab's encode).  compute_only: the parity stays in slabs; "
+                        "all_to_all: block-distributed result, rank g holds parity blocks [g*M/G, (g+1)*M/G) whole; exchange_only: all_to_all without the "
+                        "encode; all_to_all_in_out: the data block-distributed as well (mirror transpose in front); gather_to_root: RCCL gather into full "
+                        "blocks on rank 0 (no pack, the root encodes straight into the full blocks)"
+                        % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
+                "scaling": "strong", "sub_slabs": sub, "mode_order": list(ONE_STRIPE_MODES),
+                "link_model": "link_bytes_in_max_rank = bytes entering the busiest rank per stripe; link_GBps_in_max_rank = that / ms_per_stripe; "
+                              "link_peak_GBps = the rate exchange_only reached in THIS run (the all-to-all of the same bytes with no encode around it: "
+                              "what RCCL over these links delivers), link_roofline_frac = rate / that; link_peak_assumed_GBps = min(G-1,7) links x %.1f GB/s "
+                              "per direction (half of ~153.6 GB/s per link, never measured here)" % LINK_GBPS_PER_DIRECTION_ASSUMED})
+    with watch("setup"):
+        injected_fault("before_the_modes", rank, world)
+        senc = fastecc_amd.Encoder(n, k, args.block_bytes // world // sub, device=local, field=field)
+        tune(senc)
+        out["plan"] = senc.plan()
+        # this rank's slab, resident as `sub` contiguous column sub-slabs [sub][k][wsub] (what a scatter delivers), and its whole data blocks
+        if p61:
+            slab = random_stripe_p61(k * w, device, seed=0x5EED + rank).view(sub, k, wsub)
+            blocks = None  # (the block-distributed input needs every rank to derive the same stripe: GF(0xFFF00001) only)
+        else:
+            slab = torch.stack([splitmix_window(device, S32, 0, k, rank * w + h * wsub, wsub) for h in range(sub)])
+            blocks = splitmix_window(device, S32, rank * kg, kg, 0, S32)
+        pslab = torch.empty_like(slab)
     wsp_g, wsp_a, wsp_b, wsp_x = {}, {}, {}, {}
     # gather_to_root: the root keeps its slab at the full block pitch ([k][world*w] arrays, its own columns filled): with "row_pitch_words"
     # its encoder reads the sub-slab there and writes the parity straight into the full parity blocks, so the root's part is neither sent
@@ -735,87 +781,127 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
         for h in range(sub):
             senc.encode(slab[h], pslab[h], stream=stream)
 
-    modes = [("compute_only", encode_all),
-             ("gather_to_root", lambda: sharding.encode_sub_slabs_and_gather(gslab, enc_fn, k, dst=0, workspace=wsp_g, collective_on_host=gloo,
-                                                                             root_in_place=in_place)),
-             ("all_to_all", lambda: sharding.encode_all_to_all(slab, enc_fn, k, workspace=wsp_a, collective_on_host=gloo))]
-    if blocks is not None:
-        modes.append(("all_to_all_in_out", lambda: sharding.encode_all_to_all(blocks, enc_fn, k, data_is_blocks=True, sub_slabs=sub, workspace=wsp_b,
-                                                                              collective_on_host=gloo)))
-    modes.append(("exchange_only", lambda: sharding.encode_all_to_all(slab, lambda d, o: None, k, workspace=wsp_x, collective_on_host=gloo)))
-    stripe_bytes = float(k) * args.block_bytes  # data = parity bytes of the (2k,k) stripe
-    G = world
+    groups = {}  # mode -> its own process group (None = the default one)
+
+    def make(name):
+        grp = groups.get(name)
+        if name == "compute_only":
+            return encode_all
+        if name == "all_to_all":
+            return lambda: sharding.encode_all_to_all(slab, enc_fn, k, workspace=wsp_a, collective_on_host=gloo, group=grp)
+        if name == "exchange_only":
+            return lambda: sharding.encode_all_to_all(slab, lambda d, o: None, k, workspace=wsp_x, collective_on_host=gloo, group=grp)
+        if name == "all_to_all_in_out":
+            if blocks is None:
+                return None
+            return lambda: sharding.encode_all_to_all(blocks, enc_fn, k, data_is_blocks=True, sub_slabs=sub, workspace=wsp_b, collective_on_host=gloo,
+                                                      group=grp)
+        return lambda: sharding.encode_sub_slabs_and_gather(gslab, enc_fn, k, dst=0, workspace=wsp_g, collective_on_host=gloo, root_in_place=in_place,
+                                                            group=grp)
+
     link_in = {"compute_only": 0.0, "gather_to_root": (G - 1) / G * stripe_bytes, "all_to_all": (G - 1) / G**2 * stripe_bytes,
                "all_to_all_in_out": 2 * (G - 1) / G**2 * stripe_bytes, "exchange_only": (G - 1) / G**2 * stripe_bytes}
-    link_peak = min(G - 1, 7) * LINK_GBPS_PER_DIRECTION
-    out = {"what": "ONE stripe of k=2^%d x %d B blocks in %d column slabs of %d B per block, one per rank, each resident as %d contiguous sub-slab(s) "
-                   "(the exchange of one sub-slab runs on side streams under the next sub-slab's encode).  compute_only: the parity stays in slabs; "
-                   "gather_to_root: RCCL gather into full blocks on rank 0 (no pack, the root encodes straight into the full blocks); all_to_all: "
-                   "block-distributed result, rank g holds parity blocks [g*M/G, (g+1)*M/G) whole; all_to_all_in_out: the data block-distributed as "
-                   "well (mirror transpose in front); exchange_only: all_to_all without the encode"
-                   % (args.log2k, args.block_bytes, world, args.block_bytes // world, sub),
-           "scaling": "strong", "sub_slabs": sub, "plan": senc.plan(),
-           "link_model": "link_bytes_in_max_rank = bytes entering the busiest rank per stripe; link_roofline_frac = that / ms_per_stripe / "
-                         "(min(G-1,7) links x %.1f GB/s per direction, an assumed figure: half of ~153.6 GB/s per link)" % LINK_GBPS_PER_DIRECTION}
-    for name, fn in modes:
+    def everyone_ok(ok):
+        """The ranks agree (default group) whether a mode's warm-up went through everywhere: a rank that raised must not go on to the next
+        mode's collectives while the others enter this mode's barriers."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
+
+    for name in ONE_STRIPE_MODES:
         try:
-            for _ in range(max(1, args.warmup)):
-                fn()
-            ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
-            rec = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * stripe_bytes / (ms * 1e-3) / 1e9, 2), "link_bytes_in_max_rank": int(link_in[name])}
-            if world > 1 and link_in[name]:
-                rate = link_in[name] / (ms * 1e-3) / 1e9
-                rec.update({"link_GBps_in_max_rank": round(rate, 1), "link_peak_GBps": round(link_peak, 1), "link_roofline_frac": round(rate / link_peak, 4)})
-            out[name] = rec
-        except Exception as e:  # noqa: BLE001
-            out[name] = {"error": repr(e)}
-            if world > 1:  # a failed collective leaves the communicator unusable: stop here and report what exists
-                out["aborted_after"] = name
-                return out
-    # ---- what was timed is also right ----
-    checks = {}
-    encode_all()
-    torch.cuda.synchronize()
-    mine_a = wsp_a.get("parity_sub")
-    ok_local = mine_a is not None and bool(torch.equal(mine_a, pslab))
-    full = wsp_g.get("parity_full")
-    if rank == 0 and full is not None:  # the root's own columns of the gathered blocks = its slab
-        ok_local = ok_local and bool(torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w)))
-    flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
-    if world > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    checks["slabs_equal_compute_only_on_every_rank"] = bool(flag.item() == 1.0)
-    for key, wsp in (("all_to_all", wsp_a), ("all_to_all_in_out", wsp_b)):
-        mineb = wsp.get("parity_blocks")
-        if mineb is None:
-            continue
-        if world > 1:
-            piece = mineb.cpu() if gloo else mineb
-            got = [torch.empty_like(piece) for _ in range(world)] if rank == 0 else None
-            dist.gather(piece, gather_list=got, dst=0)
-        else:
-            got = [mineb]
-        if rank == 0:
-            whole = torch.cat([g.to(device) for g in got], dim=0)  # [M, S]: every rank's whole parity blocks in block order
-            res = {"equals_gather_to_root": bool(torch.equal(whole, full)) if full is not None else None}
-            if not p61:
+            with watch(name):
+                if world > 1 and name in OWN_GROUP_MODES:
+                    # every rank takes part in every new_group call, in this order; a mode that cannot get a communicator of its own
+                    # runs on the default one
+                    try:
+                        groups[name] = dist.new_group(backend=backend)
+                    except Exception as e:  # noqa: BLE001
+                        out.setdefault("notes", []).append("%s: dist.new_group failed (%r), running on the default group" % (name, e))
+                fn = make(name)
+                if fn is None:
+                    continue
+                err = None
                 try:
-                    from oracle import Oracle
-                    with open(os.path.join(ROOT, "tests", "golden", "golden_hashes.json")) as f:
-                        gold = json.load(f)
-                    want = [c for c in gold.get("survey_appendix_b", []) + gold.get("cases", [])
-                            if c.get("input") == "splitmix" and c.get("log2N") == args.log2k and c.get("block_bytes") == args.block_bytes]
-                    if want:
-                        import numpy as np
-                        h = Oracle().hash(whole.cpu().numpy().view(np.uint32))
-                        res.update({"reference_parity_hash": h, "expected": want[0]["hash_parity"], "status": "ok" if h == want[0]["hash_parity"] else "FAILED"})
+                    injected_fault(name, rank, world)
+                    for _ in range(max(1, args.warmup)):
+                        fn()
+                    torch.cuda.synchronize()
                 except Exception as e:  # noqa: BLE001
-                    res["hash_error"] = repr(e)
-            if "status" not in res:
-                res["status"] = "ok" if res["equals_gather_to_root"] else "FAILED"
-            checks[key] = res
-            del whole
+                    err = e
+                if not everyone_ok(err is None):
+                    raise err if err is not None else RuntimeError("%s failed on another rank" % name)
+                ms = max_over_ranks(time_steps(fn, args.steps, barrier)) / args.steps * 1e3
+            out[name] = {"ms_per_stripe": round(ms, 4), "GBps": round(2.0 * stripe_bytes / (ms * 1e-3) / 1e9, 2), "link_bytes_in_max_rank": int(link_in[name])}
+        except Exception as e:  # noqa: BLE001 — costs this mode only (ranks left inside its collective by a one-sided failure end at the timer)
+            out[name] = {"error": repr(e)}
+    # ---- the link figures: every exchanging mode against what the bare exchange reached in this run ----
+    if world > 1:
+        assumed = min(G - 1, 7) * LINK_GBPS_PER_DIRECTION_ASSUMED
+        xo = out.get("exchange_only") or {}
+        measured = link_in["exchange_only"] / (xo["ms_per_stripe"] * 1e-3) / 1e9 if "ms_per_stripe" in xo else None
+        out["link_peak_GBps"] = None if measured is None else round(measured, 1)
+        out["link_peak_source"] = "exchange_only of this run" if measured is not None else "not measured (exchange_only did not complete)"
+        out["link_peak_assumed_GBps"] = round(assumed, 1)
+        for name in ONE_STRIPE_MODES:
+            rec = out.get(name) or {}
+            if "ms_per_stripe" in rec and link_in[name]:
+                rate = link_in[name] / (rec["ms_per_stripe"] * 1e-3) / 1e9
+                rec["link_GBps_in_max_rank"] = round(rate, 1)
+                rec["link_roofline_frac"] = None if measured is None else round(rate / measured, 4)
+                rec["link_frac_of_assumed_peak"] = round(rate / assumed, 4)
+    # ---- what was timed is also right (collectives on the default group; a failure here costs the checks, not the timings) ----
+    checks = {}
+    try:
+        with watch("checks"):
+            encode_all()
+            torch.cuda.synchronize()
+            mine_a = wsp_a.get("parity_sub")
+            ok_local = mine_a is not None and bool(torch.equal(mine_a, pslab))
+            full = wsp_g.get("parity_full")
+            if rank == 0 and full is not None:  # the root's own columns of the gathered blocks = its slab
+                ok_local = ok_local and bool(torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w)))
+            flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            checks["slabs_equal_compute_only_on_every_rank"] = bool(flag.item() == 1.0)
+            for key, wsp in (("all_to_all", wsp_a), ("all_to_all_in_out", wsp_b)):
+                mineb = wsp.get("parity_blocks")
+                if mineb is None:
+                    continue
+                if world > 1:
+                    piece = mineb.cpu() if gloo else mineb
+                    got = [torch.empty_like(piece) for _ in range(world)] if rank == 0 else None
+                    dist.gather(piece, gather_list=got, dst=0)
+                else:
+                    got = [mineb]
+                if rank == 0:
+                    whole = torch.cat([g.to(device) for g in got], dim=0)  # [M, S]: every rank's whole parity blocks in block order
+                    res = {"equals_gather_to_root": bool(torch.equal(whole, full)) if full is not None else None}
+                    if not p61:
+                        try:
+                            from oracle import Oracle
+                            with open(os.path.join(ROOT, "tests", "golden", "golden_hashes.json")) as f:
+                                gold = json.load(f)
+                            want = [c for c in gold.get("survey_appendix_b", []) + gold.get("cases", [])
+                                    if c.get("input") == "splitmix" and c.get("log2N") == args.log2k and c.get("block_bytes") == args.block_bytes]
+                            if want:
+                                import numpy as np
+                                h = Oracle().hash(whole.cpu().numpy().view(np.uint32))
+                                res.update({"reference_parity_hash": h, "expected": want[0]["hash_parity"], "status": "ok" if h == want[0]["hash_parity"] else "FAILED"})
+                        except Exception as e:  # noqa: BLE001
+                            res["hash_error"] = repr(e)
+                    if "status" not in res:
+                        res["status"] = "unchecked (no golden hash at this size, no gathered copy)" if res["equals_gather_to_root"] is None else \
+                                        "ok" if res["equals_gather_to_root"] else "FAILED"
+                    checks[key] = res
+                    del whole
+    except Exception as e:  # noqa: BLE001
+        checks["error"] = repr(e)
     out["checks"] = checks
+    out["complete"] = True
     senc.close()
     if penc is not None:
         penc.close()
@@ -1030,6 +1116,11 @@ def main():
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
             "config": {"workload": workload, "stripes_per_step": args.batch, "plan": enc.plan(), "parallelism": par},
             "data_only_GBps": round(v / 2, 2),
+            # the same ONE stripe without any exchange (parity left in column slabs): read a 1 -> N curve with `value` (exchange included at
+            # N > 1, none at N = 1) and with this (no exchange at any N)
+            "compute_only_GBps": ((one or {}).get("compute_only") or {}).get("GBps"),
+            "compute_only_ms_per_stripe": ((one or {}).get("compute_only") or {}).get("ms_per_stripe"),
+            "exchange_only_ms_per_stripe": ((one or {}).get("exchange_only") or {}).get("ms_per_stripe") if world > 1 else None,
             "replicas": replicas,
             "parity_check": check,
             "roofline": roof, "cpu_baseline": cpu,
@@ -1045,19 +1136,45 @@ def main():
             line["one_stripe_c_abi"] = cabi
         print(json.dumps(line), flush=True)
 
-    # N > 1: the sharded mode below is the first thing in this file that needs every rank to make progress together inside
-    # RCCL transfers of whole parity slabs.  If it stalls, the replica number measured above must still reach the driver:
-    # after --sharded-timeout seconds rank 0 prints the line without it and every rank leaves.
-    def give_up():
-        emit({"error": "the one_stripe modes did not finish within %d s; the line carries the replica measurement only" % args.sharded_timeout})
+    # N > 1: the one-stripe modes below are the first thing in this file that needs every rank to make progress together inside
+    # RCCL transfers of whole parity slabs.  Whatever happens there, the measurements already taken must reach the driver:
+    #   * every mode runs under a per-mode timer (--mode-timeout); the whole section under --sharded-timeout;
+    #   * at expiry rank 0 prints the line with `one_partial` as it stands (the replica measurement, every finished mode — `value` is
+    #     all_to_all, which runs first among the exchanging modes) and every rank leaves.
+    one_partial = {}
+    armed = {"timer": None}
+
+    def give_up(where, seconds):
+        one_partial.setdefault(where, {})
+        if isinstance(one_partial[where], dict) and "ms_per_stripe" not in one_partial[where]:
+            one_partial[where] = {"error": "no progress within %d s (stalled); the line was printed by the watchdog" % seconds}
+        one_partial["stalled_in"] = where
+        one_partial["complete"] = False
+        emit(one_partial)
         sys.stdout.flush()
         if rank != 0:
             time.sleep(3)  # let rank 0 print before its collectives see a peer disappear
         os._exit(0)
 
+    class watch:  # noqa: N801 — `with watch(name):` around one mode
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            if world > 1 and args.mode_timeout > 0:
+                armed["timer"] = threading.Timer(args.mode_timeout, give_up, args=(self.name, args.mode_timeout))
+                armed["timer"].daemon = True
+                armed["timer"].start()
+
+        def __exit__(self, *exc):
+            if armed["timer"] is not None:
+                armed["timer"].cancel()
+                armed["timer"] = None
+            return False
+
     watchdog = None
     if world > 1 and args.sharded_timeout > 0:
-        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog = threading.Timer(args.sharded_timeout, give_up, args=("one_stripe_section", args.sharded_timeout))
         watchdog.daemon = True
         watchdog.start()
 
@@ -1069,11 +1186,11 @@ def main():
                  and (args.block_bytes // world) % (16 if p61 else 4) == 0 and k % world == 0)
     if shardable:
         try:
-            if os.environ.get("FASTECC_BENCH_TEST_STALL") and rank == world - 1:
-                time.sleep(1e6)  # test hook for the watchdog above: one rank never reaches the collectives
-            one = one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61)
-        except Exception as e:  # noqa: BLE001 — the replica number above must survive a failure of these modes
-            one = {"error": repr(e)}
+            one = one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backend, stream, tune, barrier, max_over_ranks, k, n, p61,
+                                   one_partial, watch)
+        except Exception as e:  # noqa: BLE001 — the replica number above and the modes already measured must survive a failure here
+            one_partial["error"] = repr(e)
+            one = one_partial
 
     if watchdog is not None:
         watchdog.cancel()

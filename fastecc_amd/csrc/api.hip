@@ -710,6 +710,7 @@ int stage_transfer(fastecc_ctx* c, const StageJob& j, hipStream_t st, int thread
 
 int stage_download(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st)
 {
+    if (bytes == 0) return FASTECC_OK;
     // one "row" per slot-sized piece keeps the 2-D copies wide
     const size_t width = std::min<size_t>(bytes, (size_t)1 << 20);
     const size_t rows = bytes / width, rest = bytes - rows * width;
@@ -743,8 +744,7 @@ int encode_host_pageable(fastecc_ctx* c, const uint32_t* data, uint32_t* parity,
     hipStream_t s_up = c->slab_stream[0], s_cp = c->slab_stream[1], s_dn = c->slab_stream[2];
     HIP_TRY(hipEventRecord(c->slab_fork, st));
     for (hipStream_t q : {s_up, s_cp, s_dn}) HIP_TRY(hipStreamWaitEvent(q, c->slab_fork, 0));
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int T = (int)std::min<unsigned>(6u, std::max<unsigned>(2u, hw / 4u));
+    const int T = 0;  // stage_transfer's own rule: the "stage_threads" option when it is set, else min(6, hardware threads / 4)
     std::thread down;
     int down_rc = FASTECC_OK;
     char down_text[256] = "";
@@ -773,9 +773,10 @@ int encode_host_pageable(fastecc_ctx* c, const uint32_t* data, uint32_t* parity,
                                           : stage_transfer(c, StageJob{false, (char*)(parity + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_dn, T);
                 if (down_rc != FASTECC_OK) snprintf(down_text, sizeof down_text, "%s", fastecc_last_error_detail());
             });
-        } catch (...) {  // no thread: this slab comes down on the calling thread
-            HIP_TRY(hipStreamWaitEvent(s_dn, c->slab_done[h], 0));
-            rc = stage_transfer(c, StageJob{false, (char*)(parity + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_dn, T);
+        } catch (...) {  // no thread: this slab comes down on the calling thread (a failure here still falls through to the settling code below)
+            const hipError_t w = hipStreamWaitEvent(s_dn, c->slab_done[h], 0);
+            rc = w != hipSuccess ? hip_fail(w, "encode_host_pageable")
+               : stage_transfer(c, StageJob{false, (char*)(parity + (size_t)h * width), pitch, (char*)(c->dbuf + (size_t)h * width), pitch, wbytes, c->N}, s_dn, T);
         }
     }
     const int rd = join_down();

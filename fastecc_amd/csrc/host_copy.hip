@@ -8,8 +8,9 @@
 #include <stdint.h>
 #include <string.h>
 
-#ifndef __HIP_DEVICE_COMPILE__
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
+#define FASTECC_HOST_COPY_AVX2 1  // x86-64 hosts only; every other host takes the memcpy rows below
 #endif
 
 #include "internal.hpp"
@@ -17,6 +18,7 @@
 namespace fastecc {
 
 #ifndef __HIP_DEVICE_COMPILE__
+#ifdef FASTECC_HOST_COPY_AVX2
 namespace {
 
 __attribute__((target("avx2"))) void copy_rows_avx2(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t width, size_t rows)
@@ -45,15 +47,18 @@ __attribute__((target("avx2"))) void copy_rows_avx2(char* dst, size_t dst_pitch,
 }
 
 }  // namespace
+#endif
 
 void host_copy_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t width, size_t rows)
 {
+#ifdef FASTECC_HOST_COPY_AVX2
     static const bool avx2 = __builtin_cpu_supports("avx2");
     // streaming stores want 32-byte aligned destinations in every row
     if (avx2 && width >= 64 && (((uintptr_t)dst | dst_pitch) & 31u) == 0) {
         copy_rows_avx2(dst, dst_pitch, src, src_pitch, width, rows);
         return;
     }
+#endif
     for (size_t r = 0; r < rows; r++) memcpy(dst + r * dst_pitch, src + r * src_pitch, width);
 }
 #else

@@ -270,6 +270,8 @@ int device_level_table(uint32_t** dst, int n, uint32_t root_of_order_N, const st
 // their readers, on the same streams) are waited for first, so the old tables are not overwritten under a kernel.
 int upload_twiddles(fastecc_ctx* c)
 {
+    // (the build events cover the builds and the readers on the building stream; readers on other streams hold no event: every caller that
+    //  changes a plan on a live context — fastecc_set_plan, fastecc_set_option — waits for the whole device under a DeviceGuard first)
     for (int i = 0; i < 5; i++)
         if ((c->tw_pending & (1u << i)) && c->tw_event[i]) (void)hipEventSynchronize(c->tw_event[i]);
     c->tw_pending = 0;
@@ -291,6 +293,40 @@ const uint32_t* twiddle_table(fastecc_ctx* c, int which, hipStream_t st)
         }
         return *slot;
     }
+    // A call that is being captured into a graph must not leave "ready, built on st" behind: the build kernel and its event would be graph
+    // nodes, i.e. the table would not exist before the first replay, an eager call on the same stream would read it unbuilt, and a call on
+    // any other stream would wait for an event that never completes outside the graph.  The table is then built eagerly, on a stream of its
+    // own outside the capture (relaxed capture mode for the allocation and the launch), and waited for here; the captured call only reads it.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    hipStream_t caller = st;
+    hipStreamCaptureMode prev_mode = hipStreamCaptureModeRelaxed;
+    if (capturing) {
+        if (hipThreadExchangeStreamCaptureMode(&prev_mode) != hipSuccess) {
+            (void)hip_fail(hipGetLastError(), "hipThreadExchangeStreamCaptureMode");
+            return nullptr;
+        }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hip_fail(hipGetLastError(), "hipStreamCreateWithFlags(twiddle table during capture)");
+            (void)hipThreadExchangeStreamCaptureMode(&prev_mode);
+            return nullptr;
+        }
+    }
+    auto leave_capture = [&](bool ok) -> bool {
+        if (!capturing) return ok;
+        if (ok && hipStreamSynchronize(st) != hipSuccess) {
+            (void)hip_fail(hipGetLastError(), "hipStreamSynchronize(twiddle table during capture)");
+            ok = false;
+        }
+        (void)hipStreamDestroy(st);
+        (void)hipThreadExchangeStreamCaptureMode(&prev_mode);
+        st = caller;
+        return ok;
+    };
     const uint32_t wN = gf::h_root((uint32_t)c->N), wNi = gf::h_inv(wN);
     int rc = FASTECC_OK;
     switch (which) {
@@ -307,7 +343,12 @@ const uint32_t* twiddle_table(fastecc_ctx* c, int which, hipStream_t st)
         rc = device_level_table(slot, nf, gf::h_root((uint32_t)c->M), sl, st);
     }
     }
-    if (rc != FASTECC_OK) return nullptr;
+    if (!leave_capture(rc == FASTECC_OK)) return nullptr;
+    if (capturing) {  // complete and visible to every stream: nothing pending, nothing tied to the captured stream
+        c->tw_pending &= ~bit;
+        c->tw_ready |= bit;
+        return *slot;
+    }
     // no host synchronisation: the table's first reader follows on the same stream; other streams wait for this event (above)
     hipError_t e = hipSuccess;
     if (!c->tw_event[which]) e = hipEventCreateWithFlags(&c->tw_event[which], hipEventDisableTiming);

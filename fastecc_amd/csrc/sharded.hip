@@ -50,7 +50,9 @@ struct Shard {
     bool used = false;
     char* data_slab = nullptr;    // lazy: [k][slab_bytes], for callers that hand over full stripes
     char* parity_slab = nullptr;  // lazy: [n-k][slab_bytes], when the caller keeps no parity slabs
-    std::vector<hipStream_t> s_peer;              // lazy, all-to-all on the copy engines: one stream per destination, so the G links work side by side
+    std::vector<hipStream_t> s_peer;              // lazy, all-to-all on the copy engines: one stream per destination AND direction of the pipeline
+                                                  // ([lane * G + d]; lane 0 = the data push in front, 1 = the parity transpose behind), so the G links
+                                                  // work side by side and the push of sub-slab h + 1 is not queued behind the wait for compute h
     std::vector<hipEvent_t> ev_peer;
 };
 
@@ -125,6 +127,7 @@ struct Sharded {
     bool copy_engine_refused = false;  // mode 2 was forced by an error return of hipMemcpy2DAsync
     int all_pairs = 0;   // fastecc_encode_sharded_blocks: 0 = not tried, 1 = every slab device can access every other one, -1 = it cannot
     hipEvent_t fork = nullptr;
+    int stage_threads = 0;  // option "stage_threads" as last set through this context (0 = automatic)
     int fault_at = 0;    // tests only (option "inject_fault"): the fault_at-th slab step of the next call fails after its work has been enqueued
     int fault_step = 0;
     std::string text;
@@ -285,7 +288,9 @@ int run_host_pageable(fastecc_ctx* shell, const void* data_stripe, void* parity_
         if (sh.used) SH_TRY(hipEventSynchronize(sh.ev_all));
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    const int T = (int)std::min<unsigned>(4u, std::max<unsigned>(1u, hw / (2u * (unsigned)G)));
+    // helper threads per slab: the "stage_threads" option of the slab contexts where it is set, else a share of the host's threads
+    const int set_by_option = s->stage_threads;
+    const int T = set_by_option > 0 ? set_by_option : (int)std::min<unsigned>(4u, std::max<unsigned>(1u, hw / (2u * (unsigned)G)));
     std::vector<int> rcs((size_t)G, FASTECC_OK);
     std::vector<std::string> texts((size_t)G);
     std::mutex fault_mu;
@@ -365,33 +370,35 @@ int enable_all_pairs(Sharded* s)
 // gather_mode 2: ONE kernel storing through the peer mappings on `st`.  gather_mode 1: G pitched copies on the copy engines, each on the
 // stream of its destination (after `after`, joined into `st` again), so the transfers to different peers run side by side.
 int all_to_all_step(Sharded* s, Shard& sh, void* const* dst, size_t dpitch, const char* src, size_t spitch, size_t sstride, size_t width, size_t rows,
-                    hipStream_t st, hipEvent_t after)
+                    hipStream_t st, hipEvent_t after, int lane)
 {
     const int G = (int)s->shards.size();
     if (rows == 0 || width == 0) return FASTECC_OK;
     if (s->gather_mode != 2) {
         if (sh.s_peer.empty()) {
-            sh.s_peer.assign(G, nullptr);
-            sh.ev_peer.assign(G, nullptr);
-            for (int d = 0; d < G; d++) {
+            sh.s_peer.assign(2 * (size_t)G, nullptr);
+            sh.ev_peer.assign(2 * (size_t)G, nullptr);
+            for (int d = 0; d < 2 * G; d++) {
                 SH_TRY(hipStreamCreateWithFlags(&sh.s_peer[d], hipStreamNonBlocking));
                 SH_TRY(hipEventCreateWithFlags(&sh.ev_peer[d], hipEventDisableTiming));
             }
         }
+        hipStream_t* const peer = sh.s_peer.data() + (size_t)(lane ? G : 0);
+        hipEvent_t* const pev = sh.ev_peer.data() + (size_t)(lane ? G : 0);
         bool refused = false;
         for (int d = 0; d < G && !refused; d++) {
-            SH_TRY(hipStreamWaitEvent(sh.s_peer[d], after, 0));
-            const hipError_t e = hipMemcpy2DAsync(dst[d], dpitch, src + (size_t)d * sstride, spitch, width, rows, hipMemcpyDefault, sh.s_peer[d]);
+            SH_TRY(hipStreamWaitEvent(peer[d], after, 0));
+            const hipError_t e = hipMemcpy2DAsync(dst[d], dpitch, src + (size_t)d * sstride, spitch, width, rows, hipMemcpyDefault, peer[d]);
             if (e != hipSuccess) {  // a runtime that refuses pitched peer copies: the copy kernel takes over for good (as in copy_window)
                 (void)hipGetLastError();
                 s->gather_mode = 2;
                 s->copy_engine_refused = true;
                 refused = true;
-                for (int f = 0; f < d; f++) SH_TRY(hipStreamSynchronize(sh.s_peer[f]));  // what was enqueued is simply repeated below
+                for (int f = 0; f < d; f++) SH_TRY(hipStreamSynchronize(peer[f]));  // what was enqueued is simply repeated below
                 break;
             }
-            SH_TRY(hipEventRecord(sh.ev_peer[d], sh.s_peer[d]));
-            SH_TRY(hipStreamWaitEvent(st, sh.ev_peer[d], 0));
+            SH_TRY(hipEventRecord(pev[d], peer[d]));
+            SH_TRY(hipStreamWaitEvent(st, pev[d], 0));
         }
         if (!refused) return FASTECC_OK;
     }
@@ -461,7 +468,7 @@ int run_blocks_body(fastecc_ctx* shell, const void* const* data, bool data_block
                 SH_TRY(hipSetDevice(sh.device));
                 for (int d = 0; d < G; d++) dst[d] = s->shards[d].data_slab + (size_t)g * kg * slab + col;
                 SH_TRY(hipEventRecord(sh.ev_up[h], sh.s_up));  // the point the copy-engine form forks from; recorded again after the step
-                const int rc = all_to_all_step(s, sh, dst.data(), slab, (const char*)data[g] + col, full, slab, wbytes, kg, sh.s_up, sh.ev_up[h]);
+                const int rc = all_to_all_step(s, sh, dst.data(), slab, (const char*)data[g] + col, full, slab, wbytes, kg, sh.s_up, sh.ev_up[h], 0);
                 if (rc != FASTECC_OK) return rc;
                 SH_TRY(hipEventRecord(sh.ev_up[h], sh.s_up));
             }
@@ -480,7 +487,7 @@ int run_blocks_body(fastecc_ctx* shell, const void* const* data, bool data_block
             SH_TRY(hipEventRecord(sh.ev_comp[h], sh.s_comp));
             SH_TRY(hipStreamWaitEvent(sh.s_down, sh.ev_comp[h], 0));
             for (int d = 0; d < G; d++) dst[d] = (char*)parity_blocks[d] + (size_t)g * slab + col;
-            const int rc2 = all_to_all_step(s, sh, dst.data(), full, sh.parity_slab + col, slab, (size_t)mg * slab, wbytes, mg, sh.s_down, sh.ev_comp[h]);
+            const int rc2 = all_to_all_step(s, sh, dst.data(), full, sh.parity_slab + col, slab, (size_t)mg * slab, wbytes, mg, sh.s_down, sh.ev_comp[h], 1);
             if (rc2 != FASTECC_OK) return rc2;
         }
     }
@@ -697,6 +704,7 @@ int sharded_forward(fastecc_ctx* shell, int what, const char* name, int value)
         describe(shell);
         return FASTECC_OK;
     }
+    if (what == SH_SET_OPTION && !strcmp(name, "stage_threads") && value >= 0 && value <= 64) s->stage_threads = value;  // (also forwarded)
     for (Shard& sh : s->shards) {
         int rc = FASTECC_OK;
         switch (what) {

@@ -26,7 +26,8 @@ def build(force=False):
     srcs = [os.path.join(HERE, f) for f in ("fastecc_oracle.c", "fastecc_oracle_p61.c")]
     have_ref = os.path.exists("/root/reference/ntt.cpp")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
-    ref_missing = have_ref and not os.path.exists(os.path.join(HERE, "_ref", "libfastecc_ref.so"))
+    ref_so, shim = os.path.join(HERE, "_ref", "libfastecc_ref.so"), os.path.join(HERE, "ref_shim.cpp")
+    ref_missing = have_ref and (not os.path.exists(ref_so) or os.path.getmtime(ref_so) < os.path.getmtime(shim))  # absent, or older than the shim
     if force or stale or ref_missing:
         subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), check=True,
                        stdout=subprocess.DEVNULL)
@@ -279,10 +280,10 @@ class Reference:
         return a
 
     def small_ntt(self, f, inverse=False):
-        """The reference's NTT3 / NTT9 codelet (ntt.cpp:25-44, 113-146) on a vector of 3 or 9 words."""
+        """The reference's NTT2 / NTT4 (ntt.cpp:16-22, 50-62) or NTT3 / NTT9 codelet (ntt.cpp:25-44, 113-146) on a vector of 2, 4, 3 or 9 words."""
         a = np.ascontiguousarray(f, dtype=np.uint32).copy()
         if self.lib.ref_small_ntt(a, a.size, int(inverse)) != 0:
-            raise ValueError("the reference has codelets of order 3 and 9 only")
+            raise ValueError("the reference has codelets of order 2, 3, 4 and 9 only (or oracle/_ref predates the order-2 / order-4 entries)")
         return a
 
     def encode_inplace(self, a):

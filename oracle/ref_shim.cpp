@@ -80,10 +80,20 @@ void ref_encode(uint32_t* data, size_t N, size_t size)
     gather_logical(data, ptrs, size);
 }
 
-// The reference's odd-order codelets (ntt.cpp:25-44, 113-146), which none of its drivers reaches: f[0..order) in place.
-// order 3 or 9; anything else leaves f untouched and returns -1.
+// The reference's small-order codelets, f[0..order) in place: NTT2 / NTT4 (ntt.cpp:16-22, 50-62; natural order out — NTT4 ends
+// with the swap of its two middle values) and the odd-order ones (ntt.cpp:25-44, 113-146), which none of its drivers reaches.
+// order 2, 3, 4 or 9; anything else leaves f untouched and returns -1.
 int ref_small_ntt(uint32_t* f, int order, int inverse)
 {
+    if (order == 2) {  // its own inverse up to the factor 1/2, which the reference's transforms never apply
+        NTT2<T, P>(f[0], f[1]);
+        return 0;
+    }
+    if (order == 4) {
+        if (inverse) NTT4<T, P, true>(f[0], f[1], f[2], f[3]);
+        else         NTT4<T, P, false>(f[0], f[1], f[2], f[3]);
+        return 0;
+    }
     if (order == 3) {
         if (inverse) NTT3<T, P, true>(f[0], f[1], f[2]);
         else         NTT3<T, P, false>(f[0], f[1], f[2]);

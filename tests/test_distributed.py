@@ -127,8 +127,7 @@ def _worker(rank, world, port, N, S, sub_slabs, use_gpu, q):
         dist.destroy_process_group()
 
 
-def _run_two_ranks(N, S, sub_slabs, use_gpu):
-    world = 2
+def _run_two_ranks(N, S, sub_slabs, use_gpu, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -139,7 +138,7 @@ def _run_two_ranks(N, S, sub_slabs, use_gpu):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(r[0] for r in results) == [0, 1]
+    assert sorted(r[0] for r in results) == list(range(world))
     for rank, ok_cols, ok_stripes, ok_max in results:
         assert ok_cols, "column-sharded encode + gather differs from the full encode (rank %d)" % rank
         assert ok_stripes and ok_max
@@ -154,6 +153,17 @@ def test_two_rank_gloo_column_slabs_and_stripes(N, S, sub_slabs):
 @pytest.mark.parametrize("N,S,sub_slabs", [(1 << 10, 1024, 2), (1 << 12, 256, 4), (64, 8, 2)])
 def test_two_rank_gloo_with_the_hip_encoder(hip_lib, N, S, sub_slabs):
     _run_two_ranks(N, S, sub_slabs, use_gpu=True)
+
+
+# BASELINE configs[3] IS eight ranks: 4 KB blocks = 1024 words -> 128-word slabs -> two 64-word sub-slabs, k/8 whole blocks per rank.
+@pytest.mark.parametrize("N,S,sub_slabs", [(64, 1024, 2), (8, 1024, 2)])
+def test_eight_rank_gloo_headline_geometry_gather(N, S, sub_slabs):
+    _run_two_ranks(N, S, sub_slabs, use_gpu=False, world=8)
+
+
+@pytest.mark.gpu
+def test_eight_rank_gloo_headline_geometry_gather_with_the_hip_encoder(hip_lib):
+    _run_two_ranks(1 << 10, 1024, 2, use_gpu=True, world=8)
 
 
 @pytest.mark.gpu
@@ -254,6 +264,19 @@ def _run_a2a(world, N, S, sub_slabs, use_gpu):
 @pytest.mark.parametrize("world,N,S,sub_slabs", [(2, 64, 8, 2), (2, 128, 256, 2), (4, 64, 8, 1), (4, 128, 256, 2), (4, 256, 512, 4), (4, 32, 4, 1)])
 def test_gloo_all_to_all_block_distributed(world, N, S, sub_slabs):
     _run_a2a(world, N, S, sub_slabs, use_gpu=False)
+
+
+# eight ranks at the headline geometry (128-word slabs in two 64-word sub-slabs), data in slabs and block-distributed (both in _worker_a2a)
+@pytest.mark.parametrize("N,S,sub_slabs", [(64, 1024, 2), (8, 1024, 2), (128, 1024, 4)])
+def test_eight_rank_gloo_all_to_all_headline_geometry(N, S, sub_slabs):
+    from fastecc_amd import sharding
+    assert sharding.sub_slab_count(1024 // 8, 2) == 2 and 1024 // 8 // 2 == 64
+    _run_a2a(8, N, S, sub_slabs, use_gpu=False)
+
+
+@pytest.mark.gpu
+def test_eight_rank_gloo_all_to_all_headline_geometry_with_the_hip_encoder(hip_lib):
+    _run_a2a(8, 1 << 11, 1024, 2, use_gpu=True)
 
 
 @pytest.mark.gpu

@@ -493,6 +493,29 @@ def test_ntt_equals_unmodified_reference(torch_cuda, fe, log2n, S):
             assert np.array_equal(got, ref.ntt(x, inverse, Reference.REC))
 
 
+@pytest.mark.parametrize("order", [2, 4])
+def test_ntt_of_order_2_and_4_equals_the_reference_codelets(torch_cuda, fe, order):
+    """fastecc_ntt at N = 2, 4 against NTT2 / NTT4 (ntt.cpp:16-22, 50-62) themselves, column by column, natural
+    order in and out (NTT4's closing swap included), both directions."""
+    from oracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref not prebuilt")
+    ref = Reference()
+    if not hasattr(ref.lib, "ref_small_ntt") or ref.lib.ref_small_ntt(np.zeros(4, np.uint32), 4, 0) != 0:
+        pytest.skip("oracle/_ref predates the order-2 / order-4 entries of ref_small_ntt")
+    torch = torch_cuda
+    for S in (1, 33, 1024):
+        x = rand_stripe(np.random.default_rng(100 * order + S), order, S)
+        x[:, 0] = np.array([0, P - 1, 1, P - 2], dtype=np.uint32)[:order]
+        with fe.Encoder(2 * order, order, 4 * S) as enc:
+            for inverse in (False, True):
+                d = to_dev(torch, x)
+                enc.ntt(d, inverse)
+                torch.cuda.synchronize()
+                want = np.stack([ref.small_ntt(x[:, c], inverse) for c in range(S)], axis=1)
+                assert np.array_equal(to_host(d), want), (order, S, inverse)
+
+
 def test_check_range_counts_non_field_words(torch_cuda, fe):
     """Inputs must be < p (README.md:160-162); fastecc_check_range finds the ones that are not."""
     torch = torch_cuda
@@ -678,3 +701,25 @@ def test_first_call_does_not_synchronise_and_tables_follow_the_streams(torch_cud
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(N, S), want)
+    # (c) the captured call is the context's FIRST: its tables must exist before any replay (they are built outside the capture), so an
+    # eager call on another stream, and one on the capture stream itself, are right before the graph has ever run; then the replay is too
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        out, o1, o2, t1 = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(d), d.clone()
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap, capture_error_mode="relaxed"):
+            enc.encode(d, out, stream=torch.cuda.current_stream().cuda_stream)
+        enc.encode(d, o1, stream=s1.cuda_stream)      # another stream, no replay yet
+        enc.encode(d, o2, stream=cap.cuda_stream)     # the stream the capture ran on, no replay yet
+        enc.ntt(t1, stream=s2.cuda_stream)            # a table kind the capture never touched: the ordinary lazy build
+        torch.cuda.synchronize()
+        assert np.array_equal(o1.cpu().numpy().view(np.uint32).reshape(N, S), want)
+        assert np.array_equal(o2.cpu().numpy().view(np.uint32).reshape(N, S), want)
+        assert np.array_equal(t1.cpu().numpy().view(np.uint32).reshape(N, S), oracle.ntt_fast(x))
+        assert not out.any()                           # the captured call itself has not run
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(N, S), want)

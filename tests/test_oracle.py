@@ -270,6 +270,24 @@ def test_reference_codelets_of_order_3_and_9(oracle, reference):
             assert np.array_equal(reference.small_ntt(f, inverse), want), (order, inverse)
 
 
+def test_reference_codelets_of_order_2_and_4(oracle, reference):
+    """NTT2 / NTT4 (ntt.cpp:16-22, 50-62) — the codelets every power-of-two transform of the reference bottoms out in — compute the
+    order-2 / order-4 transform of the definition in natural order (NTT4: after its closing swap), and so do the oracle's own
+    transforms at N = 2, 4 (pinned to the reference's code rather than to the mathematics)."""
+    if not hasattr(reference.lib, "ref_small_ntt") or reference.lib.ref_small_ntt(np.zeros(4, np.uint32), 4, 0) != 0:
+        pytest.skip("oracle/_ref predates the order-2 / order-4 entries of ref_small_ntt: rebuild it where /root/reference exists")
+    from oracle import Reference
+    rng = np.random.default_rng(24)
+    edge = np.array([0, 1, P - 1, P - 2], dtype=np.uint32)
+    for order in (2, 4):
+        for inverse in (False, True):
+            for f in [rng.integers(0, P, size=order, dtype=np.uint64).astype(np.uint32) for _ in range(20)] + [edge[:order], edge[::-1][:order].copy()]:
+                got = reference.small_ntt(f, inverse)
+                assert np.array_equal(got, oracle.slow_ntt(f.reshape(order, 1), inverse).reshape(-1)), (order, inverse)
+                assert np.array_equal(got, oracle.ntt_fast(f.reshape(order, 1), inverse).reshape(-1)), (order, inverse)
+                assert np.array_equal(got, reference.ntt(f.reshape(order, 1), inverse, Reference.MFA).reshape(-1)), (order, inverse)
+
+
 def test_p61_oracle_decoder_round_trip():
     """orc61_decode (O(N^2) Lagrange) restores what orc61_encode produced: the checker of the GF(p61^2) HIP decoder."""
     from oracle import OracleP61
