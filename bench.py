@@ -62,6 +62,17 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # the radix-2 GF(p) butterfly measured in isolation (tools/microbench.hip radix: 3796 radix-2 / 3826-3829 radix-4 form,
 # profiles/r03/microbench_radix4_vs_radix2.jsonl).
 VALU_PEAK_GBFLY = 3830.0
+VALU_PEAK_CLOCK_GHZ = 2.39  # the clock that loop sustains (profiles/r02/microbench_bfly_sustained_r02.jsonl: 2393 MHz at 1055 W; profiles/r05: GRBM cycles / duration)
+PMC_VALU = os.path.join("profiles", "r05", "pmc_valu_default_plan.json")
+
+
+def pmc_valu():
+    """The committed counter summary of the default plan's kernels at the headline size (tools/pmc_valu.py), or None."""
+    try:
+        with open(os.path.join(ROOT, PMC_VALU)) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def parse():
@@ -206,7 +217,7 @@ def pmc_traffic(kernel):
         return None
 
 
-ROCPROF_STATS = os.path.join("profiles", "r04", "rocprofv3_kernel_stats_bench_default.csv")
+ROCPROF_STATS = os.path.join("profiles", "r05", "rocprofv3_kernel_stats_bench_default.csv")
 
 
 def rocprof_avg_ms(kernel):
@@ -1020,12 +1031,23 @@ def main():
             traffic = pmc_traffic(name)
             headline = args.log2k == 19 and args.block_bytes == 4096 and not p61 and m_blocks == k and args.batch == 1 and not args.plan and not args.option
             prof_ms = rocprof_avg_ms(name) if headline else None
-            # The fused MID tile is bound by integer VALU issue (SQ_INSTS_VALU / duration: profiles/r01/pmc_default_plan_summary.json,
-            # profiles/r02/mid_valu_analysis.md), the outer passes by HBM: `bound` says which; achieved / peak / frac stay the HBM
-            # figures the contract asks for, the VALU figures are in `valu`.
-            roof = {"bound": "valu" if "_mid" in name else "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # `bound` comes from counters, not from the kernel's name: profiles/r05/pmc_valu_default_plan.json (tools/pmc_valu.py) holds, for the
+            # default plan's three kernels at the headline size, VALU instructions issued per SIMD and cycle against the isolated butterfly
+            # loop's rate (valu_issue_frac) and the algorithmic HBM rate against what a copy reaches (hbm_frac_achievable); the larger one names
+            # the bound.  achieved / peak / frac stay the HBM figures the contract asks for.  Other sizes / plans / fields have no counter file:
+            # their `bound` is labelled as assumed.
+            pmc = pmc_valu() if headline else None
+            ev = (pmc or {}).get("kernels", {}).get(name)
+            roof = {"bound": ev["bound"] if ev else ("valu" if "_mid" in name else "hbm"),
+                    "bound_source": (PMC_VALU + " (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE of this command and of the isolated butterfly loop, committed; "
+                                                "not measured in this run)") if ev else "assumed from the kernel's kind (no counter file for this size / plan / field)",
+                    "bound_evidence": None if not ev else {k2: ev[k2] for k2 in ("valu_issue_frac", "cycles_per_valu_instruction", "hbm_frac_achievable", "clock_GHz",
+                                                                                  "valu_busy_gfx94x_formula", "wave_cycles_split")},
+                    "per_kernel_bound": None if not pmc else {kn: {k2: e[k2] for k2 in ("bound", "valu_issue_frac", "hbm_frac_achievable", "clock_GHz")}
+                                                              for kn, e in pmc["kernels"].items()},
+                    "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json = profiles/r04/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
+                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json = profiles/r05/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
                                                                    "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)",
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
                     "frac_rocprof": None if not prof_ms else round(per_launch / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -1038,7 +1060,15 @@ def main():
                     "valu": {"what": "radix-2 butterflies per second over the whole encode (2*log2(k)*k/2 per element column, "
                                      "plus k/2 butterfly-equivalents for the per-block factor multiply)",
                              "achieved_Gbfly_per_s": round(bfly, 1), "microbench_peak_Gbfly_per_s": None if p61 else VALU_PEAK_GBFLY,
-                             "frac": None if p61 else round(bfly / VALU_PEAK_GBFLY, 4)},
+                             "frac": None if p61 else round(bfly / VALU_PEAK_GBFLY, 4),
+                             # the isolated loop runs at 2.39 GHz (no HBM traffic, 1055 W); the encode at ~2.0 GHz (1358 of 1400 W): the same yardstick at
+                             # the clock the encode's kernels ran at, and the instruction-level version of it (all VALU instructions of the three kernels
+                             # at the isolated loop's issue rate)
+                             "microbench_clock_GHz": None if p61 else VALU_PEAK_CLOCK_GHZ,
+                             "encode_clock_GHz": None if not pmc else round(pmc["encode"]["cycles"] / pmc["encode"]["sum_of_kernel_ms"] / 1e6, 3),
+                             "frac_at_encode_clock": None if not pmc else round(bfly / (VALU_PEAK_GBFLY * pmc["encode"]["cycles"] / pmc["encode"]["sum_of_kernel_ms"] / 1e6
+                                                                                        / VALU_PEAK_CLOCK_GHZ), 4),
+                             "issue_floor_frac": None if not pmc else pmc["encode"]["valu_floor_frac"]},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},
                     "launches_per_step": {kn: v[1] // args.steps for kn, v in sorted(kernels.items())}}
         if not args.no_parity_check and args.batch == 1 and m_blocks == k:

@@ -13,6 +13,8 @@ MICROBENCH_PATH = os.path.join(LIB_DIR, "microbench")
 
 HIP_SOURCES = ["plan.hip", "options.hip", "kernels.hip", "tile_kernels.hip", "mixed_kernels.hip", "mixed_kernels_pfa.hip", "mixed_kernels_pfa2.hip", "mixed_kernels_pfa3.hip", "gf61_kernels.hip", "gf61_decode.hip", "pack_kernels.hip", "direct.hip", "decode.hip", "sharded.hip", "host_copy.hip", "api.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# experiments only (e.g. -DFASTECC_DIRECT_ABLATION: timing ablations of direct.hip, wrong results on purpose): extra flags from the environment
+HIP_FLAGS += os.environ.get("FASTECC_EXTRA_HIPFLAGS", "").split()
 
 
 def hipcc():
@@ -85,7 +87,7 @@ def build_host(force=False, verbose=False):
 
 def build_microbench(force=False, verbose=False):
     """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
-    for name in ("microbench", "microbench_valu2", "microbench_p61"):
+    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma"):
         src = os.path.join(ROOT, "tools", name + ".hip")
         out = os.path.join(LIB_DIR, name)
         if not os.path.exists(src):

@@ -252,7 +252,10 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // stage (G steps of 8 rows) everything the NEXT stage needs is requested — its weight fragments into registers (parked in the other half
 // of the LDS buffer at the end of the stage) and its rows into a second register set — and lands while this stage's MFMAs run.
 // Addresses: one buffer descriptor per chunk for the rows, one for the fragments; a lane-constant offset plus a scalar one per request.
-template <int MT>
+// ABL (builds with -DFASTECC_DIRECT_ABLATION only; results are then WRONG on purpose): timing ablations that name the kernel's limiter —
+// bit 0: no row loads inside the loop, bit 1: no LDS reads of A fragments inside the loop, bit 2: no fragment staging (loads, LDS writes,
+// barrier) inside the loop, bit 3: no digit arithmetic.  profiles/r05/direct_mfma_ablation.jsonl.
+template <int MT, int ABL = 0, int NBX = 0>
 __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_mfma_kernel(const MfmaArgs a)
 {
     constexpr int G = MFMA_G, WN = G * MT / 4;  // uint4 of weight fragments per thread and stage
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
     // NB row buffers: stage s lives in buffer s % NB and, once its steps have been turned into B fragments, the buffer is refilled with
     // stage s + NB — that many stages of rows (NB * G * 4 KB per wave) are in flight, which is what hides the HBM latency when only one or
     // two waves fit a SIMD.  Stages past the end re-read the chunk's first stages (never used), so no bound has to be checked.
-    constexpr int NB = MT >= 4 ? 2 : 1;
+    constexpr int NB = NBX ? NBX : MT >= 4 ? 2 : 1;
     v2u x[NB][G][4];
     v4u wreg[WN];
 #pragma unroll
@@ -315,9 +318,11 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
             const uint32_t s = s0 + nb;
             if (s < stages) {  // workgroup-uniform
                 const uint32_t sw = s + 1 < stages ? s + 1 : 0, sx = s + NB < stages ? s + NB : 0;
+                if (!(ABL & 4)) {
 #pragma unroll
-                for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], sw * G * step_bytes, 0);
-                const uint4* wcur = wl[s & 1u];
+                    for (int q = 0; q < WN; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(frag_desc, wv[q], sw * G * step_bytes, 0);
+                }
+                const uint4* wcur = wl[(ABL & 4) ? 0 : (s & 1u)];
                 // A fragments: PF of them on their way from LDS ahead of the MFMAs that use them — with ONE wave per SIMD (MT = 8) nothing else
                 // runs while this wave sits in an s_waitcnt, and one fragment ahead (two MFMAs = 64 cycles) is about the latency of a ds_read_b128
                 constexpr int PF = 3, RING = 4;
@@ -329,16 +334,18 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
                     v4i bf[2];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        bf[0][i] = (int)balanced_digits(x[nb][g][i][0]);
-                        bf[1][i] = (int)balanced_digits(x[nb][g][i][1]);
+                        bf[0][i] = (int)((ABL & 8) ? x[nb][g][i][0] : balanced_digits(x[nb][g][i][0]));
+                        bf[1][i] = (int)((ABL & 8) ? x[nb][g][i][1] : balanced_digits(x[nb][g][i][1]));
                     }
+                    if (!(ABL & 1)) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[nb][g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (sx * G + g) + i) * row_bytes, 0);
+                        for (int i = 0; i < 4; ++i) x[nb][g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (sx * G + g) + i) * row_bytes, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the arithmetic
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int t = g * MT + mt;
-                        if (t + PF < G * MT) af[(t + PF) % RING] = wcur[(t + PF) * 64 + lane];
+                        if (t + PF < G * MT && !(ABL & 2)) af[(t + PF) % RING] = wcur[(t + PF) * 64 + lane];
                         v4i av;
                         av[0] = (int)af[t % RING].x; av[1] = (int)af[t % RING].y; av[2] = (int)af[t % RING].z; av[3] = (int)af[t % RING].w;
                         acc[mt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[0], acc[mt][0], 0, 0, 0);
@@ -346,9 +353,11 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 4)) {
 #pragma unroll
-                for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
-                __syncthreads();
+                    for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -719,7 +728,31 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
         switch (mt) {
             case 2: hipLaunchKernelGGL(direct_mfma_kernel<2>, grid, dim3(256), 0, st, a); break;
             case 4: hipLaunchKernelGGL(direct_mfma_kernel<4>, grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL(direct_mfma_kernel<8>, grid, dim3(256), 0, st, a); break;
+            default:
+#ifdef FASTECC_DIRECT_ABLATION
+            {
+                static const int abl = [] { const char* e = getenv("FASTECC_DIRECT_ABLATE"); return e ? atoi(e) : 0; }();
+                switch (abl) {
+                    case 1: hipLaunchKernelGGL((direct_mfma_kernel<8, 1>), grid, dim3(256), 0, st, a); break;
+                    case 2: hipLaunchKernelGGL((direct_mfma_kernel<8, 2>), grid, dim3(256), 0, st, a); break;
+                    case 3: hipLaunchKernelGGL((direct_mfma_kernel<8, 3>), grid, dim3(256), 0, st, a); break;
+                    case 4: hipLaunchKernelGGL((direct_mfma_kernel<8, 4>), grid, dim3(256), 0, st, a); break;
+                    case 5: hipLaunchKernelGGL((direct_mfma_kernel<8, 5>), grid, dim3(256), 0, st, a); break;
+                    case 6: hipLaunchKernelGGL((direct_mfma_kernel<8, 6>), grid, dim3(256), 0, st, a); break;
+                    case 7: hipLaunchKernelGGL((direct_mfma_kernel<8, 7>), grid, dim3(256), 0, st, a); break;
+                    case 8: hipLaunchKernelGGL((direct_mfma_kernel<8, 8>), grid, dim3(256), 0, st, a); break;
+                    case 15: hipLaunchKernelGGL((direct_mfma_kernel<8, 15>), grid, dim3(256), 0, st, a); break;
+                    case 103: hipLaunchKernelGGL((direct_mfma_kernel<8, 0, 3>), grid, dim3(256), 0, st, a); break;
+                    case 104: hipLaunchKernelGGL((direct_mfma_kernel<8, 0, 4>), grid, dim3(256), 0, st, a); break;
+                    case 105: hipLaunchKernelGGL((direct_mfma_kernel<8, 0, 5>), grid, dim3(256), 0, st, a); break;
+                    default: hipLaunchKernelGGL((direct_mfma_kernel<8, 0>), grid, dim3(256), 0, st, a); break;
+                }
+                break;
+            }
+#else
+                hipLaunchKernelGGL(direct_mfma_kernel<8>, grid, dim3(256), 0, st, a);
+                break;
+#endif
         }
         DIR_TRY(hipGetLastError());
         if (tail_chunks) {  // the last data rows and the parity rows used as nodes
