@@ -95,6 +95,13 @@ def test_a_rank_that_never_arrives_leaves_the_replica_line(hip_lib):
     assert line["value"] == line["replicas"]["value"] > 0
 
 
+def test_a_process_group_that_never_comes_up_leaves_a_line(hip_lib):
+    """One rank never joins torch.distributed: rank 0 prints its own timing (no collective was possible) instead of nothing."""
+    line = _bench(2, fault="startup", extra=("--startup-timeout", "12"))
+    assert "UNAVAILABLE" in line["collectives"] and line["scaling"] == "weak" and line["n_gpus"] == 2
+    assert line["value"] > 0 and line["ms_per_step"] == line["rank0_local_ms_per_step"]
+
+
 def test_eight_rank_headline_geometry_control_flow(hip_lib):
     """Eight ranks, 4 KB blocks: 128-word slabs in two 64-word sub-slabs, k/8 whole blocks per rank (the geometry of configs[3])."""
     line = _bench(8)
