@@ -701,7 +701,12 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
     if (use_mfma) {
         // M-tiles per workgroup (measured: profiles/r03/direct_bench.jsonl; round 4: 8 tiles at one wave per SIMD and 4 tiles at two waves per SIMD with
         // twice the sweeps take the same time — 0.70 / 1.23 / 2.33 ms for 64 / 128 / 256 outputs — so latency is not what holds the kernel at ~45 % of the MFMA rate)
+#ifdef FASTECC_DIRECT_ABLATION
+        static const int mt_env = [] { const char* e = getenv("FASTECC_DIRECT_MT"); return e ? atoi(e) : 0; }();
+        const int mt = mt_env ? mt_env : p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
+#else
         const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
+#endif
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
         const uint32_t steps_alloc = bulk / 8u + MFMA_G;  // zero steps at the end: the prefetch of a stage never leaves the table

@@ -67,7 +67,7 @@ def main():
             out = torch.empty(m * S, dtype=torch.int32, device="cuda:0")
             ref = None
             for name, kernel, dmax in (("pipeline", 0, 0), ("valu", 1, 256), ("mfma", 2, 256)):
-                if name == "valu" and m > 64:
+                if name == "valu" and (m > 64 or os.environ.get("FASTECC_BENCH_DIRECT_FAST")):
                     continue
                 enc.set_option("direct_kernel", kernel)
                 enc.set_option("encode_direct_max", dmax)
