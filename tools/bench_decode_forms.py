@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 import fastecc_amd as fe  # noqa: E402
 
-k, S = 1 << 19, 1024
+k, S = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19), 1024
 stream = torch.cuda.current_stream().cuda_stream
 data = torch.randint(0, 0xFFF00001, (k * S,), dtype=torch.int64, device="cuda:0").to(torch.int32)
 parity = torch.empty_like(data)
@@ -36,10 +36,14 @@ with fe.Encoder(2 * k, k, 4 * S) as enc:
     dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
     dp[lost[lost < k]] = 0
     pp[lost[lost >= k] - k] = 0
+    saved = data.clone()
     for form, split in (("split_small_form", 1), ("split_block_groups", 2), ("unsplit_2k_point_transform", 0)):
         enc.set_option("decode_split", split)
         enc.decode_prepare(dp, pp)
-        row = {"form": form, "decode_ms": round(event_ms(lambda: enc.decode(data, parity, stream=stream)), 3),
+        data.view(k, S)[torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0")] = -1
+        enc.decode(data, parity, stream=stream)
+        torch.cuda.synchronize()
+        row = {"form": form, "log2k": int(np.log2(k)), "restored": bool(torch.equal(data, saved)), "decode_ms": round(event_ms(lambda: enc.decode(data, parity, stream=stream)), 3),
                "repair_ms": round(event_ms(lambda: enc.repair(data, parity, stream=stream)), 3)}
         enc.profile(True)
         enc.profile_reset()
