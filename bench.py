@@ -561,6 +561,55 @@ def other_field_p61(fastecc_amd, device, stream, steps=10):
                 "parity_pin": "no upstream code exists for this field: pinned to this repository's oracle and Python big-integer goldens"}
 
 
+def other_field_p61_cosets(fastecc_amd, device, stream, steps=5):
+    """n = 4k over the 64-bit field (more parity than data blocks, native transforms): (2^19, 2^17) x 64 KB, 8 GiB of data -> 24 GiB of parity, HIP
+    events; two element columns of the result re-computed by the oracle's composition (checker only)."""
+    import numpy as np
+    from oracle import OracleP61
+    k, bb, e = 1 << 17, 65536, 2
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 48 * 2**30:
+        return {"skipped": "needs 40 GiB of free HBM, %.0f GiB free" % (free / 2**30)}
+    data = random_stripe_p61(k * (bb // 8), device, seed=0x614)
+    parity = torch.empty(3 * data.numel(), dtype=data.dtype, device=device)
+    with fastecc_amd.Encoder(k << e, k, bb, device=device.index or 0, field=fastecc_amd.FIELD_GF_P61_SQUARED) as enc:
+        for _ in range(2):
+            enc.encode(data, parity, stream=stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            enc.encode(data, parity, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        enc.profile(True)
+        enc.profile_reset()
+        enc.encode(data, parity, stream=stream)
+        kernels = enc.profile_read()
+        enc.profile(False)
+        plan = enc.plan()
+    o = OracleP61()
+    elems = bb // 16
+    cols = [0, elems - 1]
+    idx = torch.tensor([2 * c + j for c in cols for j in (0, 1)], device=device)
+    x = data.view(k, 2 * elems)[:, idx].cpu().numpy().view(np.uint64)
+    got = parity.view(3 * k, 2 * elems)[:, idx].cpu().numpy().view(np.uint64)
+    gens = []
+    for j in range(1, e + 1):
+        w = o.root(k << j)
+        gens += [o.cpow(w, c) for c in range(1, 1 << j, 2)]
+    coef = o.ntt(np.ascontiguousarray(x), inverse=True)
+    inv_n = o.cinv((k % P61, 0))
+    want = np.concatenate([o.ntt(o.scale_blocks(coef, inv_n, g)) for g in gens])
+    return {"workload": "RS encode k=2^17 data -> 3 x 2^17 parity blocks (n = 4k), 65536 B blocks, GF((2^61-1)^2): 8 GiB in, 24 GiB out", "ms_per_step": round(ms, 3),
+            "GBps_data_plus_parity": round(4.0 * k * bb / ms / 1e6, 1), "steps": steps, "plan": plan,
+            "launches_per_encode": {kn: v[1] for kn, v in sorted(kernels.items())}, "per_kernel_avg_ms": {kn: round(v[0] / v[1], 3) for kn, v in sorted(kernels.items())},
+            "parity_check": {"status": "ok" if np.array_equal(got, want) else "FAILED",
+                             "what": "element columns %s of all three cosets re-computed by the oracle's composition (iNTT, block i *= g^i / N, NTT per coset generator)" % cols},
+            "parity_pin": "no upstream code exists for this field: pinned to this repository's oracle and Python big-integer goldens (tests/golden/golden_p61.json coset_cases)"}
+
+
 def other_paths_child(args):
     """The widened rows in a process of their own (one JSON object, progressively: the parent keeps the last complete line)."""
     import fastecc_amd
@@ -586,6 +635,12 @@ def other_paths_child(args):
             out["configs4_64bit_field"] = other_field_p61(fastecc_amd, device, stream)
         except Exception as e:  # noqa: BLE001
             out["configs4_64bit_field"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+        torch.cuda.empty_cache()
+        try:
+            out["p61_n_equals_4k"] = other_field_p61_cosets(fastecc_amd, device, stream)
+        except Exception as e:  # noqa: BLE001
+            out["p61_n_equals_4k"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
 

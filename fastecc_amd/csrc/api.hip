@@ -425,6 +425,10 @@ int encode_pow2(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStrea
 {
     if (c->p61) {
         P61Hooks hk(c);
+        if (c->cosets > 1) {  // n = 4k / 8k: the DIF half once into a k-block work stripe, MID and the DIT half once per coset
+            if (p61::encode_cosets_needs_work(c->p61) && !c->scratch) HIP_TRY(hipMalloc((void**)&c->scratch, c->N * (size_t)c->S * 4));
+            return p61::encode_cosets(c->p61, (const uint64_t*)data, (uint64_t*)parity, (uint64_t*)c->scratch, st, c->profiling ? &hk.h : nullptr);
+        }
         return p61::encode(c->p61, (const uint64_t*)data, (uint64_t*)parity, st, c->profiling ? &hk.h : nullptr);
     }
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
@@ -956,7 +960,6 @@ int fastecc_create(fastecc_ctx** out, uint64_t n, uint64_t k, uint64_t block_byt
     int fold = 0, cosets = 1;
     if (pow2 && (n == 4 * k || n == 8 * k)) {
         cosets = (int)(n / k) - 1;
-        if (f61) return FASTECC_E_UNSUPPORTED;
     } else {
         if (m > N1) return FASTECC_E_UNSUPPORTED;
         int lgm = 0;
@@ -1079,7 +1082,8 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
         return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
     }
     if (f61) {
-        int rc = p61::create(&c->p61, lg, block_bytes / 16, g_detail, sizeof g_detail);
+        int rc = cosets > 1 ? p61::create_cosets(&c->p61, lg, block_bytes / 16, cosets, g_detail, sizeof g_detail)
+                            : p61::create(&c->p61, lg, block_bytes / 16, g_detail, sizeof g_detail);
         if (rc == FASTECC_OK) {
             const hipError_t e = hipMalloc((void**)&c->factor, 8);  // counter of fastecc_check_range
             if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(counter)");

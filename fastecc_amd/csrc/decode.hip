@@ -561,6 +561,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     const CtxInfo ci = info_of(c);
     if (ci.field == FASTECC_FIELD_GF_P61_SQUARED) {
         // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are always (2k,k) with k a power of two
+        if (ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // n = 4k / 8k over this field: encode only (the decoder's transform is built for positions of order 2k)
         DeviceScope ds61(ci.device);
         if (!ds61.ok) return FASTECC_E_DEVICE;
         CallScope call61(c);

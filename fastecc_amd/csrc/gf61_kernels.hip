@@ -638,7 +638,8 @@ struct Path {
     uint64_t* tw_inv = nullptr;  // inverse roots, the same packing
     uint64_t* tw_ntt_fwd = nullptr;  // the two again, packed for the stand-alone transform's plan when its register runs
     uint64_t* tw_ntt_inv = nullptr;  // differ from the encode plan's (a MID tile there, register passes here); else null
-    uint64_t* dscale = nullptr;
+    uint64_t* dscale = nullptr;  // per-block factors by position; `cosets` tables of N elements back to back
+    int cosets = 1;              // 1: the (2k,k) code; 3 / 7: n = 4k / 8k (one table per coset of evaluation points, create_cosets)
     SmallRoots sr{};  // forward w_16^(1,3,5,7)
     std::string text;
 };
@@ -895,7 +896,7 @@ struct FusedEnds {
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
 int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint64_t* out, const uint64_t* tw_dif,
                const uint64_t* tw_dit, bool inverse_roots, hipStream_t st, const LaunchHooks* hooks, uint64_t col0 = 0, uint64_t width = 0,
-               const FusedEnds* ends = nullptr)
+               const FusedEnds* ends = nullptr, const uint64_t* dscale = nullptr)
 {
     if (width == 0) width = p->elems;
     in += 2 * col0;  // element columns [col0, col0 + width) of every block: independent transforms
@@ -922,7 +923,7 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         }
         a.tw_dif = tw_dif;
         a.tw_dit = tw_dit;
-        a.dscale = p->dscale;
+        a.dscale = dscale ? dscale : p->dscale;
         a.elems = (uint32_t)width;
         a.pitch = (uint32_t)p->elems;
         a.col_chunks = (uint32_t)((width + 63) / 64);
@@ -966,6 +967,44 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
 }  // namespace
 
 int create(Path** out, int n, uint64_t elems, char* detail, size_t cap) { return create_transform(out, n, elems, FACTOR_ENCODE, detail, cap); }
+
+// n = 4k / 8k (cosets = 3 / 7): the parity is f on the cosets g <w_k> of the data points inside the n-th roots of unity, in the nesting order of
+// include/fastecc.h — g = w_2k; w_4k, w_4k^3; w_8k, w_8k^3, w_8k^5, w_8k^7 — block j of coset g being f(g w_k^j): RS.cpp:40-63 with g in place
+// of root(2N).  One table of per-block factors g^m / N per coset; the DIF half of the encode is shared (encode_cosets).
+int create_cosets(Path** out, int n, uint64_t elems, int cosets, char* detail, size_t cap)
+{
+    if (cosets != 3 && cosets != 7) return FASTECC_E_INVAL;
+    int rc = create_transform(out, n, elems, FACTOR_ENCODE, detail, cap);
+    if (rc != FASTECC_OK) return rc;
+    Path* p = *out;
+    uint64_t* all = nullptr;
+    hipError_t e = hipMalloc((void**)&all, (size_t)cosets * 2 * p->N * 8);
+    if (e == hipSuccess) {
+        const gf61::Elem c = gf61::h_inv(gf61::Elem{p->N % gf61::P, 0});
+        for (int t = 0; t < cosets && e == hipSuccess; t++) {
+            // coset t: generator w_(2^j k)^odd with j = floor(log2(t + 1)) + 1 and the (t + 2 - 2^(j-1))-th odd exponent
+            int j = 1;
+            while ((1 << j) - 1 <= t) j++;
+            const uint64_t odd = 2ull * (uint64_t)(t + 1 - (1 << (j - 1))) + 1ull;
+            const gf61::Elem g = gf61::h_pow(gf61::h_root(p->N << j), odd);
+            hipLaunchKernelGGL(k_block_factors, dim3((unsigned)((p->N + 255) / 256)), dim3(256), 0, nullptr, all + (size_t)t * 2 * p->N, c.re, c.im, g.re, g.im, n, false);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
+    if (e != hipSuccess) {
+        if (all) (void)hipFree(all);
+        rc = fail(detail, cap, e, "gf61 coset factors");
+        destroy(p);
+        *out = nullptr;
+        return rc;
+    }
+    (void)hipFree(p->dscale);
+    p->dscale = all;
+    p->cosets = cosets;
+    return FASTECC_OK;
+}
+int cosets_of(const Path* p) { return p ? p->cosets : 1; }
 
 int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail, size_t cap) { return create_transform_mid(out, n, elems, factor, 0, detail, cap); }
 
@@ -1129,6 +1168,30 @@ int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, cons
     // inverse roots on the way down (interpolate), forward roots on the way up (evaluate) — RS.cpp:41,63
     return run_passes(p, p->enc, data, parity, p->tw_inv, p->tw_fwd, true, st, hooks);
 }
+
+// n = 4k / 8k: the DIF passes once (data -> work, k blocks; with no DIF pass in the plan MID reads the data itself), then MID and the DIT passes
+// once per coset with that coset's factors, coset t writing parity blocks [t k, (t + 1) k).
+int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks)
+{
+    size_t mid = 0;
+    while (mid < p->enc.size() && p->enc[mid].mode != MODE_MID) mid++;
+    if (mid >= p->enc.size()) return FASTECC_E_UNSUPPORTED;
+    const std::vector<Pass> head(p->enc.begin(), p->enc.begin() + (long)mid), tail(p->enc.begin() + (long)mid, p->enc.end());
+    const uint64_t* src = data;
+    if (!head.empty()) {
+        if (!work) return FASTECC_E_INVAL;
+        const int rc = run_passes(p, head, data, work, p->tw_inv, p->tw_fwd, true, st, hooks);
+        if (rc != FASTECC_OK) return rc;
+        src = work;
+    }
+    for (int t = 0; t < p->cosets; t++) {
+        const int rc = run_passes(p, tail, src, parity + (size_t)t * p->N * p->elems * 2, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, nullptr,
+                                  p->dscale + (size_t)t * 2 * p->N);
+        if (rc != FASTECC_OK) return rc;
+    }
+    return FASTECC_OK;
+}
+bool encode_cosets_needs_work(const Path* p) { return p && !p->enc.empty() && p->enc[0].mode != MODE_MID; }
 
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks)
 {

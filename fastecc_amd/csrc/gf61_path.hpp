@@ -26,6 +26,9 @@ int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
 // 2^(n+1) is needed) instead of the encoder's w_2N^m / N (FACTOR_ENCODE).  All tables of a path are built by kernels.
 enum { FACTOR_ENCODE = 0, FACTOR_INDEX = 1 };
 int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail, size_t detail_cap);
+// n = 4k / 8k (cosets = 3 / 7 further cosets of evaluation points, include/fastecc.h's nesting order): encode_cosets only
+int create_cosets(Path** out, int n, uint64_t elems, int cosets, char* detail, size_t detail_cap);
+int cosets_of(const Path* p);
 // create_transform with the MID pass forced to `force_mid` levels (0 = the plan's own choice, also when no such plan exists)
 int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int force_mid, char* detail, size_t detail_cap);
 // Only the EVEN output positions of `big`'s transform (size 2^(n+1), created with force_mid = 7): DIF passes of `big`, a MID tile that folds
@@ -52,6 +55,9 @@ int encode_ends(Path* p, const uint64_t* data, const uint64_t* parity, const uin
 void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);
+// a create_cosets path: parity = cosets * k blocks; work = a k-block stripe of the caller's (needed when encode_cosets_needs_work)
+int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks);
+bool encode_cosets_needs_work(const Path* p);
 // the element columns [col0, col0 + width) of every block only (data / parity are the stripes' base addresses)
 int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col0, uint64_t width, hipStream_t st, const LaunchHooks* hooks);
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);

@@ -65,7 +65,10 @@ enum {
      * the rules fastecc_create documents for GF(0xFFF00001) — the data zero-extended to N blocks, parity block j = block j * 2^fold of the
      * (2N,N) parity, fold = min(log2 N - ceil(log2(n-k)), 4) — through padded copies of the stripes inside the context (two N-block work
      * stripes: encode, decode_prepare, decode and repair on device memory, encode also on host memory; not encode_columns / ntt /
-     * check_range, and no n = 4k, 8k).
+     * check_range).  n = 4k and n = 8k with k = 2^m (more parity than data blocks, fastecc_create's coset rule and nesting order with this
+     * field's roots: w_2k; w_4k, w_4k^3; w_8k, w_8k^3, w_8k^5, w_8k^7) are native transforms — the DIF half once into a k-block work stripe
+     * of the context, MID and the DIT half once per coset: fastecc_encode on device and host memory (out of place only), set_plan, profile;
+     * decode_prepare returns FASTECC_E_UNSUPPORTED for them (this field's decoder works on positions of order 2k).
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
 };

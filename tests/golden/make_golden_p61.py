@@ -87,17 +87,56 @@ def encode(words, N, elems):
     return out
 
 
+def coset_generators(N, e):
+    """The evaluation cosets of the n = 2^e N codes, in the nesting order of include/fastecc.h: w_2N; w_4N, w_4N^3; w_8N, w_8N^3, w_8N^5, w_8N^7."""
+    gens = []
+    for j in range(1, e + 1):
+        w = root(N << j)
+        gens += [cpow(w, c) for c in range(1, 1 << j, 2)]
+    return gens
+
+
+def encode_cosets(words, N, elems, e):
+    """n = 2^e N: parity block t N + j = f(g_t w_N^j), f the interpolating polynomial of the data (degree < N), straight from the definition."""
+    wN = root(N)
+    inv_wN, inv_N = cinv(wN), cinv((N % P, 0))
+    gens = coset_generators(N, e)
+    out = [0] * (len(gens) * len(words))
+    for c in range(elems):
+        vals = [(words[(i * elems + c) * 2], words[(i * elems + c) * 2 + 1]) for i in range(N)]
+        coef = []
+        for m in range(N):
+            acc = (0, 0)
+            for i in range(N):
+                acc = cadd(acc, cmul(vals[i], cpow(inv_wN, i * m)))
+            coef.append(cmul(acc, inv_N))
+        for t, g in enumerate(gens):
+            for j in range(N):
+                x = cmul(g, cpow(wN, j))
+                acc = (0, 0)
+                for m in range(N):
+                    acc = cadd(acc, cmul(coef[m], cpow(x, m)))
+                out[((t * N + j) * elems + c) * 2], out[((t * N + j) * elems + c) * 2 + 1] = acc
+    return out
+
+
 def main():
     cases = []
     for N, elems, seed in ((2, 1, 0x1234), (4, 2, 0x1234), (16, 1, 7), (32, 2, 99)):
         words = splitmix_words(N * elems * 2, seed)
         cases.append({"N": N, "elems": elems, "seed": seed, "data": [str(w) for w in words],
                       "parity": [str(w) for w in encode(words, N, elems)]})
+    coset_cases = []
+    for N, elems, e, seed in ((2, 1, 2, 5), (4, 2, 2, 6), (8, 1, 3, 7), (16, 1, 2, 8)):
+        words = splitmix_words(N * elems * 2, seed)
+        coset_cases.append({"N": N, "elems": elems, "e": e, "seed": seed, "data": [str(w) for w in words],
+                            "parity": [str(w) for w in encode_cosets(words, N, elems, e)]})
     doc = {
         "p": str(P), "generator": [str(v) for v in G], "w_2^62": [str(v) for v in W62],
         "roots": {str(t): [str(v) for v in root(1 << t)] for t in (1, 2, 3, 4, 8, 16, 19, 20)},
         "inv_2^19": str(pow(1 << 19, P - 2, P)),
         "cases": cases,
+        "coset_cases": coset_cases,
     }
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_p61.json")
     with open(path, "w") as f:

@@ -444,3 +444,78 @@ def test_other_n_k_over_the_64_bit_field(torch_cuda, fe, orc61, k, m, elems):
             dp[: m + 1] = 0
             with pytest.raises(fe.FastEccError):
                 enc.decode_prepare(dp, pp)
+
+
+def p61_coset_generators(orc61, N, e):
+    """w_2N; w_4N, w_4N^3; w_8N, w_8N^3, w_8N^5, w_8N^7 — the nesting order of include/fastecc.h."""
+    gens = []
+    for j in range(1, e + 1):
+        w = orc61.root(N << j)
+        gens += [orc61.cpow(w, c) for c in range(1, 1 << j, 2)]
+    return gens
+
+
+def p61_oracle_coset_parity(orc61, x, e):
+    """RS.cpp:40-63 with each coset generator in place of root(2N): iNTT, block i *= g^i / N, NTT."""
+    N = x.shape[0]
+    coef = orc61.ntt(x, inverse=True)
+    inv_n = orc61.cinv((N % P61, 0))
+    return np.concatenate([orc61.ntt(orc61.scale_blocks(coef, inv_n, g)) for g in p61_coset_generators(orc61, N, e)])
+
+
+def test_multi_coset_golden_vectors(torch_cuda, fe, orc61):
+    """n = 4k / 8k over the 64-bit field against the independent big-integer vectors (tests/golden/make_golden_p61.py: the parity blocks straight
+    from the definition f(g w_k^j)), and the oracle's composition against the same vectors."""
+    doc = json.load(open(os.path.join(HERE, "golden", "golden_p61.json")))
+    for case in doc["coset_cases"]:
+        N, elems, e = case["N"], case["elems"], case["e"]
+        rows = ((1 << e) - 1) * N
+        x = np.array([int(w) for w in case["data"]], dtype=np.uint64).reshape(N, 2 * elems)
+        want = np.array([int(w) for w in case["parity"]], dtype=np.uint64).reshape(rows, 2 * elems)
+        assert (p61_oracle_coset_parity(orc61, x, e) == want).all(), (N, e)
+        with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+            d = to_dev(torch_cuda, x)
+            out = torch_cuda.empty(rows * 2 * elems, dtype=torch_cuda.int64, device="cuda:0")
+            enc.encode(d, out)
+            assert (to_host(out).reshape(rows, 2 * elems) == want).all(), (N, elems, e)
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 6, 7, 9, 12, 13, 14])
+@pytest.mark.parametrize("e", [2, 3])
+def test_multi_coset_parity_matches_oracle(torch_cuda, fe, orc61, logn, e):
+    """More parity than data blocks over GF((2^61-1)^2): the n - k parity blocks are f on the 2^e - 1 cosets of the data points, k blocks per
+    coset, codes nest (the first k blocks are the (2k,k) parity).  Sizes cover a MID-only plan, one and two tile chunks around MID."""
+    N, elems = 1 << logn, (21 if logn < 12 else 66)
+    x = rand_stripe(np.random.default_rng(61000 + 10 * logn + e), N, elems)
+    want = p61_oracle_coset_parity(orc61, x, e)
+    rows = ((1 << e) - 1) * N
+    with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        dx = to_dev(torch_cuda, x)
+        out = torch_cuda.full((rows * 2 * elems,), 5, dtype=torch_cuda.int64, device="cuda:0")
+        for _ in range(2):  # twice: the work stripe and the tables are reused
+            enc.encode(dx, out)
+            got = to_host(out).reshape(rows, 2 * elems)
+            assert (got < P61).all()
+            assert (got[:N] == orc61.encode(x)).all(), enc.plan()   # the codes nest
+            assert (got == want).all(), enc.plan()
+        assert (to_host(dx).reshape(x.shape) == x).all()
+        host_out = np.empty_like(want)
+        enc.encode(x, host_out, mem=fe.MEM_HOST)
+        assert (host_out == want).all()
+        with pytest.raises(fe.FastEccError):
+            enc.encode(dx)  # in place is impossible: the parity is larger than the data
+        with pytest.raises(fe.FastEccError) as ei:
+            enc.decode_prepare(np.ones(N, np.uint8), np.ones(rows, np.uint8))  # these codes are encode-only in this field
+        assert ei.value.code == fe.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("plan", [2, 4, 13, 24])
+def test_multi_coset_plans(torch_cuda, fe, orc61, plan):
+    N, elems, e = 1 << 12, 40, 2
+    x = rand_stripe(np.random.default_rng(61 + plan), N, elems)
+    want = p61_oracle_coset_parity(orc61, x, e)
+    with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        enc.set_plan(plan)
+        out = torch_cuda.empty(3 * N * 2 * elems, dtype=torch_cuda.int64, device="cuda:0")
+        enc.encode(to_dev(torch_cuda, x), out)
+        assert (to_host(out).reshape(3 * N, 2 * elems) == want).all(), enc.plan()

@@ -142,6 +142,29 @@ def test_p61_oracle_against_independent_golden():
         assert (o.encode_by_definition(x) == want).all()
 
 
+def test_p61_oracle_multi_coset_composition_against_independent_golden():
+    """n = 4k / 8k over the 64-bit field: the oracle's composition (iNTT, block i *= g^i / N, NTT per coset generator g, the nesting order of
+    include/fastecc.h) gives the big-integer vectors computed straight from the definition f(g w_k^j) (tests/golden/make_golden_p61.py)."""
+    import json
+    import oracle as orc
+    o = orc.OracleP61()
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_p61.json")))
+    assert len(doc["coset_cases"]) >= 4
+    for case in doc["coset_cases"]:
+        N, e = case["N"], case["e"]
+        x = np.array([int(w) for w in case["data"]], dtype=np.uint64).reshape(N, -1)
+        want = np.array([int(w) for w in case["parity"]], dtype=np.uint64).reshape(((1 << e) - 1) * N, -1)
+        gens = []
+        for j in range(1, e + 1):
+            w = o.root(N << j)
+            gens += [o.cpow(w, c) for c in range(1, 1 << j, 2)]
+        coef = o.ntt(x, inverse=True)
+        inv_n = o.cinv((N % ((1 << 61) - 1), 0))
+        got = np.concatenate([o.ntt(o.scale_blocks(coef, inv_n, g)) for g in gens])
+        assert (got == want).all(), (N, e)
+        assert (got[:N] == o.encode(x)).all()  # the codes nest: coset 0 is the (2k,k) parity
+
+
 def test_p61_oracle_fast_transform_is_the_definition():
     import oracle as orc
     o = orc.OracleP61()
