@@ -20,7 +20,13 @@ fastecc_create_sharded / fastecc_encode_sharded in the C ABI (csrc/sharded.hip).
 Everything here is index arithmetic on torch tensors plus collectives; the encode itself is passed in as a callable
 so the same code runs with the HIP encoder on GPUs and — in the CPU unit tests only — with the oracle.
 """
+import os
+
 import torch
+
+# Test hook (tests/test_gpu_rccl_single_rank.py): with a ONE-rank process group the collectives are normally skipped; set, they are issued anyway,
+# so that a 1-GPU box runs the very RCCL calls of the N > 1 path (arguments, dtypes, contiguity, streams) against the real library.
+FORCE_COLLECTIVES = bool(os.environ.get("FASTECC_SHARDING_FORCE_COLLECTIVES"))
 
 
 def stripes_for_rank(n_stripes, rank, world):
@@ -122,7 +128,7 @@ def encode_slab_and_gather(data_slab, encode_columns, parity_rows, parity_full=N
             send = piece
         if collective_on_host:
             send = send.cpu()
-        if world == 1:
+        if world == 1 and not (FORCE_COLLECTIVES and ranked):
             pending.append((h, None, [send]))
             continue
         recv = [buf("recv%d_%d" % (h, g), (parity_rows, ws), cdev) for g in range(world)] if rank == dst else None
@@ -215,7 +221,7 @@ def encode_sub_slabs_and_gather(data_sub, encode_fn, parity_rows, parity_full=No
         if on_gpu:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                if world > 1:
+                if world > 1 or (FORCE_COLLECTIVES and ranked):
                     # in place: the root's part is already home; its slot of the gather gets a scratch tensor (distinct memory from the
                     # receive slot, so that no backend has to cope with an input that aliases its own output)
                     piece = buf("root_dummy", (parity_rows, ws)) if in_place else mine[h]
@@ -325,7 +331,7 @@ def encode_all_to_all(data, encode_fn, parity_rows, data_is_blocks=False, sub_sl
 
     def exchange(dst, src):
         """dst[j] <- rank j's src[rank] (dst, src: [world, rows, ws] contiguous)."""
-        if world == 1:
+        if world == 1 and not (FORCE_COLLECTIVES and ranked):
             dst.copy_(src)
         elif collective_on_host:
             got = torch.empty(src.shape, dtype=src.dtype)
