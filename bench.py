@@ -288,6 +288,19 @@ def parity_check_p61(data, parity, k, block_bytes):
             "what": "element columns %s of the timed stripe re-encoded by oracle/fastecc_oracle_p61.c (no upstream output exists for this field)" % cols}
 
 
+def oracle_columns(data, got, k, S, rows_out, which, cols=(0, -1)):
+    """Two word columns of a result re-computed by the CPU oracle (checker only; columns are independent transforms): `which` maps the oracle's
+    encoder to the expected rows.  Returns "ok" / "FAILED" — the entry is then pinned to the oracle, not only to another plan of this library."""
+    import numpy as np
+    from oracle import Oracle
+    orc = Oracle()
+    idx = torch.tensor([c % S for c in cols], device=data.device)
+    x = np.ascontiguousarray(data.view(k, S)[:, idx].cpu().numpy().view(np.uint32))
+    want = which(orc, x)
+    have = got.view(rows_out, S)[:, idx].cpu().numpy().view(np.uint32)
+    return "ok" if want.shape == have.shape and np.array_equal(want, have) else "FAILED"
+
+
 def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stream):
     """Short, checked timings of the rows around the headline path, so that the driver's record carries them too —
     they are NOT the metric.  `data` / `parity` are the codeword the timed context just produced.  Every entry verifies what it timed."""
@@ -357,8 +370,10 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             ms = event_ms(lambda: small.encode(data, p_direct, stream=stream), 10)
             small.set_option("encode_direct_max", 0)
             small.encode(data, p_pipe, stream=stream)
+            stride4 = 1 << min(log2k - 2, 4)  # parity block j = block j * 2^fold of the (2k,k) parity (include/fastecc.h)
             out["encode_k_plus_4_parity"] = {"ms": round(ms, 3), "data_GBps": round(k * block_bytes / ms / 1e6, 1),
-                                             "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe))}
+                                             "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe)),
+                                             "oracle_columns": oracle_columns(data, p_direct, k, S, 4, lambda orc, x: orc.encode_fast(x)[::stride4][:4])}
     except Exception as e:  # noqa: BLE001
         out["small_m_error"] = repr(e)
     # --- more parity blocks, still one read of the data (matrix cores)
@@ -370,8 +385,10 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             small.set_option("encode_direct_max", 0)
             small.encode(data, p_pipe, stream=stream)
             ms_pipe = event_ms(lambda: small.encode(data, p_pipe, stream=stream), 5)
+            stride64 = 1 << min(log2k - 6, 4)
             out["encode_k_plus_64_parity"] = {"ms": round(ms, 3), "data_GBps": round(k * block_bytes / ms / 1e6, 1), "transform_pipeline_ms": round(ms_pipe, 3),
-                                              "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe))}
+                                              "same_parity_as_the_transform_pipeline": bool(torch.equal(p_direct, p_pipe)),
+                                              "oracle_columns": oracle_columns(data, p_direct, k, S, 64, lambda orc, x: orc.encode_fast(x)[::stride64][:64])}
     except Exception as e:  # noqa: BLE001
         out["k_plus_64_error"] = repr(e)
     # --- the stripe in HOST memory (what RS.cpp times, RS.cpp:25-38): pinned buffers in and out over the host link, column slabs
@@ -493,7 +510,8 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             mixed.set_option("fuse_radix", 0)
             mixed.encode(src, p_plain, stream=stream)
             out["encode_mixed_radix_3x2^%d" % max(log2k - 2, 1)] = {"ms": round(ms, 3), "GBps": round(2.0 * km * block_bytes / ms / 1e6, 1), "plan": plan,
-                                                                     "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain))}
+                                                                     "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain)),
+                                                                     "oracle_columns": oracle_columns(src, p_fused, km, S, km, lambda orc, x: orc.encode_mixed(x))}
     except Exception as e:  # noqa: BLE001
         out["mixed_radix_error"] = repr(e)
     # --- a composite odd factor of the prime-factor map (21 * 2^(log2k - 5) data blocks: the order the seven plain factors would round up to is 14 % larger)
@@ -507,7 +525,8 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
             pfa.set_option("fuse_radix", 0)
             pfa.encode(src, p_plain, stream=stream)
             out["encode_mixed_radix_21x2^%d" % max(log2k - 5, 1)] = {"ms": round(ms, 3), "GBps": round(2.0 * kp * block_bytes / ms / 1e6, 1), "plan": plan,
-                                                                      "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain))}
+                                                                      "same_parity_as_the_unfused_plan": bool(torch.equal(p_fused, p_plain)),
+                                                                      "oracle_columns": oracle_columns(src, p_fused, kp, S, kp, lambda orc, x: orc.encode_mixed(x))}
     except Exception as e:  # noqa: BLE001
         out["mixed_radix_pfa_error"] = repr(e)
     return out
