@@ -581,7 +581,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
             data_present = dfull.data();
             parity_present = pfull.data();
         }
-        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail);
+        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail, ci.decode_split);
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
         return rc;
     }

@@ -212,6 +212,27 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ dat
     st(work + ((uint64_t)u * elems + col) * 2, v);
 }
 
+// even / odd split, small form of the parity half: row m of `small` = parity block m << h times fin[2 (m << h) + 1] (zero rows where that
+// parity block is lost or not in use: nothing is read there)
+__global__ __launch_bounds__(256) void k_split_small_gather(const uint64_t* __restrict__ parity, uint64_t* __restrict__ small, const uint64_t* __restrict__ fin,
+                                                            uint32_t elems, int h, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t m = (uint32_t)(item / col_chunks);
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t j = (uint64_t)m << h;
+    const uint64_t fre = as_constant(fin)[2ull * (2 * j + 1)], fim = as_constant(fin)[2ull * (2 * j + 1) + 1];
+    Elem v{0, 0};
+    if ((fre | fim) != 0) v = gf61::mul(ld(parity + (j * elems + col) * 2), gf61::make_twiddle(fre, fim), k);  // lazy: the transform's first pass takes it
+    st(small + ((uint64_t)m * elems + col) * 2, v);
+}
+
 // data[i] = work[stride * i] * gout[i] for the erased data blocks (gout != 0)
 __global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ work, uint64_t* __restrict__ data, const uint64_t* __restrict__ gout,
                                                  uint32_t elems, uint32_t col_chunks, uint64_t items, uint32_t stride)
@@ -471,6 +492,19 @@ struct Decoder {
     uint64_t* rec = nullptr;           // k blocks: x p'(x) at the data positions, written by the folded transform (lazy)
     uint64_t* again = nullptr;         // k parity blocks of the re-encode (lazy, repair only)
     uint64_t* stage = nullptr;         // data + parity stripes of a host-memory call (lazy)
+    // even / odd split ((2k,k) codes, k >= 2^11; the scheme of decode.hip's header): the data chain runs on `splitp`, a size-k path with the factor
+    // (2m + k) / 2k; of the parity half only the blocks at multiples of 2^split_shift are used (the others count as erased in the locator), so its
+    // DIF is the DIF of k >> shift rows (`small[shift]`, its stripe `small_buf`) and MID reads block p >> shift of it.
+    Path* splitp = nullptr;
+    bool split_unavailable = false;      // no such plan / no memory: the folded 2k-point transform serves
+    Path* small[6] = {};
+    uint64_t* small_buf = nullptr;       // small_rows blocks (grown on demand: k >> shift)
+    uint64_t small_rows = 0;
+    uint64_t* split_af = nullptr;        // k elements by position: -1/2 w^(-bitrev(p))
+    uint64_t* split_work = nullptr;      // k blocks: the data chain's intermediate stripe
+    uint8_t* state_real = nullptr;       // the caller's flags (the locator's `state` counts unused parity blocks as lost)
+    int split_shift = 0;
+    bool split_ready = false;
     uint64_t erased_data = 0, erased_parity = 0;
     bool built = false;  // contexts, buffers and the w^u table exist
     // few losses: the direct path
@@ -494,6 +528,10 @@ void destroy_decoder(Decoder* d)
     destroy(d->transform);
     destroy(d->half);
     destroy(d->pattern);
+    destroy(d->splitp);
+    for (Path* t : d->small) destroy(t);
+    for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real})
+        if (b) (void)hipFree(b);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
                     (void*)d->gout, (void*)d->gout_all, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->rec, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
@@ -503,7 +541,7 @@ void destroy_decoder(Decoder* d)
 }
 
 int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
-                   size_t cap)
+                   size_t cap, int split)
 {
     const uint64_t N = 1ull << log2k, NC = 2 * N;
     std::vector<uint8_t> state(NC);
@@ -514,6 +552,28 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         state[2 * i + 1] = parity_present[i] ? ST_HELD : ST_LOST;
         erased_data += !data_present[i];
         erased_parity += !parity_present[i];
+    }
+    // ---- even / odd split: recovering e data blocks takes e parity blocks, so the others may count as erased too; take them at multiples of 2^h of
+    // the parity half (largest h <= 5 that leaves enough survivors) and the parity half's transform shrinks to k >> h rows ----
+    const std::vector<uint8_t> state_real = state;
+    int split_shift = 0;
+    const bool few = erased_data + erased_parity != 0 && (int)(erased_data + erased_parity) <= std::min(direct_max, 16);
+    if (split && log2k >= 11 && erased_data != 0 && !few && !(*slot && (*slot)->split_unavailable)) {
+        uint64_t at_multiple[6] = {};
+        for (uint64_t j = 0; j < N; j++)
+            if (parity_present[j])
+                for (int h = 1; h <= 5 && (j & ((1ull << h) - 1)) == 0; h++) at_multiple[h]++;
+        // a pattern that has lost parity blocks too may be REPAIRED (lost parity rebuilt as well): with the split that is decode + re-encode, without it
+        // one transform over all 2k positions — measured at k = 2^19: the split wins the repair from h = 3 (8.5 against 9.3 ms at h = 5) and loses it at
+        // h = 1 (10.5 against 9.1), while the decode alone always gains (4.5 against 7.2 ms at h = 5, 6.3 against 7.0 at h = 1)
+        const int h_min = erased_parity != 0 ? 3 : 1;
+        for (int h = 5; h >= h_min && split_shift == 0; h--)
+            if (at_multiple[h] >= erased_data) split_shift = h;
+        if (split_shift != 0) {
+            const uint64_t mask = (1ull << split_shift) - 1;
+            for (uint64_t j = 0; j < N; j++)
+                if (j & mask) state[2 * j + 1] = ST_LOST;  // not in use: a root of the locator like a lost one (nothing of it is rebuilt from this state)
+        }
     }
     {
         uint64_t count = 0;  // branch-free: on a random pattern an "if (lost) push_back" mispredicts at every other position
@@ -537,6 +597,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     d->elems = elems;
     d->erased_data = erased_data;
     d->erased_parity = erased_parity;
+    d->split_ready = false;
+    d->split_shift = 0;
     const uint64_t T = N;  // the most losses the code tolerates, a power of two already
     int lgT = log2k;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
@@ -664,6 +726,53 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     hipStream_t s0 = nullptr;
     // (the caller has waited for the last decode that used the previous pattern)
     D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
+    if (!d->state_real) D61_TRY(hipMalloc((void**)&d->state_real, NC));
+    D61_TRY(hipMemcpyAsync(d->state_real, state_real.data(), NC, hipMemcpyHostToDevice, s0));
+    if (split_shift != 0) {
+        // the split transform's paths and tables (once; the small transform per shift).  Anything missing — no plan of the needed shape, no memory
+        // — leaves the folded 2k-point transform in charge: it decodes the same pattern (the unused parity blocks are unused there as well).
+        const int rc_split = [&]() -> int {
+            if (!d->splitp) {
+                int rc = FASTECC_E_UNSUPPORTED;
+                for (int mid : {5, 6, 0}) {  // MID with the addend is leanest at 5 or 6 levels (78 VGPRs; the 7-level one spills)
+                    if (d->splitp) destroy(d->splitp);
+                    d->splitp = nullptr;
+                    rc = create_transform_mid(&d->splitp, log2k, elems, FACTOR_SPLIT, mid, detail, cap);
+                    if (rc != FASTECC_OK) return rc;
+                    if (split_decode_supported(d->splitp)) break;
+                }
+                if (!split_decode_supported(d->splitp)) return FASTECC_E_UNSUPPORTED;
+            }
+            if (!d->split_af) {
+                D61_TRY(hipMalloc((void**)&d->split_af, N * 16));
+                const int rc = split_addend_factors(d->split_af, log2k, s0);
+                if (rc != FASTECC_OK) return rc;
+            }
+            if (!d->split_work) D61_TRY(hipMalloc((void**)&d->split_work, N * elems * 16));
+            if (d->small_rows < (N >> split_shift)) {
+                if (d->small_buf) (void)hipFree(d->small_buf);
+                d->small_buf = nullptr;
+                d->small_rows = 0;
+                D61_TRY(hipMalloc((void**)&d->small_buf, (N >> split_shift) * elems * 16));
+                d->small_rows = N >> split_shift;
+            }
+            if (!d->small[split_shift]) {
+                const int rc = create(&d->small[split_shift], log2k - split_shift, elems, detail, cap);  // only its stand-alone transform's DIF passes are used
+                if (rc != FASTECC_OK) return rc;
+            }
+            return FASTECC_OK;
+        }();
+        if (rc_split != FASTECC_OK) {
+            (void)hipGetLastError();
+            if (rc_split != FASTECC_E_NOMEM && rc_split != FASTECC_E_UNSUPPORTED) return rc_split;
+            destroy(d->splitp);
+            d->splitp = nullptr;
+            d->split_unavailable = true;  // (the pattern stays as it is: the folded transform decodes it)
+        } else {
+            d->split_shift = split_shift;
+            d->split_ready = true;
+        }
+    }
     if (erased_data == 0 && erased_parity == 0) {
         D61_TRY(hipStreamSynchronize(s0));
         d->ready = true;
@@ -702,7 +811,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         if (rc != FASTECC_OK) return rc;
     }
     d->gout_all_valid = false;
-    if (erased_data != 0 && erased_parity != 0) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
+    if (erased_data != 0 && erased_parity != 0 && split_shift == 0) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
+        // (not with the split: its locator counts the unused parity blocks as lost — the lost parity is re-encoded from the repaired data instead)
         if (!d->gout_all && hipMalloc((void**)&d->gout_all, NC * 16) != hipSuccess) {
             (void)hipGetLastError();
             d->gout_all = nullptr;
@@ -756,7 +866,21 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         if (rc == FASTECC_OK) return FASTECC_OK;
         if (rc != FASTECC_E_UNSUPPORTED) return rc;
     }
-    if (d->erased_data != 0) {
+    bool data_done = false;
+    if (d->erased_data != 0 && d->split_ready) {
+        // even / odd split: r~ = DIF of the k >> h parity rows in use (times l), then the data chain — DIF of data * l, g = (2m+k)/2k q~ - 1/2 w^-m r~
+        // between the halves of MID, DIT, and only the rebuilt blocks stored, times 1 / (w^2i l'(w^2i)), straight into the data stripe
+        const int h = d->split_shift;
+        const uint64_t rows = d->N >> h, items = rows * col_chunks;
+        hipLaunchKernelGGL(k_split_small_gather, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, parity, d->small_buf, d->fin, elems, h, col_chunks, items);
+        D61_TRY(hipGetLastError());
+        int rc = dif_only(d->small[h], d->small_buf, true, s0, hooks);
+        if (rc == FASTECC_OK)
+            rc = split_decode(d->splitp, data, d->fin, 2, d->small_buf, h, d->split_af, d->split_work, d->gout, data, s0, hooks);
+        if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+        data_done = rc == FASTECC_OK;
+    }
+    if (d->erased_data != 0 && !data_done) {
         if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
         // x p'(x) at the even (data) positions only where the plans pair up (encode_fold) — then the gather rides in the first DIF tile and the
         // scatter in the last DIT tile where there are such passes — else on all 2k points
@@ -799,7 +923,7 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         const int rc = encode(rebuild_with, data, d->again, s0, hooks);
         if (rc != FASTECC_OK) return rc;
         const uint64_t items = d->N * col_chunks;
-        hipLaunchKernelGGL(k_restore, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->state, elems, col_chunks, items);
+        hipLaunchKernelGGL(k_restore, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->state_real ? d->state_real : d->state, elems, col_chunks, items);
         D61_TRY(hipGetLastError());
     }
     return FASTECC_OK;

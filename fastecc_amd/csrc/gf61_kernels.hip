@@ -33,7 +33,7 @@ namespace p61 {
 
 namespace {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5, MODE_DIF_ROWS = 6, MODE_MID_ADD = 7 };
 
 // forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
 struct SmallRoots {
@@ -57,6 +57,14 @@ struct PassArgs {
     const uint64_t* in2;
     const uint64_t* side;
     uint64_t* out2;  // MODE_DIT_SCATTER, optional: the output rows are codeword positions — row i goes to (i even ? out : out2)[i / 2]
+    // the split decoder (gf61_decode.hip, "even / odd split"):
+    //   MODE_DIF_ROWS  block u of `in` times side[u * side_stride] on the way in (zero = block not in use, never read)
+    //   MODE_MID_ADD   between the halves of MID, position p gets + addend[p >> addend_shift] * addend_factor[p]; addend is a stripe of
+    //                  (N >> addend_shift) blocks in the position order a DIF leaves (block q = coefficient bitrev(q))
+    uint32_t side_stride;
+    const uint64_t* addend;
+    const uint64_t* addend_factor;
+    int addend_shift;
 };
 
 using gf61::Elem;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     // value to the same address from the same wave — so the kernel has no divergent region at all.  (With an "if (live)" around the stores
     // the compiler sinks the whole second half of the tile into that branch, where its scheduling barriers no longer apply.)
     const uint32_t col = min(cc * 64u + lane, a.elems - 1u);
-    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD) ? 0 : a.s;
+    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD || MODE == MODE_MID_ADD) ? 0 : a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
     const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
@@ -445,8 +453,18 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     auto exchange = [&](auto wrow, auto rrow) { exchange_of(x, wrow, rrow); };
 
     const uint32_t off_a = (g << s) + lo;  // layout A: x[j] = block (.. + j * 2^(s+L2) + off_a)
-    if constexpr (MODE == MODE_DIF || MODE == MODE_DIF_GATHER) {
-        if constexpr (MODE == MODE_DIF_GATHER) {
+    if constexpr (MODE == MODE_DIF || MODE == MODE_DIF_GATHER || MODE == MODE_DIF_ROWS) {
+        if constexpr (MODE == MODE_DIF_ROWS) {
+            // the split decoder's first pass over the data half: block u times its factor (wave-uniform); a block not in use (factor 0: lost)
+            // is a zero row that is never read
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint64_t u = block0 + ((uint64_t)row_a(j) << s);
+                const uint64_t fre = as_constant(a.side)[2 * u * a.side_stride], fim = as_constant(a.side)[2 * u * a.side_stride + 1];
+                x[j] = Elem{0, 0};
+                if ((fre | fim) != 0) x[j] = gf61::mul(load_elem(a.in + u * row_words + 2u * col), gf61::make_twiddle(fre, fim), k);
+            }
+        } else if constexpr (MODE == MODE_DIF_GATHER) {
             // the decoder's gather in the first pass of its transform: position u is data block u/2 or parity block u/2 times a per-position
             // factor (wave-uniform), and an erased position (factor 0) is a zero row that is never read
 #pragma unroll
@@ -519,6 +537,27 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
         const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
+        if constexpr (MODE == MODE_MID_ADD) {
+            // + addend[p >> shift] * factor[p]: the other half of the split decoder's coefficient vector.  2^shift consecutive positions read
+            // the same block of the (small) addend stripe: it is fetched once per run (p is wave-uniform, so is the branch).
+            const uint64_t p0 = ((uint64_t)hi << LOGT) + (uint64_t)g * R;
+            const_u64_ptr af = as_constant(a.addend_factor) + 2 * p0;
+            if (a.addend_shift >= LOGR) {  // (uniform) the lane's R positions lie in ONE block of the addend stripe: p0 is a multiple of R
+                const Elem ad = load_elem(a.addend + (p0 >> a.addend_shift) * row_words + 2u * col);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    x[j] = gf61::add(x[j], gf61::mul(ad, gf61::make_twiddle(af[2 * j], af[2 * j + 1]), k), k);
+                    __builtin_amdgcn_sched_barrier(0);  // one position at a time: the products of all R positions at once do not fit the registers
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const Elem ad = load_elem(a.addend + ((p0 + (uint64_t)j) >> a.addend_shift) * row_words + 2u * col);
+                    x[j] = gf61::add(x[j], gf61::mul(ad, gf61::make_twiddle(af[2 * j], af[2 * j + 1]), k), k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         dit_levels<LOGR, true, false, L2>(x, a.tw_dit, 0u, 0, k, a.sr);
         __syncthreads();  // every lane has finished reading the first exchange
         exchange(row_b, row_a);
@@ -619,6 +658,8 @@ hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const Pass
         if constexpr (LOGT == 7) return launch_tile_one<LOGT, MODE_MID_FOLD, false, SPLIT, true>(a, tiles, st);
         else return hipErrorInvalidValue;
     case MODE_DIF_GATHER: return launch_tile_one<LOGT, MODE_DIF_GATHER, false, SPLIT, true>(a, tiles, st);
+    case MODE_DIF_ROWS: return launch_tile_one<LOGT, MODE_DIF_ROWS, false, SPLIT, true>(a, tiles, st);
+    case MODE_MID_ADD: return launch_tile_one<LOGT, MODE_MID_ADD, false, SPLIT, true>(a, tiles, st);
     case MODE_DIT_SCATTER: return launch_tile_one<LOGT, MODE_DIT_SCATTER, true, SPLIT, false>(a, tiles, st);
     default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT, true>(a, tiles, st);
     }
@@ -812,14 +853,27 @@ __global__ __launch_bounds__(256) void k_run_table(uint64_t* __restrict__ tab, u
 
 // per-block factors c * w^i (RS.cpp:51-54: c = 1/N, w of order 2N), stored by position: position q holds coefficient bitrev_n(q)
 // (by_index: c * i instead — the derivative's factor in the decoder's x p'(x), gf61_decode.hip)
+// (plus: + plus_re, a real constant — the split decoder's factor (2i + k) / 2k = i / k + 1 / 2, FACTOR_SPLIT)
 __global__ __launch_bounds__(256) void k_block_factors(uint64_t* __restrict__ d, uint64_t c_re, uint64_t c_im, uint64_t w_re, uint64_t w_im, int n,
-                                                       bool by_index)
+                                                       bool by_index, uint64_t plus_re = 0)
 {
     const uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (q >= (1ull << n)) return;
     const uint64_t i = n ? __brevll(q) >> (64 - n) : 0;
     const gf61::Opaque k = gf61::make_opaque();
     const Elem v = gf61::mul_canon(by_index ? Elem{i, 0} : gf61::pow_canon(Elem{w_re, w_im}, i, k), Elem{c_re, c_im}, k);
+    d[2 * q] = gf61::canon(gf61::add(v.re, plus_re, k));
+    d[2 * q + 1] = v.im;
+}
+// the split decoder's factor of the parity half's coefficients, by position: position q holds coefficient m = bitrev_n(q): -1/2 * w^(-m), w of order 2k
+// (wi = w^-1)
+__global__ __launch_bounds__(256) void k_split_addend_factors(uint64_t* __restrict__ d, uint64_t c_re, uint64_t c_im, uint64_t wi_re, uint64_t wi_im, int n)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (q >= (1ull << n)) return;
+    const uint64_t m = n ? __brevll(q) >> (64 - n) : 0;
+    const gf61::Opaque k = gf61::make_opaque();
+    const Elem v = gf61::mul_canon(gf61::pow_canon(Elem{wi_re, wi_im}, m, k), Elem{c_re, c_im}, k);
     d[2 * q] = v.re;
     d[2 * q + 1] = v.im;
 }
@@ -891,6 +945,12 @@ struct FusedEnds {
     const uint64_t* last_side = nullptr;   // set: plan.back() must be a canonical DIT tile; it then writes to last_out
     uint64_t* last_out = nullptr;
     uint64_t* last_out2 = nullptr;         // set: the rows are codeword positions, even ones go to last_out, odd ones here (PassArgs::out2)
+    // the split decoder: the first pass takes block u of `in` times first_side[u * first_rows_stride] (MODE_DIF_ROWS instead of the gather);
+    // MID adds mid_addend[p >> mid_shift] * mid_addend_factor[p] between its halves (MODE_MID_ADD; MID must be a tile that is not the last pass)
+    uint32_t first_rows_stride = 0;
+    const uint64_t* mid_addend = nullptr;
+    const uint64_t* mid_addend_factor = nullptr;
+    int mid_shift = 0;
 };
 
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
@@ -910,9 +970,17 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         a.out = out;
         if (ends && ends->first_side && qi == 0) {
             if (!q.tile || q.mode != MODE_DIF || !inverse_roots) return FASTECC_E_UNSUPPORTED;
-            mode = MODE_DIF_GATHER;
+            mode = ends->first_rows_stride ? MODE_DIF_ROWS : MODE_DIF_GATHER;
             a.in2 = ends->first_in2;
             a.side = ends->first_side;
+            a.side_stride = ends->first_rows_stride;
+        }
+        if (ends && ends->mid_addend && q.mode == MODE_MID) {
+            if (!q.tile || q.canon || qi + 1 == plan.size()) return FASTECC_E_UNSUPPORTED;
+            mode = MODE_MID_ADD;
+            a.addend = ends->mid_addend + 2 * col0;
+            a.addend_factor = ends->mid_addend_factor;
+            a.addend_shift = ends->mid_shift;
         }
         if (ends && ends->last_side && qi + 1 == plan.size()) {
             if (!q.tile || q.mode != MODE_DIT || !q.canon || mode != q.mode) return FASTECC_E_UNSUPPORTED;
@@ -935,13 +1003,15 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         const dim3 grid((unsigned)blocks);
         char name[32];
         snprintf(name, sizeof name, "p61_%s%s%d%s", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr,
-                 mode == MODE_DIF_GATHER ? "_gather" : mode == MODE_DIT_SCATTER ? "_scatter" : "");
+                 mode == MODE_DIF_GATHER ? "_gather" : mode == MODE_DIT_SCATTER ? "_scatter" : mode == MODE_DIF_ROWS ? "_rows" : mode == MODE_MID_ADD ? "_add" : "");
         Scope sc(hooks, st, name, 2ull * p->N * width * 16ull);
         hipError_t e;
         if (q.tile) {
             if (q.logr == 5) {  // MID only (tile_shape_mid)
-                if (mode != MODE_MID) return FASTECC_E_UNSUPPORTED;
-                if (p->split == 2) e = q.canon ? launch_tile_one<5, MODE_MID, true, 2, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 2, true>(a, (unsigned)blocks, st);
+                if (mode == MODE_MID_ADD) e = p->split == 2 ? launch_tile_one<5, MODE_MID_ADD, false, 2, true>(a, (unsigned)blocks, st)
+                                                            : launch_tile_one<5, MODE_MID_ADD, false, 1, true>(a, (unsigned)blocks, st);
+                else if (mode != MODE_MID) return FASTECC_E_UNSUPPORTED;
+                else if (p->split == 2) e = q.canon ? launch_tile_one<5, MODE_MID, true, 2, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 2, true>(a, (unsigned)blocks, st);
                 else e = q.canon ? launch_tile_one<5, MODE_MID, true, 1, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 1, true>(a, (unsigned)blocks, st);
             } else if (q.logr == 6 && p->split == 2) e = launch_tile_mode<6, 2>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
             else if (q.logr == 6) e = launch_tile_mode<6, 1>(mode, q.canon, inverse_roots, a, (unsigned)blocks, st);
@@ -1128,8 +1198,9 @@ int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int forc
         const gf61::Elem w2N = gf61::h_root(2 * p->N), c = gf61::h_inv(gf61::Elem{p->N % gf61::P, 0});
         hipError_t e = hipMalloc((void**)&p->dscale, 2 * p->N * 8);
         if (e == hipSuccess) {
+            const uint64_t half = gf61::h_inv(gf61::Elem{2, 0}).re;  // FACTOR_SPLIT: (2 m + N) / 2N = m / N + 1 / 2
             hipLaunchKernelGGL(k_block_factors, dim3((unsigned)((p->N + 255) / 256)), dim3(256), 0, nullptr, p->dscale, c.re, c.im, w2N.re, w2N.im, n,
-                               factor == FACTOR_INDEX);
+                               factor == FACTOR_INDEX || factor == FACTOR_SPLIT, factor == FACTOR_SPLIT ? half : 0ull);
             e = hipGetLastError();
         }
         if (e != hipSuccess) rc = fail(detail, cap, e, "gf61 block factors");
@@ -1192,6 +1263,52 @@ int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* wor
     return FASTECC_OK;
 }
 bool encode_cosets_needs_work(const Path* p) { return p && !p->enc.empty() && p->enc[0].mode != MODE_MID; }
+
+// The stand-alone transform's DIF passes WITHOUT the closing block permutation: block q of the result holds coefficient bitrev(q) — the
+// order MID's first half leaves, which is what the split decoder's addend is read in.
+int dif_only(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks)
+{
+    const uint64_t* tw = inverse ? (p->tw_ntt_inv ? p->tw_ntt_inv : p->tw_inv) : (p->tw_ntt_fwd ? p->tw_ntt_fwd : p->tw_fwd);
+    return run_passes(p, p->fwd, data, data, tw, tw, inverse, st, hooks);
+}
+
+// The split decoder's data chain on a FACTOR_SPLIT path of size k (gf61_decode.hip): DIF passes over data[i] * rows_factor[i * rows_stride] (into
+// `work`, then in place), MID with + addend[p >> shift] * addend_factor[p] between its halves, DIT passes, the last of which stores only the rows
+// with gout[i] != 0, times gout[i], into data_out.  FASTECC_E_UNSUPPORTED unless the plan is [DIF tile .. MID tile .. canonical DIT tile].
+bool split_decode_supported(const Path* p)
+{
+    if (!p || p->enc.size() < 3) return false;
+    const Pass &first = p->enc.front(), &last = p->enc.back();
+    bool mid_ok = false;
+    for (size_t i = 1; i + 1 < p->enc.size(); i++)
+        if (p->enc[i].mode == MODE_MID) mid_ok = p->enc[i].tile && !p->enc[i].canon;
+    return first.tile && first.mode == MODE_DIF && last.tile && last.mode == MODE_DIT && last.canon && mid_ok;
+}
+int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uint32_t rows_stride, const uint64_t* addend, int addend_shift,
+                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks)
+{
+    if (!split_decode_supported(p) || rows_stride == 0) return FASTECC_E_UNSUPPORTED;
+    FusedEnds f;
+    f.first_side = rows_factor;
+    f.first_rows_stride = rows_stride;
+    f.mid_addend = addend;
+    f.mid_addend_factor = addend_factor;
+    f.mid_shift = addend_shift;
+    f.last_side = gout;
+    f.last_out = data_out;
+    return run_passes(p, p->enc, data, work, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, &f);
+}
+// addend_factor table of the split decoder for a path of size 2^n: n-bit position q -> -1/2 w_2N^(-bitrev(q)) (2^n elements, device memory of the caller)
+int split_addend_factors(uint64_t* table, int n, hipStream_t st)
+{
+    const uint64_t N = 1ull << n;
+    const gf61::Elem wi = gf61::h_inv(gf61::h_root(2 * N));
+    const gf61::Elem half = gf61::h_inv(gf61::Elem{2, 0});
+    const gf61::Elem neg_half{gf61::h_subp(0, half.re), 0};
+    hipLaunchKernelGGL(k_split_addend_factors, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, table, neg_half.re, neg_half.im, wi.re, wi.im, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FASTECC_OK : fail(nullptr, 0, e, "p61 split addend factors");
+}
 
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks)
 {

@@ -24,7 +24,7 @@ int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
 // The same pipeline — DIF over all levels with the inverse roots, the block holding coefficient m times its factor, DIT back
 // with the forward roots — with the factor m / 2^n (FACTOR_INDEX: the decoder's x p'(x) transform, gf61_decode.hip; no root of order
 // 2^(n+1) is needed) instead of the encoder's w_2N^m / N (FACTOR_ENCODE).  All tables of a path are built by kernels.
-enum { FACTOR_ENCODE = 0, FACTOR_INDEX = 1 };
+enum { FACTOR_ENCODE = 0, FACTOR_INDEX = 1, FACTOR_SPLIT = 2 };  // FACTOR_SPLIT: (2 m + 2^n) / 2^(n+1), the split decoder's data chain
 int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail, size_t detail_cap);
 // n = 4k / 8k (cosets = 3 / 7 further cosets of evaluation points, include/fastecc.h's nesting order): encode_cosets only
 int create_cosets(Path** out, int n, uint64_t elems, int cosets, char* detail, size_t detail_cap);
@@ -61,6 +61,13 @@ bool encode_cosets_needs_work(const Path* p);
 // the element columns [col0, col0 + width) of every block only (data / parity are the stripes' base addresses)
 int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col0, uint64_t width, hipStream_t st, const LaunchHooks* hooks);
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);
+// the same without the closing block permutation: block q of the result holds coefficient bitrev(q)
+int dif_only(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);
+// ---- the decoder's even / odd split (gf61_decode.hip): the data chain on a path made with FACTOR_SPLIT ----
+bool split_decode_supported(const Path* p);
+int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uint32_t rows_stride, const uint64_t* addend, int addend_shift,
+                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks);
+int split_addend_factors(uint64_t* table, int n, hipStream_t st);
 // words >= p among the 2 * elems * k words of a stripe; `counter` is a device uint64 the caller zeroed
 int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counter, hipStream_t st);
 
@@ -75,8 +82,9 @@ void destroy_decoder(Decoder* d);
 // data_present / parity_present: k flags each (non-zero = the block survives).  Synchronous.  The current device must be
 // the target device.  *slot is created on first use and reused.
 // direct_max: patterns with at most that many lost blocks (<= 16) get the direct one-pass path instead of locator + transform.
+// split != 0: patterns that lose data blocks run the even / odd split where a plan of the needed shape exists (k >= 2^11; gf61_decode.hip)
 int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
-                   size_t detail_cap);
+                   size_t detail_cap, int split = 1);
 // Recover the erased data blocks in place (device pointers, enqueued on st); rebuild_with != null: also re-encode with that
 // path (the context's encoder) and write the lost parity blocks into `parity`.
 int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hipStream_t st, const LaunchHooks* hooks);

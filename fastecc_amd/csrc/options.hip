@@ -36,7 +36,7 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
 {
     if (!c || !name) return FASTECC_E_INVAL;
     if (c->sharded) return sharded_forward(c, SH_SET_OPTION, name, value);
-    if (c->p61 && strcmp(name, "decode_direct_max") != 0) return FASTECC_E_UNSUPPORTED;  // the other options tune the GF(0xFFF00001) tile kernels
+    if (c->p61 && strcmp(name, "decode_direct_max") != 0 && strcmp(name, "decode_split") != 0) return FASTECC_E_UNSUPPORTED;  // the other options tune the GF(0xFFF00001) tile kernels
     CallLock lk(c->mu);
     if (!strcmp(name, "row_pitch_words")) {
         // DEVICE stripes passed to fastecc_encode are then [k][pitch] words with the first block_bytes/4 of each

@@ -60,7 +60,7 @@ enum {
      * Supported by create/destroy/encode/encode_blocks/ntt/check_range/decode_prepare/decode/repair/profile/plan_string and
      * fastecc_set_plan (0 = default: LDS tiles; 1..4 = register passes with that many radix-2 levels; 10+L / 20+L = tiles with a
      * 64 / 128 KiB exchange buffer); the 32-bit-word entry points
-     * (scale_blocks, gf_binary, set_option other than "decode_direct_max") return FASTECC_E_UNSUPPORTED.
+     * (scale_blocks, gf_binary, set_option other than "decode_direct_max" and "decode_split") return FASTECC_E_UNSUPPORTED.
      * Codes: (2k,k) with k = 2^m, 1 <= m <= 24, run on the caller's stripes.  Any other k <= 2^24 with n - k <= N = 2^ceil(log2 k) follows
      * the rules fastecc_create documents for GF(0xFFF00001) — the data zero-extended to N blocks, parity block j = block j * 2^fold of the
      * (2N,N) parity, fold = min(log2 N - ceil(log2(n-k)), 4) — through padded copies of the stripes inside the context (two N-block work
@@ -393,7 +393,10 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  decoder's 2k-point transform as two transforms of k points — the data half, and of the parity half only the blocks needed: the
  *                  survivors at multiples of 2^h of that half (largest h <= 5 that leaves as many as there are lost data blocks), whose transform is
  *                  one of k >> h rows (2 % of the codeword lost: decode 7.1 -> 3.8 ms at k = 2^19 x 4 KB), else the surviving blocks of the first
- *                  few block groups (what round 3 always did: 2 = that form only); 0 = one transform of 2k points.  Same bits;
+ *                  few block groups (what round 3 always did: 2 = that form only); 0 = one transform of 2k points.  Same bits.
+ *                  GF((2^61-1)^2), k >= 2^11: 0 / 1 (default 1) — the same split in its k >> h form (h = 5 .. 1; from h = 3 when parity blocks are
+ *                  lost too, since fastecc_repair then re-encodes instead of running one transform over all 2k positions): decode 7.2 -> 4.5 ms at
+ *                  k = 2^19 x 4 KB and 2 % lost, 72 ms = 1.14 x the encode at 64 KB blocks; patterns it does not take run the folded 2k-point transform;
  *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),
  *                  2 = MFMA (i8 digits; falls back to 1 where it cannot run).  Same bits either way;
  *   "fuse_radix" = 0 / 1 (default 1; mixed-radix contexts): the odd-radix level fused into the outer tile passes, or as its own passes;

@@ -519,3 +519,83 @@ def test_multi_coset_plans(torch_cuda, fe, orc61, plan):
         out = torch_cuda.empty(3 * N * 2 * elems, dtype=torch_cuda.int64, device="cuda:0")
         enc.encode(to_dev(torch_cuda, x), out)
         assert (to_host(out).reshape(3 * N, 2 * elems) == want).all(), enc.plan()
+
+
+@pytest.mark.parametrize("logn,elems", [(11, 5), (12, 33), (13, 64), (14, 20), (16, 9)])
+def test_decode_split_matches_the_folded_transform(torch_cuda, fe, orc61, logn, elems):
+    """The even / odd split of the (2k,k) decoder (k >= 2^11: the data chain on a size-k path with the addend between the halves of MID, the parity
+    half as a transform of k >> h rows) against the folded 2k-point transform (option "decode_split" = 0) and against the original data: patterns
+    that make h = 5 .. 1, patterns whose parity losses sit ON the multiples of 2^h, data-only and parity-too losses, decode and repair; erased
+    blocks hold garbage.  Bit-exact."""
+    torch = torch_cuda
+    N = 1 << logn
+    rng = np.random.default_rng(4242 + logn)
+    x = rand_stripe(rng, N, elems)
+    dx = to_dev(torch, x)
+    with encoder(fe, N, elems) as enc:
+        par_dev = torch.empty_like(dx)
+        enc.encode(dx, par_dev)
+        par = to_host(par_dev).reshape(N, 2 * elems)
+        if N * elems <= (1 << 17):
+            assert (par == orc61.encode(x)).all()
+        patterns = []
+        for frac_d, frac_p in ((0.02, 0.0), (0.02, 0.02), (0.001, 0.001), (0.1, 0.0), (0.2, 0.0), (0.3, 0.0), (0.45, 0.0), (0.2, 0.2), (0.01, 0.6)):
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[rng.permutation(N)[: max(17, int(N * frac_d))]] = 0   # (more than 16 losses: not the direct path)
+            pp[rng.permutation(N)[: int(N * frac_p)]] = 0
+            patterns.append((dp, pp))
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)          # every parity block at a multiple of 32 is gone: h must drop
+        dp[rng.permutation(N)[:40]] = 0
+        pp[::32] = 0
+        patterns.append((dp, pp))
+        dp, pp = np.ones(N, np.uint8), np.zeros(N, np.uint8)         # only the parity blocks at multiples of 32 survive, as many data blocks are lost
+        pp[::32] = 1
+        dp[rng.permutation(N)[: N // 32]] = 0
+        patterns.append((dp, pp))
+        for dp, pp in patterns:
+            damaged, dpar = x.copy(), par.copy()
+            damaged[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            dpar[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+            got = {}
+            for split in (1, 0):
+                enc.set_option("decode_split", split)
+                enc.decode_prepare(dp, pp)
+                d, q = to_dev(torch, damaged), to_dev(torch, dpar)
+                enc.decode(d, q)
+                torch.cuda.synchronize()
+                assert (to_host(d).reshape(x.shape) == x).all(), (split, int((dp == 0).sum()), int((pp == 0).sum()))
+                assert (to_host(q).reshape(par.shape) == dpar).all()      # decode leaves the parity alone
+                enc.repair(d, q)
+                torch.cuda.synchronize()
+                assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(par.shape) == par).all(), split
+                hx, hp = damaged.copy(), dpar.copy()
+                enc.repair(hx, hp, mem=fe.MEM_HOST)                       # host stripes through the same path
+                assert (hx == x).all() and (hp == par).all(), split
+            enc.set_option("decode_split", 1)
+
+
+def test_decode_split_is_what_runs(torch_cuda, fe):
+    """At k = 2^13 a 2 % loss runs the split: its kernels are the ones the profile shows (rows on the way in, the addend in MID, the scatter on the
+    way out, the small transform of k / 32 rows), and none of the folded transform's."""
+    torch = torch_cuda
+    N, elems = 1 << 13, 64
+    rng = np.random.default_rng(7)
+    x = rand_stripe(rng, N, elems)
+    dx = to_dev(torch, x)
+    with encoder(fe, N, elems) as enc:
+        par = torch.empty_like(dx)
+        enc.encode(dx, par)
+        dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+        dp[rng.permutation(N)[: N // 50]] = 0
+        enc.decode_prepare(dp, pp)
+        bad = dx.clone()
+        bad.view(N, -1)[torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0")] = -1
+        enc.profile(True)
+        enc.profile_reset()
+        enc.decode(bad, par)
+        torch.cuda.synchronize()
+        names = set(enc.profile_read())
+        enc.profile(False)
+        assert torch.equal(bad, dx)
+        assert any(n.endswith("_rows") for n in names) and any(n.endswith("_add") for n in names) and any(n.endswith("_scatter") for n in names), names
+        assert not any(n.endswith("_gather") for n in names), names
