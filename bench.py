@@ -358,8 +358,12 @@ def other_paths(fastecc_amd, enc, data, parity, log2k, block_bytes, device, stre
                 enc.decode(data, parity, stream=stream)
                 ok_d = bool(torch.equal(dv[di], saved_d))
                 ms_d = event_ms(lambda: enc.decode(data, parity, stream=stream), 5)
-                out["decode_2_percent_of_the_codeword_lost"] = {"decode_ms": round(ms_d, 3), "restored": ok_d,
-                                                                "codeword_GBps": round(2.0 * k * block_bytes / ms_d / 1e6, 1)}
+                enc_ms = event_ms(lambda: enc.encode(data, parity, stream=stream), 5)  # (the parity it writes is the parity that is there)
+                out["decode_2_percent_of_the_codeword_lost"] = {"decode_ms": round(ms_d, 3), "restored": ok_d, "encode_ms_same_context": round(enc_ms, 3),
+                                                                "decode_over_encode": round(ms_d / enc_ms, 3),
+                                                                "what": "structurally an encode plus a bit: the data half runs the encoder's three passes (per-block "
+                                                                        "factors on the way in, the parity half's k / 32-row transform added inside MID, only the "
+                                                                        "rebuilt blocks stored) — price it against the encode, not against the codeword's bytes"}
     except Exception as e:  # noqa: BLE001
         out["decode_error"] = repr(e)
     # --- a code with 4 parity blocks: direct evaluation against the transform pipeline of the same context

@@ -79,7 +79,7 @@ def test_a_failing_mode_costs_only_itself(hip_lib, mode):
 
 def test_a_stalled_gather_cannot_take_the_value(hip_lib):
     """The last rank never enters gather_to_root's collectives: that mode's timer prints the line, `value` is still all_to_all."""
-    line = _bench(2, fault="gather_to_root:stall", mode_timeout=12)
+    line = _bench(2, fault="gather_to_root:stall", mode_timeout=6)
     one = _value_is_all_to_all(line, 2)
     assert one["stalled_in"] == "gather_to_root" and one["complete"] is False
     assert "error" in one["gather_to_root"] and "stalled" in one["gather_to_root"]["error"]
@@ -89,7 +89,7 @@ def test_a_stalled_gather_cannot_take_the_value(hip_lib):
 
 def test_a_rank_that_never_arrives_leaves_the_replica_line(hip_lib):
     """Nothing of the one-stripe section completes: the line falls back to the replica measurement and says so."""
-    line = _bench(2, fault="all:stall", mode_timeout=12)
+    line = _bench(2, fault="all:stall", mode_timeout=6)
     assert line["scaling"] == "weak" and "REPLICAS" in line["metric"]
     assert line["one_stripe"]["stalled_in"] in ("setup", "compute_only")  # rank 0 waits for the missing rank in the first agreement
     assert line["value"] == line["replicas"]["value"] > 0
@@ -97,7 +97,7 @@ def test_a_rank_that_never_arrives_leaves_the_replica_line(hip_lib):
 
 def test_a_process_group_that_never_comes_up_leaves_a_line(hip_lib):
     """One rank never joins torch.distributed: rank 0 prints its own timing (no collective was possible) instead of nothing."""
-    line = _bench(2, fault="startup", extra=("--startup-timeout", "12"))
+    line = _bench(2, fault="startup", extra=("--startup-timeout", "8"))
     assert "UNAVAILABLE" in line["collectives"] and line["scaling"] == "weak" and line["n_gpus"] == 2
     assert line["value"] > 0 and line["ms_per_step"] == line["rank0_local_ms_per_step"]
 
