@@ -380,7 +380,7 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *   "host_pipeline" = 0 / 1 (default 0): 1 = FASTECC_MEM_HOST encodes of (2k,k) stripes of 256 MiB and more move pageable memory through two
  *                  rings of pinned slots (64 MiB each, allocated at the first such call) served by helper threads, slab h going up while
  *                  slab h - 1 comes down; 0 = upload, encode, download one after the other (the download still through its ring).  The
- *                  pipeline is bounded by what the host's cores copy, not by the link: 65-100 ms against a steady 81-86 for 2 + 2 GiB in
+ *                  pipeline is bounded by what the host's cores copy, not by the link: 65-100 ms against 81-97 (by box) for 2 + 2 GiB in
  *                  a 16-CPU share of an EPYC 9575F (profiles/r04/host_pageable_pipeline.jsonl) — worth it on a host with cores to spare;
  *   "encode_direct_max" = 0..256 (default 160): codes with at most this many parity blocks (n - k) are encoded straight from the Lagrange
  *                  basis — one read of the data (0.4 ms up to 16 parity blocks ... 1.4 ms for 128 at k = 2^19 x 4 KB) instead of the transform
