@@ -770,7 +770,7 @@ int encode_host_pageable(fastecc_ctx* c, const uint32_t* data, uint32_t* parity,
         rc = join_down();  // slab h - 1 is home; its ring is free for slab h
         if (rc != FASTECC_OK) break;
         try {
-            down = std::thread([c, h, width, pitch, wbytes, parity, s_dn, T, &down_rc, &down_text] {
+            down = std::thread([c, h, width, pitch, wbytes, parity, s_dn, &down_rc, &down_text] {
                 (void)hipSetDevice(c->device);
                 hipError_t w = hipStreamWaitEvent(s_dn, c->slab_done[h], 0);
                 down_rc = w != hipSuccess ? hip_fail(w, "encode_host_pageable")
