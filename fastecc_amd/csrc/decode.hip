@@ -561,7 +561,8 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     const CtxInfo ci = info_of(c);
     if (ci.field == FASTECC_FIELD_GF_P61_SQUARED) {
         // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are always (2k,k) with k a power of two
-        if (ci.cosets != 1) return FASTECC_E_UNSUPPORTED;  // n = 4k / 8k over this field: encode only (the decoder's transform is built for positions of order 2k)
+        int e61 = 1;
+        while ((1 << e61) < ci.cosets + 1) e61++;  // n = 4k / 8k: the same decoder on the (k << e)-th roots of unity (gf61_decode.hip)
         DeviceScope ds61(ci.device);
         if (!ds61.ok) return FASTECC_E_DEVICE;
         CallScope call61(c);
@@ -581,7 +582,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
             data_present = dfull.data();
             parity_present = pfull.data();
         }
-        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail, ci.decode_split);
+        const int rc = p61::decode_prepare(&decoder61_of(c), ci.log2k, ci.words / 4, data_present, parity_present, ci.direct_max, detail, sizeof detail, ci.decode_split, e61);
         if (rc != FASTECC_OK && detail[0]) set_error_detail(detail, hipErrorUnknown);
         return rc;
     }

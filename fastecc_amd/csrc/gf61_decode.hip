@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_locator_columns(const uint64_t* __restr
 // l = L w^(-u pad) on the points (the padding), see decode.hip finish_tables_kernel
 __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv, const uint8_t* __restrict__ state, const uint64_t* __restrict__ wpow,
                                                 uint64_t* __restrict__ fin, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad,
-                                                uint64_t* __restrict__ gout_all)
+                                                uint64_t* __restrict__ gout_all, int e = 1)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
@@ -179,9 +179,10 @@ __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv,
     const Elem corr = ld(wpow + 2ull * (back == 0 ? 0 : NC - back));
     const bool held = state[u] == ST_HELD;
     st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * u), corr, k) : Elem{0, 0});
-    if ((u & 1u) == 0 || gout_all) {
+    const bool data_pos = (u & ((1u << e) - 1u)) == 0;  // data block i sits at position i << e (e = 1: the (2k,k) code; 2, 3: n = 4k, 8k)
+    if (data_pos || gout_all) {
         const Elem g = held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * u + 2), corr, k), k);
-        if ((u & 1u) == 0) st(gout + 2ull * (u >> 1), g);
+        if (data_pos) st(gout + 2ull * (u >> e), g);
         if (gout_all) st(gout_all + 2ull * u, g);  // every lost position, parity too: fastecc_repair in one transform
     }
 }
@@ -231,6 +232,45 @@ __global__ __launch_bounds__(256) void k_split_small_gather(const uint64_t* __re
     Elem v{0, 0};
     if ((fre | fim) != 0) v = gf61::mul(ld(parity + (j * elems + col) * 2), gf61::make_twiddle(fre, fim), k);  // lazy: the transform's first pass takes it
     st(small + ((uint64_t)m * elems + col) * 2, v);
+}
+
+// n = 4k / 8k: work[u] = block srcmap[u] (bit 31: of the parity stripe) times fin[u]; zero rows where fin == 0 (nothing is read there)
+__global__ __launch_bounds__(256) void k_gather_map(const uint64_t* __restrict__ data, const uint64_t* __restrict__ parity, uint64_t* __restrict__ work,
+                                                    const uint64_t* __restrict__ fin, const uint32_t* __restrict__ srcmap, uint32_t elems, uint32_t col_chunks,
+                                                    uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t u = (uint32_t)(item / col_chunks);
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t fre = as_constant(fin)[2ull * u], fim = as_constant(fin)[2ull * u + 1];
+    Elem v{0, 0};
+    if ((fre | fim) != 0) {
+        const uint32_t m = srcmap[u];
+        const uint64_t* src = ((m >> 31) ? parity : data) + ((uint64_t)(m & 0x7FFFFFFFu) * elems + col) * 2;
+        v = gf61::mul(ld(src), gf61::make_twiddle(fre, fim), k);
+    }
+    st(work + ((uint64_t)u * elems + col) * 2, v);
+}
+// ... and parity[q] = again[q] for the lost parity blocks (lost[q] != 0)
+__global__ __launch_bounds__(256) void k_restore_map(const uint64_t* __restrict__ again, uint64_t* __restrict__ parity, const uint8_t* __restrict__ lost,
+                                                     uint32_t elems, uint32_t col_chunks, uint64_t items)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
+    if (item >= items) return;
+    const uint32_t cc = (uint32_t)(item % col_chunks);
+    const uint32_t q = (uint32_t)(item / col_chunks);
+    if (!lost[q]) return;
+    const uint32_t col = cc * 64u + lane;
+    if (col >= elems) return;
+    st(parity + ((uint64_t)q * elems + col) * 2, ld(again + ((uint64_t)q * elems + col) * 2));
 }
 
 // data[i] = work[stride * i] * gout[i] for the erased data blocks (gout != 0)
@@ -495,6 +535,14 @@ struct Decoder {
     // even / odd split ((2k,k) codes, k >= 2^11; the scheme of decode.hip's header): the data chain runs on `splitp`, a size-k path with the factor
     // (2m + k) / 2k; of the parity half only the blocks at multiples of 2^split_shift are used (the others count as erased in the locator), so its
     // DIF is the DIF of k >> shift rows (`small[shift]`, its stripe `small_buf`) and MID reads block p >> shift of it.
+    // n = 4k / 8k (e = 2 / 3): the same scheme on the (k << e)-th roots of unity — data block i at position i << e, block j of coset t at
+    // c 2^(e-jt) + (j << e) (include/fastecc.h's nesting order) — with the unfolded transform of all k << e positions, a gather through `srcmap`
+    // and up to n - k erasures (T = k << e roots in the locator's tree)
+    int e = 1;
+    uint64_t M = 0;                      // parity blocks: (2^e - 1) k
+    uint32_t* srcmap = nullptr;          // e > 1: position -> block (bit 31: parity stripe)
+    uint8_t* parity_lost = nullptr;      // e > 1: M flags, the caller's lost parity blocks
+    uint64_t* cos_work = nullptr;        // e > 1, repair: the k-block work stripe of the re-encode
     Path* splitp = nullptr;
     bool split_unavailable = false;      // no such plan / no memory: the folded 2k-point transform serves
     Path* small[6] = {};
@@ -530,7 +578,7 @@ void destroy_decoder(Decoder* d)
     destroy(d->pattern);
     destroy(d->splitp);
     for (Path* t : d->small) destroy(t);
-    for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real})
+    for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real, (void*)d->srcmap, (void*)d->parity_lost, (void*)d->cos_work})
         if (b) (void)hipFree(b);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
@@ -541,17 +589,38 @@ void destroy_decoder(Decoder* d)
 }
 
 int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
-                   size_t cap, int split)
+                   size_t cap, int split, int e)
 {
-    const uint64_t N = 1ull << log2k, NC = 2 * N;
+    if (e < 1 || e > 3 || (*slot && (*slot)->built && (*slot)->e != e)) return FASTECC_E_INVAL;
+    const uint64_t N = 1ull << log2k, NC = N << e, M = NC - N;
+    if (NC > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
     std::vector<uint8_t> state(NC);
     std::vector<uint32_t> erased(NC + 1);
+    std::vector<uint32_t> srcmap(e > 1 ? NC : 0);
+    std::vector<uint8_t> plost(e > 1 ? M : 0);
     uint64_t erased_data = 0, erased_parity = 0;
     for (uint64_t i = 0; i < N; i++) {
-        state[2 * i] = data_present[i] ? ST_HELD : ST_LOST;
-        state[2 * i + 1] = parity_present[i] ? ST_HELD : ST_LOST;
+        state[i << e] = data_present[i] ? ST_HELD : ST_LOST;
         erased_data += !data_present[i];
-        erased_parity += !parity_present[i];
+        if (e > 1) srcmap[i << e] = (uint32_t)i;
+    }
+    for (uint64_t q = 0; q < M; q++) {
+        // parity block q = block j of coset t: generator w_(2^jt k)^c, jt = floor(log2(t + 1)) + 1, c the (t + 2 - 2^(jt-1))-th odd number (include/fastecc.h)
+        const uint64_t t = q >> log2k, j = q & (N - 1);
+        int jt = 1;
+        while ((1ull << jt) - 1 <= t) jt++;
+        const uint64_t c = 2 * (t + 1 - (1ull << (jt - 1))) + 1;
+        const uint64_t u = (c << (e - jt)) + (j << e);
+        state[u] = parity_present[q] ? ST_HELD : ST_LOST;
+        erased_parity += !parity_present[q];
+        if (e > 1) {
+            srcmap[u] = (uint32_t)q | 0x80000000u;
+            plost[q] = !parity_present[q];
+        }
+    }
+    if (e > 1) {
+        split = 0;       // the even / odd split and the direct path are the (2k,k) code's
+        direct_max = 0;
     }
     // ---- even / odd split: recovering e data blocks takes e parity blocks, so the others may count as erased too; take them at multiples of 2^h of
     // the parity half (largest h <= 5 that leaves enough survivors) and the parity half's transform shrinks to k >> h rows ----
@@ -583,7 +652,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         }
         erased.resize(count);
     }
-    if (erased.size() > N) return FASTECC_E_INVAL;  // fewer than k blocks survive
+    if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
 
     if (!*slot) {
         *slot = new (std::nothrow) Decoder();
@@ -599,8 +668,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     d->erased_parity = erased_parity;
     d->split_ready = false;
     d->split_shift = 0;
-    const uint64_t T = N;  // the most losses the code tolerates, a power of two already
-    int lgT = log2k;
+    d->e = e;
+    d->M = M;
+    const uint64_t T = e == 1 ? N : NC;  // a power of two >= n - k, the most losses the code tolerates (3k -> 4k, 7k -> 8k: the roots beyond are padding)
+    int lgT = e == 1 ? log2k : log2k + e;
     const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
 
     d->direct = 0;
@@ -684,11 +755,11 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         PhaseTimer pt;
         // only the even (data) positions of this transform are wanted: a 7-level MID here pairs with the 6-level MID of a size-k path,
         // whose DIT passes finish the folded transform (encode_fold); where no such pair of plans exists all 2k outputs are computed
-        int rc = create_transform_mid(&d->transform, log2k + 1, elems, FACTOR_INDEX, 7, detail, cap);
+        int rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, e == 1 ? 7 : 0, detail, cap);
         pt.mark("transform path");
-        if (rc == FASTECC_OK && log2k >= 6) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, 6, detail, cap);
+        if (rc == FASTECC_OK && log2k >= 6 && e == 1) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, 6, detail, cap);
         pt.mark("half path");
-        if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + 1, 2, detail, cap);  // only its stand-alone transform is used
+        if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + e, 2, detail, cap);  // only its stand-alone transform is used
         pt.mark("pattern path");
         if (rc != FASTECC_OK) return rc;
         d->tree.assign(lgT, nullptr);
@@ -708,6 +779,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         D61_TRY(hipMalloc((void**)&d->gout, N * 16));
         D61_TRY(hipMalloc((void**)&d->erased, T * 4));
         D61_TRY(hipMalloc((void**)&d->state, NC));
+        if (e > 1) {
+            D61_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
+            D61_TRY(hipMalloc((void**)&d->parity_lost, M));
+        }
         const gf61::Elem w = gf61::h_root(NC);
         hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, nullptr, d->wpow, w.re, w.im, (uint32_t)NC);
         D61_TRY(hipGetLastError());
@@ -728,6 +803,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
     if (!d->state_real) D61_TRY(hipMalloc((void**)&d->state_real, NC));
     D61_TRY(hipMemcpyAsync(d->state_real, state_real.data(), NC, hipMemcpyHostToDevice, s0));
+    if (e > 1) {
+        D61_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, s0));  // (fixed per code; cheap next to the locator)
+        D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, s0));
+    }
     if (split_shift != 0) {
         // the split transform's paths and tables (once; the small transform per shift).  Anything missing — no plan of the needed shape, no memory
         // — leaves the folded 2k-point transform in charge: it decodes the same pattern (the unused parity blocks are unused there as well).
@@ -811,7 +890,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         if (rc != FASTECC_OK) return rc;
     }
     d->gout_all_valid = false;
-    if (erased_data != 0 && erased_parity != 0 && split_shift == 0) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
+    if (erased_data != 0 && erased_parity != 0 && split_shift == 0 && e == 1) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
         // (not with the split: its locator counts the unused parity blocks as lost — the lost parity is re-encoded from the repaired data instead)
         if (!d->gout_all && hipMalloc((void**)&d->gout_all, NC * 16) != hipSuccess) {
             (void)hipGetLastError();
@@ -820,7 +899,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         d->gout_all_valid = d->gout_all != nullptr;
     }
     hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()),
-                       d->gout_all_valid ? d->gout_all : nullptr);
+                       d->gout_all_valid ? d->gout_all : nullptr, e);
     D61_TRY(hipGetLastError());
     D61_TRY(hipStreamSynchronize(s0));
     d->ready = true;
@@ -867,6 +946,31 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         if (rc != FASTECC_E_UNSUPPORTED) return rc;
     }
     bool data_done = false;
+    if (d->e > 1) {
+        // n = 4k / 8k: gather through the position map, x p'(x) on all k << e positions, the data positions (multiples of 2^e) scattered back
+        if (d->erased_data != 0) {
+            if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
+            uint64_t items = d->NC * col_chunks;
+            hipLaunchKernelGGL(k_gather_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, d->srcmap, elems, col_chunks, items);
+            D61_TRY(hipGetLastError());
+            const int rc = encode(d->transform, d->work, d->work, s0, hooks);
+            if (rc != FASTECC_OK) return rc;
+            items = d->N * col_chunks;
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->work, data, d->gout, elems, col_chunks, items, 1u << d->e);
+            D61_TRY(hipGetLastError());
+        }
+        if (rebuild) {  // the lost parity blocks: the encoder again on the repaired data, only the lost ones written
+            if (cosets_of(rebuild_with) != (1 << d->e) - 1) return FASTECC_E_INVAL;
+            if (!d->again) D61_TRY(hipMalloc((void**)&d->again, d->M * d->elems * 16));
+            if (encode_cosets_needs_work(rebuild_with) && !d->cos_work) D61_TRY(hipMalloc((void**)&d->cos_work, d->N * d->elems * 16));
+            const int rc = encode_cosets(rebuild_with, data, d->again, d->cos_work, s0, hooks);
+            if (rc != FASTECC_OK) return rc;
+            const uint64_t items = d->M * col_chunks;
+            hipLaunchKernelGGL(k_restore_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->parity_lost, elems, col_chunks, items);
+            D61_TRY(hipGetLastError());
+        }
+        return FASTECC_OK;
+    }
     if (d->erased_data != 0 && d->split_ready) {
         // even / odd split: r~ = DIF of the k >> h parity rows in use (times l), then the data chain — DIF of data * l, g = (2m+k)/2k q~ - 1/2 w^-m r~
         // between the halves of MID, DIT, and only the rebuilt blocks stored, times 1 / (w^2i l'(w^2i)), straight into the data stripe
@@ -937,16 +1041,16 @@ int decode_host(Decoder* d, void* data, void* parity, Path* rebuild_with, hipStr
     const size_t cap = 0;
     const bool rebuild = rebuild_with != nullptr && d->erased_parity != 0;
     if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
-    const size_t stripe = d->N * d->elems * 16;
-    if (!d->stage) D61_TRY(hipMalloc((void**)&d->stage, 2 * stripe));
+    const size_t stripe = d->N * d->elems * 16, pstripe = (d->e > 1 ? d->M : d->N) * d->elems * 16;
+    if (!d->stage) D61_TRY(hipMalloc((void**)&d->stage, stripe + pstripe));
     uint64_t* ddata = d->stage;
     uint64_t* dpar = d->stage + stripe / 8;
     D61_TRY(hipMemcpyAsync(ddata, data, stripe, hipMemcpyHostToDevice, s0));
-    D61_TRY(hipMemcpyAsync(dpar, parity, stripe, hipMemcpyHostToDevice, s0));
+    D61_TRY(hipMemcpyAsync(dpar, parity, pstripe, hipMemcpyHostToDevice, s0));
     const int rc = decode(d, ddata, dpar, rebuild_with, s0, hooks);
     if (rc != FASTECC_OK) return rc;
     if (d->erased_data != 0) D61_TRY(hipMemcpyAsync(data, ddata, stripe, hipMemcpyDeviceToHost, s0));
-    if (rebuild) D61_TRY(hipMemcpyAsync(parity, dpar, stripe, hipMemcpyDeviceToHost, s0));
+    if (rebuild) D61_TRY(hipMemcpyAsync(parity, dpar, pstripe, hipMemcpyDeviceToHost, s0));
     D61_TRY(hipStreamSynchronize(s0));
     return FASTECC_OK;
 }

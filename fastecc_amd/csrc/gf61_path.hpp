@@ -83,8 +83,10 @@ void destroy_decoder(Decoder* d);
 // the target device.  *slot is created on first use and reused.
 // direct_max: patterns with at most that many lost blocks (<= 16) get the direct one-pass path instead of locator + transform.
 // split != 0: patterns that lose data blocks run the even / odd split where a plan of the needed shape exists (k >= 2^11; gf61_decode.hip)
+// e = 1: the (2k,k) code; e = 2 / 3: n = 4k / 8k (parity_present then has (2^e - 1) k flags in the stripe's block order; no split, no direct path;
+// a slot serves one e)
 int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* data_present, const uint8_t* parity_present, int direct_max, char* detail,
-                   size_t detail_cap, int split = 1);
+                   size_t detail_cap, int split = 1, int e = 1);
 // Recover the erased data blocks in place (device pointers, enqueued on st); rebuild_with != null: also re-encode with that
 // path (the context's encoder) and write the lost parity blocks into `parity`.
 int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hipStream_t st, const LaunchHooks* hooks);

@@ -67,8 +67,9 @@ enum {
      * stripes: encode, decode_prepare, decode and repair on device memory, encode also on host memory; not encode_columns / ntt /
      * check_range).  n = 4k and n = 8k with k = 2^m (more parity than data blocks, fastecc_create's coset rule and nesting order with this
      * field's roots: w_2k; w_4k, w_4k^3; w_8k, w_8k^3, w_8k^5, w_8k^7) are native transforms — the DIF half once into a k-block work stripe
-     * of the context, MID and the DIT half once per coset: fastecc_encode on device and host memory (out of place only), set_plan, profile;
-     * decode_prepare returns FASTECC_E_UNSUPPORTED for them (this field's decoder works on positions of order 2k).
+     * of the context, MID and the DIT half once per coset: fastecc_encode on device and host memory (out of place only), set_plan, profile,
+     * and decode_prepare / decode / repair on device and host memory: the decoder's scheme on the n-th roots of unity, any n - k lost blocks
+     * (one transform of n points; neither the few-loss direct path nor the even / odd split, which are the (2k,k) code's).
      */
     FASTECC_FIELD_GF_P61_SQUARED = 1
 };

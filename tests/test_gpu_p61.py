@@ -504,9 +504,38 @@ def test_multi_coset_parity_matches_oracle(torch_cuda, fe, orc61, logn, e):
         assert (host_out == want).all()
         with pytest.raises(fe.FastEccError):
             enc.encode(dx)  # in place is impossible: the parity is larger than the data
-        with pytest.raises(fe.FastEccError) as ei:
-            enc.decode_prepare(np.ones(N, np.uint8), np.ones(rows, np.uint8))  # these codes are encode-only in this field
-        assert ei.value.code == fe.E_UNSUPPORTED
+        # erasure decoding on the (k << e)-th roots of unity: any n - k blocks may go (data and parity), decode leaves the parity alone, repair
+        # brings the lost parity blocks back too; erased blocks hold garbage
+        rng = np.random.default_rng(logn * 100 + e)
+        n = N << e
+        for nlost in sorted({1, 3, min(n - N, 40), (n - N) // 2, n - N}):
+            lost = rng.permutation(n)[:nlost]
+            dp, pp = np.ones(N, np.uint8), np.ones(rows, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            bad_x, bad_p = x.copy(), want.copy()
+            bad_x[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            bad_p[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+            enc.decode_prepare(dp, pp)
+            d, q = to_dev(torch_cuda, bad_x), to_dev(torch_cuda, bad_p)
+            enc.decode(d, q)
+            torch_cuda.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all(), (nlost, enc.plan())
+            assert (to_host(q).reshape(want.shape) == bad_p).all(), nlost
+            enc.repair(d, q)
+            torch_cuda.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
+            if logn <= 9:
+                hx, hp = bad_x.copy(), bad_p.copy()
+                enc.repair(hx, hp, mem=fe.MEM_HOST)
+                assert (hx == x).all() and (hp == want).all(), nlost
+        with pytest.raises(fe.FastEccError) as ei:   # one block too many
+            lost = rng.permutation(n)[: n - N + 1]
+            dp, pp = np.ones(N, np.uint8), np.ones(rows, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            enc.decode_prepare(dp, pp)
+        assert ei.value.code == fe.E_INVAL
 
 
 @pytest.mark.parametrize("plan", [2, 4, 13, 24])
