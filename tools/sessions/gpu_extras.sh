@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box extras of round 3: radix-4 microbenchmark, the p61 bench line, a 2-rank gloo run of bench.py's multi-rank control flow (both ranks
-# on device 0), the direct-path timings.  usage: tools/gpu_extras.sh <tag>
+# on device 0), the direct-path timings.  usage: tools/sessions/gpu_extras.sh <tag>
 set -u
 TAG=${1:-extras}
 OUT=gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GF((2^61-1)^2) session: parity tests of the field, then the configs[4] bench line and its rocprofv3 kernel stats.
-# usage: tools/gpu_p61.sh <tag>
+# usage: tools/sessions/gpu_p61.sh <tag>
 set -u
 TAG=${1:-p61}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_p61.py tests/test_gpu_sharded.py -m gpu -x -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest.log"

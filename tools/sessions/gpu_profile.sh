@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiling session for profiles/<round>/: rocprofv3 --kernel-trace --stats of the two bench commands, and HBM traffic
 # (FETCH_SIZE / WRITE_SIZE, one counter per run) of the kernels of both fields.
-# usage: tools/gpu_profile.sh <tag>
+# usage: tools/sessions/gpu_profile.sh <tag>
 set -u
 TAG=${1:-prof}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 R=$(pwd)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session A: the full GPU suite, the default bench line + its rocprofv3 summary, the multi-rank control flow on one GPU
 # (gloo, every rank on device 0), the column-slab overlap experiment on the headline, HBM traffic of the default plan.
-# usage: tools/gpu_r04_a.sh <tag>
+# usage: tools/sessions/gpu_r04_a.sh <tag>
 set -u
 TAG=${1:-r04a}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 R=$(pwd)

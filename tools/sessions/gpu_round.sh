@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: full -m gpu suite, smoke, the default bench line, rocprofv3 --kernel-trace --stats of the same
 # command, and the C++ host driver.  Everything lands in gpurun_out/<tag>/.
-# usage: tools/gpu_round.sh <tag> [pytest args...]
+# usage: tools/sessions/gpu_round.sh <tag> [pytest args...]
 set -u
 TAG=${1:-run}; shift || true
 OUT=gpurun_out/$TAG
