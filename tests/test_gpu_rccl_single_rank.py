@@ -25,6 +25,7 @@ from fastecc_amd import sharding
 from oracle import Oracle
 
 assert sharding.FORCE_COLLECTIVES
+print("imports ok", flush=True)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -94,6 +95,6 @@ def test_sharding_collectives_on_real_rccl_with_one_rank(hip_lib):
     env = dict(os.environ, FASTECC_SHARDING_FORCE_COLLECTIVES="1", FASTECC_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    if "RCCL group up" not in r.stdout:  # the library itself did not come up on this box (no fabric / shared memory for it): nothing of ours ran
+    if "imports ok" in r.stdout and "RCCL group up" not in r.stdout:  # the library itself did not come up on this box (no fabric / shared memory for it): nothing of ours ran
         pytest.skip("RCCL could not initialise a one-rank group here: " + (r.stderr or r.stdout)[-400:])
     assert r.returncode == 0 and "RCCL single-rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
