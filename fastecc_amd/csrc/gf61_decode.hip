@@ -273,6 +273,16 @@ __global__ __launch_bounds__(256) void k_restore_map(const uint64_t* __restrict_
     st(parity + ((uint64_t)q * elems + col) * 2, ld(again + ((uint64_t)q * elems + col) * 2));
 }
 
+// split repair: gout_par[j] = gout_all[2j + 1] for the parity blocks the CALLER lost (state_real), zero for the rest — the locator's state counts the
+// unused parity blocks as lost too, and those are not to be rewritten
+__global__ __launch_bounds__(256) void k_gout_par(const uint64_t* __restrict__ gout_all, const uint8_t* __restrict__ state_real, uint64_t* __restrict__ gout_par,
+                                                  uint32_t N)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    st(gout_par + 2ull * j, state_real[2u * j + 1u] == ST_HELD ? Elem{0, 0} : ld(gout_all + 2ull * (2u * j + 1u)));
+}
+
 // data[i] = work[stride * i] * gout[i] for the erased data blocks (gout != 0)
 __global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ work, uint64_t* __restrict__ data, const uint64_t* __restrict__ gout,
                                                  uint32_t elems, uint32_t col_chunks, uint64_t items, uint32_t stride)
@@ -551,6 +561,12 @@ struct Decoder {
     uint64_t* split_af = nullptr;        // k elements by position: -1/2 w^(-bitrev(p))
     uint64_t* split_work = nullptr;      // k blocks: the data chain's intermediate stripe
     uint8_t* state_real = nullptr;       // the caller's flags (the locator's `state` counts unused parity blocks as lost)
+    // fastecc_repair through the split: a second MID + DIT chain over the same two halves gives x p'(x) at the odd positions — the lost parity blocks
+    uint64_t* split_q2 = nullptr;        // k blocks: q~ as the data chain's MID leaves it after its first half (lazy)
+    uint64_t* split_pos_odd = nullptr;   // k elements by position: -1/2 w^(+bitrev(p))
+    uint64_t* gout_par = nullptr;        // k elements by parity block: 1 / (w^(2j+1) l'(w^(2j+1))) where the caller lost block j, else 0
+    bool split_repair_ready = false;
+    bool split_pos_odd_built = false;
     int split_shift = 0;
     bool split_ready = false;
     uint64_t erased_data = 0, erased_parity = 0;
@@ -578,7 +594,8 @@ void destroy_decoder(Decoder* d)
     destroy(d->pattern);
     destroy(d->splitp);
     for (Path* t : d->small) destroy(t);
-    for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real, (void*)d->srcmap, (void*)d->parity_lost, (void*)d->cos_work})
+    for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real, (void*)d->srcmap, (void*)d->parity_lost, (void*)d->cos_work,
+                    (void*)d->split_q2, (void*)d->split_pos_odd, (void*)d->gout_par})
         if (b) (void)hipFree(b);
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
@@ -632,10 +649,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         for (uint64_t j = 0; j < N; j++)
             if (parity_present[j])
                 for (int h = 1; h <= 5 && (j & ((1ull << h) - 1)) == 0; h++) at_multiple[h]++;
-        // a pattern that has lost parity blocks too may be REPAIRED (lost parity rebuilt as well): with the split that is decode + re-encode, without it
-        // one transform over all 2k positions — measured at k = 2^19: the split wins the repair from h = 3 (8.5 against 9.3 ms at h = 5) and loses it at
-        // h = 1 (10.5 against 9.1), while the decode alone always gains (4.5 against 7.2 ms at h = 5, 6.3 against 7.0 at h = 1)
-        const int h_min = erased_parity != 0 ? 3 : 1;
+        // (a pattern that has lost parity blocks too may be REPAIRED: the split then runs a second MID + DIT chain for the odd positions — or, without
+        //  the memory for its extra stripe, re-encodes — see decode())
+        const int h_min = 1;
         for (int h = 5; h >= h_min && split_shift == 0; h--)
             if (at_multiple[h] >= erased_data) split_shift = h;
         if (split_shift != 0) {
@@ -667,6 +683,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     d->erased_data = erased_data;
     d->erased_parity = erased_parity;
     d->split_ready = false;
+    d->split_repair_ready = false;
     d->split_shift = 0;
     d->e = e;
     d->M = M;
@@ -890,8 +907,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         if (rc != FASTECC_OK) return rc;
     }
     d->gout_all_valid = false;
-    if (erased_data != 0 && erased_parity != 0 && split_shift == 0 && e == 1) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
-        // (not with the split: its locator counts the unused parity blocks as lost — the lost parity is re-encoded from the repaired data instead)
+    if (erased_data != 0 && erased_parity != 0 && e == 1) {  // fastecc_repair can then rebuild everything in one transform (no memory for the table: decode + encode)
+        // (with the split the locator counts the unused parity blocks as lost: the table then only feeds gout_par below)
         if (!d->gout_all && hipMalloc((void**)&d->gout_all, NC * 16) != hipSuccess) {
             (void)hipGetLastError();
             d->gout_all = nullptr;
@@ -901,6 +918,24 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()),
                        d->gout_all_valid ? d->gout_all : nullptr, e);
     D61_TRY(hipGetLastError());
+    if (d->split_ready && d->gout_all_valid) {
+        // the second chain's tables: the factor of q~ by position (once) and the lost parity blocks' output factors (this pattern)
+        const hipError_t e1 = d->split_pos_odd ? hipSuccess : hipMalloc((void**)&d->split_pos_odd, N * 16);
+        const hipError_t e2 = e1 != hipSuccess ? e1 : d->gout_par ? hipSuccess : hipMalloc((void**)&d->gout_par, N * 16);
+        if (e2 == hipSuccess) {
+            if (!d->split_pos_odd_built) {
+                const int rc = split_addend_factors(d->split_pos_odd, log2k, s0, true);
+                if (rc != FASTECC_OK) return rc;
+                d->split_pos_odd_built = true;
+            }
+            hipLaunchKernelGGL(k_gout_par, grid(N), dim3(256), 0, s0, d->gout_all, d->state_real, d->gout_par, (uint32_t)N);
+            D61_TRY(hipGetLastError());
+            d->split_repair_ready = true;
+        } else {
+            (void)hipGetLastError();  // no memory for the tables: the split decodes, the lost parity is re-encoded
+        }
+    }
+    if (d->split_ready) d->gout_all_valid = false;  // (the one-transform repair is the unsplit pattern's)
     D61_TRY(hipStreamSynchronize(s0));
     d->ready = true;
     return FASTECC_OK;
@@ -979,10 +1014,22 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         hipLaunchKernelGGL(k_split_small_gather, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, parity, d->small_buf, d->fin, elems, h, col_chunks, items);
         D61_TRY(hipGetLastError());
         int rc = dif_only(d->small[h], d->small_buf, true, s0, hooks);
+        // (repair: the data chain also stores q~, and a second MID + DIT chain turns it and the same r~ into the lost parity blocks)
+        bool second = rebuild && d->split_repair_ready;
+        if (second && !d->split_q2 && hipMalloc((void**)&d->split_q2, d->N * d->elems * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            d->split_q2 = nullptr;
+            second = false;  // no room for the extra stripe: the lost parity is re-encoded below
+        }
         if (rc == FASTECC_OK)
-            rc = split_decode(d->splitp, data, d->fin, 2, d->small_buf, h, d->split_af, d->split_work, d->gout, data, s0, hooks);
+            rc = split_decode(d->splitp, data, d->fin, 2, d->small_buf, h, d->split_af, d->split_work, d->gout, data, s0, hooks, second ? d->split_q2 : nullptr);
         if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
         data_done = rc == FASTECC_OK;
+        if (data_done && second) {
+            rc = split_repair_parity(d->splitp, d->split_q2, d->split_pos_odd, d->small_buf, h, d->split_work, d->gout_par, parity, s0, hooks);
+            if (rc != FASTECC_OK && rc != FASTECC_E_UNSUPPORTED) return rc;
+            if (rc == FASTECC_OK) return FASTECC_OK;  // data and parity are whole again
+        }
     }
     if (d->erased_data != 0 && !data_done) {
         if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));

@@ -33,7 +33,7 @@ namespace p61 {
 
 namespace {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5, MODE_DIF_ROWS = 6, MODE_MID_ADD = 7 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5, MODE_DIF_ROWS = 6, MODE_MID_ADD = 7, MODE_MID_UP = 8 };
 
 // forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
 struct SmallRoots {
@@ -61,10 +61,13 @@ struct PassArgs {
     //   MODE_DIF_ROWS  block u of `in` times side[u * side_stride] on the way in (zero = block not in use, never read)
     //   MODE_MID_ADD   between the halves of MID, position p gets + addend[p >> addend_shift] * addend_factor[p]; addend is a stripe of
     //                  (N >> addend_shift) blocks in the position order a DIF leaves (block q = coefficient bitrev(q))
+    //   keep           MODE_MID_ADD, optional: the tile as it is after MID's first half (before any factor) is also stored here, by position
+    //   MODE_MID_UP    MID's second half alone on such a stored stripe (`in`), with the same "+ addend * factor": fastecc_repair's second chain
     uint32_t side_stride;
     const uint64_t* addend;
     const uint64_t* addend_factor;
     int addend_shift;
+    uint64_t* keep;
 };
 
 using gf61::Elem;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     // value to the same address from the same wave — so the kernel has no divergent region at all.  (With an "if (live)" around the stores
     // the compiler sinks the whole second half of the tile into that branch, where its scheduling barriers no longer apply.)
     const uint32_t col = min(cc * 64u + lane, a.elems - 1u);
-    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD || MODE == MODE_MID_ADD) ? 0 : a.s;
+    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD || MODE == MODE_MID_ADD || MODE == MODE_MID_UP) ? 0 : a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
     const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
@@ -529,15 +532,29 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
 #pragma unroll
         for (int j = 0; j < RH; ++j) store_elem(a.out + (half0 + (uint32_t)j * G + g) * row_words + 2u * col, CANON ? gf61::canon(y[j]) : y[j]);
     } else {
-        load(row_a);
-        dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
-        exchange(row_a, row_b);
-        dif_levels<LOGR, true, true, L2>(x, a.tw_dif, 0u, 0, k, a.sr);
+        if constexpr (MODE == MODE_MID_UP) {
+            load(row_b);  // the stored first half: position p = hi*T + g*R + j
+        } else {
+            load(row_a);
+            dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
+            exchange(row_a, row_b);
+            dif_levels<LOGR, true, true, L2>(x, a.tw_dif, 0u, 0, k, a.sr);
+            if constexpr (MODE == MODE_MID_ADD) {
+                if (a.keep) {  // (uniform) the repair's second chain starts from these values
+                    uint64_t off = (((uint64_t)hi << LOGT) + (uint64_t)g * R) * row_words;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        store_elem(a.keep + off + 2u * col, gf61::canon(x[j]));
+                        off += row_words;
+                    }
+                }
+            }
+        }
         // position p = hi*T + g*R + j holds coefficient bitrev_n(p); dscale is stored in position order
         const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
-        if constexpr (MODE == MODE_MID_ADD) {
+        if constexpr (MODE == MODE_MID_ADD || MODE == MODE_MID_UP) {
             // + addend[p >> shift] * factor[p]: the other half of the split decoder's coefficient vector.  2^shift consecutive positions read
             // the same block of the (small) addend stripe: it is fetched once per run (p is wave-uniform, so is the branch).
             const uint64_t p0 = ((uint64_t)hi << LOGT) + (uint64_t)g * R;
@@ -559,7 +576,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
             }
         }
         dit_levels<LOGR, true, false, L2>(x, a.tw_dit, 0u, 0, k, a.sr);
-        __syncthreads();  // every lane has finished reading the first exchange
+        if constexpr (MODE != MODE_MID_UP) __syncthreads();  // every lane has finished reading the first exchange
         exchange(row_b, row_a);
         dit_levels<LOGR, false, false>(x, a.tw_dit, g, L2, k, a.sr);
         store(row_a);
@@ -660,6 +677,7 @@ hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const Pass
     case MODE_DIF_GATHER: return launch_tile_one<LOGT, MODE_DIF_GATHER, false, SPLIT, true>(a, tiles, st);
     case MODE_DIF_ROWS: return launch_tile_one<LOGT, MODE_DIF_ROWS, false, SPLIT, true>(a, tiles, st);
     case MODE_MID_ADD: return launch_tile_one<LOGT, MODE_MID_ADD, false, SPLIT, true>(a, tiles, st);
+    case MODE_MID_UP: return launch_tile_one<LOGT, MODE_MID_UP, false, SPLIT, true>(a, tiles, st);
     case MODE_DIT_SCATTER: return launch_tile_one<LOGT, MODE_DIT_SCATTER, true, SPLIT, false>(a, tiles, st);
     default:       return canon ? launch_tile_one<LOGT, MODE_MID, true, SPLIT, true>(a, tiles, st) : launch_tile_one<LOGT, MODE_MID, false, SPLIT, true>(a, tiles, st);
     }
@@ -951,6 +969,8 @@ struct FusedEnds {
     const uint64_t* mid_addend = nullptr;
     const uint64_t* mid_addend_factor = nullptr;
     int mid_shift = 0;
+    uint64_t* mid_keep = nullptr;  // MODE_MID_ADD also stores the tile after its first half here
+    bool mid_up = false;           // MID runs its second half only, on such a stored stripe (MODE_MID_UP; MID is then the plan's first pass)
 };
 
 // inverse_roots: tw_dif holds inverse roots (selects the conjugate small roots inside the DIF runs)
@@ -977,10 +997,11 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         }
         if (ends && ends->mid_addend && q.mode == MODE_MID) {
             if (!q.tile || q.canon || qi + 1 == plan.size()) return FASTECC_E_UNSUPPORTED;
-            mode = MODE_MID_ADD;
+            mode = ends->mid_up ? MODE_MID_UP : MODE_MID_ADD;
             a.addend = ends->mid_addend + 2 * col0;
             a.addend_factor = ends->mid_addend_factor;
             a.addend_shift = ends->mid_shift;
+            a.keep = ends->mid_keep && !ends->mid_up ? ends->mid_keep + 2 * col0 : nullptr;
         }
         if (ends && ends->last_side && qi + 1 == plan.size()) {
             if (!q.tile || q.mode != MODE_DIT || !q.canon || mode != q.mode) return FASTECC_E_UNSUPPORTED;
@@ -1003,13 +1024,15 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
         const dim3 grid((unsigned)blocks);
         char name[32];
         snprintf(name, sizeof name, "p61_%s%s%d%s", q.tile ? "tile_" : "", q.mode == MODE_DIF ? "dif" : q.mode == MODE_DIT ? "dit" : "mid", q.logr,
-                 mode == MODE_DIF_GATHER ? "_gather" : mode == MODE_DIT_SCATTER ? "_scatter" : mode == MODE_DIF_ROWS ? "_rows" : mode == MODE_MID_ADD ? "_add" : "");
+                 mode == MODE_DIF_GATHER ? "_gather" : mode == MODE_DIT_SCATTER ? "_scatter" : mode == MODE_DIF_ROWS ? "_rows" : mode == MODE_MID_ADD ? "_add" : mode == MODE_MID_UP ? "_up" : "");
         Scope sc(hooks, st, name, 2ull * p->N * width * 16ull);
         hipError_t e;
         if (q.tile) {
             if (q.logr == 5) {  // MID only (tile_shape_mid)
                 if (mode == MODE_MID_ADD) e = p->split == 2 ? launch_tile_one<5, MODE_MID_ADD, false, 2, true>(a, (unsigned)blocks, st)
                                                             : launch_tile_one<5, MODE_MID_ADD, false, 1, true>(a, (unsigned)blocks, st);
+                else if (mode == MODE_MID_UP) e = p->split == 2 ? launch_tile_one<5, MODE_MID_UP, false, 2, true>(a, (unsigned)blocks, st)
+                                                                : launch_tile_one<5, MODE_MID_UP, false, 1, true>(a, (unsigned)blocks, st);
                 else if (mode != MODE_MID) return FASTECC_E_UNSUPPORTED;
                 else if (p->split == 2) e = q.canon ? launch_tile_one<5, MODE_MID, true, 2, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 2, true>(a, (unsigned)blocks, st);
                 else e = q.canon ? launch_tile_one<5, MODE_MID, true, 1, true>(a, (unsigned)blocks, st) : launch_tile_one<5, MODE_MID, false, 1, true>(a, (unsigned)blocks, st);
@@ -1285,10 +1308,12 @@ bool split_decode_supported(const Path* p)
     return first.tile && first.mode == MODE_DIF && last.tile && last.mode == MODE_DIT && last.canon && mid_ok;
 }
 int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uint32_t rows_stride, const uint64_t* addend, int addend_shift,
-                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks)
+                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks,
+                 uint64_t* keep)
 {
     if (!split_decode_supported(p) || rows_stride == 0) return FASTECC_E_UNSUPPORTED;
     FusedEnds f;
+    f.mid_keep = keep;
     f.first_side = rows_factor;
     f.first_rows_stride = rows_stride;
     f.mid_addend = addend;
@@ -1298,11 +1323,31 @@ int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uin
     f.last_out = data_out;
     return run_passes(p, p->enc, data, work, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, &f);
 }
+// fastecc_repair's second chain: x p'(x) at the ODD positions (the parity blocks) is the k-point transform of h[m] = -1/2 w^m q~[m] + (2m+k)/2k r~[m]
+// (decode.hip's header) — MID's second half alone on the q~ that split_decode kept, the two factor tables exchanged (data_factor: -1/2 w^m by
+// position; the path's own table now scales the addend), then the DIT passes, the last of which stores parity block j times gout_par[j] where
+// that is not zero.  work: a k-block stripe (split_decode's may be reused once it has finished).
+int split_repair_parity(Path* p, const uint64_t* keep, const uint64_t* data_factor, const uint64_t* addend, int addend_shift, uint64_t* work,
+                        const uint64_t* gout_par, uint64_t* parity_out, hipStream_t st, const LaunchHooks* hooks)
+{
+    if (!split_decode_supported(p)) return FASTECC_E_UNSUPPORTED;
+    size_t mid = 0;
+    while (mid < p->enc.size() && p->enc[mid].mode != MODE_MID) mid++;
+    const std::vector<Pass> tail(p->enc.begin() + (long)mid, p->enc.end());
+    FusedEnds f;
+    f.mid_addend = addend;
+    f.mid_addend_factor = p->dscale;
+    f.mid_shift = addend_shift;
+    f.mid_up = true;
+    f.last_side = gout_par;
+    f.last_out = parity_out;
+    return run_passes(p, tail, keep, work, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, &f, data_factor);
+}
 // addend_factor table of the split decoder for a path of size 2^n: n-bit position q -> -1/2 w_2N^(-bitrev(q)) (2^n elements, device memory of the caller)
-int split_addend_factors(uint64_t* table, int n, hipStream_t st)
+int split_addend_factors(uint64_t* table, int n, hipStream_t st, bool forward)
 {
     const uint64_t N = 1ull << n;
-    const gf61::Elem wi = gf61::h_inv(gf61::h_root(2 * N));
+    const gf61::Elem wi = forward ? gf61::h_root(2 * N) : gf61::h_inv(gf61::h_root(2 * N));  // forward: -1/2 w^(+bitrev(q)), the parity chain's factor of q~
     const gf61::Elem half = gf61::h_inv(gf61::Elem{2, 0});
     const gf61::Elem neg_half{gf61::h_subp(0, half.re), 0};
     hipLaunchKernelGGL(k_split_addend_factors, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, table, neg_half.re, neg_half.im, wi.re, wi.im, n);

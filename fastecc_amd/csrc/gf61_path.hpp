@@ -66,8 +66,11 @@ int dif_only(Path* p, uint64_t* data, bool inverse, hipStream_t st, const Launch
 // ---- the decoder's even / odd split (gf61_decode.hip): the data chain on a path made with FACTOR_SPLIT ----
 bool split_decode_supported(const Path* p);
 int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uint32_t rows_stride, const uint64_t* addend, int addend_shift,
-                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks);
-int split_addend_factors(uint64_t* table, int n, hipStream_t st);
+                 const uint64_t* addend_factor, uint64_t* work, const uint64_t* gout, uint64_t* data_out, hipStream_t st, const LaunchHooks* hooks,
+                 uint64_t* keep = nullptr);  // keep: a k-block stripe that receives q~ (the tiles after MID's first half) for split_repair_parity
+int split_repair_parity(Path* p, const uint64_t* keep, const uint64_t* data_factor, const uint64_t* addend, int addend_shift, uint64_t* work,
+                        const uint64_t* gout_par, uint64_t* parity_out, hipStream_t st, const LaunchHooks* hooks);
+int split_addend_factors(uint64_t* table, int n, hipStream_t st, bool forward = false);
 // words >= p among the 2 * elems * k words of a stripe; `counter` is a device uint64 the caller zeroed
 int count_out_of_range(Path* p, const uint64_t* data, unsigned long long* counter, hipStream_t st);
 

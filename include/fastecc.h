@@ -395,8 +395,7 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  survivors at multiples of 2^h of that half (largest h <= 5 that leaves as many as there are lost data blocks), whose transform is
  *                  one of k >> h rows (2 % of the codeword lost: decode 7.1 -> 3.8 ms at k = 2^19 x 4 KB), else the surviving blocks of the first
  *                  few block groups (what round 3 always did: 2 = that form only); 0 = one transform of 2k points.  Same bits.
- *                  GF((2^61-1)^2), k >= 2^11: 0 / 1 (default 1) — the same split in its k >> h form (h = 5 .. 1; from h = 3 when parity blocks are
- *                  lost too, since fastecc_repair then re-encodes instead of running one transform over all 2k positions): decode 7.2 -> 4.5 ms at
+ *                  GF((2^61-1)^2), k >= 2^11: 0 / 1 (default 1) — the same split in its k >> h form (h = 5 .. 1): decode 7.2 -> 4.5 ms, repair 9.2 -> 6.8 ms (a second MID + DIT chain for the lost parity blocks) at
  *                  k = 2^19 x 4 KB and 2 % lost, 72 ms = 1.14 x the encode at 64 KB blocks; patterns it does not take run the folded 2k-point transform;
  *   "direct_kernel" = 0 / 1 / 2 (default 0 = choose): the kernel of those direct paths — 1 = VALU (96-bit lazy accumulation, any rows),
  *                  2 = MFMA (i8 digits; falls back to 1 where it cannot run).  Same bits either way;

@@ -628,3 +628,18 @@ def test_decode_split_is_what_runs(torch_cuda, fe):
         assert torch.equal(bad, dx)
         assert any(n.endswith("_rows") for n in names) and any(n.endswith("_add") for n in names) and any(n.endswith("_scatter") for n in names), names
         assert not any(n.endswith("_gather") for n in names), names
+        # fastecc_repair of a pattern that lost parity too: a second MID + DIT chain over the same two halves (MID's second half alone on the q~ the
+        # data chain kept), no re-encode
+        pp[rng.permutation(N)[: N // 50]] = 0
+        enc.decode_prepare(dp, pp)
+        bad, badp = dx.clone(), par.clone()
+        bad.view(N, -1)[torch.from_numpy(np.flatnonzero(dp == 0)).to("cuda:0")] = -1
+        badp.view(N, -1)[torch.from_numpy(np.flatnonzero(pp == 0)).to("cuda:0")] = -2
+        enc.profile(True)
+        enc.profile_reset()
+        enc.repair(bad, badp)
+        torch.cuda.synchronize()
+        names = set(enc.profile_read())
+        enc.profile(False)
+        assert torch.equal(bad, dx) and torch.equal(badp, par)
+        assert any(n.endswith("_up") for n in names) and not any(n.endswith("mid5") or n.endswith("mid6") or n.endswith("mid7") for n in names), names
