@@ -91,6 +91,21 @@ void build_plans(fastecc_ctx* c)
         for (const Pass& p : c->encode_plan) tiles = tiles && p.tile && p.wide == 0;  // (tiles of several address windows: not measured in this split)
         if (tiles) return;
     }
+    // Narrow blocks at k = 2^19 (64 .. 511 words in whole 64-word rows: the sub-slabs of ONE stripe spread over 2, 4 or 8 GPUs):
+    // 128- and 256-byte pieces of a block per request make the slim 32-word outer tiles the slow part, so the 9-level outer chunks run as tiles
+    // of 64-word rows around MID10 (plan 4100's shape): 256 B blocks 4.38 -> 4.06 ms per 2 GiB-equivalent, 512 B 4.04 -> 3.94, 1 KB 3.79 -> 3.62
+    // (profiles/r05/narrow_block_plans.jsonl; at 2 KB and above the rule above holds, at 128 B there are no 64-word rows).
+    const bool narrow = c->plan_auto && !c->classic_plan && c->tile_mid == 10 && !c->tile_mid_wide && c->split2 && c->slim_outer && c->q <= 1 && !c->p61 &&
+                        c->fold == 0 && c->cosets == 1 && c->n == 19 && c->S >= 64 && c->S < 512 && (c->S % 64) == 0 && c->ld == c->S;
+    if (narrow) {
+        const bool outer64 = c->outer64;
+        c->outer64 = true;
+        build_plans_with(c, c->tile_mid);
+        c->outer64 = outer64;
+        bool tiles = c->encode_plan.size() == 3;
+        for (const Pass& p : c->encode_plan) tiles = tiles && p.tile && p.wide == 0;
+        if (tiles) return;
+    }
     build_plans_with(c, c->tile_mid);
 }
 

@@ -128,6 +128,12 @@ def test_tile_eligibility_follows_the_block_span(hip_lib):
     assert describe(hip_lib, 1 << 19, 4096)[1].startswith("T32:dif10@9,T32:mid9@0,T32:dit10@9")
     assert describe(hip_lib, 1 << 19, 4096, 3100)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")
     assert describe(hip_lib, 1 << 19, 8192)[1].startswith("SW32:dif9@10,T32:mid10@0,SW32:dit9@10")
+    # narrow blocks in whole 64-word rows at k = 2^19 (the sub-slabs of a stripe over 2 .. 8 GPUs): 64-word-row outer tiles around MID10
+    for bb in (256, 512, 1024):
+        assert describe(hip_lib, 1 << 19, bb)[1].startswith("T64:dif9@10,T32:mid10@0,T64:dit9@10"), bb
+    assert describe(hip_lib, 1 << 19, 128)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")     # no 64-word rows
+    assert describe(hip_lib, 1 << 19, 384)[1].startswith("S32:dif9@10,T32:mid10@0,S32:dit9@10")     # 96 words: not whole 64-word rows
+    assert describe(hip_lib, 1 << 18, 512)[1].startswith("S32:dif8@10,T32:mid10@0,S32:dit8@10")     # the rule is for the 9-level outer chunks
     assert describe(hip_lib, 1 << 18, 16384)[1].startswith("SW32:dif8@10,T32:mid10@0,SW32:dit8@10")
     assert describe(hip_lib, 1 << 19, 16384)[1].startswith("SW4x32:dif9@10,T32:mid10@0,SW4x32:dit9@10")
     assert describe(hip_lib, 1 << 19, 32768)[1].startswith("SW8x32:dif9@10,T32:mid10@0,SW8x32:dit9@10")
