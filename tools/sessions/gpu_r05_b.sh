@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round 5, session B: direct MFMA kernel variants (XOR digits, one N-tile per wave at two waves per SIMD), A/B in separate processes.
+# NOTE: ran against an EXPERIMENTAL build of csrc/direct.hip (XOR digits, one N-tile per wave: env FASTECC_DIRECT_NT / _G) that was measured null and is not in
+# the tree; kept as the record of how profiles/r05/direct_mfma_variants_*.jsonl were made.
 set -u
 TAG=${1:-r05b}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_direct.py tests/test_gpu_decode.py -m gpu -x -q > "$OUT/pytest_direct.log" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_direct.log"

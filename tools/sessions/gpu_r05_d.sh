@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round 5, session D: timing ablations of direct_mfma_kernel<8> (library built with -DFASTECC_DIRECT_ABLATION; ablated results are wrong on purpose)
+# NOTE: needs the library built with FASTECC_EXTRA_HIPFLAGS=-DFASTECC_DIRECT_ABLATION (fastecc_amd/_build.py); variants 103-105 / 200 ran against experimental
+# builds (deeper row prefetch, LDS ring) that are not in the tree.
 set -u
 TAG=${1:-r05d}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 for abl in ${ABLS:-0 1 2 4 8 3 5 6 7 15}; do
