@@ -64,12 +64,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 VALU_PEAK_GBFLY = 3830.0
 VALU_PEAK_CLOCK_GHZ = 2.39  # the clock that loop sustains (profiles/r02/microbench_bfly_sustained_r02.jsonl: 2393 MHz at 1055 W; profiles/r05: GRBM cycles / duration)
 PMC_VALU = os.path.join("profiles", "r05", "pmc_valu_default_plan.json")
+PMC_VALU_P61 = os.path.join("profiles", "r05", "pmc_valu_p61.json")  # the 64-bit field at the configs[4] size (tools/pmc_valu_p61.py)
 
 
-def pmc_valu():
+def pmc_valu(path=PMC_VALU):
     """The committed counter summary of the default plan's kernels at the headline size (tools/pmc_valu.py), or None."""
     try:
-        with open(os.path.join(ROOT, PMC_VALU)) as f:
+        with open(os.path.join(ROOT, path)) as f:
             return json.load(f)
     except Exception:
         return None
@@ -573,7 +574,14 @@ def other_field_p61(fastecc_amd, device, stream, steps=10):
         if dom:
             name, (ms_total, launches, nbytes) = dom
             ach = nbytes / ms_total / 1e6
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            pmc = pmc_valu(PMC_VALU_P61)  # counters of this size's kernels (tools/pmc_valu_p61.py): DIF7 / DIT7 run nearer a copy's rate, MID5 nearer the issue rate
+            ev = (pmc or {}).get("kernels", {}).get(name)
+            roof = {"bound": ev["bound"] if ev else "hbm",
+                    "bound_source": PMC_VALU_P61 + " (rocprofv3 --pmc, committed; not measured in this run)" if ev else "assumed (no counter file)",
+                    "per_kernel_bound": None if not pmc else {kn: {k2: e[k2] for k2 in ("bound", "valu_issue_frac", "hbm_frac_achievable", "clock_GHz")}
+                                                              for kn, e in pmc["kernels"].items()},
+                    "encode_floors": None if not pmc else {k2: pmc["encode"][k2] for k2 in ("valu_floor_frac", "hbm_floor_frac_achievable", "clock_GHz")},
+                    "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "avg_kernel_ms": round(ms_total / launches, 3), "alg_bytes_per_launch": nbytes / launches,
                     "encode": {"achieved": round(2.0 * k * bb / ms / 1e6, 1), "frac": round(2.0 * k * bb / ms / 1e6 / HBM_PEAK_GBPS, 4),
                                "hbm_trips": int(round(sum(v[1] for v in kernels.values()) / steps))}}
@@ -1214,12 +1222,14 @@ def main():
             # loop's rate (valu_issue_frac) and the algorithmic HBM rate against what a copy reaches (hbm_frac_achievable); the larger one names
             # the bound.  achieved / peak / frac stay the HBM figures the contract asks for.  Other sizes / plans / fields have no counter file:
             # their `bound` is labelled as assumed.
-            pmc = pmc_valu() if headline else None
+            cfg5 = p61 and args.log2k == 19 and args.block_bytes == 65536 and m_blocks == k and args.batch == 1 and not args.plan and not args.option
+            pmc_file = PMC_VALU if headline else PMC_VALU_P61 if cfg5 else None
+            pmc = pmc_valu(pmc_file) if pmc_file else None
             ev = (pmc or {}).get("kernels", {}).get(name)
             roof = {"bound": ev["bound"] if ev else ("valu" if "_mid" in name else "hbm"),
-                    "bound_source": (PMC_VALU + " (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE of this command and of the isolated butterfly loop, committed; "
+                    "bound_source": (pmc_file + " (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE of this command and of the isolated butterfly loop, committed; "
                                                 "not measured in this run)") if ev else "assumed from the kernel's kind (no counter file for this size / plan / field)",
-                    "bound_evidence": None if not ev else {k2: ev[k2] for k2 in ("valu_issue_frac", "cycles_per_valu_instruction", "hbm_frac_achievable", "clock_GHz",
+                    "bound_evidence": None if not ev else {k2: ev.get(k2) for k2 in ("valu_issue_frac", "cycles_per_valu_instruction", "hbm_frac_achievable", "clock_GHz",
                                                                                   "valu_busy_gfx94x_formula", "wave_cycles_split")},
                     "per_kernel_bound": None if not pmc else {kn: {k2: e[k2] for k2 in ("bound", "valu_issue_frac", "hbm_frac_achievable", "clock_GHz")}
                                                               for kn, e in pmc["kernels"].items()},
@@ -1244,7 +1254,7 @@ def main():
                              # at the isolated loop's issue rate)
                              "microbench_clock_GHz": None if p61 else VALU_PEAK_CLOCK_GHZ,
                              "encode_clock_GHz": None if not pmc else round(pmc["encode"]["cycles"] / pmc["encode"]["sum_of_kernel_ms"] / 1e6, 3),
-                             "frac_at_encode_clock": None if not pmc else round(bfly / (VALU_PEAK_GBFLY * pmc["encode"]["cycles"] / pmc["encode"]["sum_of_kernel_ms"] / 1e6
+                             "frac_at_encode_clock": None if not pmc or p61 else round(bfly / (VALU_PEAK_GBFLY * pmc["encode"]["cycles"] / pmc["encode"]["sum_of_kernel_ms"] / 1e6
                                                                                         / VALU_PEAK_CLOCK_GHZ), 4),
                              "issue_floor_frac": None if not pmc else pmc["encode"]["valu_floor_frac"]},
                     "per_kernel_avg_ms": {kn: round(v[0] / v[1], 4) for kn, v in sorted(kernels.items())},

@@ -87,7 +87,7 @@ def build_host(force=False, verbose=False):
 
 def build_microbench(force=False, verbose=False):
     """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
-    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma"):
+    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma", "microbench_f64", "proto_mid_f64"):
         src = os.path.join(ROOT, "tools", name + ".hip")
         out = os.path.join(LIB_DIR, name)
         if not os.path.exists(src):
