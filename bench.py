@@ -67,6 +67,16 @@ PMC_VALU = os.path.join("profiles", "r05", "pmc_valu_default_plan.json")
 PMC_VALU_P61 = os.path.join("profiles", "r05", "pmc_valu_p61.json")  # the 64-bit field at the configs[4] size (tools/pmc_valu_p61.py)
 
 
+# Test hook (tests/test_gpu_bench_rccl_one_rank.py): a one-rank process group is brought up and used as if the job had several ranks, so that
+# the RCCL-specific lines of this file (device-side reductions, communicators per mode, object gathers) run against the real library on a
+# 1-GPU box.  Together with FASTECC_SHARDING_FORCE_COLLECTIVES the one_stripe modes then issue their collectives too.  Never set by the driver.
+ONE_RANK_GROUP = os.environ.get("FASTECC_BENCH_TEST_ONE_RANK_GROUP", "") == "1"
+
+
+def dist_on(world):
+    return world > 1 or ONE_RANK_GROUP
+
+
 def pmc_valu(path=PMC_VALU):
     """The committed counter summary of the default plan's kernels at the headline size (tools/pmc_valu.py), or None."""
     try:
@@ -969,7 +979,7 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
     def everyone_ok(ok):
         """The ranks agree (default group) whether a mode's warm-up went through everywhere: a rank that raised must not go on to the next
         mode's collectives while the others enter this mode's barriers."""
-        if world == 1:
+        if not dist_on(world):
             return ok
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -978,7 +988,7 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
     for name in ONE_STRIPE_MODES:
         try:
             with watch(name):
-                if world > 1 and name in OWN_GROUP_MODES:
+                if dist_on(world) and name in OWN_GROUP_MODES:
                     # every rank takes part in every new_group call, in this order; a mode that cannot get a communicator of its own
                     # runs on the default one
                     try:
@@ -1029,14 +1039,14 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
             if rank == 0 and full is not None:  # the root's own columns of the gathered blocks = its slab
                 ok_local = ok_local and bool(torch.equal(full[:, :w], pslab.permute(1, 0, 2).reshape(k, w)))
             flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if gloo else device)
-            if world > 1:
+            if dist_on(world):
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             checks["slabs_equal_compute_only_on_every_rank"] = bool(flag.item() == 1.0)
             for key, wsp in (("all_to_all", wsp_a), ("all_to_all_in_out", wsp_b)):
                 mineb = wsp.get("parity_blocks")
                 if mineb is None:
                     continue
-                if world > 1:
+                if dist_on(world):
                     piece = mineb.cpu() if gloo else mineb
                     got = [torch.empty_like(piece) for _ in range(world)] if rank == 0 else None
                     dist.gather(piece, gather_list=got, dst=0)
@@ -1135,7 +1145,7 @@ def main():
     # ---- N > 1: this rank's own measurement first, with no collective anywhere near it, THEN the process group under a timer.  RCCL has never run
     # under this file before the driver's first multi-GPU box: if the process group (or its first barrier) does not come up, rank 0 still prints
     # a line — its own timing of its stripe, times N — and says what it is. ----
-    if world > 1:
+    if dist_on(world):
         import torch.distributed as dist
         for _ in range(args.warmup):
             step()
@@ -1173,12 +1183,12 @@ def main():
         startup.cancel()
 
     def barrier():
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_on(world):
             return x
         t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1286,7 +1296,7 @@ def main():
 
     devices = [identity()]
     dist_info = {"world_size": 1, "backend": None}
-    if world > 1:
+    if dist_on(world):
         try:
             every_rec = [None] * world
             dist.all_gather_object(every_rec, devices[0])
@@ -1379,7 +1389,7 @@ def main():
             self.name = name
 
         def __enter__(self):
-            if world > 1 and args.mode_timeout > 0:
+            if dist_on(world) and args.mode_timeout > 0:
                 armed["timer"] = threading.Timer(args.mode_timeout, give_up, args=(self.name, args.mode_timeout))
                 armed["timer"].daemon = True
                 armed["timer"].start()
@@ -1391,7 +1401,7 @@ def main():
             return False
 
     watchdog = None
-    if world > 1 and args.sharded_timeout > 0:
+    if dist_on(world) and args.sharded_timeout > 0:
         watchdog = threading.Timer(args.sharded_timeout, give_up, args=("one_stripe_section", args.sharded_timeout))
         watchdog.daemon = True
         watchdog.start()
@@ -1463,7 +1473,7 @@ def main():
             other_paths_result.update({"error": repr(e)})
     emit(one, cabi, cpu)
     enc.close()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
         dist.destroy_process_group()
 
