@@ -321,3 +321,98 @@ def test_random_split_decoder_configuration(torch_cuda, fe, seed):
             enc.repair(d, q)
             torch.cuda.synchronize()
             assert torch.equal(d, data) and torch.equal(q, parity), (k, m, S, count, split)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_p61_split_decoder_configuration(torch_cuda, fe, seed):
+    """The 64-bit field's even / odd split of the (2k,k) decoder (k from 2^11 up): random k, ragged element counts, random patterns from a handful
+    of lost data blocks to as many as a split form admits plus random parity losses — decode and repair against the original stripes with the
+    split on and off (the encoder is pinned to the oracle elsewhere; at these sizes the two decoders check each other)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(61700 + seed)
+    k = 1 << int(rng.integers(11, 14))
+    E = int(rng.choice([1, 2, 3, 5, 8]))  # 16-byte elements per block
+    g = torch.Generator(device="cuda:0").manual_seed(100 + seed)
+    data = torch.randint(0, P61, (k * 2 * E,), dtype=torch.int64, device="cuda:0", generator=g)
+    parity = torch.empty_like(data)
+    nd = int(rng.choice([1, 5, k // 64, k // 40, k // 20, k // 8]))
+    npar = int(rng.choice([0, 1, 7, k // 16, k // 2, k - nd]))
+    npar = min(npar, k - nd)
+    dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
+    dp[rng.permutation(k)[:nd]] = 0
+    pp[rng.permutation(k)[:npar]] = 0
+    dmask, pmask = torch.from_numpy(dp == 0).to("cuda:0"), torch.from_numpy(pp == 0).to("cuda:0")
+    with fe.Encoder(2 * k, k, 16 * E, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        enc.encode(data, parity)
+        for split in (1, 0):
+            enc.set_option("decode_split", split)
+            enc.decode_prepare(dp, pp)
+            d, q = data.clone(), parity.clone()
+            d.view(k, 2 * E)[dmask] = -1
+            q.view(k, 2 * E)[pmask] = -2
+            damaged_q = q.clone()
+            enc.decode(d, q)
+            torch.cuda.synchronize()
+            assert torch.equal(d, data) and torch.equal(q, damaged_q), (k, E, nd, npar, split)
+            d.view(k, 2 * E)[dmask] = -5
+            enc.repair(d, q)
+            torch.cuda.synchronize()
+            assert torch.equal(d, data) and torch.equal(q, parity), (k, E, nd, npar, split)
+            enc.repair(d, q)  # a second call on the same tables (the kept half-transform is rewritten)
+            torch.cuda.synchronize()
+            assert torch.equal(d, data) and torch.equal(q, parity), (k, E, nd, npar, split)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_p61_coset_configuration(torch_cuda, fe, seed):
+    """n = 4k / 8k over the 64-bit field: random k, element counts and plans; the codes nest (the first k parity blocks are the (2k,k) code's, pinned to
+    the oracle), any n - k blocks may go."""
+    from oracle import OracleP61
+    orc = OracleP61()
+    torch = torch_cuda
+    rng = np.random.default_rng(61900 + seed)
+    k = 1 << int(rng.integers(1, 12))
+    e = int(rng.choice([2, 3]))
+    E = int(rng.choice([1, 2, 3, 7, 16, 33]))
+    if k * E > 30000:
+        E = max(1, 30000 // k)
+    rows = ((1 << e) - 1) * k
+    x = rng.integers(0, P61, size=(k, 2 * E), dtype=np.uint64)
+    x.reshape(-1)[:2] = [P61 - 1, 0]
+    with fe.Encoder(k << e, k, 16 * E, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        plan = int(rng.choice([0, 0, 1, 2, 3, 4, 12, 13, 14, 23, 24]))
+        try:
+            enc.set_plan(plan)
+        except fe.FastEccError:
+            plan = 0
+        what = (k, e, E, plan, enc.plan())
+        d = torch.from_numpy(x.view(np.int64).reshape(-1).copy()).to("cuda:0")
+        out = torch.empty(rows * 2 * E, dtype=torch.int64, device="cuda:0")
+        enc.encode(d, out)
+        torch.cuda.synchronize()
+        par = out.cpu().numpy().view(np.uint64).reshape(rows, 2 * E)
+        assert (par < P61).all(), what
+        assert np.array_equal(par[:k], orc.encode(x)), what
+        nlost = int(rng.choice([1, 2, (rows + 1) // 2, rows]))
+        lost = rng.permutation(k + rows)[:nlost]
+        dp, pp = np.ones(k, np.uint8), np.ones(rows, np.uint8)
+        dp[lost[lost < k]] = 0
+        pp[lost[lost >= k] - k] = 0
+        bx, bp = x.copy(), par.copy()
+        bx[dp == 0] = 3
+        bp[pp == 0] = 4
+        enc.decode_prepare(dp, pp)
+        if seed % 3 == 0:
+            enc.repair(bx, bp, mem=fe.MEM_HOST)
+            assert np.array_equal(bx, x) and np.array_equal(bp, par), what
+            return
+        dd = torch.from_numpy(bx.view(np.int64).reshape(-1)).to("cuda:0")
+        dq = torch.from_numpy(bp.view(np.int64).reshape(-1)).to("cuda:0")
+        enc.decode(dd, dq)
+        torch.cuda.synchronize()
+        assert np.array_equal(dd.cpu().numpy().view(np.uint64).reshape(k, 2 * E), x), what
+        assert np.array_equal(dq.cpu().numpy().view(np.uint64).reshape(rows, 2 * E), bp), what
+        enc.repair(dd, dq)
+        torch.cuda.synchronize()
+        assert np.array_equal(dd.cpu().numpy().view(np.uint64).reshape(k, 2 * E), x), what
+        assert np.array_equal(dq.cpu().numpy().view(np.uint64).reshape(rows, 2 * E), par), what
