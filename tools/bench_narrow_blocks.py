@@ -26,8 +26,11 @@ def ev(fn, reps=20):
     return a.elapsed_time(b) / reps
 
 
-PLANS = (0, 3100, 3090, 4090, 4100)
-for bb in (128, 256, 512, 1024, 2048, 4096):
+# optional arguments: block sizes and plan ids, comma separated (3100 is always measured: the others' results are compared with its parity)
+SIZES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (128, 256, 512, 1024, 2048, 4096)
+PLANS = tuple(dict.fromkeys([int(v) for v in sys.argv[2].split(",")] + [3100])) if len(sys.argv) > 2 else (0, 3100, 3090, 4090, 4100)
+PROFILE = len(sys.argv) > 3  # any third argument: per-kernel averages (HIP events around every launch) of 10 more encodes per plan
+for bb in SIZES:
     S = bb // 4
     d = torch.randint(0, 0xFFF00001, (k * S,), dtype=torch.int64, device="cuda:0").to(torch.int32)
     ref, p = torch.empty_like(d), torch.empty_like(d)
@@ -50,5 +53,12 @@ for bb in (128, 256, 512, 1024, 2048, 4096):
             best[plan] = min(best[plan], ev(lambda: encs[plan].encode(d, p, stream=st), 30))
     for plan in PLANS:
         row["plan %d" % plan] = {"ms": round(best[plan], 4), "ms_per_2GiB_equivalent": round(best[plan] * 4096 / bb, 3), "plan": encs[plan].plan(), "same_parity": same[plan]}
+        if PROFILE:
+            encs[plan].profile(True)
+            encs[plan].profile_reset()
+            for _ in range(10):
+                encs[plan].encode(d, p, stream=st)
+            row["plan %d" % plan]["kernels_avg_ms"] = {kn: round(v[0] / v[1], 4) for kn, v in encs[plan].profile_read().items()}
+            encs[plan].profile(False)
         encs[plan].close()
     print(json.dumps(row), flush=True)
