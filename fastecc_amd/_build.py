@@ -85,16 +85,20 @@ def build_host(force=False, verbose=False):
     return RS_PATH
 
 
+# the matrix-core prototypes keep their accumulators in VGPRs (the VALU reads them; the AGPR form costs a v_accvgpr_read per word)
+MICROBENCH_FLAGS = {"microbench_mfma_dft": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "proto_mid_mfma": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def build_microbench(force=False, verbose=False):
     """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
-    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma", "microbench_f64", "proto_mid_f64"):
+    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma", "microbench_f64", "proto_mid_f64", "microbench_mfma_dft", "proto_mid_mfma"):
         src = os.path.join(ROOT, "tools", name + ".hip")
         out = os.path.join(LIB_DIR, name)
         if not os.path.exists(src):
             continue
         if not (force or _newer(out, [src, os.path.join(CSRC, "gf.hpp"), os.path.join(CSRC, "gf61.hpp")])):
             continue
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", out]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, src, "-o", out] + MICROBENCH_FLAGS.get(name, [])
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
