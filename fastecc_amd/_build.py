@@ -91,7 +91,7 @@ MICROBENCH_FLAGS = {"microbench_mfma_dft": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 
 def build_microbench(force=False, verbose=False):
     """tools/microbench*.hip -> fastecc_amd/lib/microbench* (design probes, not part of the library)."""
-    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma", "microbench_f64", "proto_mid_f64", "microbench_mfma_dft", "proto_mid_mfma"):
+    for name in ("microbench", "microbench_valu2", "microbench_p61", "microbench_mfma", "microbench_f64", "proto_mid_f64", "microbench_mfma_dft", "proto_mid_mfma", "microbench_mfma_valu_overlap"):
         src = os.path.join(ROOT, "tools", name + ".hip")
         out = os.path.join(LIB_DIR, name)
         if not os.path.exists(src):

@@ -156,6 +156,98 @@ __global__ __launch_bounds__(256) void mfma_stage_kernel(StageArgs g)
     }
 }
 
+// The same stage as a two-stream pipeline inside ONE wave: the 16 MFMAs of wave-tile B are issued right after wave-tile A's four plane sums have
+// been folded into L and H (32 VALU), so they run on the matrix pipe while the VALU does A's Montgomery sums (7 per word) — and the other way round.
+// Twiddles: per-lane global loads, two words per value.  A source as above.
+__device__ __forceinline__ void issue_mfmas(v16i (&acc)[4], const uint32_t (&x)[16], const v4i* a_reg, const v4i* a_lds, int lane, bool alds,
+                                            const v16i& initL, const v16i& initH)
+{
+    v4i b[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[m][e] = (int)(x[4 * m + e] ^ 0x80808080u);
+    acc[0] = initL;
+    acc[2] = initH;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[1][e] = 0, acc[3][e] = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const v4i af = alds ? a_lds[(d * 4 + m) * 64 + lane] : a_reg[d * 4 + m];
+            acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, b[m], acc[d], 0, 0, 0);
+        }
+}
+
+template <int ALDS>
+__global__ __launch_bounds__(256) void mfma_pipe_kernel(StageArgs g)
+{
+    __shared__ v4i s_a[ALDS ? 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int half = lane >> 5;
+    if (ALDS)
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) s_a[i] = g.a_frag[i];
+    __syncthreads();
+    v4i a[ALDS ? 1 : 16];
+    if (!ALDS)
+#pragma unroll
+        for (int f = 0; f < 16; ++f) a[f] = g.a_frag[f * 64 + lane];
+    v16i initL, initH;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const v4i l4 = g.init[q * 64 + lane], h4 = g.init[(4 + q) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            initL[4 * q + e] = l4[e];
+            initH[4 * q + e] = h4[e];
+        }
+    }
+    uint32_t xa[16], xb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xa[r] = g.verify ? g.io[((size_t)wave * 16 + r) * 64 + lane] : (uint32_t)((lane * 2654435761u + r * 40503u + wave) % gf::P);
+        xb[r] = (uint32_t)((lane * 40503u + r * 2654435761u + wave + 7u) % gf::P);
+    }
+    v16i acc[4];
+    uint32_t L[16], H[16];
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            L[r] = (uint32_t)acc[0][r] + ((uint32_t)acc[1][r] << 8);
+            H[r] = (uint32_t)acc[2][r] + ((uint32_t)acc[3][r] << 8);
+        }
+    };
+    auto finish = [&](uint32_t (&x)[16], int set) {
+        const v4u* t4 = (const v4u*)(g.tw + set * 64 + half * 32);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const v4u q = t4[r >> 1];
+            x[r] = mont_sum2(L[r], q[0], H[r], q[1]);
+            x[r + 1] = mont_sum2(L[r + 1], q[2], H[r + 1], q[3]);
+        }
+    };
+    issue_mfmas(acc, xa, a, s_a, lane, ALDS, initL, initH);
+    for (int it = 0; it < g.iters; ++it) {
+        if (ALDS) asm volatile("" ::: "memory");
+        fold();                                                   // A's plane sums -> L, H: the accumulators are free again
+        issue_mfmas(acc, xb, a, s_a, lane, ALDS, initL, initH);   // B on the matrix pipe ...
+        finish(xa, it & 7);                                       // ... while the VALU finishes A
+        fold();
+        if (it + 1 < g.iters || !g.verify) issue_mfmas(acc, xa, a, s_a, lane, ALDS, initL, initH);
+        finish(xb, (it + 3) & 7);
+    }
+    if (g.verify) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g.io[((size_t)wave * 16 + r) * 64 + lane] = xa[r];
+    } else {
+        uint32_t s = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s ^= xa[r] ^ xb[r];
+        if (s == 0x12345679u) g.io[lane] = s;
+    }
+}
+
 // Baseline: five radix-2 DIF levels on the 16 registers of a lane (the fifth level pairs registers again instead of half-waves: the
 // arithmetic is the same, the v_permlane32_swap of the real tile is left out — in favour of the baseline).
 __global__ __launch_bounds__(256) void valu5_kernel(uint32_t* out, const uint32_t* __restrict__ tw, int iters)
@@ -330,6 +422,58 @@ static void run_mfma(const Tables& T, StageArgs g, uint32_t* d_io, int cus, int 
     fflush(stdout);
 }
 
+template <int ALDS>
+static void run_pipe(const Tables& T, StageArgs g, uint32_t* d_io, int cus, int wps, double valu5_ns)
+{
+    // verification: one iteration = one stage on stream A (set 0), as in verify<2, ALDS>
+    const int waves = 8;
+    std::vector<uint32_t> in((size_t)waves * 16 * 64), out(in.size());
+    for (size_t i = 0; i < in.size(); ++i) in[i] = (uint32_t)(splitmix() % gf::P);
+    CK(hipMemcpy(d_io, in.data(), in.size() * 4, hipMemcpyHostToDevice));
+    g.io = d_io;
+    g.iters = 1;
+    g.verify = 1;
+    hipLaunchKernelGGL((mfma_pipe_kernel<ALDS>), dim3(waves / 4), dim3(256), 0, nullptr, g);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out.data(), d_io, out.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (int w = 0; w < waves; ++w)
+        for (int c = 0; c < 32; ++c) {
+            uint32_t xin[32];
+            for (int hb = 0; hb < 2; ++hb)
+                for (int r = 0; r < 16; ++r) xin[16 * hb + r] = in[((size_t)w * 16 + r) * 64 + hb * 32 + c];
+            for (int hb = 0; hb < 2; ++hb)
+                for (int r = 0; r < 16; ++r) {
+                    const int o = row_of(hb, r);
+                    uint64_t sm = 0;
+                    for (int i = 0; i < 32; ++i) sm = (sm + (uint64_t)gf::h_mul(T.W[o][i], xin[i])) % gf::P;
+                    const uint32_t want = gf::h_mul((uint32_t)sm, T.twraw[hb * 16 + r]);
+                    if (out[((size_t)w * 16 + r) * 64 + hb * 32 + c] != want) ++bad;
+                }
+        }
+    const int iters = 1024, blocks = cus * wps;  // an iteration is TWO wave-stages
+    g.verify = 0;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    g.iters = 64;
+    hipLaunchKernelGGL((mfma_pipe_kernel<ALDS>), dim3(blocks), dim3(256), 0, nullptr, g);
+    CK(hipDeviceSynchronize());
+    g.iters = iters;
+    CK(hipEventRecord(e0));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((mfma_pipe_kernel<ALDS>), dim3(blocks), dim3(256), 0, nullptr, g);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 3;
+    const double ns = ms * 1e6 / ((double)iters * 2 * wps);
+    printf("{\"probe\":\"mfma_stage_two_streams_in_one_wave\",\"twiddle_source\":2,\"a_from_lds\":%d,\"waves_per_simd\":%d,\"bit_exact\":%s,\"ms\":%.4f,"
+           "\"ns_per_wave_stage_per_simd\":%.1f,\"speedup_vs_valu5\":%.3f}\n",
+           ALDS, wps, bad == 0 ? "true" : "false", ms, ns, valu5_ns / ns);
+    fflush(stdout);
+}
+
 static double run_valu5(uint32_t* d_io, const uint32_t* d_tw, int cus, int wps)
 {
     const int iters = 2048, blocks = cus * wps;
@@ -385,6 +529,8 @@ int main(int argc, char** argv)
         run_mfma<3, 0>(T, g, d_io, cus, wps, ref);
         run_mfma<2, 1>(T, g, d_io, cus, wps, ref);
         run_mfma<3, 1>(T, g, d_io, cus, wps, ref);
+        run_pipe<0>(T, g, d_io, cus, wps, ref);
+        run_pipe<1>(T, g, d_io, cus, wps, ref);
     }
     return 0;
 }

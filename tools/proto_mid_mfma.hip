@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "gf.hpp"
@@ -39,13 +40,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t CSHIFT = 1u << 30;  // both accumulator pairs start from this: L' = S_L + 2^30, H' = S_H + 2^30 in (0, 2^31)
+// Both accumulator pairs start from 2^30: L' = S_L + 2^30 and H' = S_H + 2^30 are in (0, 2^31).  The xor's share 128 sum(a) is left out where it is
+// 0 (mod p) in the combination L + 2^16 H — every row of F but the constant ones (sums over all 32nd / 16th roots of unity vanish) — and put into
+// the initial values of rows 0 and 16 exactly (T + 2^30 is in [0, 2^31) for the true sums T as well).
+constexpr uint32_t CSHIFT = 1u << 30;
 
 struct MidArgs {
     const uint32_t* in;
     uint32_t* out;
     const v4i* frag[4];   // per stage: [4 planes][4 chunks][64 lanes]
-    const v4u* fac[4];    // per stage: {f 2^32, f 2^48, K, 0} per element in the order the lanes consume them: [tile & mask][wave-tile][half][16]
+    const v4u* fac[4];    // per stage: {f 2^32, f 2^48} per element, two elements per v4u, in the order the lanes consume them: [tile & mask][wave-tile][half][16]
+    uint32_t init[4][4];  // per stage: initial values of rows 0 and 16 (registers 0 and 8 of the low half-wave): L0, H0, L16, H16
+    uint32_t kappa;       // 2^30 (1 + 2^16) mod p
     uint32_t fac_mask[4]; // tile-independent tables: 0
     uint32_t S, ld;
     uint32_t col_chunks, tiles;
@@ -53,104 +59,180 @@ struct MidArgs {
 
 __device__ __forceinline__ int row_of(int half, int r) { return 8 * (r >> 2) + 4 * half + (r & 3); }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_desc(const uint32_t* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0xFFFFFFFFu, 0x00020000);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One stage on one wave-tile: x (16 registers, canonical or any uint32) -> y (canonical), in the D layout.
-__device__ __forceinline__ void mfma_stage(uint32_t (&x)[16], const v4i (&a)[16], const v4u* __restrict__ fac, const v16i& cinit)
+// One stage on one wave-tile: x (16 registers, canonical) -> y (canonical), in the D layout.
+// `a` points at the stage's fragments in LDS for this lane, [plane][chunk] 64 v4i apart.  The two accumulator pairs are run one after the other
+// (planes 0, 1 -> L, then planes 2, 3 -> H) so that only 32 accumulator registers are live; the fragments are read four MFMAs ahead.
+// Both pairs start from 2^30 (`init`; rows 0 and 16 — registers 0 and 8 of the low half-wave — also carry the xor's share, `patch`), and what the two
+// shifts add to every result, kappa = 2^30 (1 + 2^16), has been taken off the run's first block beforehand (column 0 of F is all ones).
+struct StagePatch {
+    uint32_t l0, l8, h0, h8;  // per lane: the xor's share of rows 0 and 16 (registers 0 and 8 of the low half-wave; 0 elsewhere) in the two phases
+};
+__device__ __forceinline__ void mfma_stage(uint32_t (&x)[16], const v4i* a, const v4u* __restrict__ fac, const StagePatch& patch)
 {
     v4i b[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) b[m][e] = (int)(x[4 * m + e] ^ 0x80808080u);
-    v16i acc[4];
-    acc[0] = cinit;
-    acc[2] = cinit;
+    uint32_t L[16];
+    v4i ring[4];
+    // order of use: (0,0) (1,0) (0,1) (1,1) ... (0,3) (1,3), then the same with planes 2, 3
+    auto frag_at = [&](int i) { const int pair = i >> 3, m = (i >> 1) & 3, d = 2 * pair + (i & 1); return a[(d * 4 + m) * 64]; };
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[1][e] = 0, acc[3][e] = 0;
+    for (int i = 0; i < 4; ++i) ring[i] = frag_at(i);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int pair = 0; pair < 2; ++pair) {
+        v16i acc0, acc1;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d * 4 + m], b[m], acc[d], 0, 0, 0);
+        for (int e = 0; e < 16; ++e) acc0[e] = (int)CSHIFT, acc1[e] = 0;  // 0x40000000 is the inline constant 2.0: no registers hold it
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const v4u q = fac[r];
-        const uint32_t L = (uint32_t)acc[0][r] + ((uint32_t)acc[1][r] << 8);
-        const uint32_t H = (uint32_t)acc[2][r] + ((uint32_t)acc[3][r] << 8);
-        uint64_t t = (((uint64_t)q[3]) << 32) | q[2];
-        t += (uint64_t)L * q[0];
-        t += (uint64_t)H * q[1];
-        const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-        const uint32_t mq = lo + (lo << 20);
-        const uint32_t qq = __umulhi(mq, gf::P);
-        uint32_t res;
-        const bool borrow = __builtin_usub_overflow(hi, qq, &res);
-        x[r] = borrow ? res + gf::P : res;
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int i = pair * 8 + m * 2 + d;
+                const v4i af = ring[i & 3];
+                if (i + 4 < 16) ring[i & 3] = frag_at(i + 4);
+                if (d == 0) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, b[m], acc0, 0, 0, 0);
+                else        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, b[m], acc1, 0, 0, 0);
+            }
+        if (pair == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) L[r] = (uint32_t)acc0[r] + ((uint32_t)acc1[r] << 8);
+            L[0] += patch.l0;
+            L[8] += patch.l8;
+        } else {
+            v4u fq[2][2];
+            fq[0][0] = fac[0], fq[0][1] = fac[1];
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 4) {
+                const int cur = (r0 >> 2) & 1;
+                if (r0 + 4 < 16) fq[cur ^ 1][0] = fac[(r0 >> 1) + 2], fq[cur ^ 1][1] = fac[(r0 >> 1) + 3];
+#pragma unroll
+                for (int r = r0; r < r0 + 4; ++r) {
+                    const v4u q4 = fq[cur][(r >> 1) & 1];
+                    const uint32_t q[2] = {q4[2 * (r & 1)], q4[2 * (r & 1) + 1]};
+                    uint32_t H = (uint32_t)acc0[r] + ((uint32_t)acc1[r] << 8);
+                    if (r == 0) H += patch.h0;
+                    if (r == 8) H += patch.h8;
+                    uint64_t t = (uint64_t)L[r] * q[0];
+                    t += (uint64_t)H * q[1];
+                    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+                    const uint32_t mq = lo + (lo << 20);
+                    const uint32_t qq = __umulhi(mq, gf::P);
+                    uint32_t res;
+                    const bool borrow = __builtin_usub_overflow(hi, qq, &res);
+                    x[r] = borrow ? res + gf::P : res;
+                }
+            }
+        }
     }
 }
 
-constexpr int LDS_WORDS = 512 * 32 + 16 * 64 * 4;
+constexpr int TILE_WORDS = 512 * 32, FRAG_WORDS = 16 * 64 * 4;
+constexpr int LDS_WORDS = TILE_WORDS + 4 * FRAG_WORDS;  // 64 KiB tile + the four stages' fragments (16 KiB each): 128 KiB, one workgroup per CU
 
-__global__ __launch_bounds__(256) void mid9_mfma_kernel(const MidArgs g)
+// Persistent workgroup of 16 / WT waves: wave w takes wave-tiles w * WT .. w * WT + WT - 1 of every stage (WT = 1: 4 waves per SIMD, <= 128 VGPRs).
+template <int WT>
+__global__ __launch_bounds__(1024 / WT) void mid9_mfma_kernel(const MidArgs g)
 {
+    constexpr int THREADS = 1024 / WT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* tile = lds;
-    v4i* stage_a = reinterpret_cast<v4i*>(lds + 512 * 32);
+    const v4i* stage_a = reinterpret_cast<const v4i*>(lds + TILE_WORDS);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 31u, half = lane >> 5;
-    const uint32_t t = blockIdx.x;
-    const uint32_t cc = t % g.col_chunks, grp = t / g.col_chunks;
-    const size_t origin = (size_t)grp * 512 * g.ld + cc * 32 + c;
-    v16i cinit;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cinit[e] = (int)CSHIFT;
-    v4i a[16];
+    for (int i = threadIdx.x; i < 4096; i += THREADS) reinterpret_cast<v4i*>(lds + TILE_WORDS)[i] = g.frag[i >> 10][i & 1023];
     uint32_t x[16];
 
-    auto load_matrix = [&](int st, bool first) {
-        if (!first) lds_barrier();  // every wave has finished the previous stage: its tile writes are in LDS and its fragments are in registers
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage_a[threadIdx.x + 256 * i] = g.frag[st][threadIdx.x + 256 * i];
-        __syncthreads();
-#pragma unroll
-        for (int f = 0; f < 16; ++f) a[f] = stage_a[f * 64 + lane];
+    auto origin_of = [&](uint32_t t, uint32_t& grp) {
+        t = __builtin_amdgcn_readfirstlane(t);
+        uint32_t cc = t % g.col_chunks;
+        grp = t / g.col_chunks;
+        if ((g.col_chunks & 7u) == 0) cc = (cc & 7u) * (g.col_chunks >> 3) + (cc >> 3);  // workgroup b runs on XCD b % 8: contiguous column chunks per XCD
+        return (size_t)grp * 512 * g.ld + cc * 32;
     };
-    auto fac_of = [&](int st, uint32_t wt) { return g.fac[st] + ((((size_t)(grp & g.fac_mask[st]) * 16 + wt) * 2 + half) * 16); };
+    const uint32_t row_bytes = g.ld * 4u;
+    const uint32_t voff_in = (256u * half * g.ld + c) * 4u;   // S1 reads block wt + 16 (16 half + r)
+    const uint32_t voff_out = (64u * half * g.ld + c) * 4u;   // S4 writes block wt + 16 (8 (r / 4) + 4 half + r % 4)
+    auto patch_of = [&](int st) {
+        StagePatch p;
+        p.l0 = half ? 0u : g.init[st][0];
+        p.h0 = half ? 0u : g.init[st][1];
+        p.l8 = half ? 0u : g.init[st][2];
+        p.h8 = half ? 0u : g.init[st][3];
+        return p;
+    };
+    auto fac_of = [&](int st, uint32_t grp, uint32_t wt) { return g.fac[st] + ((((size_t)(grp & g.fac_mask[st]) * 16 + wt) * 2 + half) * 8); };
+    const uint32_t kappa = g.kappa;
+    const uint32_t kappa_lo = half ? 0u : kappa;  // runs of 32: only block 0 of the run (low half-wave, register 0) is in column 0 of F
 
-    // S1: blocks q = wt + 16 i, i = 16 half + r, from HBM
-    load_matrix(0, true);
+    uint32_t t = blockIdx.x;
+    if (t >= g.tiles) return;
+    __syncthreads();  // the fragments are in LDS
+    // S1: blocks q = wave + 16 i, i = 16 half + r, from HBM into the LDS rows q = wave + 16 rho — the rows this wave alone reads in S4, so S1 of the
+    // next tile follows S4 of the current one without a barrier
+    auto stage1 = [&](size_t origin, uint32_t grp) {
+      const __amdgpu_buffer_rsrc_t d = make_desc(g.in + origin);
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t wt = wave * 4 + j;
+      for (uint32_t wt = wave * WT; wt < wave * WT + WT; ++wt) {
+        uint32_t soff = wt * row_bytes;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = g.in[origin + (size_t)(wt + 16 * (16 * half + r)) * g.ld];
-        mfma_stage(x, a, fac_of(0, wt), cinit);
+        for (int r = 0; r < 16; ++r) {
+            x[r] = __builtin_amdgcn_raw_buffer_load_b32(d, voff_in, soff, 2);
+            soff += 16u * row_bytes;
+            asm volatile("" : "+s"(soff));
+        }
+        x[0] = gf::sub(x[0], kappa_lo);
+        mfma_stage(x, stage_a + lane, fac_of(0, grp, wt), patch_of(0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile[(wt + 16 * row_of(half, r)) * 32 + c] = x[r];
-    }
-    // S2, S3: blocks q = 32 u + i, in place
-    for (int st = 1; st <= 2; ++st) {
-        load_matrix(st, false);
+      }
+    };
+    uint32_t grp;
+    size_t origin = origin_of(t, grp);
+    stage1(origin, grp);
+    for (;;) {
+        lds_barrier();
+        // S2, S3: blocks q = 32 wave + i, in place; a wave reads back only what it wrote itself.  Two runs of 16: blocks 0 and 16 are column 0 of their group.
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t u = wave * 4 + j;
+        for (int st = 1; st <= 2; ++st) {
+#pragma unroll 1
+          for (uint32_t wt = wave * WT; wt < wave * WT + WT; ++wt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = tile[(32 * u + 16 * half + r) * 32 + c];
-            mfma_stage(x, a, fac_of(st, u), cinit);
+            for (int r = 0; r < 16; ++r) x[r] = tile[(32 * wt + 16 * half + r) * 32 + c];
+            x[0] = gf::sub(x[0], kappa);
+            mfma_stage(x, stage_a + st * 1024 + lane, fac_of(st, grp, wt), patch_of(st));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tile[(32 * u + row_of(half, r)) * 32 + c] = x[r];
+            for (int r = 0; r < 16; ++r) tile[(32 * wt + row_of(half, r)) * 32 + c] = x[r];
+          }
         }
-    }
-    // S4: blocks q = wt + 16 i, to HBM
-    load_matrix(3, false);
+        lds_barrier();
+        // S4: blocks q = wave + 16 i, to HBM
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t wt = wave * 4 + j;
+        for (uint32_t wt = wave * WT; wt < wave * WT + WT; ++wt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = tile[(wt + 16 * (16 * half + r)) * 32 + c];
-        mfma_stage(x, a, fac_of(3, wt), cinit);
+            for (int r = 0; r < 16; ++r) x[r] = tile[(wt + 16 * (16 * half + r)) * 32 + c];
+            x[0] = gf::sub(x[0], kappa_lo);
+            mfma_stage(x, stage_a + 3 * 1024 + lane, fac_of(3, grp, wt), patch_of(3));
+            const __amdgpu_buffer_rsrc_t d = make_desc(g.out + origin);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g.out[origin + (size_t)(wt + 16 * row_of(half, r)) * g.ld] = x[r];
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(x[r], d, voff_out, (wt + 16u * (8u * (r >> 2) + (r & 3))) * row_bytes, 2);
+        }
+        t += gridDim.x;
+        if (t >= g.tiles) break;
+        origin = origin_of(t, grp);
+        stage1(origin, grp);
     }
 }
 
@@ -191,14 +273,15 @@ static void dit_level(std::vector<uint32_t>& v, int h, uint32_t root_2h)
 struct HostStage {
     uint32_t F[32][32];           // F[rho][i]
     std::vector<int8_t> frag;     // [4][4][64][16]
-    uint32_t abar[32];            // sum over the K-slots of the balanced representatives (mod p) x 128: the xor's share per output row
+    uint32_t abar[32];            // sum over the K-slots of the balanced representatives (mod p): the xor's share per output row is 128 x this
+    int64_t sumL[32], sumH[32];   // the same sums as integers, split into the two accumulator pairs (digit planes 0, 1 / 2, 3)
 };
 
 // digit planes of F for the B layout "lane (half, c), register r = input i = 16 half + r", output row rho in the D layout
 static void make_fragments(HostStage& st)
 {
     st.frag.assign(4 * 4 * 64 * 16, 0);
-    for (int rho = 0; rho < 32; ++rho) st.abar[rho] = 0;
+    for (int rho = 0; rho < 32; ++rho) st.abar[rho] = 0, st.sumL[rho] = 0, st.sumH[rho] = 0;
     for (int m = 0; m < 4; ++m)
         for (int lane = 0; lane < 64; ++lane)
             for (int t = 0; t < 16; ++t) {
@@ -212,6 +295,7 @@ static void make_fragments(HostStage& st)
                     if (dig >= 128) dig -= 256;
                     bal = (bal - dig) / 256;
                     st.frag[(((size_t)d * 4 + m) * 64 + lane) * 16 + t] = (int8_t)dig;
+                    (d < 2 ? st.sumL[rho] : st.sumH[rho]) += dig * ((d & 1) ? 256 : 1);
                 }
                 if (bal != 0) {
                     fprintf(stderr, "balanced digits do not close\n");
@@ -220,16 +304,10 @@ static void make_fragments(HostStage& st)
             }
 }
 
-// {f 2^32, f 2^48, K, 0}: y = (L' f~1 + H' f~2 + K) / 2^32 with L' = S_L + 2^30, H' = S_H + 2^30 and the xor's share 128 abar[rho]:
-//   K = f~1 (128 abar[rho] - 2^30 (1 + 2^16))  (mod p)
-static void make_factor(uint32_t f, uint32_t abar_rho, uint32_t (&q)[4])
+static void make_factor(uint32_t f, uint32_t (&q)[2])
 {
-    const uint32_t f1 = gf::h_to_mont(f);
-    q[0] = f1;
+    q[0] = gf::h_to_mont(f);
     q[1] = gf::h_to_mont(gf::h_mul(f, 65536));
-    const uint32_t shift = gf::h_mul(CSHIFT % gf::P, 65537);
-    q[2] = gf::h_mul(f1, h_sub(gf::h_mul(128, abar_rho), shift));
-    q[3] = 0;
 }
 
 int main(int argc, char** argv)
@@ -285,7 +363,14 @@ int main(int argc, char** argv)
             for (int h = 16; h <= 256; h <<= 1) dit_level(v, h, root(w_dit, 2 * h));
             f3tab[q] = v[q & 15];  // row rho = 0 of F is all ones
         }
-        for (int s = 0; s < 4; ++s) make_fragments(st[s]);
+        for (int s = 0; s < 4; ++s) {
+            make_fragments(st[s]);
+            for (int rho = 0; rho < 32; ++rho)
+                if (rho != 0 && rho != 16 && st[s].abar[rho] != 0) {
+                    fprintf(stderr, "stage %d row %d: the xor's share does not vanish\n", s, rho);
+                    return 1;
+                }
+        }
     }
     // per-block factor D by position (random: the pass must work for any table)
     std::vector<uint32_t> dplain(N);
@@ -300,7 +385,7 @@ int main(int argc, char** argv)
     const uint32_t mask[4] = {0u, (uint32_t)(ntiles - 1), 0u, 0u};
     for (int stg = 0; stg < 4; ++stg) {
         const size_t tl = (size_t)mask[stg] + 1;
-        fac[stg].resize(tl * 16 * 2 * 16 * 4);
+        fac[stg].resize(tl * 16 * 2 * 16 * 2);
         for (size_t t = 0; t < tl; ++t)
             for (int wt = 0; wt < 16; ++wt)
                 for (int hb = 0; hb < 2; ++hb)
@@ -311,9 +396,9 @@ int main(int argc, char** argv)
                         if (stg == 0) f = f1tab[q];
                         if (stg == 1) f = dplain[t * 512 + q];
                         if (stg == 2) f = f3tab[q];
-                        uint32_t qd[4];
-                        make_factor(f, st[stg].abar[rho], qd);
-                        memcpy(&fac[stg][((((t * 16 + wt) * 2 + hb) * 16) + r) * 4], qd, 16);
+                        uint32_t qd[2];
+                        make_factor(f, qd);
+                        memcpy(&fac[stg][((((t * 16 + wt) * 2 + hb) * 16) + r) * 2], qd, 8);
                     }
     }
 
@@ -346,14 +431,39 @@ int main(int argc, char** argv)
         a.frag[stg] = (const v4i*)df;
         a.fac[stg] = (const v4u*)dq;
         a.fac_mask[stg] = mask[stg];
+        a.init[stg][0] = (uint32_t)(128 * st[stg].sumL[0]);
+        a.init[stg][1] = (uint32_t)(128 * st[stg].sumH[0]);
+        a.init[stg][2] = (uint32_t)(128 * st[stg].sumL[16]);
+        a.init[stg][3] = (uint32_t)(128 * st[stg].sumH[16]);
     }
+    a.kappa = gf::h_mul(CSHIFT, 65537);
+    // column 0 of F (and column 16 of the two-group stages) must be all ones over the rows it feeds: that is where kappa is taken off
+    for (int stg = 0; stg < 4; ++stg)
+        for (int rho = 0; rho < 32; ++rho) {
+            const uint32_t want0 = (stg == 1 || stg == 2) ? (rho < 16 ? 1u : 0u) : 1u, want16 = (stg == 1 || stg == 2) ? (rho < 16 ? 0u : 1u) : st[stg].F[rho][16];
+            if (st[stg].F[rho][0] != want0 || st[stg].F[rho][16] != want16) {
+                fprintf(stderr, "stage %d row %d: column 0 / 16 of F is not what the kappa correction assumes\n", stg, rho);
+                return 1;
+            }
+        }
     a.S = S;
     a.ld = S;
     a.col_chunks = S / 32;
     a.tiles = (uint32_t)(ntiles * a.col_chunks);
     const int lds_bytes = LDS_WORDS * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid9_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL(mid9_mfma_kernel, dim3(a.tiles), dim3(256), lds_bytes, nullptr, a);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid9_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const unsigned grid = std::min<unsigned>(a.tiles, (unsigned)prop.multiProcessorCount);
+    const int wt_per_wave = argc > 4 ? atoi(argv[4]) : 1;
+    auto launch = [&]() {
+        if (wt_per_wave == 1) hipLaunchKernelGGL(mid9_mfma_kernel<1>, dim3(grid), dim3(1024), lds_bytes, nullptr, a);
+        else if (wt_per_wave == 2) hipLaunchKernelGGL(mid9_mfma_kernel<2>, dim3(grid), dim3(512), lds_bytes, nullptr, a);
+        else hipLaunchKernelGGL(mid9_mfma_kernel<4>, dim3(grid), dim3(256), lds_bytes, nullptr, a);
+    };
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid9_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid9_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    launch();
     CK(hipDeviceSynchronize());
 
     std::vector<uint32_t> got(host.size());
@@ -374,9 +484,9 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(mid9_mfma_kernel, dim3(a.tiles), dim3(256), lds_bytes, nullptr, a);
+    for (int i = 0; i < 3; i++) launch();
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(mid9_mfma_kernel, dim3(a.tiles), dim3(256), lds_bytes, nullptr, a);
+    for (int i = 0; i < reps; i++) launch();
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
@@ -384,7 +494,7 @@ int main(int argc, char** argv)
     ms /= reps;
     const double bytes = 2.0 * N * S * 4;
     printf("{\"probe\":\"proto_mid9_mfma\",\"log2_blocks\":%d,\"words_per_block\":%u,\"bit_exact\":%s,\"words_checked\":%zu,\"words_wrong\":%zu,"
-           "\"ms\":%.4f,\"algorithmic_TBps\":%.3f,\"workgroup\":\"4 waves, 80 KiB LDS\",\"stages\":4}\n",
-           n, S, bad == 0 ? "true" : "false", checked, bad, ms, bytes / ms / 1e9);
+           "\"ms\":%.4f,\"algorithmic_TBps\":%.3f,\"workgroup\":\"persistent, %d waves, 128 KiB LDS\",\"stages\":4}\n",
+           n, S, bad == 0 ? "true" : "false", checked, bad, ms, bytes / ms / 1e9, 16 / wt_per_wave);
     return bad == 0 ? 0 : 1;
 }
