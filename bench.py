@@ -63,7 +63,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # profiles/r03/microbench_radix4_vs_radix2.jsonl).
 VALU_PEAK_GBFLY = 3830.0
 VALU_PEAK_CLOCK_GHZ = 2.39  # the clock that loop sustains (profiles/r02/microbench_bfly_sustained_r02.jsonl: 2393 MHz at 1055 W; profiles/r05: GRBM cycles / duration)
-PMC_VALU = os.path.join("profiles", "r05", "pmc_valu_default_plan.json")
+PROFILE_ROUND = "r06"  # the directory under profiles/ whose counter files this file quotes (regenerated together, see counters_stamp.json)
+PMC_VALU = os.path.join("profiles", PROFILE_ROUND, "pmc_valu_default_plan.json")
+COUNTERS_STAMP = os.path.join("profiles", PROFILE_ROUND, "counters_stamp.json")
 PMC_VALU_P61 = os.path.join("profiles", "r05", "pmc_valu_p61.json")  # the 64-bit field at the configs[4] size (tools/pmc_valu_p61.py)
 
 
@@ -71,10 +73,38 @@ PMC_VALU_P61 = os.path.join("profiles", "r05", "pmc_valu_p61.json")  # the 64-bi
 # the RCCL-specific lines of this file (device-side reductions, communicators per mode, object gathers) run against the real library on a
 # 1-GPU box.  Together with FASTECC_SHARDING_FORCE_COLLECTIVES the one_stripe modes then issue their collectives too.  Never set by the driver.
 ONE_RANK_GROUP = os.environ.get("FASTECC_BENCH_TEST_ONE_RANK_GROUP", "") == "1"
+# Exit codes of an N > 1 run that printed a line but did not finish: the line carries "complete": false, and the launcher sees a failure.
+EXIT_NO_GROUP = 3   # the process group never came up: the line holds rank 0's own one-GPU timing (n_gpus = 1)
+EXIT_WATCHDOG = 4   # a one-stripe mode stalled: its timer printed the line with everything measured so far
 
 
 def dist_on(world):
     return world > 1 or ONE_RANK_GROUP
+
+
+def counters_state(root=ROOT, stamp=COUNTERS_STAMP, loaded_kernels=None, csrc=None):
+    """Do the committed counter files (roofline.bound, .traffic, .frac_rocprof, .valu.issue_floor_frac are quoted from them, not measured in
+    this run) describe the binary that is running?  {"status": "ok" | "STALE" | "unstamped", "why": ...}.
+      * STALE when the sha256 of the headline kernels' sources in the tree differs from the one recorded when the counters were taken
+        (tools/stamp_counters.py), or when a kernel of the loaded library (enc.profile_read() names) is not among the recorded ones;
+      * unstamped when there is no stamp file (counter files of unknown origin are not quoted either)."""
+    try:
+        with open(os.path.join(root, stamp)) as f:
+            rec = json.load(f)
+    except Exception:
+        return {"status": "unstamped", "why": "no %s" % stamp}
+    try:
+        from fastecc_amd import _build
+        now = _build.kernel_sources_sha256(csrc=csrc)
+    except Exception as e:  # noqa: BLE001 — no sources beside the library: cannot vouch for the files
+        return {"status": "STALE", "why": "the kernel sources cannot be hashed here: %r" % e}
+    if now["sha256"] != (rec.get("sources") or {}).get("sha256"):
+        changed = sorted(f for f, h in now["files"].items() if (rec.get("sources") or {}).get("files", {}).get(f) != h)
+        return {"status": "STALE", "why": "sources changed since the counters were taken: %s" % ", ".join(changed), "stamp": stamp}
+    missing = sorted(set(loaded_kernels or ()) - set(rec.get("profile_names") or ()))
+    if missing:
+        return {"status": "STALE", "why": "kernels of the loaded library without counters: %s" % ", ".join(missing), "stamp": stamp}
+    return {"status": "ok", "stamp": stamp, "sources_sha256": now["sha256"], "session": rec.get("session")}
 
 
 def pmc_valu(path=PMC_VALU):
@@ -223,7 +253,7 @@ def cpu_baseline(log2k, block_bytes):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch for `kernel` from a committed rocprofv3 --pmc summary, if there is one."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f).get(kernel)
@@ -231,7 +261,7 @@ def pmc_traffic(kernel):
         return None
 
 
-ROCPROF_STATS = os.path.join("profiles", "r05", "rocprofv3_kernel_stats_bench_default.csv")
+ROCPROF_STATS = os.path.join("profiles", PROFILE_ROUND, "rocprofv3_kernel_stats_bench_default.csv")
 
 
 def rocprof_avg_ms(kernel):
@@ -1152,20 +1182,27 @@ def main():
         local_ms = time_steps(step, args.steps, torch.cuda.synchronize) / args.steps * 1e3
 
         def no_process_group():
+            # Only what was measured: rank 0's own stripe on ONE GPU (no barrier, no max over ranks, the other ranks may never have run).
+            # n_gpus says 1, the N-rank extrapolation sits in a key of its own, `complete` is false and the exit code is EXIT_NO_GROUP,
+            # so that a failed RCCL start cannot be recorded as a measured N-GPU result.
             if rank == 0:
                 bytes_per_encode = float(k + m_blocks) * args.block_bytes * args.batch
+                one_gpu = bytes_per_encode / (local_ms * 1e-3) / 1e9
                 print(json.dumps({
-                    "metric": "encode GB/s (data+parity bytes / s); value = REPLICAS from rank 0's OWN timing x %d ranks: the process group did not come up "
-                              "within %d s, so no barrier, no max over ranks and no one-stripe mode could run" % (world, args.startup_timeout),
-                    "value": round(world * bytes_per_encode / (local_ms * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "metric": "encode GB/s (data+parity bytes / s); value = rank 0's OWN timing of its stripe on ONE GPU: the process group of %d ranks did "
+                              "not come up within %d s, so no barrier, no max over ranks and no one-stripe mode could run" % (world, args.startup_timeout),
+                    "value": round(one_gpu, 2), "value_kind": "rank0_only", "complete": False, "unit": "GB/s", "n_gpus": 1, "requested_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": round(local_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if p61 else "u32",
-                    "data": "synthetic", "config": {"workload": "one stripe per GPU, k=2^%d x %d B blocks" % (args.log2k, args.block_bytes), "plan": enc.plan(),
-                                                    "parallelism": "%d independent stripes, one per GPU, no collective" % world},
+                    "data": "synthetic", "config": {"workload": "one stripe on one GPU, k=2^%d x %d B blocks" % (args.log2k, args.block_bytes), "plan": enc.plan(),
+                                                    "parallelism": "rank 0 alone (of %d requested ranks)" % world},
                     "collectives": "UNAVAILABLE (torch.distributed %s did not initialise or pass its first barrier within %d s)" % (backend, args.startup_timeout),
+                    "replicas_extrapolated_GBps": round(world * one_gpu, 2),
+                    "replicas_extrapolated_note": "rank 0's figure x %d ranks: NOT measured" % world,
                     "rank0_local_ms_per_step": round(local_ms, 4)}), flush=True)
             else:
                 time.sleep(3)
-            os._exit(0)
+            os._exit(EXIT_NO_GROUP)
 
         startup = threading.Timer(args.startup_timeout, no_process_group)
         startup.daemon = True
@@ -1224,33 +1261,38 @@ def main():
             per_block = args.block_bytes // 16 if p61 else S  # field elements per block
             log2m = args.log2k if args.log2m is None or m_blocks > k else args.log2m
             bfly = (args.log2k * (k / 2) + (log2m + 1) * (m_blocks / 2)) * per_block * args.batch / (ms_per_step * 1e-3) / 1e9
-            traffic = pmc_traffic(name)
             headline = args.log2k == 19 and args.block_bytes == 4096 and not p61 and m_blocks == k and args.batch == 1 and not args.plan and not args.option
-            prof_ms = rocprof_avg_ms(name) if headline else None
+            # the committed counter files are quoted only while they describe this binary (tools/stamp_counters.py); otherwise the fields say STALE
+            state = counters_state(loaded_kernels=list(kernels)) if headline else {"status": "not_applicable", "why": "counter files exist for the headline configuration only"}
+            quoted = state["status"] == "ok"
+            stale_note = None if quoted or not headline else "%s: %s" % (state["status"], state.get("why"))
+            traffic = pmc_traffic(name) if quoted or not headline else None
+            prof_ms = rocprof_avg_ms(name) if headline and quoted else None
             # `bound` comes from counters, not from the kernel's name: profiles/r05/pmc_valu_default_plan.json (tools/pmc_valu.py) holds, for the
             # default plan's three kernels at the headline size, VALU instructions issued per SIMD and cycle against the isolated butterfly
             # loop's rate (valu_issue_frac) and the algorithmic HBM rate against what a copy reaches (hbm_frac_achievable); the larger one names
             # the bound.  achieved / peak / frac stay the HBM figures the contract asks for.  Other sizes / plans / fields have no counter file:
             # their `bound` is labelled as assumed.
             cfg5 = p61 and args.log2k == 19 and args.block_bytes == 65536 and m_blocks == k and args.batch == 1 and not args.plan and not args.option
-            pmc_file = PMC_VALU if headline else PMC_VALU_P61 if cfg5 else None
+            pmc_file = (PMC_VALU if quoted else None) if headline else PMC_VALU_P61 if cfg5 else None
             pmc = pmc_valu(pmc_file) if pmc_file else None
             ev = (pmc or {}).get("kernels", {}).get(name)
             roof = {"bound": ev["bound"] if ev else ("valu" if "_mid" in name else "hbm"),
                     "bound_source": (pmc_file + " (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE of this command and of the isolated butterfly loop, committed; "
-                                                "not measured in this run)") if ev else "assumed from the kernel's kind (no counter file for this size / plan / field)",
+                                                "not measured in this run)") if ev else ("assumed from the kernel's kind (%s)" % (stale_note or "no counter file for this size / plan / field")),
+                    "committed_counters": state,
                     "bound_evidence": None if not ev else {k2: ev.get(k2) for k2 in ("valu_issue_frac", "cycles_per_valu_instruction", "hbm_frac_achievable", "clock_GHz",
                                                                                   "valu_busy_gfx94x_formula", "wave_cycles_split")},
                     "per_kernel_bound": None if not pmc else {kn: {k2: e[k2] for k2 in ("bound", "valu_issue_frac", "hbm_frac_achievable", "clock_GHz")}
                                                               for kn, e in pmc["kernels"].items()},
                     "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/pmc_traffic.json = profiles/r05/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
-                                                                   "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)",
+                    "traffic_source": stale_note if traffic is None else "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of an "
+                                                                   "earlier run of this command, corrected per MI355X_MICROARCH.md; not measured in this run)" % PROFILE_ROUND,
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": per_launch,
                     "frac_rocprof": None if not prof_ms else round(per_launch / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "rocprof_avg_kernel_ms": None if not prof_ms else round(prof_ms, 4),
-                    "rocprof_source": None if not prof_ms else ROCPROF_STATS + " (rocprofv3 --kernel-trace --stats of this command, committed; not measured in this run)",
+                    "rocprof_source": stale_note if not prof_ms else ROCPROF_STATS + " (rocprofv3 --kernel-trace --stats of this command, committed; not measured in this run)",
                     "encode": {"ms_per_step": round(ms_per_step, 4), "sum_of_kernel_ms_per_step": round(kernel_ms_per_step, 4),
                                "achieved": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac": round(bytes_per_encode / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -1323,7 +1365,9 @@ def main():
         # N > 1: `value` is BASELINE configs[3] — ONE stripe over all GPUs, the parity handed over block-distributed (all-to-all); the
         # replica figure stays in the line as `replicas`.  If that mode did not complete, the line says so and falls back to the replicas.
         a2a = (one or {}).get("all_to_all") if world > 1 else None
+        kind = "one_stripe_per_gpu"
         if a2a and "ms_per_stripe" in a2a:
+            kind = "one_stripe_all_to_all"
             v, ms, scaling = a2a["GBps"], a2a["ms_per_stripe"], "strong"
             which = ("ONE stripe over %d GPUs: column-slab encode + RCCL all-to-all into block-distributed parity (one_stripe.all_to_all)" % world)
             workload = ("RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, ONE %.0f MiB stripe sharded over %d GPUs in column slabs "
@@ -1332,13 +1376,17 @@ def main():
             par = "one stripe, %d column slabs, all-to-all of the parity (strong scaling)" % world
         else:
             v, ms, scaling = value, ms_per_step, "weak"
+            if world > 1:
+                kind = "replicas_fallback"  # a different quantity than the N > 1 headline (weak, not strong scaling): `complete` is false
             which = "one stripe per GPU" if world == 1 else "REPLICAS (one independent stripe per GPU): the one-stripe all-to-all mode did not complete, see one_stripe"
             workload = ("RS encode k=2^%d data -> %d parity blocks, %d B blocks, %s, one %.0f MiB stripe per GPU, HBM-resident, out of place"
                         % (args.log2k, m_blocks, args.block_bytes, fieldname, k * args.block_bytes / 2**20))
             par = "%d independent stripe(s), one per GPU, no collective" % world
         line = {
             "metric": "encode GB/s at %s (data+parity bytes / s); value = %s" % (code, which),
-            "value": round(v, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(v, 2), "value_kind": kind,
+            "complete": kind != "replicas_fallback" and (one or {}).get("complete", True) is not False,
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "ms_per_step_instrumented": round(ms_per_step_prof, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64" if p61 else "u32", "data": "synthetic",
@@ -1349,6 +1397,13 @@ def main():
             "compute_only_GBps": ((one or {}).get("compute_only") or {}).get("GBps"),
             "compute_only_ms_per_stripe": ((one or {}).get("compute_only") or {}).get("ms_per_stripe"),
             "exchange_only_ms_per_stripe": ((one or {}).get("exchange_only") or {}).get("ms_per_stripe") if world > 1 else None,
+            # what the links gave in THIS run (exchange_only) beside what DESIGN.md §8 assumes for one xGMI link per direction
+            "link_peak_GBps": (one or {}).get("link_peak_GBps") if world > 1 else None,
+            "link_peak_source": (one or {}).get("link_peak_source") if world > 1 else None,
+            "link_peak_assumed_GBps": (one or {}).get("link_peak_assumed_GBps") if world > 1 else None,
+            "expected_shape": None if world == 1 else (
+                "N=2 is SLOWER than N=1 by construction: one xGMI link carries a quarter of the stripe's parity (DESIGN.md §8); compare compute_only_GBps"
+                if world == 2 else "value includes the all-to-all of the parity over xGMI; compute_only_GBps is the same stripe without it (DESIGN.md §8)"),
             "replicas": replicas,
             "parity_check": check,
             "roofline": roof, "cpu_baseline": cpu,
@@ -1382,7 +1437,7 @@ def main():
         sys.stdout.flush()
         if rank != 0:
             time.sleep(3)  # let rank 0 print before its collectives see a peer disappear
-        os._exit(0)
+        os._exit(EXIT_WATCHDOG)
 
     class watch:  # noqa: N801 — `with watch(name):` around one mode
         def __init__(self, name):

@@ -1,4 +1,5 @@
 """Build recipe for the gfx950 shared library and the C++ host driver (explicit hipcc, in-tree outputs)."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,6 +16,37 @@ HIP_SOURCES = ["plan.hip", "options.hip", "kernels.hip", "tile_kernels.hip", "mi
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # experiments only (e.g. -DFASTECC_DIRECT_ABLATION: timing ablations of direct.hip, wrong results on purpose): extra flags from the environment
 HIP_FLAGS += os.environ.get("FASTECC_EXTRA_HIPFLAGS", "").split()
+
+
+FLAGS_STAMP = os.path.join(LIB_DIR, ".hip_flags")
+# the sources the committed counter files under profiles/ describe (bench.py labels them STALE when the tree has moved on)
+COUNTED_SOURCES = ["tile_kernels.hip", "gf.hpp", "ntt_device.hpp", "kernels.hpp"]
+
+
+def flags_key(flags=None):
+    """What the objects in fastecc_amd/lib were compiled with: objects are reused only under the same flag set, so an experiment's build
+    (FASTECC_EXTRA_HIPFLAGS, e.g. the direct path's timing ablations with wrong results on purpose) can never be linked into a later plain one."""
+    return hashlib.sha256(" ".join(HIP_FLAGS if flags is None else flags).encode()).hexdigest()
+
+
+def flags_changed(stamp_path=None, flags=None):
+    """True when the objects on disk were built with other flags than the current ones (or nobody recorded theirs)."""
+    try:
+        with open(stamp_path or FLAGS_STAMP) as f:
+            return f.read().strip() != flags_key(flags)
+    except OSError:
+        return True
+
+
+def kernel_sources_sha256(csrc=None, names=None):
+    """sha256 over the headline kernels' sources, file by file and combined (tools/stamp_counters.py writes it next to the counter files)."""
+    per_file, h = {}, hashlib.sha256()
+    for name in names or COUNTED_SOURCES:
+        with open(os.path.join(csrc or CSRC, name), "rb") as f:
+            data = f.read()
+        per_file[name] = hashlib.sha256(data).hexdigest()
+        h.update(name.encode() + b"\0" + data)
+    return {"sha256": h.hexdigest(), "files": per_file}
 
 
 def hipcc():
@@ -42,6 +74,8 @@ def _deps():
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> fastecc_amd/lib/libfastecc_hip.so"""
     os.makedirs(LIB_DIR, exist_ok=True)
+    if any(os.path.exists(os.path.join(LIB_DIR, src.replace(".hip", ".o"))) for src in HIP_SOURCES) and flags_changed():
+        force = True  # objects of another flag set (or of unknown origin) are never reused
     if not (force or _newer(LIB_PATH, _deps())):
         return LIB_PATH
     objs = []
@@ -67,6 +101,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(flags_key() + "\n")
     return LIB_PATH
 
 

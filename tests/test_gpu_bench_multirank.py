@@ -34,14 +34,16 @@ def _bench(world, fault=None, mode_timeout=120, log2k=12, extra=()):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "bench.py must print exactly one JSON line (rc %d)\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    line["_rc"] = r.returncode
+    return line
 
 
 def _value_is_all_to_all(line, world):
     one = line["one_stripe"]
     a2a = one["all_to_all"]
     assert "ms_per_stripe" in a2a, one
-    assert line["scaling"] == "strong" and line["n_gpus"] == world
+    assert line["scaling"] == "strong" and line["n_gpus"] == world and line["value_kind"] == "one_stripe_all_to_all"
     assert line["value"] == a2a["GBps"] and line["ms_per_step"] == a2a["ms_per_stripe"]
     assert line["compute_only_GBps"] == one["compute_only"]["GBps"]  # the exchange-free figure sits beside `value`
     assert line["replicas"]["scaling"] == "weak"
@@ -51,7 +53,8 @@ def _value_is_all_to_all(line, world):
 def test_two_rank_line_all_modes(hip_lib):
     line = _bench(2)
     one = _value_is_all_to_all(line, 2)
-    assert one["complete"] is True and "stalled_in" not in one
+    assert one["complete"] is True and "stalled_in" not in one and line["complete"] is True and line["_rc"] == 0
+    assert line["expected_shape"].startswith("N=2 is SLOWER") and line["link_peak_GBps"] == one["link_peak_GBps"] and line["link_peak_assumed_GBps"] == 76.8
     assert one["mode_order"][:3] == ["compute_only", "all_to_all", "exchange_only"] and one["mode_order"][-1] == "gather_to_root"
     for name in one["mode_order"]:
         assert "ms_per_stripe" in one[name], (name, one[name])
@@ -82,6 +85,7 @@ def test_a_stalled_gather_cannot_take_the_value(hip_lib):
     line = _bench(2, fault="gather_to_root:stall", mode_timeout=6)
     one = _value_is_all_to_all(line, 2)
     assert one["stalled_in"] == "gather_to_root" and one["complete"] is False
+    assert line["complete"] is False and line["_rc"] != 0  # the watchdog's line is marked, and the launcher sees a failure
     assert "error" in one["gather_to_root"] and "stalled" in one["gather_to_root"]["error"]
     for name in ("compute_only", "all_to_all", "exchange_only", "all_to_all_in_out"):
         assert "ms_per_stripe" in one[name]
@@ -93,18 +97,23 @@ def test_a_rank_that_never_arrives_leaves_the_replica_line(hip_lib):
     assert line["scaling"] == "weak" and "REPLICAS" in line["metric"]
     assert line["one_stripe"]["stalled_in"] in ("setup", "compute_only")  # rank 0 waits for the missing rank in the first agreement
     assert line["value"] == line["replicas"]["value"] > 0
+    assert line["value_kind"] == "replicas_fallback" and line["complete"] is False and line["_rc"] != 0
 
 
 def test_a_process_group_that_never_comes_up_leaves_a_line(hip_lib):
     """One rank never joins torch.distributed: rank 0 prints its own timing (no collective was possible) instead of nothing."""
     line = _bench(2, fault="startup", extra=("--startup-timeout", "8"))
-    assert "UNAVAILABLE" in line["collectives"] and line["scaling"] == "weak" and line["n_gpus"] == 2
+    assert "UNAVAILABLE" in line["collectives"] and line["scaling"] == "weak"
+    # only what was measured: one GPU; the two-rank extrapolation is in a key of its own and the run counts as failed
+    assert line["n_gpus"] == 1 and line["requested_gpus"] == 2 and line["complete"] is False and line["value_kind"] == "rank0_only" and line["_rc"] != 0
     assert line["value"] > 0 and line["ms_per_step"] == line["rank0_local_ms_per_step"]
+    assert abs(line["replicas_extrapolated_GBps"] - 2 * line["value"]) < 0.02
 
 
 def test_eight_rank_headline_geometry_control_flow(hip_lib):
     """Eight ranks, 4 KB blocks: 128-word slabs in two 64-word sub-slabs, k/8 whole blocks per rank (the geometry of configs[3])."""
     line = _bench(8)
     one = _value_is_all_to_all(line, 8)
-    assert one["sub_slabs"] == 2 and one["complete"] is True
+    assert one["sub_slabs"] == 2 and one["complete"] is True and line["complete"] is True
+    assert "all-to-all" in line["expected_shape"]
     assert one["checks"]["all_to_all"]["status"] == "ok" and one["checks"]["all_to_all_in_out"]["status"] == "ok"
