@@ -248,6 +248,95 @@ __global__ __launch_bounds__(256) void mfma_pipe_kernel(StageArgs g)
     }
 }
 
+// The arithmetic floor of the pipelined form: no memory traffic at all in the loop (fragments in registers, uniform twiddles in SGPRs), the
+// instruction order pinned with sched_group_barrier: one MFMA, then PER VALU instructions of the OTHER stream's Montgomery sums, sixteen times.
+template <int PER>
+__global__ __launch_bounds__(256) void mfma_pipe_floor_kernel(StageArgs g)
+{
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    v4i a[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) a[f] = g.a_frag[f * 64 + lane];
+    v16i initL, initH;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const v4i l4 = g.init[q * 64 + lane], h4 = g.init[(4 + q) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            initL[4 * q + e] = l4[e];
+            initH[4 * q + e] = h4[e];
+        }
+    }
+    uint32_t xa[16], xb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xa[r] = g.verify ? g.io[((size_t)wave * 16 + r) * 64 + lane] : (uint32_t)((lane * 2654435761u + r * 40503u + wave) % gf::P);
+        xb[r] = (uint32_t)((lane * 40503u + r * 2654435761u + wave + 7u) % gf::P);
+    }
+    v16i acc[4];
+    uint32_t L[16], H[16];
+    const uint32_t* __restrict__ tws = g.tw;
+    auto half_iteration = [&](uint32_t (&xin)[16], uint32_t (&xout)[16], int set) {
+        // fold the finished plane sums of `xout`'s stream, start `xin`'s MFMAs, finish `xout`
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            L[r] = (uint32_t)acc[0][r] + ((uint32_t)acc[1][r] << 8);
+            H[r] = (uint32_t)acc[2][r] + ((uint32_t)acc[3][r] << 8);
+        }
+        v4i b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[m][e] = (int)(xin[4 * m + e] ^ 0x80808080u);
+        __builtin_amdgcn_sched_barrier(0);  // the accumulators are free from here on: nothing below reads the old plane sums
+        acc[0] = initL;
+        acc[2] = initH;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[1][e] = 0, acc[3][e] = 0;
+        const uint32_t* __restrict__ t = tws + set * 64;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d * 4 + m], b[m], acc[d], 0, 0, 0);
+                const int r = m * 4 + d;
+                xout[r] = mont_sum2(L[r], t[2 * r], H[r], t[2 * r + 1]);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+        }
+    };
+    // prologue: stream A's MFMAs
+    {
+        v4i b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[m][e] = (int)(xa[4 * m + e] ^ 0x80808080u);
+        acc[0] = initL;
+        acc[2] = initH;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[1][e] = 0, acc[3][e] = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d * 4 + m], b[m], acc[d], 0, 0, 0);
+    }
+    for (int it = 0; it < g.iters; ++it) {
+        half_iteration(xb, xa, it & 7);        // B's MFMAs beside A's Montgomery sums
+        half_iteration(xa, xb, (it + 3) & 7);  // A's next MFMAs beside B's
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s ^= xa[r] ^ xb[r] ^ (uint32_t)acc[0][r];
+    if (g.verify) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g.io[((size_t)wave * 16 + r) * 64 + lane] = xa[r];
+    } else if (s == 0x12345679u) g.io[lane] = s;
+}
+
 // Baseline: five radix-2 DIF levels on the 16 registers of a lane (the fifth level pairs registers again instead of half-waves: the
 // arithmetic is the same, the v_permlane32_swap of the real tile is left out — in favour of the baseline).
 __global__ __launch_bounds__(256) void valu5_kernel(uint32_t* out, const uint32_t* __restrict__ tw, int iters)
@@ -474,6 +563,33 @@ static void run_pipe(const Tables& T, StageArgs g, uint32_t* d_io, int cus, int 
     fflush(stdout);
 }
 
+template <int PER>
+static void run_floor(StageArgs g, uint32_t* d_io, int cus, int wps, double valu5_ns)
+{
+    const int iters = 1024, blocks = cus * wps;  // an iteration is TWO wave-stages
+    g.verify = 0;
+    g.io = d_io;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    g.iters = 64;
+    hipLaunchKernelGGL((mfma_pipe_floor_kernel<PER>), dim3(blocks), dim3(256), 0, nullptr, g);
+    CK(hipDeviceSynchronize());
+    g.iters = iters;
+    CK(hipEventRecord(e0));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((mfma_pipe_floor_kernel<PER>), dim3(blocks), dim3(256), 0, nullptr, g);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 3;
+    const double ns = ms * 1e6 / ((double)iters * 2 * wps);
+    printf("{\"probe\":\"mfma_stage_pipelined_floor\",\"what\":\"no memory traffic, fragments in registers, uniform twiddles, order pinned: 1 MFMA then %d VALU\","
+           "\"waves_per_simd\":%d,\"ms\":%.4f,\"ns_per_wave_stage_per_simd\":%.1f,\"speedup_vs_valu5\":%.3f}\n",
+           PER, wps, ms, ns, valu5_ns / ns);
+    fflush(stdout);
+}
+
 static double run_valu5(uint32_t* d_io, const uint32_t* d_tw, int cus, int wps)
 {
     const int iters = 2048, blocks = cus * wps;
@@ -529,6 +645,8 @@ int main(int argc, char** argv)
         run_mfma<3, 0>(T, g, d_io, cus, wps, ref);
         run_mfma<2, 1>(T, g, d_io, cus, wps, ref);
         run_mfma<3, 1>(T, g, d_io, cus, wps, ref);
+        run_floor<7>(g, d_io, cus, wps, ref);
+        run_floor<9>(g, d_io, cus, wps, ref);
         run_pipe<0>(T, g, d_io, cus, wps, ref);
         run_pipe<1>(T, g, d_io, cus, wps, ref);
     }
