@@ -1077,6 +1077,16 @@ static int create_impl(fastecc_ctx** out, uint64_t n, uint64_t k, int lg, uint64
     if (!f61) build_plans(c);
 
     DeviceGuard dg(device);
+    if (dg.ok && !f61) {  // the engine's code objects, loaded once per process and device (kernels.hpp)
+        static std::mutex preload_mu;
+        static bool preloaded[64] = {};
+        std::lock_guard<std::mutex> lk(preload_mu);
+        if (device < 64 && !preloaded[device]) {
+            preload_pass_kernels();
+            preload_tile_kernels();
+            preloaded[device] = true;
+        }
+    }
     if (!dg.ok) {
         delete c;
         return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
@@ -1324,6 +1334,35 @@ bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order)
                         order[k++] = pos0 + ((g + 2 * i * G + half * G + far * (T / 2)) << s);
     }
     return true;
+}
+
+// The same order written by a kernel (the host loop above and the upload of its N words were 0.5 ms a piece in the first fastecc_decode_prepare).
+namespace {
+__global__ __launch_bounds__(256) void tile_order_kernel(uint32_t* __restrict__ order, uint32_t N, int logt, int l2, int rlog, int s)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t T = 1u << logt, G = 1u << l2;
+    const uint32_t half = k & 1u, far = (k >> 1) & 1u, i = (k >> 2) & ((1u << (rlog - 1)) - 1u), g = (k >> (rlog + 1)) & (G - 1u), tile = k >> logt;
+    const uint32_t lo = tile & ((1u << s) - 1u), hi = tile >> s;
+    order[k] = ((hi << (s + logt)) + lo) + ((g + 2u * i * G + half * G + far * (T / 2u)) << s);
+}
+}  // namespace
+
+bool gather_tile_order_device(const fastecc_ctx* c, uint32_t* order, hipStream_t st)
+{
+    if (c->encode_plan.empty() || !c->encode_plan[0].tile || c->N > 0x7FFFFFFFull) return false;
+    const Pass& p = c->encode_plan[0];
+    hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, st, order, (uint32_t)c->N, p.logr, p.logr - p.rlog - 1, p.rlog, p.s);
+    return hipGetLastError() == hipSuccess;
+}
+
+// Two contexts whose first passes read their blocks in the same order (what comparing two gather_tile_order vectors decided)
+bool same_tile_order(const fastecc_ctx* a, const fastecc_ctx* b)
+{
+    if (a->encode_plan.empty() || b->encode_plan.empty() || !a->encode_plan[0].tile || !b->encode_plan[0].tile) return false;
+    const Pass &p = a->encode_plan[0], &q = b->encode_plan[0];
+    return a->N == b->N && p.logr == q.logr && p.rlog == q.rlog && p.s == q.s;
 }
 
 // ---- the decoder's split transform (decode.hip, "even / odd split") on a context of k blocks whose per-block factors are (2m + k) / 2k ----

@@ -110,6 +110,9 @@ struct DecodeState {
     uint32_t* roots = nullptr;             // T words: the erased points, zero-padded
     uint32_t* dev_state = nullptr;         // NC bytes (as words/4): LOST / HELD / ZERO per position
     uint32_t* dev_erased = nullptr;        // T words: erased positions
+    uint8_t* dev_present = nullptr;        // (2k,k) layout: the caller's two presence arrays, k bytes each (the pattern is scanned on the device)
+    uint32_t* dev_counts = nullptr;        // ... and what presence_counts_kernel counts in them (8 words)
+    int tree_low = 0;                      // levels below this one are done by tree_low_levels_kernel (0: the per-thread leaves of degree 2^LEAF_LOG)
     uint32_t* tile_order = nullptr;        // NC words: first-pass order of the factors (only for the (2k,k) layout)
     bool tile_order_valid = false;
     // fastecc_repair: which parity blocks are lost (one word each), and the stripe the re-encode writes to
@@ -144,6 +147,8 @@ void destroy_decode_state(DecodeState* d)
                         d->split_rows_out_parity})
         if (b) (void)hipFree(b);
     if (d->gout_par) (void)hipFree(d->gout_par);
+    if (d->dev_present) (void)hipFree(d->dev_present);
+    if (d->dev_counts) (void)hipFree(d->dev_counts);
     if (d->recovered_full) (void)hipFree(d->recovered_full);
     if (d->pattern_ntt) fastecc_destroy(d->pattern_ntt);
     if (d->pattern_buf) (void)hipFree(d->pattern_buf);
@@ -173,7 +178,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // ST_UNUSED: a surviving parity block the split transform does not read — a root of the locator like a lost one, but nothing to rebuild
 enum : uint32_t { ST_LOST = 0, ST_HELD = 1, ST_ZERO = 2, ST_UNUSED = 3 };
-constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;  // the lowest levels of the tree are one schoolbook kernel: 16 roots per thread
+constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;
+constexpr int TREE_LOW = 10;  // tall trees: the polynomials of 2^TREE_LOW roots come from one kernel (schoolbook products in LDS) instead of six more levels  // the lowest levels of the tree are one schoolbook kernel: 16 roots per thread
 
 __device__ __forceinline__ uint32_t dev_pow(uint32_t x, uint32_t e)
 {
@@ -200,18 +206,83 @@ __global__ __launch_bounds__(256) void standard_srcmap_kernel(const uint8_t* __r
     if (u < NC) srcmap[u] = state[u] == ST_HELD ? ((u >> 1) | ((u & 1u) << 31)) : 0u;
 }
 
-// erased[] = the positions whose state is LOST or UNUSED, in any order; *counter (zero on entry) ends as their number.  One atomic per wave.
+// erased[] = the positions whose state is LOST or UNUSED, in any order; *counter (zero on entry) ends as their number.  A thread takes 16
+// positions (one 16-byte load of the state), a workgroup 4096: ONE atomic per workgroup (one per wave measured 187 us at NC = 2^20 — 16384
+// atomics on one address).
 __global__ __launch_bounds__(256) void erased_list_kernel(const uint8_t* __restrict__ state, uint32_t NC, uint32_t* __restrict__ erased, uint32_t* __restrict__ counter)
 {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool lost = u < NC && (state[u] == ST_LOST || state[u] == ST_UNUSED);
-    const uint64_t mask = __ballot(lost);
-    if (mask == 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
-    base = __shfl(base, __builtin_ctzll(mask));
-    if (lost) erased[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = u;
+    __shared__ uint32_t wave_sum[4], block_base;
+    const uint32_t u0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    uint32_t bits = 0;
+    if (u0 + 16u <= NC) {
+        const uint4 v = *reinterpret_cast<const uint4*>(state + u0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t st = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            bits |= (uint32_t)(st == ST_LOST || st == ST_UNUSED) << i;
+        }
+    } else {
+        for (uint32_t i = 0; i < 16u && u0 + i < NC; ++i) bits |= (uint32_t)(state[u0 + i] == ST_LOST || state[u0 + i] == ST_UNUSED) << i;
+    }
+    const uint32_t mine = (uint32_t)__builtin_popcount(bits), lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    if (lane == 63u) wave_sum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        block_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = block_base + incl - mine;
+    for (uint32_t w = 0; w < wave; ++w) at += wave_sum[w];
+    for (uint32_t b = bits; b; b &= b - 1u) erased[at++] = u0 + (uint32_t)__builtin_ctz(b);
+}
+
+// The reference's (2k,k) layout, pattern scan on the device: counts[0] = lost data blocks, [1] = lost parity blocks, [2 + h] = surviving parity
+// blocks at multiples of 2^h of the parity half (h = 1..5: the split transform's "small form" reads those alone).
+__global__ __launch_bounds__(256) void presence_counts_kernel(const uint8_t* __restrict__ pd, const uint8_t* __restrict__ pp, uint32_t N, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t acc[7];
+    if (threadIdx.x < 7) acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[7] = {};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const uint32_t held_p = pp[i] != 0;
+        c[0] += pd[i] == 0;
+        c[1] += 1u - held_p;
+        const int tz = __builtin_ctz(i | 32u);
+#pragma unroll
+        for (int h = 1; h <= 5; ++h) c[1 + h] += held_p & (uint32_t)(tz >= h);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        uint32_t v = c[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&acc[j], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 && acc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], acc[threadIdx.x]);
+}
+
+// ... and the per-position state from the two presence arrays: position 2i = data block i, 2i + 1 = parity block i; surviving parity blocks
+// off the multiples of `unused_mask` + 1 are UNUSED (roots of the locator like lost ones).  parity_lost[i] = 1 for a lost parity block.
+__global__ __launch_bounds__(256) void standard_state_kernel(const uint8_t* __restrict__ pd, const uint8_t* __restrict__ pp, uint32_t N, uint32_t unused_mask,
+                                                             uint8_t* __restrict__ state, uint32_t* __restrict__ parity_lost)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t held_p = pp[i] != 0;
+    const uint32_t sd = pd[i] != 0 ? ST_HELD : ST_LOST;
+    const uint32_t sp = !held_p ? ST_LOST : (i & unused_mask) ? ST_UNUSED : ST_HELD;
+    reinterpret_cast<uint16_t*>(state)[i] = (uint16_t)(sd | (sp << 8));
+    parity_lost[i] = 1u - held_p;
 }
 
 // roots[i] = w^erased[i] for i < n_erased, 0 for the padding up to T (a factor x: it only shifts the locator)
@@ -238,6 +309,54 @@ __global__ __launch_bounds__(256) void leaf_products_kernel(const uint32_t* __re
         c[0] = gf::sub(0u, gf::mul(r, c[0]));
     }
     for (uint32_t i = 0; i < leaf; ++i) x[i * m + p] = c[i];
+}
+
+// The lowest LOW levels of the product tree in ONE kernel (the per-level form costs six launches of 5-9 us per level whatever the size):
+// a workgroup takes 2^LOW roots and multiplies the monic polynomials pairwise in LDS by the schoolbook rule, degree 1 -> 2 -> ... -> 2^LOW
+// ((x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b; 2^(LOW-1) (2^LOW - 1) products per workgroup, 524 K at LOW = 10), and writes the result where
+// level LOW of the tree expects it: coefficient i of polynomial p at x[i * m + p], m = T >> LOW (the upper half of the 2 * 2^LOW rows is zero).
+template <int LOW>
+__global__ __launch_bounds__(1 << LOW) void tree_low_levels_kernel(const uint32_t* __restrict__ roots, uint32_t* __restrict__ x, uint32_t m)
+{
+    constexpr uint32_t R = 1u << LOW;  // one thread per coefficient
+    __shared__ uint32_t buf[2][R];
+    const uint32_t p = blockIdx.x, o = threadIdx.x;
+    buf[0][o] = gf::sub(0u, roots[p * R + o]);  // x - r
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < R; d <<= 1) {
+        const uint32_t t = o & (2u * d - 1u);
+        const uint32_t* a = buf[cur] + (o - t);
+        const uint32_t* b = a + d;
+        const uint32_t lo_i = t >= d ? t - d + 1u : 0u, hi_i = t < d ? t : d - 1u;
+        // the products are summed as exact integers (96 bits: at most 2^(LOW-1) terms below 2^64) and reduced once per coefficient
+        uint64_t lo = t >= d ? (uint64_t)a[t - d] + b[t - d] : 0ull;
+        uint32_t hi = 0;
+        uint32_t i = lo_i;
+        for (; i + 3u <= hi_i; i += 4u) {  // four products per turn: the LDS reads of a turn are in flight together
+            const uint32_t a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+            const uint32_t b0 = b[t - i], b1 = b[t - i - 1], b2 = b[t - i - 2], b3 = b[t - i - 3];
+            uint64_t pr = (uint64_t)a0 * b0;
+            lo += pr, hi += lo < pr;
+            pr = (uint64_t)a1 * b1;
+            lo += pr, hi += lo < pr;
+            pr = (uint64_t)a2 * b2;
+            lo += pr, hi += lo < pr;
+            pr = (uint64_t)a3 * b3;
+            lo += pr, hi += lo < pr;
+        }
+        for (; i <= hi_i; ++i) {  // (t = 2d - 1: lo_i > hi_i, no product)
+            const uint64_t pr = (uint64_t)a[i] * b[t - i];
+            lo += pr, hi += lo < pr;
+        }
+        const uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32);
+        uint32_t acc = gf::add(l0 >= gf::P ? l0 - gf::P : l0, gf::mul(l1 >= gf::P ? l1 - gf::P : l1, gf::MONT_ONE));  // 2^32 mod p
+        acc = gf::add(acc, gf::mul(hi, gf::MONT_R2));                                                              // 2^64 mod p
+        buf[cur ^ 1][o] = acc;
+        __syncthreads();
+        cur ^= 1;
+    }
+    x[(size_t)o * m + p] = buf[cur][o];
 }
 
 // y[i][q] = f[i][2q] * f[i][2q+1] * scale (rows of pitch m, m/2 results per row); scale = 1 / (2d) in Montgomery form
@@ -295,7 +414,7 @@ __global__ __launch_bounds__(256) void locator_columns_kernel(const uint32_t* __
 __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __restrict__ lv, const uint32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ wpow, uint32_t* __restrict__ fin, uint32_t* __restrict__ gout,
                                                             uint32_t NC, uint32_t pad, int e, uint32_t user_k, uint32_t q, int lg2,
-                                                            uint32_t* __restrict__ gout_par = nullptr)
+                                                            uint32_t* __restrict__ gout_par = nullptr, bool lv_bitrev = false)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
@@ -304,7 +423,7 @@ __global__ __launch_bounds__(256) void finish_tables_kernel(const uint32_t* __re
     const uint32_t corr = wpow[back == 0 ? 0 : NC - back];  // w^(-u pad)
     // where the two values for w^u sit in lv: position u for the power-of-two transform (natural order out); the way down
     // of a mixed-radix context (mixed_dif) leaves the value at w^(-v), v = q * bitrev(r) + j1, in block j1 * 2^lg2 + r
-    uint32_t at = u;
+    uint32_t at = lv_bitrev ? (__brev(u) >> (32 - lg2)) : u;  // (power of two, transform_bitrev: the value for w^u sits at the bit-reversed position)
     if (q > 1) {
         const uint32_t v = u == 0 ? 0u : NC - u;
         at = (v % q << lg2) + (__brev(v / q) >> (32 - lg2));
@@ -698,13 +817,68 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     }
     PhaseTimer pt;
     enum : uint8_t { LOST = ST_LOST, HELD = ST_HELD, ZERO = ST_ZERO };
-    // (branch-free loops: on a random pattern every "if (present)" is a coin flip — 2^20 mispredictions were most of this call's time at 50 % loss)
-    std::vector<uint8_t> state(NC, LOST);
-    // the block map serves the table-driven gather only: the (2k,k) layout reads its two stripes by position
     const bool standard_layout = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
-    std::vector<uint32_t> srcmap(standard_layout ? 0 : NC, 0);
     uint64_t erased_data = 0;
-    if (standard_layout) {
+    uint32_t split_groups = 0, split_shift = 0;
+    // ---- the reference's (2k,k) layout: the pattern is scanned on the DEVICE (the host loops below took 1.2-1.4 ms of a 2.6 ms call at k = 2^19:
+    // four passes over a million byte-sized coin flips).  Two 512 KB uploads, one counting kernel, 32 bytes back; the per-position state and the
+    // lost-parity flags are then written by a kernel.  Patterns the "small form" of the split transform does not take (too few surviving
+    // parity blocks at multiples of 2^h) keep the host path. ----
+    bool device_scan = false;
+    uint64_t device_erased_count = 0, device_erased_parity = 0;
+    DeviceScope ds(ci.device);
+    if (!ds.ok) return FASTECC_E_DEVICE;
+    CallScope call(c);  // (held from here on: the scan below already writes the context's pattern state)
+    DecodeState*& slot = decoder_of(c);
+    if (!slot) {
+        slot = new (std::nothrow) DecodeState();
+        if (!slot) return FASTECC_E_NOMEM;
+    }
+    if (standard_layout && N <= 0x7FFFFFFFull) {
+        DecodeState* d0 = slot;
+        if (!d0->dev_present) DEC_TRY(hipMalloc((void**)&d0->dev_present, 2 * N));
+        if (!d0->dev_counts) DEC_TRY(hipMalloc((void**)&d0->dev_counts, 8 * 4));
+        if (!d0->dev_state) DEC_TRY(hipMalloc((void**)&d0->dev_state, NC));
+        if (!d0->parity_lost) DEC_TRY(hipMalloc((void**)&d0->parity_lost, ci.user_m * 4));
+        {
+            const int rc = call.wait_idle();  // a decode or repair still reading the previous pattern's state
+            if (rc != FASTECC_OK) return rc;
+        }
+        d0->ready = false;
+        hipStream_t st0 = nullptr;
+        DEC_TRY(hipMemcpyAsync(d0->dev_present, data_present, N, hipMemcpyHostToDevice, st0));
+        DEC_TRY(hipMemcpyAsync(d0->dev_present + N, parity_present, N, hipMemcpyHostToDevice, st0));
+        DEC_TRY(hipMemsetAsync(d0->dev_counts, 0, 8 * 4, st0));
+        hipLaunchKernelGGL(presence_counts_kernel, dim3(128), dim3(256), 0, st0, d0->dev_present, d0->dev_present + N, (uint32_t)N, d0->dev_counts);
+        DEC_TRY(hipGetLastError());
+        uint32_t counts[8] = {};
+        DEC_TRY(hipMemcpy(counts, d0->dev_counts, sizeof counts, hipMemcpyDeviceToHost));
+        erased_data = counts[0];
+        device_erased_parity = counts[1];
+        const bool want_split0 = ci.decode_split && ci.log2k >= 17 && erased_data != 0;
+        if (want_split0 && ci.decode_split != 2)
+            for (int h = 5; h >= 1 && split_shift == 0; h--)
+                if (counts[1 + h] >= erased_data) split_shift = (uint32_t)h;
+        if (!want_split0 || split_shift != 0) {
+            device_scan = true;
+            const uint64_t unused = split_shift ? (N - device_erased_parity) - counts[1 + split_shift] : 0;
+            device_erased_count = erased_data + device_erased_parity + unused;
+            split_groups = split_shift ? 1u : 0u;  // (non-zero: "this pattern goes through the split transform" for the code below)
+            hipLaunchKernelGGL(standard_state_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st0, d0->dev_present, d0->dev_present + N, (uint32_t)N,
+                               split_shift ? (1u << split_shift) - 1u : 0u, (uint8_t*)d0->dev_state, d0->parity_lost);
+            DEC_TRY(hipGetLastError());
+        } else {
+            erased_data = 0;  // the host path counts again
+            split_shift = 0;
+        }
+    }
+    // (branch-free loops: on a random pattern every "if (present)" is a coin flip — 2^20 mispredictions were most of this call's time at 50 % loss)
+    std::vector<uint8_t> state(device_scan ? 0 : NC, LOST);
+    // the block map serves the table-driven gather only: the (2k,k) layout reads its two stripes by position
+    std::vector<uint32_t> srcmap(standard_layout ? 0 : NC, 0);
+    if (device_scan) {
+        // nothing to do on the host
+    } else if (standard_layout) {
         for (uint64_t i = 0; i < N; i++) {
             const uint32_t held_d = data_present[i] != 0, held_p = parity_present[i] != 0;
             state[2 * i] = held_d ? HELD : LOST;
@@ -730,12 +904,10 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     // (2k,k) layout, split transform: recovering e lost data blocks takes e parity blocks, not all of them — the surviving parity blocks of
     // the first few block groups of the parity stripe (group g = blocks g + (t << 10): what one tile of the first pass reads).  The others
     // are left unread: roots of the locator like the lost ones.
-    uint32_t split_groups = 0;
     // (also the zero-extended codes inside (2N,N): data block i at position 2i, parity block j at 2j + 1, fewer blocks than N in either stripe;
     // and the codes with fewer parity blocks: parity block j at position 2 (j << fold) + 1, i.e. block j << fold of the parity half)
     const bool split_layout = !mixed && ci.cosets == 1;
-    const bool want_split = ci.decode_split && split_layout && ci.log2k >= 17 && erased_data != 0;
-    uint32_t split_shift = 0;
+    const bool want_split = !device_scan && ci.decode_split && split_layout && ci.log2k >= 17 && erased_data != 0;
     if (want_split) {
         // first choice: the surviving parity blocks at multiples of 2^h of the parity half, the largest h <= 5 that still leaves as many as there are
         // lost data blocks (2 % of the codeword lost: h = 5) — r~ is then the transform of k >> h rows (see DecodeState::split_shift)
@@ -769,19 +941,12 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     if (split_groups != 0 && !srcmap.empty())
         for (uint64_t u = 1; u < NC; u += 2) srcmap[u] &= 0u - (uint32_t)(state[u] != ST_UNUSED);
     // the erased positions themselves are listed on the device (erased_list_kernel): the host needs their number only
-    uint64_t erased_count = 0;
-    for (uint64_t u = 0; u < NC; u++) erased_count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
+    uint64_t erased_count = device_erased_count;
+    if (!device_scan)
+        for (uint64_t u = 0; u < NC; u++) erased_count += (unsigned)(state[u] == LOST) + (unsigned)(state[u] == ST_UNUSED);
     if (erased_count > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive: not decodable
-    pt.mark("pattern scan (host)");
+    pt.mark(device_scan ? "pattern scan (device)" : "pattern scan (host)");
 
-    DeviceScope ds(ci.device);
-    if (!ds.ok) return FASTECC_E_DEVICE;
-    CallScope call(c);
-    DecodeState*& slot = decoder_of(c);
-    if (!slot) {
-        slot = new (std::nothrow) DecodeState();
-        if (!slot) return FASTECC_E_NOMEM;
-    }
     DecodeState* d = slot;
     d->ready = false;
     d->erased_data = erased_data;
@@ -790,7 +955,9 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     d->standard = !mixed && ci.cosets == 1 && ci.fold == 0 && !ci.zero_extended;
     d->mixed = mixed;
     pt.mark("lock, state");
-    {
+    if (device_scan) {
+        d->erased_parity = device_erased_parity;  // (the flags were written by standard_state_kernel)
+    } else {
         std::vector<uint32_t> plost(ci.user_m);
         d->erased_parity = 0;
         for (uint64_t q = 0; q < ci.user_m; q++) d->erased_parity += (plost[q] = parity_present[q] ? 0u : 1u);
@@ -816,7 +983,8 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     int lgT = 0;
     while ((1ull << lgT) < T) lgT++;
     if (erased_count > T) return FASTECC_E_UNSUPPORTED;
-    const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
+    // the levels below 2^TREE_LOW roots per polynomial are one kernel (tree_low_levels_kernel) when the tree is tall enough to have them
+    const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
     if (!d->pattern_ntt) {
@@ -847,7 +1015,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
         if (rc != FASTECC_OK) return rc;
     }
     pt.mark("transform context");
-    if (d->tree_T != T) {
+    if (d->tree_T != T || d->tree_low != leaf_log) {
         // level k >= leaf_log multiplies pairs of degree-2^k polynomials: transforms of length 2^(k+1) on T / 2^k columns
         for (fastecc_ctx* t : d->tree_ctx)
             if (t) fastecc_destroy(t);
@@ -867,6 +1035,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
         DEC_TRY(hipMalloc((void**)&d->roots, T * 4));
         DEC_TRY(hipMalloc((void**)&d->dev_erased, (T + 1) * 4));  // + the counter of erased_list_kernel
         d->tree_T = T;
+        d->tree_low = leaf_log;
     }
     pt.mark("tree contexts + buffers");
     if (!d->wpow) {
@@ -901,12 +1070,11 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
             // per-block factor (2m + k) / 2k = m / k + 1 / 2
             int rc = create_ramp_transform_ctx(&d->split, ci.log2k, ci.words * 4, 0, gf::h_inv((uint32_t)N), ci.device, gf::h_inv(2u));
             if (rc != FASTECC_OK) return rc;
-            std::vector<uint32_t> order;
-            if (!split_decode_supported(d->split) || split_decode_groups(d->split) != 1024u || !gather_tile_order(d->split, order)) return FASTECC_E_UNSUPPORTED;
+            if (!split_decode_supported(d->split) || split_decode_groups(d->split) != 1024u) return FASTECC_E_UNSUPPORTED;
             for (uint32_t** b : {&d->split_order, &d->split_rows_data, &d->split_rows_parity, &d->split_rows_out, &d->split_pos_parity, &d->split_pos_data_odd,
                                  &d->split_rows_out_parity})
                 DEC_TRY(hipMalloc((void**)b, N * 4));
-            DEC_TRY(hipMemcpy(d->split_order, order.data(), N * 4, hipMemcpyHostToDevice));
+            if (!gather_tile_order_device(d->split, d->split_order, st)) return FASTECC_E_UNSUPPORTED;
             {
                 // the parity half's low levels when few block groups are in use (run_split_decode): what the DIF levels with strides 512 ... 16
                 // make of a 1024-block tile in which block q0 alone is 1 — simulated here exactly as the tile does them, (a, b) -> (a + b,
@@ -996,18 +1164,16 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
         if (!d->transform_full) {
             const int rc = create_ramp_transform_ctx(&d->transform_full, lgc, ci.words * 4, 0, gf::h_inv((uint32_t)NC), ci.device);
             if (rc != FASTECC_OK && rc != FASTECC_E_NOMEM) return rc;
-            std::vector<uint32_t> o1, o2;
-            d->full_ok = d->transform_full && gather_tile_order(d->transform, o1) == gather_tile_order(d->transform_full, o2) && o1 == o2;
+            d->full_ok = d->transform_full && same_tile_order(d->transform, d->transform_full);
             if (getenv("FASTECC_TRACE_PREPARE"))
                 fprintf(stderr, "[fastecc prepare] one-transform repair: context %s, same first-pass order %d (%s | %s)\n", d->transform_full ? "built" : "none",
                         (int)d->full_ok, fastecc_plan_string(d->transform), d->transform_full ? fastecc_plan_string(d->transform_full) : "");
         }
     }
     if (d->standard && !d->tile_order_valid) {
-        std::vector<uint32_t> order;
-        if (gather_tile_order(d->transform, order)) {
+        if (same_tile_order(d->transform, d->transform)) {  // (a tile first pass: the order exists)
             DEC_TRY(hipMalloc((void**)&d->tile_order, NC * 4));
-            DEC_TRY(hipMemcpy(d->tile_order, order.data(), NC * 4, hipMemcpyHostToDevice));
+            if (!gather_tile_order_device(d->transform, d->tile_order, st)) return FASTECC_E_DEVICE;
             DEC_TRY(hipMalloc((void**)&d->fin_first_pass, NC * 4));
         } else {
             d->fin_first_pass = d->fin;
@@ -1022,18 +1188,19 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
 
     pt.mark("tables, tile order");
     // ---- this pattern ----
-    DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
+    if (!device_scan) DEC_TRY(hipMemcpyAsync(d->dev_state, state.data(), NC, hipMemcpyHostToDevice, st));
     auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
     if (!srcmap.empty()) DEC_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, st));
     else hipLaunchKernelGGL(standard_srcmap_kernel, grid(NC), dim3(256), 0, st, (const uint8_t*)d->dev_state, (uint32_t)NC, d->srcmap);
     // the list of erased positions (any order: the locator is their product); its counter sits behind the list
     DEC_TRY(hipMemsetAsync(d->dev_erased + T, 0, 4, st));
-    hipLaunchKernelGGL(erased_list_kernel, grid(NC), dim3(256), 0, st, (const uint8_t*)d->dev_state, (uint32_t)NC, d->dev_erased, d->dev_erased + T);
+    hipLaunchKernelGGL(erased_list_kernel, grid((NC + 15) / 16), dim3(256), 0, st, (const uint8_t*)d->dev_state, (uint32_t)NC, d->dev_erased, d->dev_erased + T);
     hipLaunchKernelGGL(roots_kernel, grid(T), dim3(256), 0, st, d->roots, d->dev_erased, d->wpow, (uint32_t)erased_count, (uint32_t)T);
     // leaves: T / leaf polynomials of degree `leaf`, side by side ([coefficient][polynomial]); the upper half of the
     // 2*leaf rows the first product needs is zero
     DEC_TRY(hipMemsetAsync(d->tree_x, 0, 2 * T * 4, st));
-    hipLaunchKernelGGL(leaf_products_kernel, grid(T >> leaf_log), dim3(256), 0, st, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
+    if (leaf_log == TREE_LOW) hipLaunchKernelGGL(tree_low_levels_kernel<TREE_LOW>, dim3((unsigned)(T >> leaf_log)), dim3(1 << TREE_LOW), 0, st, d->roots, d->tree_x, (uint32_t)(T >> leaf_log));
+    else hipLaunchKernelGGL(leaf_products_kernel, grid(T >> leaf_log), dim3(256), 0, st, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
     DEC_TRY(hipGetLastError());
     uint32_t* x = d->tree_x;
     uint32_t* spare = d->tree_y;  // x / spare swap roles level by level; tree_f always holds the transforms
@@ -1057,13 +1224,14 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     hipLaunchKernelGGL(locator_columns_kernel, grid(NC), dim3(256), 0, st, x, d->pattern_buf, (uint32_t)T, (uint32_t)NC);
     DEC_TRY(hipGetLastError());
     {
+        // (power of two: the values stay in bit-reversed order, finish_tables_kernel reads them there — the reordering pass of fastecc_ntt was 87 us)
         const int rc = mixed ? mixed_dif(d->pattern_ntt, d->pattern_buf, d->pattern_buf, st)
-                             : fastecc_ntt(d->pattern_ntt, d->pattern_buf, 0, FASTECC_MEM_DEVICE, st);
+                             : transform_bitrev(d->pattern_ntt, d->pattern_buf, d->pattern_buf, false, false, 2, st);
         if (rc != FASTECC_OK) return rc;
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
                        (uint32_t)(T - erased_count), e, (uint32_t)ci.user_k, (uint32_t)(mixed ? ci.q : 1), lgc,
-                       parity_factors ? d->gout_par : nullptr);
+                       parity_factors ? d->gout_par : nullptr, !mixed);
     DEC_TRY(hipGetLastError());
     if (d->fin_first_pass != d->fin) {
         hipLaunchKernelGGL(permute_kernel, grid(NC), dim3(256), 0, st, d->fin, d->tile_order, d->fin_first_pass, (uint32_t)NC);

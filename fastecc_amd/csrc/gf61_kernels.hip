@@ -655,8 +655,8 @@ hipError_t launch_tile_one(const PassArgs& a, unsigned tiles, hipStream_t st)
     constexpr int lds_bytes = (1 << LOGT) * (64 / SPLIT) * 16;
     static bool configured[64] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    if (dev < 0 || dev >= 64 || !configured[dev]) {  // > 64 KiB of dynamic LDS is opt-in per kernel and device
+    if (lds_bytes > 64 * 1024 && hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (lds_bytes > 64 * 1024 && (dev < 0 || dev >= 64 || !configured[dev])) {  // > 64 KiB of dynamic LDS is opt-in per kernel and device (0.2 ms per call: not for the small tiles)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) configured[dev] = true;

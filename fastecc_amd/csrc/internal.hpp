@@ -118,6 +118,8 @@ int transform_bitrev(fastecc_ctx* c, const uint32_t* in, uint32_t* out, bool dit
 // else fills `order` with order[i] = codeword position whose factor is entry i of the table (two-window DIF tile:
 // the factors of one wave are contiguous).
 bool gather_tile_order(const fastecc_ctx* c, std::vector<uint32_t>& order);
+bool gather_tile_order_device(const fastecc_ctx* c, uint32_t* order, hipStream_t st);  // the same N words, written on the device
+bool same_tile_order(const fastecc_ctx* a, const fastecc_ctx* b);
 // The decoder's split transform (decode.hip, "even / odd split") on a context of k blocks created by create_ramp_transform_ctx with the factor
 // (2m + k) / 2k: data and parity stripes each through the plan's first DIF tile with per-block factors (tile order: gather_tile_order; a zero
 // factor = block not used), the parity half only in its first `parity_groups` block groups (group g = blocks g + (t << s), t < group_rows; the

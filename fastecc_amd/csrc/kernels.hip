@@ -301,4 +301,10 @@ hipError_t launch_gf_binary(int op, const uint32_t* x, const uint32_t* y, uint32
     return hipGetLastError();
 }
 
+void preload_pass_kernels()
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(ntt_pass_kernel<5, 1, MODE_DIF>)) != hipSuccess) (void)hipGetLastError();  // (speed only)
+}
+
 }  // namespace fastecc

@@ -110,6 +110,11 @@ std::vector<uint32_t> radix_dft_table(int q, uint32_t wq);  // host: wq = the pr
 hipError_t launch_radix(int q, bool dit, int vec, RadixArgs a, hipStream_t st);
 
 hipError_t launch_pass(int logr, int vec, int mode, PassArgs a, hipStream_t st);
+// The code objects of the two engine translation units (kernels.hip, tile_kernels.hip) are loaded by the runtime at the first launch of one of
+// their kernels — 1.3 ms for kernels.hip, found inside the first fastecc_decode_prepare (profiles/r06/prepare_trace_warm.txt).  These load them
+// at the first fastecc_create on a device instead (once per process and device).
+void preload_pass_kernels();
+void preload_tile_kernels();
 bool tile_supported(int logt, bool pair, int logr = 5);
 int tile_max_fold(int logt, bool pair, int logr = 5);
 bool tile_wide_supported(int logt, bool pair, int logr = 5);

@@ -670,11 +670,12 @@ static hipError_t launch_one(const TileArgs& a, hipStream_t st)
 {
     using C = TileCfg<LOGT, LOGR, PAIR, SPLIT>;
     auto kern = ntt_tile_kernel<LOGT, LOGR, PAIR, MODE, SPLIT, NWIN, SZ>;
-    // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done
+    // > 64 KiB of dynamic LDS must be enabled per kernel AND per device; remember which devices are done.  Smaller tiles need no attribute — and
+    // the call costs ~0.2 ms per instantiation: the decoder's first fastecc_decode_prepare touches a dozen tile shapes (profiles/r06/prepare_trace.txt)
     static bool configured[64] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    if (dev < 0 || dev >= 64 || !configured[dev]) {
+    if (C::LDS_BYTES > 64 * 1024 && hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (C::LDS_BYTES > 64 * 1024 && (dev < 0 || dev >= 64 || !configured[dev])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) configured[dev] = true;
@@ -838,6 +839,12 @@ hipError_t launch_tile(int logt, bool pair, int logr, int mode, const TileArgs& 
         case 8: return launch_mode<8, 5, false>(mode, a, st);
         default: return launch_mode<9, 5, false>(mode, a, st);
     }
+}
+
+void preload_tile_kernels()
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(ntt_tile_kernel<9, 5, true, MODE_MID, 2>)) != hipSuccess) (void)hipGetLastError();  // (speed only)
 }
 
 }  // namespace fastecc

@@ -15,10 +15,16 @@ import fastecc_amd as fe  # noqa: E402
 frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 p61 = len(sys.argv) > 3 and sys.argv[3] == "p61"
+warm = len(sys.argv) > 3 and sys.argv[3] == "warm"  # an encode first, as in bench.py's other_paths: the encoder's kernels are loaded before the first prepare
 k = 1 << (18 if p61 else 19)
 torch.zeros(1, device="cuda:0")
 with fe.Encoder(2 * k, k, 4096, field=fe.FIELD_GF_P61_SQUARED if p61 else fe.FIELD_GF_FFF00001) as enc:
     rng = np.random.default_rng(1)
+    if warm:
+        d = torch.zeros(k * 1024, dtype=torch.int32, device="cuda:0")
+        q = torch.empty_like(d)
+        enc.encode(d, q)
+        torch.cuda.synchronize()
     for call in range(calls):
         lost = rng.permutation(2 * k)[: max(1, int(2 * k * frac))]
         dp, pp = np.ones(k, np.uint8), np.ones(k, np.uint8)
