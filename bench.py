@@ -1098,6 +1098,21 @@ def one_stripe_modes(args, fastecc_amd, field, device, local, rank, world, backe
                                 res.update({"reference_parity_hash": h, "expected": want[0]["hash_parity"], "status": "ok" if h == want[0]["hash_parity"] else "FAILED"})
                         except Exception as e:  # noqa: BLE001
                             res["hash_error"] = repr(e)
+                    else:
+                        # the 64-bit field has no upstream output: the first element column of the block-distributed parity (rank 0's own
+                        # data column) re-encoded by this repository's CPU oracle — the gate of configs[4]'s N > 1 line
+                        try:
+                            import numpy as np
+                            from oracle import OracleP61
+                            x = np.ascontiguousarray(slab[0][:, 0:2].cpu().numpy().view(np.uint64))
+                            want = OracleP61().encode(x)
+                            have = whole[:, 0:2].cpu().numpy().view(np.uint64)
+                            res["oracle_column"] = "ok" if want.shape == have.shape and np.array_equal(want, have) else "FAILED"
+                            res["oracle_column_what"] = "element column 0 of all %d parity blocks against oracle/fastecc_oracle_p61.c" % whole.shape[0]
+                            if res["oracle_column"] != "ok":
+                                res["status"] = "FAILED"
+                        except Exception as e:  # noqa: BLE001
+                            res["oracle_column"] = "error: %r" % e
                     if "status" not in res:
                         res["status"] = "unchecked (no golden hash at this size, no gathered copy)" if res["equals_gather_to_root"] is None else \
                                         "ok" if res["equals_gather_to_root"] else "FAILED"

@@ -117,3 +117,16 @@ def test_eight_rank_headline_geometry_control_flow(hip_lib):
     assert one["sub_slabs"] == 2 and one["complete"] is True and line["complete"] is True
     assert "all-to-all" in line["expected_shape"]
     assert one["checks"]["all_to_all"]["status"] == "ok" and one["checks"]["all_to_all_in_out"]["status"] == "ok"
+
+
+def test_eight_rank_64bit_field_control_flow(hip_lib):
+    """BASELINE configs[4]'s line (GF((2^61-1)^2), 64 KB blocks, eight ranks) at a reduced k: the same modes, `value` = all_to_all, and the
+    block-distributed parity pinned to the CPU oracle (one element column) as well as to the gathered copy."""
+    line = _bench(8, extra=("--field", "p61"))
+    one = _value_is_all_to_all(line, 8)
+    assert line["dtype"] == "u64" and "2^61" in line["config"]["workload"] and one["complete"] is True and line["complete"] is True
+    assert one["checks"]["slabs_equal_compute_only_on_every_rank"] is True
+    a2a = one["checks"]["all_to_all"]
+    assert a2a["status"] == "ok" and a2a["equals_gather_to_root"] is True and a2a["oracle_column"] == "ok"
+    assert "all_to_all_in_out" not in one or "ms_per_stripe" not in (one.get("all_to_all_in_out") or {})  # (needs a stripe every rank can derive: 32-bit field only)
+    assert line["parity_check"]["status"] == "ok"
