@@ -711,7 +711,7 @@ def other_field_p61_cosets(fastecc_amd, device, stream, steps=5):
             d1.record()
             torch.cuda.synchronize()
             decode = {"lost_data_blocks": int(k // 50), "decode_ms": round(d0.elapsed_time(d1) / 2, 3), "restored": ok,
-                      "what": "gather through the position map, x p'(x) on all 4k positions (a transform of 2^19 blocks), scatter of the data positions"}
+                      "what": "x p'(x) at the k data positions only: the way down on all 4k positions (2^19 blocks), one folding MID tile (every fourth position), the way up on k positions; gather through the position map and scatter where the plan's end passes are tiles"}
             del saved
         except Exception as e2:  # noqa: BLE001
             decode = {"error": repr(e2)}

@@ -679,7 +679,7 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     if (sharded_of(c)) return sharded_decode_prepare(c, data_present, parity_present);
     const CtxInfo ci = info_of(c);
     if (ci.field == FASTECC_FIELD_GF_P61_SQUARED) {
-        // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are always (2k,k) with k a power of two
+        // the 64-bit field has its own decoder (gf61_decode.hip); its contexts are (2k,k), (4k,k) or (8k,k) with k a power of two (and their zero-extended relatives)
         int e61 = 1;
         while ((1 << e61) < ci.cosets + 1) e61++;  // n = 4k / 8k: the same decoder on the (k << e)-th roots of unity (gf61_decode.hip)
         DeviceScope ds61(ci.device);

@@ -772,9 +772,18 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         PhaseTimer pt;
         // only the even (data) positions of this transform are wanted: a 7-level MID here pairs with the 6-level MID of a size-k path,
         // whose DIT passes finish the folded transform (encode_fold); where no such pair of plans exists all 2k outputs are computed
-        int rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, e == 1 ? 7 : 0, detail, cap);
+        // (n = 4k: every FOURTH position — the size-4k transform's 7-level MID pairs with the 5-level MID of a size-k path; n = 8k: all positions)
+        int rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, e <= 2 ? 7 : 0, detail, cap);
         pt.mark("transform path");
-        if (rc == FASTECC_OK && log2k >= 6 && e == 1) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, 6, detail, cap);
+        if (rc == FASTECC_OK && log2k >= 6 && e <= 2) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, e == 1 ? 6 : 5, detail, cap);
+        if (rc == FASTECC_OK && e == 2 && !(fold_caps(d->transform, d->half) & FOLD_PAIRS)) {
+            // the two plans do not pair up at this size: the transform keeps its own choice of MID and computes all 4k outputs
+            destroy(d->transform);
+            d->transform = nullptr;
+            destroy(d->half);
+            d->half = nullptr;
+            rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, 0, detail, cap);
+        }
         pt.mark("half path");
         if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + e, 2, detail, cap);  // only its stand-alone transform is used
         pt.mark("pattern path");
@@ -935,7 +944,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             (void)hipGetLastError();  // no memory for the tables: the split decodes, the lost parity is re-encoded
         }
     }
-    if (d->split_ready) d->gout_all_valid = false;  // (the one-transform repair is the unsplit pattern's)
+    // (the one-transform repair is the unsplit pattern's.  Also when the split's paths or buffers could NOT be built: the locator's state then still
+    //  counts the unused parity blocks as lost, so gout_all is non-zero there and that repair would rewrite up to k (1 - 2^-h) parity blocks the
+    //  caller holds — decode + re-encode restores only what state_real says is lost)
+    if (d->split_ready || split_shift != 0) d->gout_all_valid = false;
     D61_TRY(hipStreamSynchronize(s0));
     d->ready = true;
     return FASTECC_OK;
@@ -985,14 +997,39 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         // n = 4k / 8k: gather through the position map, x p'(x) on all k << e positions, the data positions (multiples of 2^e) scattered back
         if (d->erased_data != 0) {
             if (!d->work) D61_TRY(hipMalloc((void**)&d->work, d->NC * d->elems * 16));
+            // n = 4k: x p'(x) at the data positions only — the way down on all 4k positions, the folding MID tile, the way up on k positions
+            // (encode_fold), the gather through the position map in the first tile and the scatter in the last where the plans have such passes
+            const int caps = d->half ? fold_caps(d->transform, d->half) : 0;
+            const bool folded = (caps & FOLD_PAIRS) != 0, fused_gather = folded && (caps & FOLD_GATHERS), fused_scatter = folded && (caps & FOLD_SCATTERS);
             uint64_t items = d->NC * col_chunks;
-            hipLaunchKernelGGL(k_gather_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, d->srcmap, elems, col_chunks, items);
-            D61_TRY(hipGetLastError());
-            const int rc = encode(d->transform, d->work, d->work, s0, hooks);
-            if (rc != FASTECC_OK) return rc;
-            items = d->N * col_chunks;
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->work, data, d->gout, elems, col_chunks, items, 1u << d->e);
-            D61_TRY(hipGetLastError());
+            if (!fused_gather) {
+                hipLaunchKernelGGL(k_gather_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, d->srcmap, elems, col_chunks, items);
+                D61_TRY(hipGetLastError());
+            }
+            if (folded) {
+                if (!d->rec) D61_TRY(hipMalloc((void**)&d->rec, d->N * d->elems * 16));
+                FoldEnds ends;
+                if (fused_gather) {
+                    ends.parity = parity;
+                    ends.fin = d->fin;
+                    ends.map = d->srcmap;
+                }
+                if (fused_scatter) {
+                    ends.gout = d->gout;
+                    ends.data_out = data;
+                }
+                const int rc = encode_fold(d->transform, d->half, fused_gather ? data : d->work, d->work, d->rec, s0, hooks, &ends);
+                if (rc != FASTECC_OK) return rc;
+            } else {
+                const int rc = encode(d->transform, d->work, d->work, s0, hooks);
+                if (rc != FASTECC_OK) return rc;
+            }
+            if (!fused_scatter) {
+                items = d->N * col_chunks;
+                hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, folded ? d->rec : d->work, data, d->gout, elems, col_chunks, items,
+                                   folded ? 1u : 1u << d->e);
+                D61_TRY(hipGetLastError());
+            }
         }
         if (rebuild) {  // the lost parity blocks: the encoder again on the repaired data, only the lost ones written
             if (cosets_of(rebuild_with) != (1 << d->e) - 1) return FASTECC_E_INVAL;

@@ -33,7 +33,8 @@ namespace p61 {
 
 namespace {
 
-enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5, MODE_DIF_ROWS = 6, MODE_MID_ADD = 7, MODE_MID_UP = 8 };
+enum { MODE_DIF = 0, MODE_DIT = 1, MODE_MID = 2, MODE_MID_FOLD = 3, MODE_DIF_GATHER = 4, MODE_DIT_SCATTER = 5, MODE_DIF_ROWS = 6, MODE_MID_ADD = 7, MODE_MID_UP = 8,
+       MODE_MID_FOLD4 = 9 };  // MID_FOLD keeping every FOURTH output position (the decoder of the n = 4k codes)
 
 // forward w_16^1, ^3, ^5, ^7 (re, im): the only general constants inside a run of levels; the inverse roots are their conjugates
 struct SmallRoots {
@@ -56,6 +57,7 @@ struct PassArgs {
     // only where side[u] != 0; row i of the output is stored, times side[i], only where side[i] != 0
     const uint64_t* in2;
     const uint64_t* side;
+    const uint32_t* map;  // MODE_DIF_GATHER, optional: row u of the input is block map[u] & 0x7FFFFFFF of `in` (bit 31 set: of `in2`) instead of block u / 2 (n = 4k / 8k codes)
     uint64_t* out2;  // MODE_DIT_SCATTER, optional: the output rows are codeword positions — row i goes to (i even ? out : out2)[i / 2]
     // the split decoder (gf61_decode.hip, "even / odd split"):
     //   MODE_DIF_ROWS  block u of `in` times side[u * side_stride] on the way in (zero = block not in use, never read)
@@ -391,7 +393,7 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
     // value to the same address from the same wave — so the kernel has no divergent region at all.  (With an "if (live)" around the stores
     // the compiler sinks the whole second half of the tile into that branch, where its scheduling barriers no longer apply.)
     const uint32_t col = min(cc * 64u + lane, a.elems - 1u);
-    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD || MODE == MODE_MID_ADD || MODE == MODE_MID_UP) ? 0 : a.s;
+    const int s = (MODE == MODE_MID || MODE == MODE_MID_FOLD || MODE == MODE_MID_FOLD4 || MODE == MODE_MID_ADD || MODE == MODE_MID_UP) ? 0 : a.s;
     const uint32_t lo = grp & ((1u << s) - 1u);
     const uint32_t hi = grp >> s;
     const uint64_t block0 = ((uint64_t)hi << (s + LOGT)) + lo;  // stripe block of tile row q: block0 + (q << s)
@@ -475,8 +477,15 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
                 const uint64_t u = block0 + ((uint64_t)row_a(j) << s);
                 const uint64_t fre = as_constant(a.side)[2 * u], fim = as_constant(a.side)[2 * u + 1];
                 x[j] = Elem{0, 0};
-                if ((fre | fim) != 0)
-                    x[j] = gf61::mul(load_elem(((u & 1u) ? a.in2 : a.in) + (u >> 1) * row_words + 2u * col), gf61::make_twiddle(fre, fim), k);
+                if ((fre | fim) != 0) {
+                    uint64_t from_second = u & 1u, block = u >> 1;
+                    if (a.map) {  // (uniform) the position map of the codes whose parity sits at other positions than the odd ones
+                        const uint32_t m = ((const uint32_t __attribute__((address_space(4)))*)(reinterpret_cast<uintptr_t>(a.map)))[u];
+                        from_second = m >> 31;
+                        block = m & 0x7FFFFFFFu;
+                    }
+                    x[j] = gf61::mul(load_elem((from_second ? a.in2 : a.in) + block * row_words + 2u * col), gf61::make_twiddle(fre, fim), k);
+                }
             }
         } else {
             load(row_a);
@@ -504,6 +513,60 @@ __global__ __launch_bounds__((1 << (LOGT - LOGR)) * 64, 4) void p61_tile_kernel(
             }
         } else {
             store(row_a);
+        }
+    } else if constexpr (MODE == MODE_MID_FOLD4) {
+        // MID of a transform of which only every FOURTH output position is wanted (n = 4k codes: the data sit at the multiples of 4): two DIT
+        // levels fold away, four consecutive positions into one, and what is left is the second half of the 5-level MID tile (8 registers, 4
+        // waves) of the QUARTER-size transform: its low 2 levels here on the 4 folded values a lane holds, one exchange into that tile's layout
+        // (waves 0-3 take 8 rows each, the others only keep the barriers), its high 3 levels with that transform's collected twiddles (a.tw_dit),
+        // and the T/4 rows go to the quarter-size stripe `out`.
+        static_assert(LOGT == 7 && LOGR == 4, "the folding tile is the 7-level one");
+        constexpr int RQ = R / 4, GQ = 4, RS = 8;  // values per lane after the fold; the 5-level tile: 4 waves of 8 registers
+        load(row_a);
+        dif_levels<LOGR, false, true>(x, a.tw_dif, g, L2, k, a.sr);
+        exchange(row_a, row_b);
+        dif_levels<LOGR, true, true, L2>(x, a.tw_dif, 0u, 0, k, a.sr);
+        const_u64_ptr d = as_constant(a.dscale) + 2 * (((size_t)hi << LOGT) + (size_t)g * R);
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = gf61::mul(x[j], gf61::make_twiddle(d[2 * j], d[2 * j + 1]), k);
+        Elem y[RQ];
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) {
+            const Elem u0{gf61::add(x[4 * j].re, x[4 * j + 1].re, k), gf61::add(x[4 * j].im, x[4 * j + 1].im, k)};
+            const Elem u1{gf61::add(x[4 * j + 2].re, x[4 * j + 3].re, k), gf61::add(x[4 * j + 2].im, x[4 * j + 3].im, k)};
+            y[j] = Elem{gf61::add(u0.re, u1.re, k), gf61::add(u0.im, u1.im, k)};
+        }
+        dit_levels<2, true, false, 2>(y, a.tw_dit, 0u, 0, k, a.sr);  // folded rows g * 4 + j: the quarter-size tile's two low levels
+        __syncthreads();  // every lane has finished reading the first exchange
+        Elem z[RS];
+        // write rows g * 4 + j (32 of them), read rows j * 4 + g in waves 0-3
+#pragma unroll
+        for (int round = 0; round < SPLIT; ++round) {
+            const bool mine = SPLIT == 1 || my_round == (uint32_t)round;
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < RQ; ++j) {
+                    u64x2 t;
+                    t.x = y[j].re;
+                    t.y = y[j].im;
+                    my_lds[(g * RQ + (uint32_t)j) * WS] = t;
+                }
+            }
+            __syncthreads();
+            if (mine && g < (uint32_t)GQ) {
+#pragma unroll
+                for (int j = 0; j < RS; ++j) {
+                    const u64x2 t = my_lds[((uint32_t)j * GQ + g) * WS];
+                    z[j] = Elem{t.x, t.y};
+                }
+            }
+            if (round + 1 < SPLIT) __syncthreads();
+        }
+        if (g < (uint32_t)GQ) {  // (wave-uniform; no barrier below)
+            dit_levels<3, false, false>(z, a.tw_dit, g, 2, k, a.sr);
+            const uint64_t quarter0 = (uint64_t)hi << (LOGT - 2);
+#pragma unroll
+            for (int j = 0; j < RS; ++j) store_elem(a.out + (quarter0 + (uint32_t)j * GQ + g) * row_words + 2u * col, CANON ? gf61::canon(z[j]) : z[j]);
         }
     } else if constexpr (MODE == MODE_MID_FOLD) {
         // MID of a transform of which only the EVEN output positions are wanted (the decoder's x p'(x), gf61_decode.hip): at the first DIT
@@ -673,6 +736,9 @@ hipError_t launch_tile_mode(int mode, bool canon, bool inverse_roots, const Pass
     case MODE_DIT: return canon ? launch_tile_one<LOGT, MODE_DIT, true, SPLIT, false>(a, tiles, st) : launch_tile_one<LOGT, MODE_DIT, false, SPLIT, false>(a, tiles, st);
     case MODE_MID_FOLD:
         if constexpr (LOGT == 7) return launch_tile_one<LOGT, MODE_MID_FOLD, false, SPLIT, true>(a, tiles, st);
+        else return hipErrorInvalidValue;
+    case MODE_MID_FOLD4:
+        if constexpr (LOGT == 7) return launch_tile_one<LOGT, MODE_MID_FOLD4, false, SPLIT, true>(a, tiles, st);
         else return hipErrorInvalidValue;
     case MODE_DIF_GATHER: return launch_tile_one<LOGT, MODE_DIF_GATHER, false, SPLIT, true>(a, tiles, st);
     case MODE_DIF_ROWS: return launch_tile_one<LOGT, MODE_DIF_ROWS, false, SPLIT, true>(a, tiles, st);
@@ -960,6 +1026,7 @@ struct Scope {
 struct FusedEnds {
     const uint64_t* first_in2 = nullptr;
     const uint64_t* first_side = nullptr;  // set: plan[0] must be a DIF tile
+    const uint32_t* first_map = nullptr;   // the gather's position map (PassArgs::map)
     const uint64_t* last_side = nullptr;   // set: plan.back() must be a canonical DIT tile; it then writes to last_out
     uint64_t* last_out = nullptr;
     uint64_t* last_out2 = nullptr;         // set: the rows are codeword positions, even ones go to last_out, odd ones here (PassArgs::out2)
@@ -993,6 +1060,7 @@ int run_passes(Path* p, const std::vector<Pass>& plan, const uint64_t* in, uint6
             mode = ends->first_rows_stride ? MODE_DIF_ROWS : MODE_DIF_GATHER;
             a.in2 = ends->first_in2;
             a.side = ends->first_side;
+            a.map = ends->first_rows_stride ? nullptr : ends->first_map;
             a.side_stride = ends->first_rows_stride;
         }
         if (ends && ends->mid_addend && q.mode == MODE_MID) {
@@ -1105,16 +1173,18 @@ int create_transform(Path** out, int n, uint64_t elems, int factor, char* detail
 // 7-level MID tile, `half` a size-2^n path with a 6-level MID tile.  DIF passes of `big` (in -> work, then in place), the folding MID tile
 // (work -> out, 2^n blocks), DIT passes of `half` above its MID, in place on `out`.  FASTECC_E_UNSUPPORTED when the two plans do not pair up.
 namespace {
-// the two paths pair up when big's MID is a 7-level tile and half's a 6-level one (same exchange split)
+// the two paths pair up when big's MID is a 7-level tile and the small one's a 6-level tile (half the size) or a 5-level tile (a quarter of
+// the size), same exchange split
 bool fold_pairs(Path* big, Path* half, size_t* mb_out, size_t* mh_out)
 {
-    if (!big || !half || big->n != half->n + 1 || big->elems != half->elems) return false;
+    if (!big || !half || (big->n != half->n + 1 && big->n != half->n + 2) || big->elems != half->elems) return false;
+    const int f = big->n - half->n;
     size_t mb = 0, mh = 0;
     while (mb < big->enc.size() && big->enc[mb].mode != MODE_MID) mb++;
     while (mh < half->enc.size() && half->enc[mh].mode != MODE_MID) mh++;
     if (mb == big->enc.size() || mh == half->enc.size()) return false;
     const Pass &qb = big->enc[mb], &qh = half->enc[mh];
-    if (!qb.tile || qb.logr != 7 || !qh.tile || qh.logr != 6 || big->split != half->split) return false;
+    if (!qb.tile || qb.logr != 7 || !qh.tile || qh.logr != 7 - f || big->split != half->split) return false;
     *mb_out = mb;
     *mh_out = mh;
     return true;
@@ -1144,6 +1214,7 @@ int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint6
         if (ends && ends->fin) {
             fe.first_in2 = ends->parity;
             fe.first_side = ends->fin;
+            fe.first_map = ends->map;
         }
         const int rc = run_passes(big, down, in, work, big->tw_inv, big->tw_fwd, true, st, hooks, 0, 0, &fe);
         if (rc != FASTECC_OK) return rc;
@@ -1163,9 +1234,10 @@ int encode_fold(Path* big, Path* half, const uint64_t* in, uint64_t* work, uint6
         a.s = 0;
         a.sr = big->sr;
         if (a.items > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
-        Scope sc(hooks, st, "p61_tile_mid7_fold", (big->N + half->N) * big->elems * 16ull);
-        const hipError_t e = big->split == 2 ? launch_tile_mode<7, 2>(MODE_MID_FOLD, false, true, a, (unsigned)a.items, st)
-                                             : launch_tile_mode<7, 1>(MODE_MID_FOLD, false, true, a, (unsigned)a.items, st);
+        const int fold_mode = big->n == half->n + 2 ? MODE_MID_FOLD4 : MODE_MID_FOLD;
+        Scope sc(hooks, st, fold_mode == MODE_MID_FOLD4 ? "p61_tile_mid7_fold4" : "p61_tile_mid7_fold", (big->N + half->N) * big->elems * 16ull);
+        const hipError_t e = big->split == 2 ? launch_tile_mode<7, 2>(fold_mode, false, true, a, (unsigned)a.items, st)
+                                             : launch_tile_mode<7, 1>(fold_mode, false, true, a, (unsigned)a.items, st);
         if (e != hipSuccess) return fail(nullptr, 0, e, "p61 folding MID tile");
     }
     if (up.empty()) return FASTECC_OK;  // (the MID tile then wrote lazy values: the caller's next step accepts them)

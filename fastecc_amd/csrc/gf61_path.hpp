@@ -32,7 +32,8 @@ int cosets_of(const Path* p);
 // create_transform with the MID pass forced to `force_mid` levels (0 = the plan's own choice, also when no such plan exists)
 int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int force_mid, char* detail, size_t detail_cap);
 // Only the EVEN output positions of `big`'s transform (size 2^(n+1), created with force_mid = 7): DIF passes of `big`, a MID tile that folds
-// the first DIT level away, DIT passes of `half` (size 2^n, force_mid = 6).  in: 2^(n+1) blocks; work: 2^(n+1) blocks (may be `in`); out: 2^n blocks.
+// the first DIT level away, DIT passes of `half` (size 2^n, force_mid = 6).  With `big` of size 2^(n+2) and `half` created with force_mid = 5:
+// every FOURTH output position (two levels fold away; the decoder of the n = 4k codes).  in: 2^(n+1) blocks; work: 2^(n+1) blocks (may be `in`); out: 2^n blocks.
 // FASTECC_E_UNSUPPORTED if the plans of the two do not pair up.
 // ends (optional): the decoder's gather and scatter run inside the first and the last pass —
 //   fin  != null: `in` is the data stripe, `parity` the parity stripe; position u of the input is (u even ? data : parity)[u / 2] * fin[u], read
@@ -42,6 +43,7 @@ int create_transform_mid(Path** out, int n, uint64_t elems, int factor, int forc
 struct FoldEnds {
     const uint64_t* parity = nullptr;
     const uint64_t* fin = nullptr;
+    const uint32_t* map = nullptr;  // with fin: position u of the input is block map[u] & 0x7FFFFFFF of `in` (bit 31: of `parity`) — the n = 4k layout
     const uint64_t* gout = nullptr;
     uint64_t* data_out = nullptr;
 };

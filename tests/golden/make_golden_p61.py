@@ -127,7 +127,9 @@ def main():
         cases.append({"N": N, "elems": elems, "seed": seed, "data": [str(w) for w in words],
                       "parity": [str(w) for w in encode(words, N, elems)]})
     coset_cases = []
-    for N, elems, e, seed in ((2, 1, 2, 5), (4, 2, 2, 6), (8, 1, 3, 7), (16, 1, 2, 8)):
+    # (64, 1, 2, 9): the smallest n = 4k code whose DECODER runs the folded transform (every fourth position: gf61_decode.hip) — the GPU test
+    # erases 3k blocks of this codeword and must get this data back
+    for N, elems, e, seed in ((2, 1, 2, 5), (4, 2, 2, 6), (8, 1, 3, 7), (16, 1, 2, 8), (64, 1, 2, 9)):
         words = splitmix_words(N * elems * 2, seed)
         coset_cases.append({"N": N, "elems": elems, "e": e, "seed": seed, "data": [str(w) for w in words],
                             "parity": [str(w) for w in encode_cosets(words, N, elems, e)]})

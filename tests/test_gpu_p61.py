@@ -480,6 +480,58 @@ def test_multi_coset_golden_vectors(torch_cuda, fe, orc61):
             assert (to_host(out).reshape(rows, 2 * elems) == want).all(), (N, elems, e)
 
 
+@pytest.mark.parametrize("logn,elems", [(6, 1), (7, 70), (9, 64), (11, 66), (12, 2), (13, 20)])
+def test_decode_of_the_n_equals_4k_code_is_folded(torch_cuda, fe, orc61, logn, elems):
+    """n = 4k: only the k data positions (the multiples of 4) of the decoder's 4k-point transform are wanted, so it runs as the big path's DIF
+    passes, ONE folding MID tile (four consecutive positions into one, the second half of the quarter-size path's 5-level MID) and the DIT passes
+    of the size-k path — the profile shows that kernel — and where the plan starts and ends with tiles the gather (through the position map) and
+    the scatter ride in them.  Round trip with the LAST tolerable loss (3k blocks); at k = 64 the codeword is the independent big-integer vector
+    of tests/golden/golden_p61.json, so the decoder's output is pinned to it, not only to this library's encoder."""
+    torch = torch_cuda
+    N, e = 1 << logn, 2
+    rows = 3 * N
+    if (logn, elems) == (6, 1):
+        case = [c for c in json.load(open(os.path.join(HERE, "golden", "golden_p61.json")))["coset_cases"] if c["N"] == 64 and c["e"] == 2][0]
+        x = np.array([int(w) for w in case["data"]], dtype=np.uint64).reshape(N, 2 * elems)
+        want = np.array([int(w) for w in case["parity"]], dtype=np.uint64).reshape(rows, 2 * elems)
+    else:
+        x = rand_stripe(np.random.default_rng(4000 + logn), N, elems)
+        want = p61_oracle_coset_parity(orc61, x, e)
+    with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        out = torch.empty(rows * 2 * elems, dtype=torch.int64, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        assert (to_host(out).reshape(rows, 2 * elems) == want).all()
+        rng = np.random.default_rng(logn)
+        for nlost in (3 * N, N):
+            lost = rng.permutation(4 * N)[:nlost]
+            dp, pp = np.ones(N, np.uint8), np.ones(rows, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            if not (dp == 0).any():
+                dp[0] = 0
+                pp[np.flatnonzero(pp == 0)[0]] = 1
+            bad_x, bad_p = x.copy(), want.copy()
+            bad_x[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            bad_p[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+            d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+            enc.decode_prepare(dp, pp)
+            enc.profile(True)
+            enc.profile_reset()
+            enc.decode(d, q)
+            torch.cuda.synchronize()
+            prof = enc.profile_read()
+            enc.profile(False)
+            if int((dp == 0).sum()) + int((pp == 0).sum()) > 16:  # (fewer: the direct path)
+                assert prof.get("p61_tile_mid7_fold4", (0, 0, 0))[1] == 1, prof
+                if logn in (11, 12):
+                    assert any(name.endswith("_gather") for name in prof) and any(name.endswith("_scatter") for name in prof), prof
+            assert (to_host(d).reshape(x.shape) == x).all(), (nlost, enc.plan())
+            assert (to_host(q).reshape(want.shape) == bad_p).all()  # decode leaves the parity stripe alone
+            enc.repair(d, q)
+            torch.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
+
+
 @pytest.mark.parametrize("logn", [1, 2, 5, 6, 7, 9, 12, 13, 14])
 @pytest.mark.parametrize("e", [2, 3])
 def test_multi_coset_parity_matches_oracle(torch_cuda, fe, orc61, logn, e):
