@@ -78,6 +78,13 @@ EXIT_NO_GROUP = 3   # the process group never came up: the line holds rank 0's o
 EXIT_WATCHDOG = 4   # a one-stripe mode stalled: its timer printed the line with everything measured so far
 
 
+_ACTIVE_TEST_HOOKS = [v for v in ("FASTECC_BENCH_TEST_ONE_RANK_GROUP", "FASTECC_BENCH_TEST_STALL", "FASTECC_BENCH_BACKEND", "FASTECC_SHARDING_FORCE_COLLECTIVES")
+                      if os.environ.get(v)]
+if _ACTIVE_TEST_HOOKS:  # a stray exported variable must not change what the driver measures silently: say so, loudly, on every rank
+    print("[bench.py] TEST HOOKS ACTIVE in the environment: %s - this is NOT a production measurement" % ", ".join(
+        "%s=%s" % (v, os.environ[v]) for v in _ACTIVE_TEST_HOOKS), file=sys.stderr, flush=True)
+
+
 def dist_on(world):
     return world > 1 or ONE_RANK_GROUP
 
@@ -1425,6 +1432,8 @@ def main():
             "one_stripe": one,
             "devices": devices, "distributed": dist_info,
         }
+        if _ACTIVE_TEST_HOOKS:
+            line["test_hooks_active"] = {v: os.environ[v] for v in _ACTIVE_TEST_HOOKS}
         if other_paths_result:
             line["other_paths"] = other_paths_result
         if p61:

@@ -561,6 +561,7 @@ struct Decoder {
     uint64_t* split_af = nullptr;        // k elements by position: -1/2 w^(-bitrev(p))
     uint64_t* split_work = nullptr;      // k blocks: the data chain's intermediate stripe
     uint8_t* state_real = nullptr;       // the caller's flags (the locator's `state` counts unused parity blocks as lost)
+    uint32_t lost_coset_mask = 0;        // n = 4k / 8k: bit t set = coset t (parity blocks [t k, (t+1) k)) has lost a block: fastecc_repair re-encodes those cosets only
     // fastecc_repair through the split: a second MID + DIT chain over the same two halves gives x p'(x) at the odd positions — the lost parity blocks
     uint64_t* split_q2 = nullptr;        // k blocks: q~ as the data chain's MID leaves it after its first half (lazy)
     uint64_t* split_pos_odd = nullptr;   // k elements by position: -1/2 w^(+bitrev(p))
@@ -832,6 +833,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     if (e > 1) {
         D61_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, s0));  // (fixed per code; cheap next to the locator)
         D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, s0));
+        d->lost_coset_mask = 0;
+        for (uint64_t q = 0; q < M; q++)
+            if (plost[q]) d->lost_coset_mask |= 1u << (q / N);
     }
     if (split_shift != 0) {
         // the split transform's paths and tables (once; the small transform per shift).  Anything missing — no plan of the needed shape, no memory
@@ -1035,7 +1039,7 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
             if (cosets_of(rebuild_with) != (1 << d->e) - 1) return FASTECC_E_INVAL;
             if (!d->again) D61_TRY(hipMalloc((void**)&d->again, d->M * d->elems * 16));
             if (encode_cosets_needs_work(rebuild_with) && !d->cos_work) D61_TRY(hipMalloc((void**)&d->cos_work, d->N * d->elems * 16));
-            const int rc = encode_cosets(rebuild_with, data, d->again, d->cos_work, s0, hooks);
+            const int rc = encode_cosets(rebuild_with, data, d->again, d->cos_work, s0, hooks, d->lost_coset_mask);  // only the cosets with a lost block
             if (rc != FASTECC_OK) return rc;
             const uint64_t items = d->M * col_chunks;
             hipLaunchKernelGGL(k_restore_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->parity_lost, elems, col_chunks, items);

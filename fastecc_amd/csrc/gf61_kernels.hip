@@ -1337,7 +1337,7 @@ int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, cons
 
 // n = 4k / 8k: the DIF passes once (data -> work, k blocks; with no DIF pass in the plan MID reads the data itself), then MID and the DIT passes
 // once per coset with that coset's factors, coset t writing parity blocks [t k, (t + 1) k).
-int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks)
+int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks, uint32_t coset_mask)
 {
     size_t mid = 0;
     while (mid < p->enc.size() && p->enc[mid].mode != MODE_MID) mid++;
@@ -1351,6 +1351,7 @@ int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* wor
         src = work;
     }
     for (int t = 0; t < p->cosets; t++) {
+        if (!((coset_mask >> t) & 1u)) continue;  // (fastecc_repair: cosets that have lost no block are not computed again)
         const int rc = run_passes(p, tail, src, parity + (size_t)t * p->N * p->elems * 2, p->tw_inv, p->tw_fwd, true, st, hooks, 0, 0, nullptr,
                                   p->dscale + (size_t)t * 2 * p->N);
         if (rc != FASTECC_OK) return rc;

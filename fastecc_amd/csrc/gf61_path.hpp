@@ -58,7 +58,8 @@ void destroy(Path* p);
 
 int encode(Path* p, const uint64_t* data, uint64_t* parity, hipStream_t st, const LaunchHooks* hooks);
 // a create_cosets path: parity = cosets * k blocks; work = a k-block stripe of the caller's (needed when encode_cosets_needs_work)
-int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks);
+// coset_mask: bit t set = coset t (k blocks of the parity) is computed and written; the others are left alone
+int encode_cosets(Path* p, const uint64_t* data, uint64_t* parity, uint64_t* work, hipStream_t st, const LaunchHooks* hooks, uint32_t coset_mask = 0xFFFFFFFFu);
 bool encode_cosets_needs_work(const Path* p);
 // the element columns [col0, col0 + width) of every block only (data / parity are the stripes' base addresses)
 int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col0, uint64_t width, hipStream_t st, const LaunchHooks* hooks);

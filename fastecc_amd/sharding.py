@@ -27,6 +27,10 @@ import torch
 # Test hook (tests/test_gpu_rccl_single_rank.py): with a ONE-rank process group the collectives are normally skipped; set, they are issued anyway,
 # so that a 1-GPU box runs the very RCCL calls of the N > 1 path (arguments, dtypes, contiguity, streams) against the real library.
 FORCE_COLLECTIVES = bool(os.environ.get("FASTECC_SHARDING_FORCE_COLLECTIVES"))
+if FORCE_COLLECTIVES:  # a stray exported variable must not change production timings silently
+    import sys
+    print("[fastecc_amd.sharding] TEST HOOK ACTIVE: FASTECC_SHARDING_FORCE_COLLECTIVES is set - one-rank groups issue their collectives too "
+          "(timings are NOT those of a production run)", file=sys.stderr, flush=True)
 
 
 def stripes_for_rank(n_stripes, rank, world):
