@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libfastecc_hip.so")
 RS_PATH = os.path.join(LIB_DIR, "rs_hip")
 MICROBENCH_PATH = os.path.join(LIB_DIR, "microbench")
 
-HIP_SOURCES = ["plan.hip", "options.hip", "kernels.hip", "tile_kernels.hip", "mixed_kernels.hip", "mixed_kernels_pfa.hip", "mixed_kernels_pfa2.hip", "mixed_kernels_pfa3.hip", "gf61_kernels.hip", "gf61_decode.hip", "pack_kernels.hip", "direct.hip", "decode.hip", "sharded.hip", "host_copy.hip", "api.hip"]
+HIP_SOURCES = ["plan.hip", "options.hip", "kernels.hip", "tile_kernels.hip", "mixed_kernels.hip", "mixed_kernels_pfa.hip", "mixed_kernels_pfa2.hip", "mixed_kernels_pfa3.hip", "gf61_kernels.hip", "gf61_decode.hip", "pack_kernels.hip", "direct.hip", "decode.hip", "sharded.hip", "host_copy.hip", "encode.hip", "host_stage.hip", "create.hip", "api.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # experiments only (e.g. -DFASTECC_DIRECT_ABLATION: timing ablations of direct.hip, wrong results on purpose): extra flags from the environment
 HIP_FLAGS += os.environ.get("FASTECC_EXTRA_HIPFLAGS", "").split()

@@ -1,4 +1,4 @@
-// context.hpp — what the translation units behind the C ABI share (api.hip: entry points and the encode drivers; plan.hip: pass plans
+// context.hpp — what the translation units behind the C ABI share (api.hip: entry points; encode.hip / host_stage.hip / create.hip: the drivers behind them, drivers.hpp; plan.hip: pass plans
 // and twiddle tables; options.hip: tuning options and profiling).  Nothing here is part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -136,7 +136,7 @@ struct fastecc_ctx {
     // pageable host memory (FASTECC_MEM_HOST results, fastecc_encode_blocks) moves through rings of pinned slots served by helper threads (lazy)
     static constexpr int STAGE_SLOTS = 4;
     static constexpr size_t STAGE_SLOT_BYTES = (size_t)16 << 20;
-    struct StageRing {  // pinned slots between pageable host memory and the copy engine, one ring per direction (api.hip stage_transfer)
+    struct StageRing {  // pinned slots between pageable host memory and the copy engine, one ring per direction (host_stage.hip stage_transfer)
         char* slots = nullptr;
         hipEvent_t event[STAGE_SLOTS] = {};
     };

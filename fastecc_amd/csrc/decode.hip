@@ -21,7 +21,7 @@
 // positions are the k-point forward transform of  g[m] = m P[m] + (m+k) P[m+k] = (2m+k)/2k q~[m] - 1/2 w^-m r~[m].  So the 2k-point
 // pipeline becomes: the encoder's own three passes over the data half (blocks times l(w^2i) on the way in, g's second term added between
 // the halves of MID, only the rebuilt blocks stored on the way out) plus r~ — the first pass over the few parity block groups in use, and
-// the low levels over a stripe that is zero elsewhere (run_split_decode in api.hip; tile modes in tile_kernels.hip).
+// the low levels over a stripe that is zero elsewhere (run_split_decode in encode.hip; tile modes in tile_kernels.hip).
 //
 // The other codes are the same thing on the (k << e)-th roots of unity (fastecc_decode_prepare): positions that hold no
 // block of the code count as erased, zero-extended data blocks as known zeros, the transform has fold = e.

@@ -1,4 +1,4 @@
-// host_copy.hip — the host side of the staging rings (api.hip stage_transfer): rows of a column slab between the caller's pageable stripe
+// host_copy.hip — the host side of the staging rings (host_stage.hip stage_transfer): rows of a column slab between the caller's pageable stripe
 // (one piece of `width` bytes every `pitch` bytes: 512 bytes of every 4 KB block at 8 slabs) and the packed rows of a pinned slot.
 // Host code only.  Plain memcpy moved 37-45 GB/s per direction with six threads on an EPYC 9575F: a piece per page defeats the hardware
 // prefetchers (they stop at 4 KB boundaries), and ordinary stores read every destination line before overwriting it.  Here the source

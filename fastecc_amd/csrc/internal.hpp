@@ -1,4 +1,4 @@
-// internal.hpp — what decode.hip needs from api.hip (nothing here is part of the ABI).
+// internal.hpp — what decode.hip needs from api.hip / encode.hip / host_stage.hip / create.hip (nothing here is part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,7 +46,7 @@ int direct_encode_build(DirectEncode** out, uint64_t N, uint64_t K, uint64_t m, 
 int direct_encode_run(DirectEncode* de, const uint32_t* data, uint32_t* parity, int kernel, hipStream_t st);
 void direct_encode_destroy(DirectEncode* de);
 
-// ---- api.hip ----
+// ---- api.hip, encode.hip, host_stage.hip, create.hip ----
 struct CtxInfo {
     int device, field, fold, cosets, log2k;
     uint64_t k, words, pitch;  // blocks, words per block, words between device blocks
@@ -83,10 +83,10 @@ void set_error_detail(const char* what, hipError_t e);
 void set_error_text(const char* text);  // this thread's fastecc_last_error_detail, verbatim (a worker thread's text republished on the caller's)
 // host_copy.hip: `rows` pieces of `width` bytes between two pitched host buffers (software prefetch + streaming stores)
 void host_copy_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t width, size_t rows);
-// a rows x width rectangle between PAGEABLE host memory and the device through c's ring of pinned slots (api.hip stage_transfer); c's call lock is
+// a rows x width rectangle between PAGEABLE host memory and the device through c's ring of pinned slots (host_stage.hip stage_transfer); c's call lock is
 // the caller's business; threads = 0: the default number of helper threads
 int stage_rect(fastecc_ctx* c, bool to_device, void* host, size_t host_pitch, void* dev, size_t dev_pitch, size_t width, size_t rows, hipStream_t st, int threads);
-// device -> pageable host memory through a ring of pinned slots emptied by helper threads (api.hip); synchronous; c's call lock held by the caller
+// device -> pageable host memory through a ring of pinned slots emptied by helper threads (host_stage.hip); synchronous; c's call lock held by the caller
 int download_pageable(fastecc_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
 
 // A transform context (GF(0xFFF00001)): DIF over all log2k levels with inverse roots, the block holding coefficient m
@@ -158,7 +158,7 @@ int p61_work_stripes(fastecc_ctx* c, uint64_t** data_full, uint64_t** parity_ful
 int encode_unlocked(fastecc_ctx* c, const uint32_t* data, uint32_t* parity, hipStream_t st);
 
 // Calls on one context are serialised on the host, and work that uses the context's internal device buffers is ordered
-// between streams (api.hip: fastecc_ctx::mu / buf_event).  decode.hip's entry points take part through this scope:
+// between streams (encode.hip: fastecc_ctx::mu / buf_event).  decode.hip's entry points take part through this scope:
 // the constructor locks, begin() makes `st` wait for the previous user of the internal buffers, end() records this one.
 class CallScope {
 public:

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits)
 // l = sl + t with half-size h = 2^l.  The twiddle of the butterfly whose lower block is p is
 // (root of order 2h)^(p mod h) (ntt.cpp:254-283), p mod h = (m << sl) + off with m = j mod 2^t.
 //
-// Twiddles come from a LEVEL-PACKED table built by the host for the plan in use (api.hip,
+// Twiddles come from a LEVEL-PACKED table built by the host for the plan in use (plan.hip,
 // build_level_table): level l occupies entries [2^l, 2^(l+1)) and is stored in the order the kernel
 // consumes it, entry 2^l + (off << t) + m — so the 2^t twiddles a wave needs at one level are contiguous
 // and arrive with one or two wide scalar loads (s_load_dwordx2..x16) instead of 2^t separate ones.

@@ -268,7 +268,7 @@ int run_body(fastecc_ctx* shell, const void* const* data_slabs, const void* data
 }
 
 // Stripes in PAGEABLE host memory (fastecc_encode with FASTECC_MEM_HOST on a sharded context): every slab has a host thread of its own that
-// moves its columns through the slab context's rings of pinned slots (api.hip stage_transfer: helper threads gather / scatter the rows, the
+// moves its columns through the slab context's rings of pinned slots (host_stage.hip stage_transfer: helper threads gather / scatter the rows, the
 // copy engine of that GPU moves the slots over that GPU's host link), encodes, and brings the parity home — all slabs side by side.  The
 // runtime's own pageable copies are synchronous and ran the slabs one after the other (8 slabs on one device: 330 ms for 2 + 2 GiB).
 // Synchronous; the caller's stream has been waited for.

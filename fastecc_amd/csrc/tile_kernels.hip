@@ -140,7 +140,7 @@ __device__ __forceinline__ void pair_level_dit(uint32_t (&x)[1 << LOGR][1], cons
 //               exist (col >= S): the hardware bounds check then returns 0 / drops the store, so ragged
 //               block sizes need no branches;
 // s_block_off = 32-bit byte offset of the tile block, wave-uniform (SGPR).
-// The host only selects a tile pass when a tile spans < 2^32 - 2^16 bytes (tile_fits, api.hip), so live lane
+// The host only selects a tile pass when a tile spans < 2^32 - 2^16 bytes (tile_fits, plan.hip), so live lane
 // offset + block offset stay below num_records = 2^32-1 and "offset | dead_mask" = 2^32-1 is always out of range.
 // Workgroup barrier for the LDS exchanges.  __syncthreads() also fences global memory (s_waitcnt
 // vmcnt(0)), which would drain the previous tile's stores at every exchange;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__((TileCfg<LOGT, LOGR, PAIR>::THREADS), (LOGR <= 4 ||
                 if (gather) {
                     // paired order: register 2i holds tile block g + 2i*G (+ G in the high half-wave), register 2i+1 that
                     // block + T/2; a zero factor (erased block) turns whatever was read into 0
-                    // row_factor is stored in TILE order (api.hip, gather_tile_order): the 2R factors of a wave are contiguous,
+                    // row_factor is stored in TILE order (encode.hip, gather_tile_order): the 2R factors of a wave are contiguous,
                     // [j/2][+T/2][high half-wave], so they arrive with a few wide scalar loads
                     const_u32_ptr f = as_constant(a.row_factor) + (((size_t)(v.hi << s) + v.lo) * G + g) * (2 * R);
 #pragma unroll

@@ -204,7 +204,7 @@ def test_host_memory_and_block_pointer_forms(torch_cuda, fe, oracle):
 
 
 def test_host_memory_results_through_the_staging_ring(torch_cuda, fe, oracle):
-    """Pageable results of 64 MiB and more leave HBM through the pinned ring that helper threads empty (api.hip stage_download): a
+    """Pageable results of 64 MiB and more leave HBM through the pinned ring that helper threads empty (host_stage.hip stage_download): a
     ragged size (no multiple of a slot, nor of the helpers' pieces), encode and transform, twice on one context (slots reused)."""
     N, S = 1 << 12, 4099  # 67.2 MB per stripe
     x = rand_stripe(np.random.default_rng(4242), N, S)
@@ -221,7 +221,7 @@ def test_host_memory_results_through_the_staging_ring(torch_cuda, fe, oracle):
 
 def test_host_memory_encode_pipelined_through_both_rings(torch_cuda, fe, oracle):
     """A 256 MiB stripe in pageable memory: column slab h goes up through one ring of pinned slots while slab h - 1 comes down through the
-    other (api.hip encode_host_pageable).  Same parity as the oracle, as the one-after-the-other sequence (option host_pipeline = 0, the default) and as
+    other (host_stage.hip encode_host_pageable).  Same parity as the oracle, as the one-after-the-other sequence (option host_pipeline = 0, the default) and as
     other slab counts; the data is left alone."""
     N, S = 1 << 16, 1024
     x = rand_stripe(np.random.default_rng(99), N, S)
