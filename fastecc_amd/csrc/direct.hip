@@ -719,10 +719,13 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
             p->frag_valid = true;
             p->mfma_pad = pad;
         }
-        // rows per chunk: about a thousand workgroups (four per CU) when the stripe is large enough for that
+        // rows per chunk: at least 512 workgroups (two rounds per CU: one workgroup of MT = 8 fills a CU) when the stripe is large enough for that.
+        // (1024 until round 6: half the prologues and epilogues — 256 accumulators read out per lane — are 4.5 % of the 64-output pass,
+        //  0.713 -> 0.681 ms; 256 is no better.  FASTECC_DIRECT_MIN_WGS overrides, for experiments.)
         const uint32_t col_groups = (S + 255u) / 256u, sweeps = (uint32_t)(pad / (8 * mt));
         uint32_t chunk_rows = 8u * MFMA_G * 8u;
-        while (chunk_rows < MFMA_ROWS && (uint64_t)(bulk / (2u * chunk_rows)) * col_groups * sweeps >= 1024u) chunk_rows *= 2u;
+        static const unsigned min_wgs = [] { const char* e = getenv("FASTECC_DIRECT_MIN_WGS"); return e ? (unsigned)atoi(e) : 512u; }();
+        while (chunk_rows < MFMA_ROWS && (uint64_t)(bulk / (2u * chunk_rows)) * col_groups * sweeps >= min_wgs) chunk_rows *= 2u;
         const uint32_t mchunks = (bulk + chunk_rows - 1) / chunk_rows;
         const uint32_t tail_chunks = rows > bulk ? (rows - bulk + TAIL_ROWS - 1) / TAIL_ROWS : 0;
         chunks = mchunks + tail_chunks;
