@@ -610,6 +610,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                    size_t cap, int split, int e)
 {
     if (e < 1 || e > 3 || (*slot && (*slot)->built && (*slot)->e != e)) return FASTECC_E_INVAL;
+    PhaseTimer pt_call;
     const uint64_t N = 1ull << log2k, NC = N << e, M = NC - N;
     if (NC > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
     std::vector<uint8_t> state(NC);
@@ -670,6 +671,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         erased.resize(count);
     }
     if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
+    pt_call.mark("pattern scan (host)");
 
     if (!*slot) {
         *slot = new (std::nothrow) Decoder();
@@ -887,6 +889,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         d->ready = true;
         return FASTECC_OK;
     }
+    pt_call.mark("set-up, uploads");
     D61_TRY(hipMemcpyAsync(d->erased, erased.data(), erased.size() * 4, hipMemcpyHostToDevice, s0));
     auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
     hipLaunchKernelGGL(k_roots, grid(T), dim3(256), 0, s0, d->roots, d->erased, d->wpow, (uint32_t)erased.size(), (uint32_t)T);
@@ -953,6 +956,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     //  caller holds — decode + re-encode restores only what state_real says is lost)
     if (d->split_ready || split_shift != 0) d->gout_all_valid = false;
     D61_TRY(hipStreamSynchronize(s0));
+    pt_call.mark("this pattern (device)");
     d->ready = true;
     return FASTECC_OK;
 }
