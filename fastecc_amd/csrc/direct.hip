@@ -255,13 +255,16 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // ABL (builds with -DFASTECC_DIRECT_ABLATION only; results are then WRONG on purpose): timing ablations that name the kernel's limiter —
 // bit 0: no row loads inside the loop, bit 1: no LDS reads of A fragments inside the loop, bit 2: no fragment staging (loads, LDS writes,
 // barrier) inside the loop, bit 3: no digit arithmetic.  profiles/r05/direct_mfma_ablation.jsonl.
-template <int MT, int ABL = 0, int NBX = 0>
-__global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_mfma_kernel(const MfmaArgs a)
+// MG = 2 (round 6): TWO groups of four waves per workgroup share the rows' columns and the staged fragments — waves 0-3 take the first MT M-tiles
+// of the sweep, waves 4-7 the next MT — so that 8 M-tiles (64 outputs) are one sweep at 128 accumulator registers per wave and TWO waves per SIMD:
+// the second group's row requests are the first group's (same addresses, the same CU's L1), and each wave reads only its own group's fragments.
+template <int MT, int ABL = 0, int NBX = 0, int MG = 1>
+__global__ __launch_bounds__(256 * MG, (MG == 2 ? 2 : MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_mfma_kernel(const MfmaArgs a)
 {
-    constexpr int G = MFMA_G, WN = G * MT / 4;  // uint4 of weight fragments per thread and stage
+    constexpr int G = MFMA_G, MTW = MT * MG, WN = G * MT / 4;  // M-tiles per workgroup; uint4 of weight fragments per thread and stage
     static_assert((G * MT) % 4 == 0, "stage size");
-    __shared__ uint4 wl[2][G * MT * 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint4 wl[2][G * MTW * 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (tid >> 6) & 3u, mg = tid >> 8;
     // workgroup b runs on XCD b % 8: all workgroups of a chunk — the column groups share its weight fragments, the sweeps its rows —
     // go to the same XCD (one L2) and are dispatched next to each other
     const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3;
@@ -278,12 +281,12 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
     const uint32_t stages = (ks1 - ks0) / G;
     const uint32_t step_bytes = a.mt_total * 1024u;  // fragments of one step, all M-tiles
     const __amdgpu_buffer_rsrc_t rows_desc = direct_desc(a.data + (size_t)ks0 * 8u * a.S, (ks1 - ks0) * 8u * row_bytes);
-    const __amdgpu_buffer_rsrc_t frag_desc = direct_desc(a.frag + ((size_t)ks0 * a.mt_total + (size_t)sweep * MT) * 64u, (ks1 - ks0 + G) * step_bytes);
+    const __amdgpu_buffer_rsrc_t frag_desc = direct_desc(a.frag + ((size_t)ks0 * a.mt_total + (size_t)sweep * MTW) * 64u, (ks1 - ks0 + G) * step_bytes);
     uint32_t wv[WN];  // where this thread's share of a stage's fragments sits, relative to the stage's first step
 #pragma unroll
     for (int q = 0; q < WN; ++q) {
-        const uint32_t e = q * 256u + tid;
-        wv[q] = (e / (MT * 64u)) * step_bytes + (e % (MT * 64u)) * 16u;
+        const uint32_t e = q * (256u * MG) + tid;
+        wv[q] = (e / (MTW * 64u)) * step_bytes + (e % (MTW * 64u)) * 16u;
     }
     v16i acc[MT][2];
 #pragma unroll
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
             for (int i = 0; i < 4; ++i) x[nb][g][i] = __builtin_amdgcn_raw_buffer_load_b64(rows_desc, voff, (8u * (st0 * G + g) + i) * row_bytes, 0);
     }
 #pragma unroll
-    for (int q = 0; q < WN; ++q) wl[0][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
+    for (int q = 0; q < WN; ++q) wl[0][q * (256u * MG) + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
     __syncthreads();
     for (uint32_t s0 = 0; s0 < stages; s0 += NB) {
 #pragma unroll
@@ -327,8 +330,9 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
                 // runs while this wave sits in an s_waitcnt, and one fragment ahead (two MFMAs = 64 cycles) is about the latency of a ds_read_b128
                 constexpr int PF = 3, RING = 4;
                 uint4 af[RING];
+                auto frag_at = [&](int t) { return wcur[((t / MT) * MTW + mg * MT + (t % MT)) * 64 + lane]; };  // step t / MT, this group's M-tile t % MT
 #pragma unroll
-                for (int t = 0; t < PF && t < G * MT; ++t) af[t] = wcur[t * 64 + lane];
+                for (int t = 0; t < PF && t < G * MT; ++t) af[t] = frag_at(t);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     v4i bf[2];
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int t = g * MT + mt;
-                        if (t + PF < G * MT && !(ABL & 2)) af[(t + PF) % RING] = wcur[(t + PF) * 64 + lane];
+                        if (t + PF < G * MT && !(ABL & 2)) af[(t + PF) % RING] = frag_at(t + PF);
                         v4i av;
                         av[0] = (int)af[t % RING].x; av[1] = (int)af[t % RING].y; av[2] = (int)af[t % RING].z; av[3] = (int)af[t % RING].w;
                         acc[mt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[0], acc[mt][0], 0, 0, 0);
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(ABL & 4)) {
 #pragma unroll
-                    for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * 256u + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
+                    for (int q = 0; q < WN; ++q) wl[(s + 1) & 1u][q * (256u * MG) + tid] = make_uint4(wreg[q][0], wreg[q][1], wreg[q][2], wreg[q][3]);
                     __syncthreads();
                 }
             }
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 3 : MT <= 4 ? 2 : 1)) void direct_m
                 const uint32_t tl = (uint32_t)t, th = (uint32_t)(t >> 32);  // th < 2^26
                 r[c] = gf::add(gf::mul(th, gf::MONT_ONE), tl >= gf::P ? tl - gf::P : tl);
             }
-            const uint32_t out = sweep * (8u * MT) + 8u * mt + 2u * q + half;
+            const uint32_t out = sweep * (8u * MTW) + 8u * (mg * MT + mt) + 2u * q + half;
             if (live) *reinterpret_cast<uint2*>(a.partial + ((size_t)chunk * a.pad + out) * a.S + col) = make_uint2(r[0], r[1]);
             __builtin_amdgcn_sched_barrier(0);  // one output at a time: 256 accumulators are not all read out before the first store
         }
@@ -707,6 +711,11 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
 #else
         const int mt = p->outputs <= 16 ? 2 : p->outputs <= 32 ? 4 : 8;
 #endif
+        // above 32 outputs: 8 M-tiles per wave, one wave per SIMD.  FASTECC_DIRECT_MG=2 (experiments): 8 M-tiles per workgroup as two groups of 4
+        // (512 threads, two waves per SIMD, still ONE sweep over the rows) — measured SLOWER, 0.74 against 0.67 ms at 64 outputs, 1.33 against 1.23 at
+        // 128 (profiles/r06/direct_mfma_two_groups.jsonl): two waves on a SIMD take matrix-pipe time from each other, as the butterfly stage found
+        static const int mg_env = [] { const char* e = getenv("FASTECC_DIRECT_MG"); return e ? atoi(e) : 1; }();
+        const bool two_groups = mt == 8 && mg_env == 2;
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
         const uint32_t steps_alloc = bulk / 8u + MFMA_G;  // zero steps at the end: the prefetch of a stage never leaves the table
@@ -758,7 +767,12 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
                 break;
             }
 #else
-                hipLaunchKernelGGL(direct_mfma_kernel<8>, grid, dim3(256), 0, st, a);
+                if (two_groups) {
+                    static const int nb_env = [] { const char* e = getenv("FASTECC_DIRECT_NB"); return e ? atoi(e) : 1; }();  // (experiment knob: row buffers in flight)
+                    if (nb_env == 2) hipLaunchKernelGGL((direct_mfma_kernel<4, 0, 2, 2>), grid, dim3(512), 0, st, a);
+                    else hipLaunchKernelGGL((direct_mfma_kernel<4, 0, 1, 2>), grid, dim3(512), 0, st, a);
+                }
+                else hipLaunchKernelGGL(direct_mfma_kernel<8>, grid, dim3(256), 0, st, a);
                 break;
 #endif
         }
