@@ -685,6 +685,14 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     d->elems = elems;
     d->erased_data = erased_data;
     d->erased_parity = erased_parity;
+    if (erased_parity == 0) {
+        // fastecc_repair's re-encode stripes (n - k and, for n = 4k / 8k, k more blocks: up to 32 + 8 GiB at 2^17 x 64 KB) are only held while the
+        // pattern has lost parity blocks; the caller has waited for the last call that used them
+        for (uint64_t** b : {&d->again, &d->cos_work}) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
+    }
     d->split_ready = false;
     d->split_repair_ready = false;
     d->split_shift = 0;
