@@ -693,6 +693,16 @@ static int launch_accumulate(DirectPass* p, const uint32_t* data, const uint32_t
 }
 
 // kernel: 0 = choose, 1 = VALU kernel, 2 = MFMA kernel (when its alignment requirements hold)
+// Experiment knobs of the matrix-core pass (FASTECC_DIRECT_MIN_WGS, FASTECC_DIRECT_MG, FASTECC_DIRECT_NB): read once; a set one announces itself on stderr,
+// so that a stray exported variable cannot change production timings silently.
+static int experiment_knob(const char* name, int fallback)
+{
+    const char* e = getenv(name);
+    if (!e) return fallback;
+    fprintf(stderr, "[fastecc direct] EXPERIMENT KNOB ACTIVE: %s=%s (default %d)\n", name, e, fallback);
+    return atoi(e);
+}
+
 int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint32_t* data_out, uint32_t* parity_out, uint32_t S, int kernel, hipStream_t st)
 {
     if (!p || !p->built) return FASTECC_E_INVAL;
@@ -714,7 +724,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
         // above 32 outputs: 8 M-tiles per wave, one wave per SIMD.  FASTECC_DIRECT_MG=2 (experiments): 8 M-tiles per workgroup as two groups of 4
         // (512 threads, two waves per SIMD, still ONE sweep over the rows) — measured SLOWER, 0.74 against 0.67 ms at 64 outputs, 1.33 against 1.23 at
         // 128 (profiles/r06/direct_mfma_two_groups.jsonl): two waves on a SIMD take matrix-pipe time from each other, as the butterfly stage found
-        static const int mg_env = [] { const char* e = getenv("FASTECC_DIRECT_MG"); return e ? atoi(e) : 1; }();
+        static const int mg_env = experiment_knob("FASTECC_DIRECT_MG", 1);
         const bool two_groups = mt == 8 && mg_env == 2;
         pad = (p->outputs + 8 * mt - 1) / (8 * mt) * (8 * mt);
         const uint32_t mt_total = (uint32_t)pad / 8u;
@@ -733,7 +743,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
         //  0.713 -> 0.681 ms; 256 is no better.  FASTECC_DIRECT_MIN_WGS overrides, for experiments.)
         const uint32_t col_groups = (S + 255u) / 256u, sweeps = (uint32_t)(pad / (8 * mt));
         uint32_t chunk_rows = 8u * MFMA_G * 8u;
-        static const unsigned min_wgs = [] { const char* e = getenv("FASTECC_DIRECT_MIN_WGS"); return e ? (unsigned)atoi(e) : 512u; }();
+        static const unsigned min_wgs = (unsigned)experiment_knob("FASTECC_DIRECT_MIN_WGS", 512);
         while (chunk_rows < MFMA_ROWS && (uint64_t)(bulk / (2u * chunk_rows)) * col_groups * sweeps >= min_wgs) chunk_rows *= 2u;
         const uint32_t mchunks = (bulk + chunk_rows - 1) / chunk_rows;
         const uint32_t tail_chunks = rows > bulk ? (rows - bulk + TAIL_ROWS - 1) / TAIL_ROWS : 0;
@@ -768,7 +778,7 @@ int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint
             }
 #else
                 if (two_groups) {
-                    static const int nb_env = [] { const char* e = getenv("FASTECC_DIRECT_NB"); return e ? atoi(e) : 1; }();  // (experiment knob: row buffers in flight)
+                    static const int nb_env = experiment_knob("FASTECC_DIRECT_NB", 1);  // (row buffers in flight)
                     if (nb_env == 2) hipLaunchKernelGGL((direct_mfma_kernel<4, 0, 2, 2>), grid, dim3(512), 0, st, a);
                     else hipLaunchKernelGGL((direct_mfma_kernel<4, 0, 1, 2>), grid, dim3(512), 0, st, a);
                 }
