@@ -39,6 +39,7 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 enum : uint32_t { ST_LOST = 0, ST_HELD = 1 };
 constexpr int LEAF_LOG = 4, LEAF = 1 << LEAF_LOG;
+constexpr int TREE_LOW = 8;  // tall trees: the polynomials of 2^TREE_LOW roots come from one kernel (k_tree_low) instead of four more levels of six to eight launches
 
 __device__ __forceinline__ Elem ld(const uint64_t* p)
 {
@@ -86,6 +87,40 @@ __global__ __launch_bounds__(256) void k_wpow(uint64_t* __restrict__ wpow, uint6
     st(wpow + 2ull * u, powc(Elem{wre, wim}, u, k));
 }
 
+// the lost positions listed on the device: sixteen positions per thread, one atomic per workgroup (the order of the list between workgroups is not
+// fixed; the locator is a product over the list and does not depend on it)
+__global__ __launch_bounds__(256) void k_erased_list(const uint8_t* __restrict__ state, uint32_t NC, uint32_t* __restrict__ erased, uint32_t* __restrict__ counter)
+{
+    __shared__ uint32_t wave_sum[4], block_base;
+    const uint32_t u0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    uint32_t bits = 0;
+    if (u0 + 16u <= NC) {
+        const uint4 v = *reinterpret_cast<const uint4*>(state + u0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bits |= (uint32_t)(((w[i >> 2] >> (8 * (i & 3))) & 0xFFu) == ST_LOST) << i;
+    } else {
+        for (uint32_t i = 0; i < 16u && u0 + i < NC; ++i) bits |= (uint32_t)(state[u0 + i] == ST_LOST) << i;
+    }
+    const uint32_t mine = (uint32_t)__builtin_popcount(bits), lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    if (lane == 63u) wave_sum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        block_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = block_base + incl - mine;
+    for (uint32_t w = 0; w < wave; ++w) at += wave_sum[w];
+    for (uint32_t b = bits; b; b &= b - 1u) erased[at++] = u0 + (uint32_t)__builtin_ctz(b);
+}
+
 __global__ __launch_bounds__(256) void k_roots(uint64_t* __restrict__ roots, const uint32_t* __restrict__ erased, const uint64_t* __restrict__ wpow,
                                                uint32_t n_erased, uint32_t T)
 {
@@ -116,23 +151,59 @@ __global__ __launch_bounds__(64) void k_leaves(const uint64_t* __restrict__ root
     for (uint32_t i = 0; i < leaf; ++i) st(x + 2ull * ((uint64_t)i * m + p), c[i]);
 }
 
-// y[i][q] = f[i][2q] * f[i][2q+1] * scale for q < m/2, zero for the other columns (rows of m elements)
+// The lowest LOW levels of the product tree in one kernel (as decode.hip's tree_low_levels_kernel): a workgroup takes 2^LOW roots, multiplies the
+// monic polynomials pairwise in LDS by the schoolbook rule, degree 1 -> 2 -> ... -> 2^LOW ((x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b), one
+// thread per coefficient, and writes coefficient i of polynomial p to x[i * m + p] (the upper half of the 2 * 2^LOW rows is zero).
+template <int LOW>
+__global__ __launch_bounds__(1 << LOW) void k_tree_low(const uint64_t* __restrict__ roots, uint64_t* __restrict__ x, uint32_t m)
+{
+    constexpr uint32_t R = 1u << LOW;
+    __shared__ uint64_t bre[2][R], bim[2][R];
+    const uint32_t p = blockIdx.x, o = threadIdx.x;
+    const gf61::Opaque k = gf61::make_opaque();
+    {
+        const Elem r = ld(roots + 2ull * ((uint64_t)p * R + o));
+        bre[0][o] = subc(0, r.re);  // x - r
+        bim[0][o] = subc(0, r.im);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < R; d <<= 1) {
+        const uint32_t t = o & (2u * d - 1u), a0 = o - t, b0 = a0 + d;
+        const uint32_t lo_i = t >= d ? t - d + 1u : 0u, hi_i = t < d ? t : d - 1u;
+        Elem acc{0, 0};
+        if (t >= d) acc = addc(Elem{bre[cur][a0 + t - d], bim[cur][a0 + t - d]}, Elem{bre[cur][b0 + t - d], bim[cur][b0 + t - d]});
+        for (uint32_t i = lo_i; i <= hi_i; ++i)  // (t = 2d - 1: lo_i > hi_i, no product)
+            acc = addc(acc, mulc(Elem{bre[cur][a0 + i], bim[cur][a0 + i]}, Elem{bre[cur][b0 + t - i], bim[cur][b0 + t - i]}, k));
+        bre[cur ^ 1][o] = acc.re;
+        bim[cur ^ 1][o] = acc.im;
+        __syncthreads();
+        cur ^= 1;
+    }
+    st(x + 2ull * ((uint64_t)o * m + p), Elem{bre[cur][o], bim[cur][o]});
+}
+
+// y[i][q] = f[i'][2q] * f[i'][2q+1] * scale for q < m/2, zero for the other columns (rows of m elements).  The transforms stay in the order
+// their DIF passes leave (dif_only: no reordering pass, 29 launches of 10 us per pattern in round 5): the value for point i is in row
+// i' = bitrev(i) of f; y is written in natural order, which is what the way back's DIF passes read.
 __global__ __launch_bounds__(256) void k_pairs(const uint64_t* __restrict__ f, uint64_t* __restrict__ y, uint32_t m, uint64_t total, uint64_t sre,
-                                               uint64_t sim)
+                                               uint64_t sim, int lg)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const gf61::Opaque k = gf61::make_opaque();
     const uint64_t i = t / m;
     const uint32_t q = (uint32_t)(t - i * m);
+    const uint64_t ir = __brev((uint32_t)i) >> (32 - lg);
     Elem v{0, 0};
-    if (q < m / 2) v = mulc(mulc(ld(f + 2 * (i * m + 2 * q)), ld(f + 2 * (i * m + 2 * q + 1)), k), Elem{sre, sim}, k);
+    if (q < m / 2) v = mulc(mulc(ld(f + 2 * (ir * m + 2 * q)), ld(f + 2 * (ir * m + 2 * q + 1)), k), Elem{sre, sim}, k);
     st(y + 2 * (i * m + q), v);
 }
 
 // (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b: xnew [4d][m/2] (upper 2d rows zero) from the cyclic products y (rows of m) and xold [d][m]
+// (y: the cyclic products as the way back's DIF passes leave them — coefficient i in row bitrev(i) of its 2d rows)
 __global__ __launch_bounds__(256) void k_combine(const uint64_t* __restrict__ y, const uint64_t* __restrict__ xold, uint64_t* __restrict__ xnew,
-                                                 uint32_t d, uint32_t m, uint64_t total, bool top)
+                                                 uint32_t d, uint32_t m, uint64_t total, bool top, int lg)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -141,7 +212,7 @@ __global__ __launch_bounds__(256) void k_combine(const uint64_t* __restrict__ y,
     const uint32_t q = (uint32_t)(t - i * half);
     Elem v{0, 0};
     if (i < 2ull * d) {
-        v = ld(y + 2 * (i * m + q));
+        v = ld(y + 2 * ((uint64_t)(__brev((uint32_t)i) >> (32 - lg)) * m + q));
         if (i >= d) v = addc(v, addc(ld(xold + 2 * ((i - d) * m + 2 * q)), ld(xold + 2 * ((i - d) * m + 2 * q + 1))));
     } else if (top) {
         return;
@@ -170,18 +241,19 @@ __global__ __launch_bounds__(256) void k_locator_columns(const uint64_t* __restr
 // l = L w^(-u pad) on the points (the padding), see decode.hip finish_tables_kernel
 __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv, const uint8_t* __restrict__ state, const uint64_t* __restrict__ wpow,
                                                 uint64_t* __restrict__ fin, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad,
-                                                uint64_t* __restrict__ gout_all, int e = 1)
+                                                uint64_t* __restrict__ gout_all, int e, int lg_nc)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NC) return;
     const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t ur = lg_nc ? (__brev(u) >> (32 - lg_nc)) : 0;  // lv keeps the order its transform's DIF passes leave: the value for w^u in row bitrev(u)
     const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
     const Elem corr = ld(wpow + 2ull * (back == 0 ? 0 : NC - back));
     const bool held = state[u] == ST_HELD;
-    st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * u), corr, k) : Elem{0, 0});
+    st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * ur), corr, k) : Elem{0, 0});
     const bool data_pos = (u & ((1u << e) - 1u)) == 0;  // data block i sits at position i << e (e = 1: the (2k,k) code; 2, 3: n = 4k, 8k)
     if (data_pos || gout_all) {
-        const Elem g = held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * u + 2), corr, k), k);
+        const Elem g = held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * ur + 2), corr, k), k);
         if (data_pos) st(gout + 2ull * (u >> e), g);
         if (gout_all) st(gout_all + 2ull * u, g);  // every lost position, parity too: fastecc_repair in one transform
     }
@@ -614,25 +686,32 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     const uint64_t N = 1ull << log2k, NC = N << e, M = NC - N;
     if (NC > 0x7FFFFFFFull) return FASTECC_E_UNSUPPORTED;
     std::vector<uint8_t> state(NC);
-    std::vector<uint32_t> erased(NC + 1);
     std::vector<uint32_t> srcmap(e > 1 ? NC : 0);
     std::vector<uint8_t> plost(e > 1 ? M : 0);
     uint64_t erased_data = 0, erased_parity = 0;
-    for (uint64_t i = 0; i < N; i++) {
-        state[i << e] = data_present[i] ? ST_HELD : ST_LOST;
-        erased_data += !data_present[i];
-        if (e > 1) srcmap[i << e] = (uint32_t)i;
-    }
-    for (uint64_t q = 0; q < M; q++) {
-        // parity block q = block j of coset t: generator w_(2^jt k)^c, jt = floor(log2(t + 1)) + 1, c the (t + 2 - 2^(jt-1))-th odd number (include/fastecc.h)
-        const uint64_t t = q >> log2k, j = q & (N - 1);
-        int jt = 1;
-        while ((1ull << jt) - 1 <= t) jt++;
-        const uint64_t c = 2 * (t + 1 - (1ull << (jt - 1))) + 1;
-        const uint64_t u = (c << (e - jt)) + (j << e);
-        state[u] = parity_present[q] ? ST_HELD : ST_LOST;
-        erased_parity += !parity_present[q];
-        if (e > 1) {
+    if (e == 1) {  // data block i at 2i, parity block j at 2j + 1: one interleaving pass
+        for (uint64_t i = 0; i < N; i++) {
+            const uint8_t a = data_present[i] != 0, b = parity_present[i] != 0;
+            state[2 * i] = a ? ST_HELD : ST_LOST;
+            state[2 * i + 1] = b ? ST_HELD : ST_LOST;
+            erased_data += !a;
+            erased_parity += !b;
+        }
+    } else {
+        for (uint64_t i = 0; i < N; i++) {
+            state[i << e] = data_present[i] ? ST_HELD : ST_LOST;
+            erased_data += !data_present[i];
+            srcmap[i << e] = (uint32_t)i;
+        }
+        for (uint64_t q = 0; q < M; q++) {
+            // parity block q = block j of coset t: generator w_(2^jt k)^c, jt = floor(log2(t + 1)) + 1, c the (t + 2 - 2^(jt-1))-th odd number (include/fastecc.h)
+            const uint64_t t = q >> log2k, j = q & (N - 1);
+            int jt = 1;
+            while ((1ull << jt) - 1 <= t) jt++;
+            const uint64_t c = 2 * (t + 1 - (1ull << (jt - 1))) + 1;
+            const uint64_t u = (c << (e - jt)) + (j << e);
+            state[u] = parity_present[q] ? ST_HELD : ST_LOST;
+            erased_parity += !parity_present[q];
             srcmap[u] = (uint32_t)q | 0x80000000u;
             plost[q] = !parity_present[q];
         }
@@ -643,34 +722,34 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     // ---- even / odd split: recovering e data blocks takes e parity blocks, so the others may count as erased too; take them at multiples of 2^h of
     // the parity half (largest h <= 5 that leaves enough survivors) and the parity half's transform shrinks to k >> h rows ----
-    const std::vector<uint8_t> state_real = state;
+    std::vector<uint8_t> state_real;  // the caller's flags, kept apart only when the split marks parity blocks as unused
     int split_shift = 0;
     const bool few = erased_data + erased_parity != 0 && (int)(erased_data + erased_parity) <= std::min(direct_max, 16);
     if (split && log2k >= 11 && erased_data != 0 && !few && !(*slot && (*slot)->split_unavailable)) {
         uint64_t at_multiple[6] = {};
-        for (uint64_t j = 0; j < N; j++)
-            if (parity_present[j])
-                for (int h = 1; h <= 5 && (j & ((1ull << h) - 1)) == 0; h++) at_multiple[h]++;
+        uint64_t by_zeros[6] = {};  // parity blocks held, by the trailing zeros of their index (capped at 5)
+        for (uint64_t j = 0; j < N; j += 2) by_zeros[__builtin_ctzll(j | 32)] += parity_present[j] != 0;
+        for (int h = 5; h >= 1; h--) at_multiple[h] = by_zeros[h] + (h < 5 ? at_multiple[h + 1] : 0);
         // (a pattern that has lost parity blocks too may be REPAIRED: the split then runs a second MID + DIT chain for the odd positions — or, without
         //  the memory for its extra stripe, re-encodes — see decode())
         const int h_min = 1;
         for (int h = 5; h >= h_min && split_shift == 0; h--)
             if (at_multiple[h] >= erased_data) split_shift = h;
         if (split_shift != 0) {
+            state_real = state;
             const uint64_t mask = (1ull << split_shift) - 1;
             for (uint64_t j = 0; j < N; j++)
                 if (j & mask) state[2 * j + 1] = ST_LOST;  // not in use: a root of the locator like a lost one (nothing of it is rebuilt from this state)
         }
     }
-    {
-        uint64_t count = 0;  // branch-free: on a random pattern an "if (lost) push_back" mispredicts at every other position
-        for (uint64_t u = 0; u < NC; u++) {
-            erased[count] = (uint32_t)u;
-            count += state[u] == ST_LOST;
-        }
-        erased.resize(count);
-    }
-    if (erased.size() > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
+    // the positions themselves are listed on the device (k_erased_list); the host needs their number, and the list itself only for the few-loss path
+    uint64_t n_erased = 0;
+    for (uint64_t u = 0; u < NC; u++) n_erased += state[u] == ST_LOST;
+    if (n_erased > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
+    std::vector<uint32_t> erased;
+    if (n_erased != 0 && (int64_t)n_erased <= std::min(direct_max, DIRECT_MAX))
+        for (uint64_t u = 0; u < NC; u++)
+            if (state[u] == ST_LOST) erased.push_back((uint32_t)u);
     pt_call.mark("pattern scan (host)");
 
     if (!*slot) {
@@ -700,7 +779,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     d->M = M;
     const uint64_t T = e == 1 ? N : NC;  // a power of two >= n - k, the most losses the code tolerates (3k -> 4k, 7k -> 8k: the roots beyond are padding)
     int lgT = e == 1 ? log2k : log2k + e;
-    const int leaf_log = std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
+    const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
 
     d->direct = 0;
     if (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX)) {
@@ -814,7 +893,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         D61_TRY(hipMalloc((void**)&d->lv, NC * 32));
         D61_TRY(hipMalloc((void**)&d->fin, NC * 16));
         D61_TRY(hipMalloc((void**)&d->gout, N * 16));
-        D61_TRY(hipMalloc((void**)&d->erased, T * 4));
+        D61_TRY(hipMalloc((void**)&d->erased, (T + 1) * 4));  // the list and its counter
         D61_TRY(hipMalloc((void**)&d->state, NC));
         if (e > 1) {
             D61_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
@@ -839,7 +918,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     // (the caller has waited for the last decode that used the previous pattern)
     D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
     if (!d->state_real) D61_TRY(hipMalloc((void**)&d->state_real, NC));
-    D61_TRY(hipMemcpyAsync(d->state_real, state_real.data(), NC, hipMemcpyHostToDevice, s0));
+    D61_TRY(hipMemcpyAsync(d->state_real, (state_real.empty() ? state : state_real).data(), NC, hipMemcpyHostToDevice, s0));
     if (e > 1) {
         D61_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, s0));  // (fixed per code; cheap next to the locator)
         D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, s0));
@@ -898,28 +977,29 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         return FASTECC_OK;
     }
     pt_call.mark("set-up, uploads");
-    D61_TRY(hipMemcpyAsync(d->erased, erased.data(), erased.size() * 4, hipMemcpyHostToDevice, s0));
     auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
-    hipLaunchKernelGGL(k_roots, grid(T), dim3(256), 0, s0, d->roots, d->erased, d->wpow, (uint32_t)erased.size(), (uint32_t)T);
+    D61_TRY(hipMemsetAsync(d->erased + T, 0, 4, s0));
+    hipLaunchKernelGGL(k_erased_list, grid((NC + 15) / 16), dim3(256), 0, s0, d->state, (uint32_t)NC, d->erased, d->erased + T);
+    hipLaunchKernelGGL(k_roots, grid(T), dim3(256), 0, s0, d->roots, d->erased, d->wpow, (uint32_t)n_erased, (uint32_t)T);
     D61_TRY(hipMemsetAsync(d->tree_x, 0, 2 * T * 16, s0));
-    hipLaunchKernelGGL(k_leaves, dim3((unsigned)(((T >> leaf_log) + 63) / 64)), dim3(64), 0, s0, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
+    if (leaf_log == TREE_LOW) hipLaunchKernelGGL(k_tree_low<TREE_LOW>, dim3((unsigned)(T >> leaf_log)), dim3(1 << TREE_LOW), 0, s0, d->roots, d->tree_x, (uint32_t)(T >> leaf_log));
+    else hipLaunchKernelGGL(k_leaves, dim3((unsigned)(((T >> leaf_log) + 63) / 64)), dim3(64), 0, s0, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
     D61_TRY(hipGetLastError());
     // three 2T-element buffers change roles level by level: a = this level's polynomials [2 deg][m] (rows deg.. zero),
     // b = their transforms and then the next level's polynomials, c = the pairwise products
     uint64_t *a = d->tree_x, *b = d->tree_f, *c = d->tree_y;
     for (int k = leaf_log; k < lgT; k++) {
         const uint64_t deg = 1ull << k, m = T >> k;
-        D61_TRY(hipMemcpyAsync(b, a, 2 * T * 16, hipMemcpyDeviceToDevice, s0));  // a survives for the combine step
-        int rc = ntt(d->tree[k], b, false, s0, nullptr);                          // all m polynomials at once
+        int rc = dif_only_to(d->tree[k], a, b, false, s0, nullptr);  // all m polynomials at once, a -> b (a survives for the combine step); no reordering pass
         if (rc != FASTECC_OK) return rc;
         const gf61::Elem scale = gf61::h_inv(gf61::Elem{(2 * deg) % P, 0});
-        hipLaunchKernelGGL(k_pairs, grid(2 * deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, 2 * deg * m, scale.re, scale.im);
+        hipLaunchKernelGGL(k_pairs, grid(2 * deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, 2 * deg * m, scale.re, scale.im, k + 1);
         D61_TRY(hipGetLastError());
-        rc = ntt(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero)
+        rc = dif_only(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero), left in bit-reversed row order
         if (rc != FASTECC_OK) return rc;
         const bool top = k + 1 == lgT;
         const uint64_t rows = top ? 2 * deg : 4 * deg;
-        hipLaunchKernelGGL(k_combine, grid(rows * (m / 2)), dim3(256), 0, s0, c, a, b, (uint32_t)deg, (uint32_t)m, rows * (m / 2), top);
+        hipLaunchKernelGGL(k_combine, grid(rows * (m / 2)), dim3(256), 0, s0, c, a, b, (uint32_t)deg, (uint32_t)m, rows * (m / 2), top, k + 1);
         D61_TRY(hipGetLastError());
         std::swap(a, b);
     }
@@ -927,7 +1007,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     hipLaunchKernelGGL(k_locator_columns, grid(NC), dim3(256), 0, s0, x, d->lv, (uint32_t)T, (uint32_t)NC);
     D61_TRY(hipGetLastError());
     {
-        const int rc = ntt(d->pattern, d->lv, false, s0, nullptr);
+        const int rc = dif_only(d->pattern, d->lv, false, s0, nullptr);  // (k_finish reads the values where the DIF passes leave them)
         if (rc != FASTECC_OK) return rc;
     }
     d->gout_all_valid = false;
@@ -939,8 +1019,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         }
         d->gout_all_valid = d->gout_all != nullptr;
     }
-    hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - erased.size()),
-                       d->gout_all_valid ? d->gout_all : nullptr, e);
+    hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - n_erased),
+                       d->gout_all_valid ? d->gout_all : nullptr, e, log2k + e);
     D61_TRY(hipGetLastError());
     if (d->split_ready && d->gout_all_valid) {
         // the second chain's tables: the factor of q~ by position (once) and the lost parity blocks' output factors (this pattern)

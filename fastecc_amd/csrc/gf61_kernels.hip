@@ -1367,6 +1367,12 @@ int dif_only(Path* p, uint64_t* data, bool inverse, hipStream_t st, const Launch
     const uint64_t* tw = inverse ? (p->tw_ntt_inv ? p->tw_ntt_inv : p->tw_inv) : (p->tw_ntt_fwd ? p->tw_ntt_fwd : p->tw_fwd);
     return run_passes(p, p->fwd, data, data, tw, tw, inverse, st, hooks);
 }
+// ... from `in` into another stripe `out` (the first pass reads `in`, the others run in place on `out`)
+int dif_only_to(Path* p, const uint64_t* in, uint64_t* out, bool inverse, hipStream_t st, const LaunchHooks* hooks)
+{
+    const uint64_t* tw = inverse ? (p->tw_ntt_inv ? p->tw_ntt_inv : p->tw_inv) : (p->tw_ntt_fwd ? p->tw_ntt_fwd : p->tw_fwd);
+    return run_passes(p, p->fwd, in, out, tw, tw, inverse, st, hooks);
+}
 
 // The split decoder's data chain on a FACTOR_SPLIT path of size k (gf61_decode.hip): DIF passes over data[i] * rows_factor[i * rows_stride] (into
 // `work`, then in place), MID with + addend[p >> shift] * addend_factor[p] between its halves, DIT passes, the last of which stores only the rows

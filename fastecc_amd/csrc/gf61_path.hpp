@@ -66,6 +66,7 @@ int encode_columns(Path* p, const uint64_t* data, uint64_t* parity, uint64_t col
 int ntt(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);
 // the same without the closing block permutation: block q of the result holds coefficient bitrev(q)
 int dif_only(Path* p, uint64_t* data, bool inverse, hipStream_t st, const LaunchHooks* hooks);
+int dif_only_to(Path* p, const uint64_t* in, uint64_t* out, bool inverse, hipStream_t st, const LaunchHooks* hooks);  // the same, out of place
 // ---- the decoder's even / odd split (gf61_decode.hip): the data chain on a path made with FACTOR_SPLIT ----
 bool split_decode_supported(const Path* p);
 int split_decode(Path* p, const uint64_t* data, const uint64_t* rows_factor, uint32_t rows_stride, const uint64_t* addend, int addend_shift,
