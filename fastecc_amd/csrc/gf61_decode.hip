@@ -121,12 +121,85 @@ __global__ __launch_bounds__(256) void k_erased_list(const uint8_t* __restrict__
     for (uint32_t b = bits; b; b &= b - 1u) erased[at++] = u0 + (uint32_t)__builtin_ctz(b);
 }
 
+// even / odd split: the parity blocks not at multiples of 2^h are not in use — roots of the locator like the lost ones (nothing of them is
+// rebuilt from this state; state_real keeps the caller's flags)
+__global__ __launch_bounds__(256) void k_mark_unused(uint8_t* __restrict__ state, uint32_t N, uint32_t mask)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N && (j & mask) != 0) state[2u * j + 1u] = ST_LOST;
+}
+
 __global__ __launch_bounds__(256) void k_roots(uint64_t* __restrict__ roots, const uint32_t* __restrict__ erased, const uint64_t* __restrict__ wpow,
                                                uint32_t n_erased, uint32_t T)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T) return;
     st(roots + 2ull * i, i < n_erased ? ld(wpow + 2ull * erased[i]) : Elem{0, 0});
+}
+
+// ---- transforms of FEW columns (the locator tree's upper levels: 2, 4, .. polynomials side by side; the pattern transform: 2 columns) ----
+// The stripe kernels give every wave 64 columns of one row: with E < 64 columns most lanes idle and a row is a 16 E-byte access.  Here the rows x E
+// array is taken as N1 x (N2 E) with N2 E = 2^CHUNK_LOG: (1) an N1-point DIF over the upper row bits by the stripe kernels, the N2 E elements of a
+// chunk being its columns (twiddles uniform per row, as those kernels want them); (2) this kernel, one workgroup per chunk c = bitrev(k1): times
+// w_N^(i2 k1) (the four-step method's diagonal), then the N2-point DIF over i2 inside LDS, twiddles per lane from the w^u table.  Row k1 + N1 k2
+// of the transform ends up at row bitrev(k1 + N1 k2), where the stripe kernels' DIF passes alone would leave it.
+constexpr int CHUNK_LOG = 12, CHUNK = 1 << CHUNK_LOG;
+constexpr uint64_t NARROW_COLUMNS = 8;  // tree levels of at most this many polynomials go this way
+template <bool INV>
+__global__ __launch_bounds__(256) void k_chunk_dif(uint64_t* __restrict__ data, const uint64_t* __restrict__ wpow, int logE, int logN1, uint32_t step_n,
+                                                   uint32_t step_n2, uint32_t nc_mask)
+{
+    __shared__ u64x2 lds[CHUNK];
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint32_t tid = threadIdx.x, k1 = __brev(blockIdx.x) >> (32 - logN1);
+    uint64_t* base = data + 2ull * CHUNK * blockIdx.x;
+    auto twiddle = [&](uint32_t ex) { return ld(wpow + 2ull * (INV ? (0u - ex) & nc_mask : ex)); };
+    auto put = [&](uint32_t i, Elem v) {
+        u64x2 t;
+        t.x = v.re;
+        t.y = v.im;
+        lds[i] = t;
+    };
+    auto get = [&](uint32_t i) {
+        const u64x2 t = lds[i];
+        return Elem{t.x, t.y};
+    };
+    auto butterfly = [&](Elem& x, Elem& y, uint32_t ex) {
+        const Elem s = addc(x, y), t{subc(x.re, y.re), subc(x.im, y.im)};
+        x = s;
+        y = mulc(t, twiddle(ex), k);
+    };
+    const int levels = CHUNK_LOG - logE;  // of the N2-point transform
+    // the diagonal and the first level on the way in: a thread takes i and i + CHUNK / 2
+#pragma unroll 2
+    for (int r = 0; r < CHUNK / 512; ++r) {
+        const uint32_t i = r * 256u + tid, j = i + CHUNK / 2;
+        Elem x = mulc(ld(base + 2ull * i), twiddle((i >> logE) * k1 * step_n), k);
+        Elem y = mulc(ld(base + 2ull * j), twiddle((j >> logE) * k1 * step_n), k);
+        butterfly(x, y, (i >> logE) * step_n2);
+        put(i, x);
+        put(j, y);
+    }
+    __syncthreads();
+    for (int l = 1; l < levels; ++l) {
+        const int hb = CHUNK_LOG - 1 - l;
+        const uint32_t low = (1u << hb) - 1u;
+        const bool last = l + 1 == levels;
+#pragma unroll 2
+        for (int r = 0; r < CHUNK / 512; ++r) {
+            const uint32_t b = r * 256u + tid, i = ((b >> hb) << (hb + 1)) | (b & low), j = i + low + 1u;
+            Elem x = get(i), y = get(j);
+            butterfly(x, y, (((i & low) >> logE) << l) * step_n2);
+            if (last) {
+                st(base + 2ull * i, x);
+                st(base + 2ull * j, y);
+            } else {
+                put(i, x);
+                put(j, y);
+            }
+        }
+        if (!last) __syncthreads();
+    }
 }
 
 // polynomial p = prod_{j < leaf} (x - roots[p*leaf + j]); coefficient i (< leaf; the monic one is implied) -> x[i*m + p]
@@ -248,15 +321,27 @@ __global__ __launch_bounds__(256) void k_finish(const uint64_t* __restrict__ lv,
     const gf61::Opaque k = gf61::make_opaque();
     const uint64_t ur = lg_nc ? (__brev(u) >> (32 - lg_nc)) : 0;  // lv keeps the order its transform's DIF passes leave: the value for w^u in row bitrev(u)
     const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
-    const Elem corr = ld(wpow + 2ull * (back == 0 ? 0 : NC - back));
     const bool held = state[u] == ST_HELD;
-    st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * ur), corr, k) : Elem{0, 0});
+    st(fin + 2ull * u, held ? mulc(ld(lv + 4ull * ur), ld(wpow + 2ull * (back == 0 ? 0 : NC - back)), k) : Elem{0, 0});
+    // the output factors: zero here, those of the lost positions from k_finish_lost (an inversion each: only the listed positions pay for one)
+    if ((u & ((1u << e) - 1u)) == 0) st(gout + 2ull * (u >> e), Elem{0, 0});
+    if (gout_all) st(gout_all + 2ull * u, Elem{0, 0});
+}
+__global__ __launch_bounds__(256) void k_finish_lost(const uint64_t* __restrict__ lv, const uint32_t* __restrict__ erased, uint32_t n_erased,
+                                                     const uint64_t* __restrict__ wpow, uint64_t* __restrict__ gout, uint32_t NC, uint32_t pad,
+                                                     uint64_t* __restrict__ gout_all, int e, int lg_nc)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_erased) return;
+    const uint32_t u = erased[j];
     const bool data_pos = (u & ((1u << e) - 1u)) == 0;  // data block i sits at position i << e (e = 1: the (2k,k) code; 2, 3: n = 4k, 8k)
-    if (data_pos || gout_all) {
-        const Elem g = held ? Elem{0, 0} : invc(mulc(ld(lv + 4ull * ur + 2), corr, k), k);
-        if (data_pos) st(gout + 2ull * (u >> e), g);
-        if (gout_all) st(gout_all + 2ull * u, g);  // every lost position, parity too: fastecc_repair in one transform
-    }
+    if (!data_pos && !gout_all) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t ur = lg_nc ? (__brev(u) >> (32 - lg_nc)) : 0;
+    const uint32_t back = (uint32_t)(((uint64_t)u * pad) % NC);
+    const Elem g = invc(mulc(ld(lv + 4ull * ur + 2), ld(wpow + 2ull * (back == 0 ? 0 : NC - back)), k), k);
+    if (data_pos) st(gout + 2ull * (u >> e), g);
+    if (gout_all) st(gout_all + 2ull * u, g);  // every lost position, parity too: fastecc_repair in one transform
 }
 
 // One wave per (row, 64-element column chunk); the row's factor is wave-uniform.
@@ -603,6 +688,7 @@ struct Decoder {
     Path* transform = nullptr;         // size 2k, factor m / 2k, `elems` columns: x p'(x) on a whole stripe
     Path* pattern = nullptr;           // size 2k, 2 columns: L and x L' on the points
     std::vector<Path*> tree;           // level k >= LEAF_LOG: size 2^(k+1), T >> k columns
+    Path *narrow_tree = nullptr, *narrow_pattern = nullptr;  // the upper row bits of the few-column transforms (k_chunk_dif): 2T / CHUNK and 2 NC / CHUNK rows of CHUNK columns
     uint64_t *tree_x = nullptr, *tree_y = nullptr, *tree_f = nullptr;  // 2T elements each
     uint64_t *wpow = nullptr, *roots = nullptr, *lv = nullptr, *fin = nullptr, *gout = nullptr;
     uint64_t* gout_all = nullptr;      // 2k factors by position (lazy: patterns that lose data AND parity), valid for the current pattern if gout_all_valid
@@ -665,6 +751,8 @@ void destroy_decoder(Decoder* d)
     destroy(d->transform);
     destroy(d->half);
     destroy(d->pattern);
+    destroy(d->narrow_tree);
+    destroy(d->narrow_pattern);
     destroy(d->splitp);
     for (Path* t : d->small) destroy(t);
     for (void* b : {(void*)d->small_buf, (void*)d->split_af, (void*)d->split_work, (void*)d->state_real, (void*)d->srcmap, (void*)d->parity_lost, (void*)d->cos_work,
@@ -722,29 +810,23 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     // ---- even / odd split: recovering e data blocks takes e parity blocks, so the others may count as erased too; take them at multiples of 2^h of
     // the parity half (largest h <= 5 that leaves enough survivors) and the parity half's transform shrinks to k >> h rows ----
-    std::vector<uint8_t> state_real;  // the caller's flags, kept apart only when the split marks parity blocks as unused
     int split_shift = 0;
+    uint64_t unused_held = 0;  // parity blocks the caller holds that the split leaves aside: they count as lost in the locator
     const bool few = erased_data + erased_parity != 0 && (int)(erased_data + erased_parity) <= std::min(direct_max, 16);
     if (split && log2k >= 11 && erased_data != 0 && !few && !(*slot && (*slot)->split_unavailable)) {
-        uint64_t at_multiple[6] = {};
-        uint64_t by_zeros[6] = {};  // parity blocks held, by the trailing zeros of their index (capped at 5)
-        for (uint64_t j = 0; j < N; j += 2) by_zeros[__builtin_ctzll(j | 32)] += parity_present[j] != 0;
-        for (int h = 5; h >= 1; h--) at_multiple[h] = by_zeros[h] + (h < 5 ? at_multiple[h + 1] : 0);
         // (a pattern that has lost parity blocks too may be REPAIRED: the split then runs a second MID + DIT chain for the odd positions — or, without
         //  the memory for its extra stripe, re-encodes — see decode())
-        const int h_min = 1;
-        for (int h = 5; h >= h_min && split_shift == 0; h--)
-            if (at_multiple[h] >= erased_data) split_shift = h;
-        if (split_shift != 0) {
-            state_real = state;
-            const uint64_t mask = (1ull << split_shift) - 1;
-            for (uint64_t j = 0; j < N; j++)
-                if (j & mask) state[2 * j + 1] = ST_LOST;  // not in use: a root of the locator like a lost one (nothing of it is rebuilt from this state)
+        for (int h = 5; h >= 1 && split_shift == 0; h--) {  // (light patterns stop at h = 5: k / 32 flags read)
+            uint64_t held = 0;
+            for (uint64_t j = 0; j < N; j += 1ull << h) held += parity_present[j] != 0;
+            if (held >= erased_data) {
+                split_shift = h;
+                unused_held = (N - erased_parity) - held;  // marked on the device (k_mark_unused): the host's `state` stays the caller's
+            }
         }
     }
     // the positions themselves are listed on the device (k_erased_list); the host needs their number, and the list itself only for the few-loss path
-    uint64_t n_erased = 0;
-    for (uint64_t u = 0; u < NC; u++) n_erased += state[u] == ST_LOST;
+    const uint64_t n_erased = erased_data + erased_parity + unused_held;
     if (n_erased > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
     std::vector<uint32_t> erased;
     if (n_erased != 0 && (int64_t)n_erased <= std::min(direct_max, DIRECT_MAX))
@@ -780,6 +862,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     const uint64_t T = e == 1 ? N : NC;  // a power of two >= n - k, the most losses the code tolerates (3k -> 4k, 7k -> 8k: the roots beyond are padding)
     int lgT = e == 1 ? log2k : log2k + e;
     const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
+    const bool narrow_tree = lgT + 1 - CHUNK_LOG >= 1, narrow_pattern = log2k + e + 1 - CHUNK_LOG >= 1;  // at least two chunks
 
     d->direct = 0;
     if (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX)) {
@@ -875,12 +958,18 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, 0, detail, cap);
         }
         pt.mark("half path");
-        if (rc == FASTECC_OK) rc = create(&d->pattern, log2k + e, 2, detail, cap);  // only its stand-alone transform is used
+        // (of these paths only the stand-alone transform is used; few columns: the upper row bits by a path of CHUNK columns, the rest by k_chunk_dif)
+        if (rc == FASTECC_OK) rc = narrow_pattern ? create(&d->narrow_pattern, log2k + e + 1 - CHUNK_LOG, CHUNK, detail, cap) : create(&d->pattern, log2k + e, 2, detail, cap);
         pt.mark("pattern path");
         if (rc != FASTECC_OK) return rc;
         d->tree.assign(lgT, nullptr);
         for (int k = leaf_log; k < lgT; k++) {
+            if (narrow_tree && (T >> k) <= NARROW_COLUMNS) continue;
             rc = create(&d->tree[k], k + 1, T >> k, detail, cap);
+            if (rc != FASTECC_OK) return rc;
+        }
+        if (narrow_tree && lgT > leaf_log) {
+            rc = create(&d->narrow_tree, lgT + 1 - CHUNK_LOG, CHUNK, detail, cap);
             if (rc != FASTECC_OK) return rc;
         }
         pt.mark("tree paths");
@@ -918,7 +1007,11 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     // (the caller has waited for the last decode that used the previous pattern)
     D61_TRY(hipMemcpyAsync(d->state, state.data(), NC, hipMemcpyHostToDevice, s0));
     if (!d->state_real) D61_TRY(hipMalloc((void**)&d->state_real, NC));
-    D61_TRY(hipMemcpyAsync(d->state_real, (state_real.empty() ? state : state_real).data(), NC, hipMemcpyHostToDevice, s0));
+    D61_TRY(hipMemcpyAsync(d->state_real, d->state, NC, hipMemcpyDeviceToDevice, s0));
+    if (split_shift != 0) {
+        hipLaunchKernelGGL(k_mark_unused, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s0, d->state, (uint32_t)N, (1u << split_shift) - 1u);
+        D61_TRY(hipGetLastError());
+    }
     if (e > 1) {
         D61_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, s0));  // (fixed per code; cheap next to the locator)
         D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, s0));
@@ -978,6 +1071,17 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     pt_call.mark("set-up, uploads");
     auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    // a transform of 2^log_rows rows of 2^logE columns (2^log_rows <= NC): the upper row bits by `top`, a path of CHUNK columns, the rest inside LDS
+    auto narrow = [&](Path* top, int log_rows, int logE, const uint64_t* in, uint64_t* out, bool inverse) -> int {
+        const int rc = in == out ? dif_only(top, out, inverse, s0, nullptr) : dif_only_to(top, in, out, inverse, s0, nullptr);
+        if (rc != FASTECC_OK) return rc;
+        const int logN1 = log_rows + logE - CHUNK_LOG;
+        const uint32_t step_n = (uint32_t)(NC >> log_rows), step_n2 = (uint32_t)(NC >> (CHUNK_LOG - logE));
+        hipLaunchKernelGGL(inverse ? k_chunk_dif<true> : k_chunk_dif<false>, dim3(1u << logN1), dim3(256), 0, s0, out, d->wpow, logE, logN1, step_n, step_n2,
+                           (uint32_t)(NC - 1));
+        const hipError_t launched = hipGetLastError();
+        return launched == hipSuccess ? FASTECC_OK : fail(detail, cap, launched, "k_chunk_dif");
+    };
     D61_TRY(hipMemsetAsync(d->erased + T, 0, 4, s0));
     hipLaunchKernelGGL(k_erased_list, grid((NC + 15) / 16), dim3(256), 0, s0, d->state, (uint32_t)NC, d->erased, d->erased + T);
     hipLaunchKernelGGL(k_roots, grid(T), dim3(256), 0, s0, d->roots, d->erased, d->wpow, (uint32_t)n_erased, (uint32_t)T);
@@ -990,12 +1094,14 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     uint64_t *a = d->tree_x, *b = d->tree_f, *c = d->tree_y;
     for (int k = leaf_log; k < lgT; k++) {
         const uint64_t deg = 1ull << k, m = T >> k;
-        int rc = dif_only_to(d->tree[k], a, b, false, s0, nullptr);  // all m polynomials at once, a -> b (a survives for the combine step); no reordering pass
+        const bool few = d->tree[k] == nullptr;  // few columns: narrow()
+        int rc = few ? narrow(d->narrow_tree, k + 1, lgT - k, a, b, false)
+                     : dif_only_to(d->tree[k], a, b, false, s0, nullptr);  // all m polynomials at once, a -> b (a survives for the combine step); no reordering pass
         if (rc != FASTECC_OK) return rc;
         const gf61::Elem scale = gf61::h_inv(gf61::Elem{(2 * deg) % P, 0});
         hipLaunchKernelGGL(k_pairs, grid(2 * deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, 2 * deg * m, scale.re, scale.im, k + 1);
         D61_TRY(hipGetLastError());
-        rc = dif_only(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero), left in bit-reversed row order
+        rc = few ? narrow(d->narrow_tree, k + 1, lgT - k, c, c, true) : dif_only(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero), left in bit-reversed row order
         if (rc != FASTECC_OK) return rc;
         const bool top = k + 1 == lgT;
         const uint64_t rows = top ? 2 * deg : 4 * deg;
@@ -1007,7 +1113,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     hipLaunchKernelGGL(k_locator_columns, grid(NC), dim3(256), 0, s0, x, d->lv, (uint32_t)T, (uint32_t)NC);
     D61_TRY(hipGetLastError());
     {
-        const int rc = dif_only(d->pattern, d->lv, false, s0, nullptr);  // (k_finish reads the values where the DIF passes leave them)
+        const int rc = d->narrow_pattern ? narrow(d->narrow_pattern, log2k + e, 1, d->lv, d->lv, false)
+                                         : dif_only(d->pattern, d->lv, false, s0, nullptr);  // (k_finish reads the values where the DIF passes leave them)
         if (rc != FASTECC_OK) return rc;
     }
     d->gout_all_valid = false;
@@ -1021,6 +1128,19 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     hipLaunchKernelGGL(k_finish, grid(NC), dim3(256), 0, s0, d->lv, d->state, d->wpow, d->fin, d->gout, (uint32_t)NC, (uint32_t)(T - n_erased),
                        d->gout_all_valid ? d->gout_all : nullptr, e, log2k + e);
+    // the inversions: one per position the CALLER lost.  The split's list also holds the parity blocks it leaves aside (their factors are never
+    // read: k_gout_par takes those of state_real's lost blocks), so its pattern gets a list of its own, in a tree buffer (all three are free by now)
+    const uint32_t* lost_list = d->erased;
+    uint64_t lost_count = n_erased;
+    if (split_shift != 0) {
+        uint32_t* scratch = reinterpret_cast<uint32_t*>(d->tree_y);  // NC positions and the counter: 4 (NC + 1) <= 32 T bytes
+        D61_TRY(hipMemsetAsync(scratch + NC, 0, 4, s0));
+        hipLaunchKernelGGL(k_erased_list, grid((NC + 15) / 16), dim3(256), 0, s0, d->state_real, (uint32_t)NC, scratch, scratch + NC);
+        lost_list = scratch;
+        lost_count = erased_data + erased_parity;
+    }
+    hipLaunchKernelGGL(k_finish_lost, grid(lost_count), dim3(256), 0, s0, d->lv, lost_list, (uint32_t)lost_count, d->wpow, d->gout, (uint32_t)NC,
+                       (uint32_t)(T - n_erased), d->gout_all_valid ? d->gout_all : nullptr, e, log2k + e);
     D61_TRY(hipGetLastError());
     if (d->split_ready && d->gout_all_valid) {
         // the second chain's tables: the factor of q~ by position (once) and the lost parity blocks' output factors (this pattern)
