@@ -14,10 +14,9 @@ out = sys.argv[1]
 rows = []
 for f in glob.glob(out + "/t/**/*kernel_trace.csv", recursive=True): rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_erased_list" in r["Kernel_Name"]]
-# the call's first kernel is the first k_erased_list of the last prepare (the split's second list comes late in the same call)
-starts = [i for i in idx if not any(0 < i - j < 20 for j in idx)]
-last = rows[starts[-1]:]
+start = [i for i, r in enumerate(rows) if "k_roots" in r["Kernel_Name"]][-1]
+while start > 0 and any(t in rows[start - 1]["Kernel_Name"] for t in ("k_erased_list", "fillBuffer", "k_mark_unused", "copyBuffer")): start -= 1
+last = rows[start:]
 t0 = int(last[0]["Start_Timestamp"])
 print("kernels in the last prepare:", len(last), "span ms", (int(last[-1]["End_Timestamp"]) - t0) / 1e6, "busy ms", sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / 1e6)
 for r in last:
