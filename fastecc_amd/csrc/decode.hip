@@ -102,6 +102,8 @@ struct DecodeState {
     // fastecc_decode_prepare's device state (lazy): the product tree of the locator
     uint64_t tree_T = 0;                   // padded number of roots: the smallest power of two >= the most losses a code tolerates
     std::vector<fastecc_ctx*> tree_ctx;    // level k (polynomials of degree d = 2^k): transforms of length 2d, T/d columns
+    fastecc_ctx* tree_top = nullptr;       // few-column levels (chunk_transform_kernel): the upper row bits, 2T / CHUNK rows of CHUNK words
+    bool pattern_narrow = false;           // pattern_ntt is such a context too (2 NC / CHUNK rows)
     uint32_t* tree_x = nullptr;            // 2T words: the level's polynomials, [coefficient][polynomial]
     uint32_t* tree_f = nullptr;            // 2T words: their transforms
     uint32_t* tree_y = nullptr;            // 2T words: the next level's polynomials (swaps roles with tree_x)
@@ -163,6 +165,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->pack_host) (void)hipHostFree(d->pack_host);
     for (fastecc_ctx* t : d->tree_ctx)
         if (t) fastecc_destroy(t);
+    if (d->tree_top) fastecc_destroy(d->tree_top);
     direct_pass_free(d->direct_data);
     direct_pass_free(d->direct_parity);
     for (uint32_t* b : {d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
@@ -390,6 +393,62 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
         return;  // the last level has no upper half
     }
     xnew[i * half + q] = v;
+}
+
+// ---- transforms of FEW columns (the locator's own: 2; the tree's top levels: 2, 4, 8 polynomials side by side) ----
+// The stripe kernels give a wave 64 or more words of one row; with E words per row most lanes idle and a row is a 4 E-byte access.  The rows x E
+// array is taken as N1 x (N2 E), N2 E = CHUNK words, as in the four-step method: the N1-point transform over the upper row bits is the stripe kernels'
+// (a chunk's words are its columns: uniform twiddles, wide accesses); this kernel, one workgroup per chunk c = bitrev(k1), does the rest inside LDS with
+// per-lane twiddles from the decoder's w^u table: DIF (natural rows in, bit-reversed out; runs AFTER the stripe kernels): times w_N^(i2 k1), then
+// the N2-point DIF over i2; DIT with the inverse roots (bit-reversed in, natural out; runs BEFORE them): the N2-point DIT, then times w_N^(-i2 k1).
+// Either way rows end up where the stripe kernels' passes alone would leave them.
+constexpr int CHUNK_LOG = 12, CHUNK = 1 << CHUNK_LOG;
+constexpr uint64_t NARROW_COLUMNS = 4;  // tree levels of at most this many polynomials go this way
+template <bool DIT>
+__global__ __launch_bounds__(256) void chunk_transform_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ wpow, int logE, int logN1, uint32_t step_n,
+                                                              uint32_t step_n2, uint32_t nc_mask)
+{
+    __shared__ uint32_t lds[CHUNK], tw[CHUNK / 2];  // the chunk; w_N2^(+-j) for j < N2 / 2 in Montgomery form
+    const uint32_t tid = threadIdx.x, k1 = __brev(blockIdx.x) >> (32 - logN1);
+    uint32_t* base = data + (size_t)CHUNK * blockIdx.x;
+    auto root = [&](uint32_t ex) { return gf::mul_mont(wpow[DIT ? (0u - ex) & nc_mask : ex], gf::MONT_R2); };
+    const int levels = CHUNK_LOG - logE;
+    const uint32_t half_rows = 1u << (levels - 1);
+    for (uint32_t j = tid; j < half_rows; j += 256u) tw[j] = root(j * step_n2);
+#pragma unroll
+    for (int r = 0; r < CHUNK / 256; ++r) {
+        const uint32_t i = r * 256u + tid;
+        uint32_t v = base[i];
+        if (!DIT) v = gf::mul_mont(v, root((i >> logE) * k1 * step_n));
+        lds[i] = v;
+    }
+    __syncthreads();
+    for (int s = 0; s < levels; ++s) {
+        // rows r and r + h, h = 2^s (DIT, bottom up) or N2 >> (s + 1) (DIF, top down); twiddle w_2h^(r mod h) = w_N2^((r mod h) N2 / 2h)
+        const int hb = DIT ? logE + s : CHUNK_LOG - 1 - s, sh = DIT ? levels - 1 - s : s;
+        const uint32_t low = (1u << hb) - 1u;
+#pragma unroll
+        for (int r = 0; r < CHUNK / 512; ++r) {
+            const uint32_t b = r * 256u + tid, i = ((b >> hb) << (hb + 1)) | (b & low), j = i + low + 1u;
+            const uint32_t x = lds[i], y = lds[j], w = tw[((i & low) >> logE) << sh];
+            if (DIT) {
+                const uint32_t t = gf::mul_mont(y, w);
+                lds[i] = gf::add(x, t);
+                lds[j] = gf::sub(x, t);
+            } else {
+                lds[i] = gf::add(x, y);
+                lds[j] = gf::mul_mont(gf::sub(x, y), w);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < CHUNK / 256; ++r) {
+        const uint32_t i = r * 256u + tid;
+        uint32_t v = lds[i];
+        if (DIT) v = gf::mul_mont(v, root((i >> logE) * k1 * step_n));
+        base[i] = v;
+    }
 }
 
 // lv[m][0] = c_m, lv[m][1] = m c_m for the locator L = x^T + sum_{m<T} c_m x^m taken modulo x^NC - 1 (exact on the NC-th
@@ -987,13 +1046,16 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const uint32_t w = gf::h_root((uint32_t)NC);
     hipStream_t st = nullptr;  // the set-up is synchronous: it runs on the default stream and ends with a synchronise
+    const bool narrow = !mixed && (1ull << lgc) == NC;  // (the w^u table then holds every root the chunks need)
     if (!d->pattern_ntt) {
         int rc;
         if (mixed) {
             const std::vector<uint32_t> ones(NC, 1u);
             rc = create_mixed_transform_ctx(&d->pattern_ntt, ci.q, lgc, 8, ones.data(), ci.device);
         } else {
-            rc = create_ntt_ctx(&d->pattern_ntt, lgc, 8, ci.device);  // only its stand-alone transform is used
+            // only its stand-alone transform is used; long ones as the upper row bits of a four-step transform (chunk_transform_kernel)
+            d->pattern_narrow = narrow && lgc + 1 - CHUNK_LOG >= 1;
+            rc = d->pattern_narrow ? create_ntt_ctx(&d->pattern_ntt, lgc + 1 - CHUNK_LOG, 4 * CHUNK, ci.device) : create_ntt_ctx(&d->pattern_ntt, lgc, 8, ci.device);
         }
         if (rc != FASTECC_OK) return rc;
     }
@@ -1019,9 +1081,17 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
         // level k >= leaf_log multiplies pairs of degree-2^k polynomials: transforms of length 2^(k+1) on T / 2^k columns
         for (fastecc_ctx* t : d->tree_ctx)
             if (t) fastecc_destroy(t);
+        if (d->tree_top) fastecc_destroy(d->tree_top);
+        d->tree_top = nullptr;
         d->tree_ctx.assign(lgT, nullptr);
+        const bool narrow_tree = narrow && lgT + 1 - CHUNK_LOG >= 1 && lgT > leaf_log;
         for (int k = leaf_log; k < lgT; k++) {
+            if (narrow_tree && (T >> k) <= NARROW_COLUMNS) continue;  // tree_top + chunk_transform_kernel
             const int rc = create_ntt_ctx(&d->tree_ctx[k], k + 1, 4 * (T >> k), ci.device);
+            if (rc != FASTECC_OK) return rc;
+        }
+        if (narrow_tree) {
+            const int rc = create_ntt_ctx(&d->tree_top, lgT + 1 - CHUNK_LOG, 4 * CHUNK, ci.device);
             if (rc != FASTECC_OK) return rc;
         }
         for (uint32_t** b : {&d->tree_x, &d->tree_f, &d->tree_y, &d->tree_p, &d->roots, &d->dev_erased}) {
@@ -1202,17 +1272,35 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     if (leaf_log == TREE_LOW) hipLaunchKernelGGL(tree_low_levels_kernel<TREE_LOW>, dim3((unsigned)(T >> leaf_log)), dim3(1 << TREE_LOW), 0, st, d->roots, d->tree_x, (uint32_t)(T >> leaf_log));
     else hipLaunchKernelGGL(leaf_products_kernel, grid(T >> leaf_log), dim3(256), 0, st, d->roots, d->tree_x, (uint32_t)leaf, (uint32_t)(T >> leaf_log));
     DEC_TRY(hipGetLastError());
+    // 2^log_rows rows of 2^logE words (2^log_rows divides NC): DIF with the forward roots (natural -> bit-reversed rows) or DIT with the inverse
+    // roots (bit-reversed -> natural); `top` has 2^(log_rows + logE) / CHUNK rows of CHUNK words
+    auto narrow_transform = [&](fastecc_ctx* top, int log_rows, int logE, const uint32_t* in, uint32_t* out, bool dit) -> int {
+        const int logN1 = log_rows + logE - CHUNK_LOG;
+        const uint32_t step_n = (uint32_t)(NC >> log_rows), step_n2 = (uint32_t)(NC >> (CHUNK_LOG - logE));
+        if (!dit) {
+            const int rc = transform_bitrev(top, in, out, false, false, CHUNK, st);
+            if (rc != FASTECC_OK) return rc;
+            hipLaunchKernelGGL(chunk_transform_kernel<false>, dim3(1u << logN1), dim3(256), 0, st, out, d->wpow, logE, logN1, step_n, step_n2, (uint32_t)(NC - 1));
+            return hipGetLastError() == hipSuccess ? FASTECC_OK : FASTECC_E_DEVICE;
+        }
+        if (in != out) return FASTECC_E_INVAL;
+        hipLaunchKernelGGL(chunk_transform_kernel<true>, dim3(1u << logN1), dim3(256), 0, st, out, d->wpow, logE, logN1, step_n, step_n2, (uint32_t)(NC - 1));
+        if (hipGetLastError() != hipSuccess) return FASTECC_E_DEVICE;
+        return transform_bitrev(top, out, out, true, true, CHUNK, st);
+    };
     uint32_t* x = d->tree_x;
     uint32_t* spare = d->tree_y;  // x / spare swap roles level by level; tree_f always holds the transforms
     for (int k = leaf_log; k < lgT; k++) {
         const uint64_t deg = 1ull << k, m = T >> k;  // m polynomials of degree deg in x: [2 deg][m], rows deg.. are zero
-        fastecc_ctx* t = d->tree_ctx[k];
-        int rc = transform_bitrev(t, x, d->tree_f, false, false, (uint32_t)m, st);                     // all of them at once
+        fastecc_ctx* t = d->tree_ctx[k];  // (none: few columns, narrow_transform)
+        int rc = t ? transform_bitrev(t, x, d->tree_f, false, false, (uint32_t)m, st)                   // all of them at once
+                   : narrow_transform(d->tree_top, k + 1, lgT - k, x, d->tree_f, false);
         if (rc != FASTECC_OK) return rc;
         const uint32_t scale = gf::h_to_mont(gf::h_inv((uint32_t)(2 * deg)));
         hipLaunchKernelGGL(pointwise_pairs_kernel, grid(2 * deg * (m / 2)), dim3(256), 0, st, d->tree_f, d->tree_p, (uint32_t)m, 2 * deg * (m / 2), scale);
         DEC_TRY(hipGetLastError());
-        rc = transform_bitrev(t, d->tree_p, d->tree_p, true, true, (uint32_t)(m / 2), st);             // the products, back in natural order
+        rc = t ? transform_bitrev(t, d->tree_p, d->tree_p, true, true, (uint32_t)(m / 2), st)          // the products, back in natural order
+               : narrow_transform(d->tree_top, k + 1, lgT - k, d->tree_p, d->tree_p, true);              // (the unused columns ride along)
         if (rc != FASTECC_OK) return rc;
         const bool top = k + 1 == lgT;
         const uint64_t rows = top ? 2 * deg : 4 * deg;
@@ -1225,8 +1313,9 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     DEC_TRY(hipGetLastError());
     {
         // (power of two: the values stay in bit-reversed order, finish_tables_kernel reads them there — the reordering pass of fastecc_ntt was 87 us)
-        const int rc = mixed ? mixed_dif(d->pattern_ntt, d->pattern_buf, d->pattern_buf, st)
-                             : transform_bitrev(d->pattern_ntt, d->pattern_buf, d->pattern_buf, false, false, 2, st);
+        const int rc = mixed               ? mixed_dif(d->pattern_ntt, d->pattern_buf, d->pattern_buf, st)
+                       : d->pattern_narrow ? narrow_transform(d->pattern_ntt, lgc, 1, d->pattern_buf, d->pattern_buf, false)
+                                           : transform_bitrev(d->pattern_ntt, d->pattern_buf, d->pattern_buf, false, false, 2, st);
         if (rc != FASTECC_OK) return rc;
     }
     hipLaunchKernelGGL(finish_tables_kernel, grid(NC), dim3(256), 0, st, d->pattern_buf, d->dev_state, d->wpow, d->fin, d->gout, (uint32_t)NC,
