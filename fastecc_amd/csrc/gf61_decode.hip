@@ -732,6 +732,7 @@ struct Decoder {
     bool built = false;  // contexts, buffers and the w^u table exist
     // few losses: the direct path
     int direct = 0, direct_pad = 0;
+    uint64_t direct_nc = 0;              // positions of the code the direct path works in (2k; NC unless e > 1)
     uint32_t* direct_coef = nullptr;     // [NC][pad][COEF_WORDS]: the limbs of each weight
     uint64_t direct_coef_elems = 0;
     uint64_t* direct_inv = nullptr;      // [DIRECT_MAX] elements
@@ -804,8 +805,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             plost[q] = !parity_present[q];
         }
     }
+    const int direct_max_user = direct_max;
     if (e > 1) {
-        split = 0;       // the even / odd split and the direct path are the (2k,k) code's
+        split = 0;       // the even / odd split and the direct path are the (2k,k) code's (the latter: of the (2k,k) code inside, see below)
         direct_max = 0;
     }
     // ---- even / odd split: recovering e data blocks takes e parity blocks, so the others may count as erased too; take them at multiples of 2^h of
@@ -832,6 +834,24 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     if (n_erased != 0 && (int64_t)n_erased <= std::min(direct_max, DIRECT_MAX))
         for (uint64_t u = 0; u < NC; u++)
             if (state[u] == ST_LOST) erased.push_back((uint32_t)u);
+    // n = 4k / 8k, few losses: the data and the FIRST coset are a (2k,k) code of their own (generator w_2k, parity blocks 0 .. k-1), and that code's
+    // direct path rebuilds the data from its 2k - few survivors — a read of 2k blocks instead of a transform over n; lost parity blocks of the other
+    // cosets are re-encoded (fastecc_repair)
+    std::vector<uint8_t> state_sub;
+    std::vector<uint32_t> erased_sub;
+    if (e > 1 && erased_data != 0 && (int64_t)erased_data <= std::min(direct_max_user, DIRECT_MAX)) {
+        uint64_t lost0 = 0;
+        for (uint64_t j = 0; j < N; j++) lost0 += !parity_present[j];
+        if ((int64_t)(erased_data + lost0) <= std::min(direct_max_user, DIRECT_MAX) && erased_data + lost0 <= N) {  // (k of the inner code's 2k blocks survive)
+            state_sub.resize(2 * N);
+            for (uint64_t i = 0; i < N; i++) {
+                state_sub[2 * i] = data_present[i] ? ST_HELD : ST_LOST;
+                state_sub[2 * i + 1] = parity_present[i] ? ST_HELD : ST_LOST;
+            }
+            for (uint64_t u = 0; u < 2 * N; u++)
+                if (state_sub[u] == ST_LOST) erased_sub.push_back((uint32_t)u);
+        }
+    }
     pt_call.mark("pattern scan (host)");
 
     if (!*slot) {
@@ -864,11 +884,31 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const bool narrow_tree = lgT + 1 - CHUNK_LOG >= 1, narrow_pattern = log2k + e + 1 - CHUNK_LOG >= 1;  // at least two chunks
 
+    // e > 1: the caller's lost parity blocks by number and the cosets that have one (what fastecc_repair re-encodes)
+    auto upload_parity_flags = [&]() -> int {
+        if (!d->parity_lost) D61_TRY(hipMalloc((void**)&d->parity_lost, M));
+        D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, nullptr));
+        d->lost_coset_mask = 0;
+        for (uint64_t q = 0; q < M; q++)
+            if (plost[q]) d->lost_coset_mask |= 1u << (q / N);
+        return FASTECC_OK;
+    };
     d->direct = 0;
-    if (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX)) {
+    const bool direct_sub = !erased_sub.empty();
+    const std::vector<uint32_t>& erased_all = erased;
+    const std::vector<uint8_t>& state_all = state;
+    const uint64_t NC_all = NC;
+    if (direct_sub || (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX))) {
         // few losses: a coefficient table, no locator tree and no transform contexts.  Out of memory for its tables is not an
         // error: the transform path below needs none of them.
         const int rc_direct = [&]() -> int {
+            const std::vector<uint32_t>& erased = direct_sub ? erased_sub : erased_all;
+            const std::vector<uint8_t>& state = direct_sub ? state_sub : state_all;
+            const uint64_t NC = direct_sub ? 2 * N : NC_all;  // (the code the path works in)
+            if (direct_sub) {
+                const int rc = upload_parity_flags();
+                if (rc != FASTECC_OK) return rc;
+            }
             const int e = (int)erased.size();
             int pad = 1;
             while (pad < e) pad <<= 1;
@@ -886,7 +926,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                 inv[2 * j + 1] = gf61::h_subp(0, r.im);
             }
             hipStream_t s0 = nullptr;
-            uint64_t* wp = d->built ? d->wpow : d->direct_wpow;
+            uint64_t* wp = direct_sub ? d->direct_wpow : d->built ? d->wpow : d->direct_wpow;  // (the inner code's table is its own: w_2k, not w_n)
             if (!wp) {
                 // the table becomes visible to later calls only once it has been filled
                 uint64_t* fresh = nullptr;
@@ -900,7 +940,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                 }
                 d->direct_wpow = wp = fresh;
             }
-            if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC));
+            if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC_all));
             // [NC][pad] weights: sized for this pattern's pad (1 GiB instead of 8 GiB at NC = 2^25 for one lost block), grown on demand
             const uint64_t coef_elems = (NC + 4) * (uint64_t)pad;  // (k_direct_accumulate fetches the rows of a trip together)
             if (d->direct_coef_elems < coef_elems) {
@@ -930,6 +970,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             D61_TRY(hipStreamSynchronize(s0));
             d->direct = e;
             d->direct_pad = pad;
+            d->direct_nc = NC;
             return FASTECC_OK;
         }();
         if (rc_direct == FASTECC_OK) {
@@ -986,7 +1027,6 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         D61_TRY(hipMalloc((void**)&d->state, NC));
         if (e > 1) {
             D61_TRY(hipMalloc((void**)&d->srcmap, NC * 4));
-            D61_TRY(hipMalloc((void**)&d->parity_lost, M));
         }
         const gf61::Elem w = gf61::h_root(NC);
         hipLaunchKernelGGL(k_wpow, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, nullptr, d->wpow, w.re, w.im, (uint32_t)NC);
@@ -1014,10 +1054,8 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     }
     if (e > 1) {
         D61_TRY(hipMemcpyAsync(d->srcmap, srcmap.data(), NC * 4, hipMemcpyHostToDevice, s0));  // (fixed per code; cheap next to the locator)
-        D61_TRY(hipMemcpyAsync(d->parity_lost, plost.data(), M, hipMemcpyHostToDevice, s0));
-        d->lost_coset_mask = 0;
-        for (uint64_t q = 0; q < M; q++)
-            if (plost[q]) d->lost_coset_mask |= 1u << (q / N);
+        const int rc = upload_parity_flags();
+        if (rc != FASTECC_OK) return rc;
     }
     if (split_shift != 0) {
         // the split transform's paths and tables (once; the small transform per shift).  Anything missing — no plan of the needed shape, no memory
@@ -1176,9 +1214,23 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
     const size_t cap = 0;
     const uint32_t elems = (uint32_t)d->elems, col_chunks = (elems + 63) / 64;
     const bool rebuild = rebuild_with != nullptr && d->erased_parity != 0;
+    // n = 4k / 8k: the lost parity blocks from the encoder again, on the repaired data; only the cosets with a lost block, only the lost ones written
+    auto rebuild_cosets = [&](uint32_t coset_mask, bool first_coset_done) -> int {
+        if (cosets_of(rebuild_with) != (1 << d->e) - 1) return FASTECC_E_INVAL;
+        if (!d->again) D61_TRY(hipMalloc((void**)&d->again, d->M * d->elems * 16));
+        if (encode_cosets_needs_work(rebuild_with) && !d->cos_work) D61_TRY(hipMalloc((void**)&d->cos_work, d->N * d->elems * 16));
+        const int rc = encode_cosets(rebuild_with, data, d->again, d->cos_work, s0, hooks, coset_mask);
+        if (rc != FASTECC_OK) return rc;
+        // (after the inner code's direct path the first coset's blocks are in place and `again` holds nothing for them)
+        const uint64_t skip = first_coset_done ? d->N : 0, items = (d->M - skip) * col_chunks;
+        hipLaunchKernelGGL(k_restore_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again + 2 * skip * elems, parity + 2 * skip * elems,
+                           d->parity_lost + skip, elems, col_chunks, items);
+        D61_TRY(hipGetLastError());
+        return FASTECC_OK;
+    };
     if (d->direct > 0) {
         if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
-        const uint32_t NC = (uint32_t)d->NC, chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const uint32_t NC = (uint32_t)d->direct_nc, chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
         const uint64_t items = (uint64_t)chunks * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
 #define FASTECC_DIRECT61(EB)                                                                                                                     \
@@ -1198,6 +1250,8 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
         hipLaunchKernelGGL(k_direct_reduce2, dim3((elems + 255) / 256, (unsigned)d->direct), dim3(256), 0, s0, stage, d->direct_pos, data, parity, elems,
                            d->direct_pad, d->direct, rebuild);
         D61_TRY(hipGetLastError());
+        // (n = 4k / 8k: that was the (2k,k) code of the data and the first coset; the other cosets' lost blocks are re-encoded)
+        if (d->e > 1 && rebuild && (d->lost_coset_mask & ~1u) != 0) return rebuild_cosets(d->lost_coset_mask & ~1u, true);
         return FASTECC_OK;
     }
     if (d->erased_data != 0 && rebuild && d->gout_all_valid) {
@@ -1247,15 +1301,9 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
                 D61_TRY(hipGetLastError());
             }
         }
-        if (rebuild) {  // the lost parity blocks: the encoder again on the repaired data, only the lost ones written
-            if (cosets_of(rebuild_with) != (1 << d->e) - 1) return FASTECC_E_INVAL;
-            if (!d->again) D61_TRY(hipMalloc((void**)&d->again, d->M * d->elems * 16));
-            if (encode_cosets_needs_work(rebuild_with) && !d->cos_work) D61_TRY(hipMalloc((void**)&d->cos_work, d->N * d->elems * 16));
-            const int rc = encode_cosets(rebuild_with, data, d->again, d->cos_work, s0, hooks, d->lost_coset_mask);  // only the cosets with a lost block
+        if (rebuild) {
+            const int rc = rebuild_cosets(d->lost_coset_mask, false);
             if (rc != FASTECC_OK) return rc;
-            const uint64_t items = d->M * col_chunks;
-            hipLaunchKernelGGL(k_restore_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, d->again, parity, d->parity_lost, elems, col_chunks, items);
-            D61_TRY(hipGetLastError());
         }
         return FASTECC_OK;
     }

@@ -532,6 +532,54 @@ def test_decode_of_the_n_equals_4k_code_is_folded(torch_cuda, fe, orc61, logn, e
             assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
 
 
+@pytest.mark.parametrize("logn,e,elems", [(1, 2, 3), (4, 2, 70), (6, 3, 5), (10, 2, 9), (12, 3, 4), (14, 2, 2)])
+def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch_cuda, fe, orc61, logn, e, elems):
+    """n = 4k / 8k with at most 16 blocks lost among the data and the FIRST coset: those 2k blocks are a (2k,k) code of their own, and its direct
+    path rebuilds the data from 2k - few survivors — no transform over n runs (the profile is empty of the paths' kernels).  Lost parity blocks of
+    the other cosets do not count against the 16; fastecc_repair re-encodes them.  Same bits as the transform path (decode_direct_max = 0) and the
+    original stripes; one loss more and the transform path runs."""
+    torch = torch_cuda
+    N = 1 << logn
+    rows = ((1 << e) - 1) * N
+    rng = np.random.default_rng(700 + 10 * logn + e)
+    x = rand_stripe(rng, N, elems)
+    want = p61_oracle_coset_parity(orc61, x, e)
+    with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        cases = []  # (lost data, lost blocks of coset 0, lost blocks of the other cosets)
+        for nd, n0, nother in ((1, 0, 0), (2, 3, 5), (9, 7, 40), (16, 0, rows), (10, 7, 0), (1, 16, 3)):
+            nd, n0 = min(nd, N), min(n0, N)
+            cases.append((nd, n0, max(0, min(nother, rows - N, rows - nd - n0))))  # (at least k blocks survive)
+        for nd, n0, nother in cases:
+            dp, pp = np.ones(N, np.uint8), np.ones(rows, np.uint8)
+            dp[rng.permutation(N)[:nd]] = 0
+            pp[rng.permutation(N)[:n0]] = 0
+            pp[N + rng.permutation(rows - N)[:nother]] = 0
+            bad_x, bad_p = x.copy(), want.copy()
+            bad_x[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            bad_p[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+            for direct_max in (16, 0):
+                enc.set_option("decode_direct_max", direct_max)
+                enc.decode_prepare(dp, pp)
+                d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+                enc.profile(True)
+                enc.profile_reset()
+                enc.decode(d, q)
+                torch.cuda.synchronize()
+                prof = enc.profile_read()
+                enc.profile(False)
+                direct = direct_max == 16 and nd + n0 <= min(16, N)  # (k of the inner code's 2k blocks must survive)
+                assert (len(prof) == 0) == direct, (nd, n0, nother, direct_max, prof)
+                assert (to_host(d).reshape(x.shape) == x).all(), (nd, n0, nother, direct_max)
+                assert (to_host(q).reshape(want.shape) == bad_p).all()  # decode leaves the parity stripe alone
+                enc.repair(d, q)
+                torch.cuda.synchronize()
+                assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), (nd, n0, nother, direct_max)
+                hx, hp = bad_x.copy(), bad_p.copy()
+                enc.repair(hx, hp, mem=fe.MEM_HOST)
+                assert (hx == x).all() and (hp == want).all(), (nd, n0, nother, direct_max)
+        enc.set_option("decode_direct_max", 16)
+
+
 @pytest.mark.parametrize("logn", [1, 2, 5, 6, 7, 9, 12, 13, 14])
 @pytest.mark.parametrize("e", [2, 3])
 def test_multi_coset_parity_matches_oracle(torch_cuda, fe, orc61, logn, e):
