@@ -986,12 +986,13 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         PhaseTimer pt;
         // only the even (data) positions of this transform are wanted: a 7-level MID here pairs with the 6-level MID of a size-k path,
         // whose DIT passes finish the folded transform (encode_fold); where no such pair of plans exists all 2k outputs are computed
-        // (n = 4k: every FOURTH position — the size-4k transform's 7-level MID pairs with the 5-level MID of a size-k path; n = 8k: all positions)
-        int rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, e <= 2 ? 7 : 0, detail, cap);
+        // (n = 4k: every FOURTH position — the size-4k transform's 7-level MID pairs with the 5-level MID of a size-k path; n = 8k: every fourth
+        //  position as well, with a size-2k path: 2k outputs instead of 8k, the data at the even ones)
+        int rc = create_transform_mid(&d->transform, log2k + e, elems, FACTOR_INDEX, 7, detail, cap);
         pt.mark("transform path");
-        if (rc == FASTECC_OK && log2k >= 6 && e <= 2) rc = create_transform_mid(&d->half, log2k, elems, FACTOR_ENCODE, e == 1 ? 6 : 5, detail, cap);
-        if (rc == FASTECC_OK && e == 2 && !(fold_caps(d->transform, d->half) & FOLD_PAIRS)) {
-            // the two plans do not pair up at this size: the transform keeps its own choice of MID and computes all 4k outputs
+        if (rc == FASTECC_OK && log2k >= 6) rc = create_transform_mid(&d->half, e == 3 ? log2k + 1 : log2k, elems, FACTOR_ENCODE, e == 1 ? 6 : 5, detail, cap);
+        if (rc == FASTECC_OK && e >= 2 && !(fold_caps(d->transform, d->half) & FOLD_PAIRS)) {
+            // the two plans do not pair up at this size: the transform keeps its own choice of MID and computes all n outputs
             destroy(d->transform);
             d->transform = nullptr;
             destroy(d->half);
@@ -1270,14 +1271,16 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
             // n = 4k: x p'(x) at the data positions only — the way down on all 4k positions, the folding MID tile, the way up on k positions
             // (encode_fold), the gather through the position map in the first tile and the scatter in the last where the plans have such passes
             const int caps = d->half ? fold_caps(d->transform, d->half) : 0;
-            const bool folded = (caps & FOLD_PAIRS) != 0, fused_gather = folded && (caps & FOLD_GATHERS), fused_scatter = folded && (caps & FOLD_SCATTERS);
+            // (n = 8k: the folded transform leaves 2k rows, the data at the even ones: k_scatter takes every second)
+            const bool folded = (caps & FOLD_PAIRS) != 0, fused_gather = folded && (caps & FOLD_GATHERS), fused_scatter = folded && (caps & FOLD_SCATTERS) && d->e == 2;
+            const int rec_shift = d->e - 2;
             uint64_t items = d->NC * col_chunks;
             if (!fused_gather) {
                 hipLaunchKernelGGL(k_gather_map, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, data, parity, d->work, d->fin, d->srcmap, elems, col_chunks, items);
                 D61_TRY(hipGetLastError());
             }
             if (folded) {
-                if (!d->rec) D61_TRY(hipMalloc((void**)&d->rec, d->N * d->elems * 16));
+                if (!d->rec) D61_TRY(hipMalloc((void**)&d->rec, (d->N << rec_shift) * d->elems * 16));
                 FoldEnds ends;
                 if (fused_gather) {
                     ends.parity = parity;
@@ -1297,7 +1300,7 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
             if (!fused_scatter) {
                 items = d->N * col_chunks;
                 hipLaunchKernelGGL(k_scatter, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s0, folded ? d->rec : d->work, data, d->gout, elems, col_chunks, items,
-                                   folded ? 1u : 1u << d->e);
+                                   folded ? 1u << rec_shift : 1u << d->e);
                 D61_TRY(hipGetLastError());
             }
         }

@@ -532,6 +532,51 @@ def test_decode_of_the_n_equals_4k_code_is_folded(torch_cuda, fe, orc61, logn, e
             assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
 
 
+@pytest.mark.parametrize("logn,elems", [(6, 3), (7, 70), (9, 64), (10, 66), (11, 2), (12, 20)])
+def test_decode_of_the_n_equals_8k_code_is_folded(torch_cuda, fe, orc61, logn, elems):
+    """n = 8k: of the decoder's 8k-point transform only the multiples of 8 are wanted; it runs as the big path's DIF passes, the folding MID tile
+    (four consecutive positions into one: the second half of a size-2k path's 5-level MID) and that path's DIT passes — 2k outputs instead of 8k,
+    the data at the even ones.  The profile shows the folding tile; round trip with the last tolerable loss (7k blocks) and with k blocks lost,
+    parity against the oracle's composition."""
+    torch = torch_cuda
+    N, e = 1 << logn, 3
+    rows = 7 * N
+    x = rand_stripe(np.random.default_rng(8000 + logn), N, elems)
+    want = p61_oracle_coset_parity(orc61, x, e)
+    with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
+        out = torch.empty(rows * 2 * elems, dtype=torch.int64, device="cuda:0")
+        enc.encode(to_dev(torch, x), out)
+        assert (to_host(out).reshape(rows, 2 * elems) == want).all()
+        rng = np.random.default_rng(logn)
+        for nlost in (7 * N, N):
+            lost = rng.permutation(8 * N)[:nlost]
+            dp, pp = np.ones(N, np.uint8), np.ones(rows, np.uint8)
+            dp[lost[lost < N]] = 0
+            pp[lost[lost >= N] - N] = 0
+            if not (dp == 0).any():
+                dp[0] = 0
+                pp[np.flatnonzero(pp == 0)[0]] = 1
+            bad_x, bad_p = x.copy(), want.copy()
+            bad_x[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            bad_p[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
+            d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
+            enc.set_option("decode_direct_max", 0)
+            enc.decode_prepare(dp, pp)
+            enc.profile(True)
+            enc.profile_reset()
+            enc.decode(d, q)
+            torch.cuda.synchronize()
+            prof = enc.profile_read()
+            enc.profile(False)
+            assert prof.get("p61_tile_mid7_fold4", (0, 0, 0))[1] == 1, prof
+            assert (to_host(d).reshape(x.shape) == x).all(), (nlost, enc.plan())
+            assert (to_host(q).reshape(want.shape) == bad_p).all()  # decode leaves the parity stripe alone
+            enc.repair(d, q)
+            torch.cuda.synchronize()
+            assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
+        enc.set_option("decode_direct_max", 16)
+
+
 @pytest.mark.parametrize("logn,e,elems", [(1, 2, 3), (4, 2, 70), (6, 3, 5), (10, 2, 9), (12, 3, 4), (14, 2, 2)])
 def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch_cuda, fe, orc61, logn, e, elems):
     """n = 4k / 8k with at most 16 blocks lost among the data and the FIRST coset: those 2k blocks are a (2k,k) code of their own, and its direct
