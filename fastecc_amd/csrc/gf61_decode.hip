@@ -256,24 +256,23 @@ __global__ __launch_bounds__(1 << LOW) void k_tree_low(const uint64_t* __restric
     st(x + 2ull * ((uint64_t)o * m + p), Elem{bre[cur][o], bim[cur][o]});
 }
 
-// y[i][q] = f[i'][2q] * f[i'][2q+1] * scale for q < m/2, zero for the other columns (rows of m elements).  The transforms stay in the order
-// their DIF passes leave (dif_only: no reordering pass, 29 launches of 10 us per pattern in round 5): the value for point i is in row
-// i' = bitrev(i) of f; y is written in natural order, which is what the way back's DIF passes read.
+// y[i][q] = f[i'][2q] * f[i'][2q+1] * scale, q < m/2 (rows of m/2 elements; f: rows of m).  The transforms stay in the order their DIF passes leave
+// (dif_only: no reordering pass, 29 launches of 10 us per pattern in round 5): the value for point i is in row i' = bitrev(i) of f; y is written
+// in natural order, which is what the way back's DIF passes read.
 __global__ __launch_bounds__(256) void k_pairs(const uint64_t* __restrict__ f, uint64_t* __restrict__ y, uint32_t m, uint64_t total, uint64_t sre,
                                                uint64_t sim, int lg)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const gf61::Opaque k = gf61::make_opaque();
-    const uint64_t i = t / m;
-    const uint32_t q = (uint32_t)(t - i * m);
+    const uint32_t half = m >> 1;
+    const uint64_t i = t / half;
+    const uint32_t q = (uint32_t)(t - i * half);
     const uint64_t ir = __brev((uint32_t)i) >> (32 - lg);
-    Elem v{0, 0};
-    if (q < m / 2) v = mulc(mulc(ld(f + 2 * (ir * m + 2 * q)), ld(f + 2 * (ir * m + 2 * q + 1)), k), Elem{sre, sim}, k);
-    st(y + 2 * (i * m + q), v);
+    st(y + 2 * (i * half + q), mulc(mulc(ld(f + 2 * (ir * m + 2 * q)), ld(f + 2 * (ir * m + 2 * q + 1)), k), Elem{sre, sim}, k));
 }
 
-// (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b: xnew [4d][m/2] (upper 2d rows zero) from the cyclic products y (rows of m) and xold [d][m]
+// (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b: xnew [4d][m/2] (upper 2d rows zero) from the cyclic products y (rows of m/2) and xold [d][m]
 // (y: the cyclic products as the way back's DIF passes leave them — coefficient i in row bitrev(i) of its 2d rows)
 __global__ __launch_bounds__(256) void k_combine(const uint64_t* __restrict__ y, const uint64_t* __restrict__ xold, uint64_t* __restrict__ xnew,
                                                  uint32_t d, uint32_t m, uint64_t total, bool top, int lg)
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(256) void k_combine(const uint64_t* __restrict__ y,
     const uint32_t q = (uint32_t)(t - i * half);
     Elem v{0, 0};
     if (i < 2ull * d) {
-        v = ld(y + 2 * ((uint64_t)(__brev((uint32_t)i) >> (32 - lg)) * m + q));
+        v = ld(y + 2 * ((uint64_t)(__brev((uint32_t)i) >> (32 - lg)) * half + q));
         if (i >= d) v = addc(v, addc(ld(xold + 2 * ((i - d) * m + 2 * q)), ld(xold + 2 * ((i - d) * m + 2 * q + 1))));
     } else if (top) {
         return;
@@ -688,6 +687,8 @@ struct Decoder {
     Path* transform = nullptr;         // size 2k, factor m / 2k, `elems` columns: x p'(x) on a whole stripe
     Path* pattern = nullptr;           // size 2k, 2 columns: L and x L' on the points
     std::vector<Path*> tree;           // level k >= LEAF_LOG: size 2^(k+1), T >> k columns
+    std::vector<Path*> tree_inv;       // the way back of level k: size 2^(k+1), T >> (k+1) columns (the products)
+    Path* narrow_tree_inv = nullptr;   // ... of the few-column levels: T / CHUNK rows of CHUNK columns
     Path *narrow_tree = nullptr, *narrow_pattern = nullptr;  // the upper row bits of the few-column transforms (k_chunk_dif): 2T / CHUNK and 2 NC / CHUNK rows of CHUNK columns
     uint64_t *tree_x = nullptr, *tree_y = nullptr, *tree_f = nullptr;  // 2T elements each
     uint64_t *wpow = nullptr, *roots = nullptr, *lv = nullptr, *fin = nullptr, *gout = nullptr;
@@ -753,6 +754,8 @@ void destroy_decoder(Decoder* d)
     destroy(d->half);
     destroy(d->pattern);
     destroy(d->narrow_tree);
+    destroy(d->narrow_tree_inv);
+    for (Path* t : d->tree_inv) destroy(t);
     destroy(d->narrow_pattern);
     destroy(d->splitp);
     for (Path* t : d->small) destroy(t);
@@ -883,6 +886,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     int lgT = e == 1 ? log2k : log2k + e;
     const int leaf_log = lgT >= TREE_LOW + 2 ? TREE_LOW : std::min(LEAF_LOG, lgT), leaf = 1 << leaf_log;
     const bool narrow_tree = lgT + 1 - CHUNK_LOG >= 1, narrow_pattern = log2k + e + 1 - CHUNK_LOG >= 1;  // at least two chunks
+    const bool narrow_tree_inv = lgT - CHUNK_LOG >= 1;  // (the products are half as many columns)
 
     // e > 1: the caller's lost parity blocks by number and the cosets that have one (what fastecc_repair re-encodes)
     auto upload_parity_flags = [&]() -> int {
@@ -1005,13 +1009,16 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
         pt.mark("pattern path");
         if (rc != FASTECC_OK) return rc;
         d->tree.assign(lgT, nullptr);
+        d->tree_inv.assign(lgT, nullptr);
         for (int k = leaf_log; k < lgT; k++) {
-            if (narrow_tree && (T >> k) <= NARROW_COLUMNS) continue;
-            rc = create(&d->tree[k], k + 1, T >> k, detail, cap);
+            const bool few = (T >> k) <= NARROW_COLUMNS;
+            if (!(narrow_tree && few)) rc = create(&d->tree[k], k + 1, T >> k, detail, cap);
+            if (rc == FASTECC_OK && !(narrow_tree_inv && few)) rc = create(&d->tree_inv[k], k + 1, T >> (k + 1), detail, cap);
             if (rc != FASTECC_OK) return rc;
         }
         if (narrow_tree && lgT > leaf_log) {
             rc = create(&d->narrow_tree, lgT + 1 - CHUNK_LOG, CHUNK, detail, cap);
+            if (rc == FASTECC_OK && narrow_tree_inv) rc = create(&d->narrow_tree_inv, lgT - CHUNK_LOG, CHUNK, detail, cap);
             if (rc != FASTECC_OK) return rc;
         }
         pt.mark("tree paths");
@@ -1138,9 +1145,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                      : dif_only_to(d->tree[k], a, b, false, s0, nullptr);  // all m polynomials at once, a -> b (a survives for the combine step); no reordering pass
         if (rc != FASTECC_OK) return rc;
         const gf61::Elem scale = gf61::h_inv(gf61::Elem{(2 * deg) % P, 0});
-        hipLaunchKernelGGL(k_pairs, grid(2 * deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, 2 * deg * m, scale.re, scale.im, k + 1);
+        hipLaunchKernelGGL(k_pairs, grid(deg * m), dim3(256), 0, s0, b, c, (uint32_t)m, deg * m, scale.re, scale.im, k + 1);
         D61_TRY(hipGetLastError());
-        rc = few ? narrow(d->narrow_tree, k + 1, lgT - k, c, c, true) : dif_only(d->tree[k], c, true, s0, nullptr);  // the products (columns m/2.. are zero and stay zero), left in bit-reversed row order
+        rc = d->tree_inv[k] == nullptr ? narrow(d->narrow_tree_inv, k + 1, lgT - k - 1, c, c, true) : dif_only(d->tree_inv[k], c, true, s0, nullptr);  // the m/2 products, left in bit-reversed row order
         if (rc != FASTECC_OK) return rc;
         const bool top = k + 1 == lgT;
         const uint64_t rows = top ? 2 * deg : 4 * deg;
