@@ -20,4 +20,7 @@ bash tools/sessions/gpu_r06_prepare_trace.sh > "$OUT/prepare_cold.txt" 2>&1
 ( echo "== FASTECC_TRACE_PREPARE=1 python tools/run_prepare.py 0.02 6 (cold process) =="; grep -v amdgpu.ids gpurun_out/r06prep/trace_002.txt; echo; echo "== kernels of the last (steady) call: rocprofv3 --kernel-trace =="; cat "$OUT/prepare_cold.txt" ) > "$OUT/profiles/prepare_trace.txt"
 bash tools/sessions/gpu_r06_prepare_trace_warm.sh > "$OUT/prepare_warm.txt" 2>&1
 ( echo "== first fastecc_decode_prepare after an encode (tools/run_prepare.py 0.02 3 warm): gaps before kernels, HIP API totals, slowest calls, phases =="; grep -v amdgpu.ids "$OUT/prepare_warm.txt" ) > "$OUT/profiles/prepare_trace_warm.txt"
+bash tools/sessions/gpu_r06_prepare_trace_p61.sh > /dev/null 2>&1; cp gpurun_out/r06prep61/prepare_trace_p61.txt "$OUT/profiles/" 2>/dev/null
+# 4. the 64-bit field's coset codes (n = 4k from bench.py's other_paths above; n = 8k here)
+timeout 600 python tools/bench_p61_n8k.py 2> /dev/null | tail -1 > "$OUT/p61_n8k.json"; cut -c1-300 "$OUT/p61_n8k.json"
 ls "$OUT/profiles"
