@@ -127,6 +127,9 @@ struct DecodeState {
     // blocks follow from the complete data (direct.hip)
     DirectPass* direct_data = nullptr;
     DirectPass* direct_parity = nullptr;
+    DirectPass* direct_both = nullptr;   // data AND parity lost: fastecc_repair's single pass (the lost parity blocks as further outputs on direct_data's nodes)
+    bool sub_both = false;               // ... is built for this pattern
+    bool sub_only_both = false;          // ... and is the only pass (few outputs: the pass is bound by the read of the survivors, fastecc_decode runs it too and drops the parity outputs)
     int sub_lost_data = 0, sub_lost_parity = 0;
     bool sub = false;
     int direct_kernel = 0;             // 0 choose, 1 VALU, 2 MFMA (option "direct_kernel")
@@ -168,6 +171,7 @@ void destroy_decode_state(DecodeState* d)
     if (d->tree_top) fastecc_destroy(d->tree_top);
     direct_pass_free(d->direct_data);
     direct_pass_free(d->direct_parity);
+    direct_pass_free(d->direct_both);
     for (uint32_t* b : {d->parity_lost, d->parity_again, d->tree_x, d->tree_f, d->tree_y, d->tree_p, d->wpow, d->roots, d->dev_state, d->dev_erased, d->tile_order})
         if (b) (void)hipFree(b);
     delete d;
@@ -805,16 +809,29 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
     };
     // ---- few losses (decided before any per-position table is built): interpolation on the surviving data points + a few parity points ----
     if (direct_limit > 0 && ci.user_k < 0xFFFFFFF0ull) {
+        PhaseTimer ptd;
         std::vector<uint32_t> R, Pl, A;
         bool over = false;
-        for (uint64_t i = 0; i < ci.user_k && !over; i++)
-            if (!data_present[i]) R.push_back((uint32_t)i), over = (int)R.size() > direct_limit;
-        for (uint64_t q = 0; q < ci.user_m && !over; q++)
-            if (!parity_present[q]) Pl.push_back((uint32_t)q), over = (int)(R.size() + Pl.size()) > direct_limit;
+        // (eight flags per step: a word without a zero byte holds no lost block — byte by byte the two scans took 0.2-0.4 ms of a 0.3-0.5 ms call at k = 2^19)
+        auto each_lost = [](const uint8_t* flags, uint64_t count, auto&& lost) {  // lost(i) returns false to stop
+            uint64_t i = 0;
+            for (; i + 8 <= count; i += 8) {
+                uint64_t v;
+                memcpy(&v, flags + i, 8);
+                if (((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) == 0) continue;
+                for (uint64_t j = i; j < i + 8; j++)
+                    if (!flags[j] && !lost(j)) return;
+            }
+            for (; i < count; i++)
+                if (!flags[i] && !lost(i)) return;
+        };
+        each_lost(data_present, ci.user_k, [&](uint64_t i) { R.push_back((uint32_t)i); return !(over = (int)R.size() > direct_limit); });
+        if (!over) each_lost(parity_present, ci.user_m, [&](uint64_t q) { Pl.push_back((uint32_t)q); return !(over = (int)(R.size() + Pl.size()) > direct_limit); });
         for (uint64_t q = 0; q < ci.user_m && !over && A.size() < R.size(); q++)
             if (parity_present[q]) A.push_back((uint32_t)q);
         if (!over && R.size() + Pl.size() >= 1 && A.size() == R.size()) {
             const int ed = (int)R.size(), ep = (int)Pl.size();
+            ptd.mark("few losses: pattern scan");
             DeviceScope ds(ci.device);
             if (!ds.ok) return FASTECC_E_DEVICE;
             CallScope call(c);
@@ -840,14 +857,19 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
                 const int rc = call.wait_idle();  // a decode still using the previous pattern
                 if (rc != FASTECC_OK) return rc;
             }
+            ptd.mark("few losses: lock, idle");
             int rc = FASTECC_OK;
-            if (ed > 0) {
+            // (up to 32 outputs a pass costs the read of the survivors whatever it computes, profiles/r03/direct_bench.jsonl: one table then serves decode and repair)
+            d->sub_only_both = ed > 0 && ep > 0 && ed + ep <= 32;
+            if (ed > 0 && !d->sub_only_both) {
                 std::vector<uint32_t> xr(ed), ya(ed);
                 for (int r = 0; r < ed; r++) xr[r] = gf::h_pow(w, (uint64_t)R[r] << e);
                 for (int a = 0; a < ed; a++) ya[a] = gf::h_pow(w, parity_position(A[a]));
                 if (!d->direct_data && !(d->direct_data = direct_pass_new())) return FASTECC_E_NOMEM;
                 rc = direct_build_interp(d->direct_data, wd, N, K, R, xr, A, ya, nullptr);
             }
+            ptd.mark("few losses: data table");
+            d->sub_both = false;
             if (rc == FASTECC_OK && ep > 0) {
                 std::vector<uint32_t> yt(ep), ct(ep), pos(ep);
                 const uint32_t inv_N = gf::h_inv((uint32_t)(N % gf::P));
@@ -856,9 +878,23 @@ static int decode_prepare_impl(fastecc_ctx* c, const uint8_t* data_present, cons
                     ct[t] = gf::h_mul(fsub(gf::h_pow(yt[t], N), 1u), inv_N);  // (y_t^N - 1) / N
                     pos[t] = 2u * Pl[t] + 1u;
                 }
-                if (!d->direct_parity && !(d->direct_parity = direct_pass_new())) return FASTECC_E_NOMEM;
-                rc = direct_build_lagrange(d->direct_parity, wd, K, yt, ct, pos, nullptr);
+                if (d->sub_only_both) {
+                    // data lost as well, few outputs: fastecc_repair reads the survivors ONCE — the lost parity blocks are further outputs on the data
+                    // pass's nodes (the surviving data and as many parity blocks), not a second pass over the repaired data.  (Above 32 outputs the
+                    // matrix cores bound the pass, not the read: 128 + 128 lost take 2.40 ms in one pass, 2.48 in two, and the set-up of the second
+                    // 256-output table costs 0.9 ms.)
+                    std::vector<uint32_t> xr(ed), ya(ed);
+                    for (int r = 0; r < ed; r++) xr[r] = gf::h_pow(w, (uint64_t)R[r] << e);
+                    for (int a = 0; a < ed; a++) ya[a] = gf::h_pow(w, parity_position(A[a]));
+                    if (!d->direct_both && !(d->direct_both = direct_pass_new())) return FASTECC_E_NOMEM;
+                    rc = direct_build_interp(d->direct_both, wd, N, K, R, xr, A, ya, nullptr, &yt, &pos);
+                    d->sub_both = rc == FASTECC_OK;
+                } else {
+                    if (!d->direct_parity && !(d->direct_parity = direct_pass_new())) return FASTECC_E_NOMEM;
+                    rc = direct_build_lagrange(d->direct_parity, wd, K, yt, ct, pos, nullptr);
+                }
             }
+            ptd.mark("few losses: parity table");
             if (rc == FASTECC_OK) {
                 d->sub = true;
                 d->sub_lost_data = ed;
@@ -1500,13 +1536,19 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         // any layout, few losses: the lost data from the surviving data + a few parity blocks, then (repair) the lost parity from the data
         const uint32_t S = (uint32_t)ci.words;
         uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
-        if (d->sub_lost_data > 0) {
-            const int rc = direct_run(d->direct_data, ddata, dparity, ddata, nullptr, S, d->direct_kernel, st);
+        if (d->sub_both && (rebuild || d->sub_only_both)) {
+            // data and parity lost: one pass over the survivors writes both (fastecc_decode: the data only)
+            const int rc = direct_run(d->direct_both, ddata, dparity, ddata, rebuild ? dpar_out : nullptr, S, d->direct_kernel, st);
             if (rc != FASTECC_OK) return rc;
-        }
-        if (rebuild) {
-            const int rc = direct_run(d->direct_parity, ddata, nullptr, nullptr, dpar_out, S, d->direct_kernel, st);
-            if (rc != FASTECC_OK) return rc;
+        } else {
+            if (d->sub_lost_data > 0) {
+                const int rc = direct_run(d->direct_data, ddata, dparity, ddata, nullptr, S, d->direct_kernel, st);
+                if (rc != FASTECC_OK) return rc;
+            }
+            if (rebuild) {
+                const int rc = direct_run(d->direct_parity, ddata, nullptr, nullptr, dpar_out, S, d->direct_kernel, st);
+                if (rc != FASTECC_OK) return rc;
+            }
         }
     } else {
     bool repaired_in_one_pass = false;

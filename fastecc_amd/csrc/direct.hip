@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void direct_reduce2_kernel(const uint32_t* __r
     uint32_t v = 0;
 #pragma unroll
     for (uint32_t g = 0; g < DIRECT_SEGS; ++g) v = gf::add(v, stage[((size_t)g * pad + j) * S + col]);
-    ((p & 1u) ? parity : data)[(size_t)(p >> 1) * S + col] = v;
+    uint32_t* out = (p & 1u) ? parity : data;
+    if (out) out[(size_t)(p >> 1) * S + col] = v;  // (no stripe given for that kind of output: fastecc_decode on a pass that also holds the lost parity blocks)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,10 +465,13 @@ __global__ __launch_bounds__(256) void lagrange_coef_kernel(uint32_t* __restrict
 }
 
 // Interpolation on the N nodes {x_i : i not lost} + {y_a}: R the lost data rows (points x_r), A as many surviving parity points y_a,
-// A(x) = prod_a (x - y_a), R(x) = prod_r (x - x_r), R_r = R / (x - x_r):
+// A(x) = prod_a (x - y_a), R(x) = prod_r (x - x_r), R_r = R / (x - x_r); node polynomial M = (x^N - 1) A / R:
 //     weight of data row i in lost row r   = C_r x_i R_r(x_i) / A(x_i),   C_r = -A(x_r) / (x_r R_r(x_r))
 //     weight of parity node a in lost row r = N A_a(x_r) R(y_a) / (x_r R_r(x_r) (y_a^N - 1) A_a(y_a)),  A_a = A / (x - y_a)
-// params: [0, CAP) x_r, [CAP, 2 CAP) y_a, [2 CAP, 3 CAP) C_r (interp_params_kernel)
+// and, for fastecc_repair in ONE pass, further targets y_t (the lost parity blocks) on the same nodes — L_u(y) = M(y) / ((y - u) M'(u)):
+//     weight of data row i in target t      = c_t x_i R(x_i) / (A(x_i) (y_t - x_i)),   c_t = (y_t^N - 1) A(y_t) / (N R(y_t))
+//     weight of parity node a in target t   = (y_t^N - 1) A_a(y_t) R(y_a) / (R(y_t) (y_a^N - 1) A_a(y_a))
+// params: [0, CAP) the targets: x_r (ed of them), then y_t (ep); [CAP, 2 CAP) y_a; [2 CAP, 3 CAP) C_r (interp_params_kernel), then c_t (host)
 __global__ __launch_bounds__(256) void interp_params_kernel(uint32_t* __restrict__ params, int ed)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,37 +485,49 @@ __global__ __launch_bounds__(256) void interp_params_kernel(uint32_t* __restrict
     params[2 * DIRECT_CAP + r] = gf::sub(0u, gf::mul(A, dev_pow(gf::mul(xr, Rr), gf::P - 2u)));
 }
 __global__ __launch_bounds__(256) void interp_coef_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t wd, uint32_t K, uint32_t rows, int ed,
-                                                          int pad)
+                                                          int ep, int pad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const uint32_t xi = dev_pow(wd, i);
-    uint32_t A = 1, run = 1;
+    // forward: the products over the targets before t — of (x_i - x_s) for the lost rows, of (y_t - x_i) for the further targets
+    uint32_t A = 1, run = 1, far = 1;
     for (int t0 = 0; t0 < pad; t0 += 16) {
         uint32_t v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+            const int t = t0 + j;
             v[j] = 0;
-            if (t0 + j < ed) {
-                A = gf::mul(A, gf::sub(xi, params[DIRECT_CAP + t0 + j]));
+            if (t < ed) {
+                A = gf::mul(A, gf::sub(xi, params[DIRECT_CAP + t]));
                 v[j] = run;  // prod_{s < t} (x_i - x_s)
-                run = gf::mul(run, gf::sub(xi, params[t0 + j]));
+                run = gf::mul(run, gf::sub(xi, params[t]));
+            } else if (t < ed + ep) {
+                v[j] = far;  // prod_{ed <= s < t} (y_s - x_i)
+                far = gf::mul(far, gf::sub(params[t], xi));
             }
         }
         coef_store_run(coef, i, t0, rows, pad, v);
     }
     const bool node = run != 0;  // x_i is one of the lost points: the row is not a node, its weights are zero
-    const uint32_t base = node ? gf::mul(xi, dev_pow(A, gf::P - 2u)) : 0u;  // x_i / A(x_i)
-    uint32_t suf = 1;
+    // one inversion for both denominators: A(x_i) and prod_t (y_t - x_i) (neither is zero: parity points are no data points)
+    const uint32_t inv = dev_pow(gf::mul(A, far), gf::P - 2u);
+    const uint32_t base = node ? gf::mul(xi, gf::mul(inv, far)) : 0u;  // x_i / A(x_i)
+    const uint32_t base_far = gf::mul(gf::mul(base, run), gf::mul(inv, A));  // x_i R(x_i) / (A(x_i) prod_t (y_t - x_i))
+    uint32_t suf = 1, suf_far = 1;
     for (int t0 = ((pad - 1) / 16) * 16; t0 >= 0; t0 -= 16) {
         uint32_t v[16];
         coef_load_run(coef, i, t0, rows, pad, v);
 #pragma unroll
         for (int j = 15; j >= 0; --j) {
-            const int r = t0 + j;
-            if (r < ed && node) {
-                const uint32_t w = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + r], base), v[j]), suf);
-                suf = gf::mul(suf, gf::sub(xi, params[r]));
+            const int t = t0 + j;
+            if (t < ed && node) {
+                const uint32_t w = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + t], base), v[j]), suf);
+                suf = gf::mul(suf, gf::sub(xi, params[t]));
+                v[j] = gf::mul(w, gf::MONT_ONE);
+            } else if (t >= ed && t < ed + ep && node) {
+                const uint32_t w = gf::mul(gf::mul(gf::mul(params[2 * DIRECT_CAP + t], base_far), v[j]), suf_far);
+                suf_far = gf::mul(suf_far, gf::sub(params[t], xi));
                 v[j] = gf::mul(w, gf::MONT_ONE);
             } else {
                 v[j] = 0;
@@ -520,27 +536,28 @@ __global__ __launch_bounds__(256) void interp_coef_kernel(uint32_t* __restrict__
         coef_store_run(coef, i, t0, rows, pad, v);
     }
 }
-// thread (a, r): the weight of parity node a in lost row r -> coef[K + a][r]
-__global__ __launch_bounds__(256) void interp_node_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t K, uint32_t N, int ed, int pad)
+// thread (a, t): the weight of parity node a in target t -> coef[K + a][t]
+__global__ __launch_bounds__(256) void interp_node_kernel(uint32_t* __restrict__ coef, const uint32_t* __restrict__ params, uint32_t K, uint32_t N, int ed, int ep, int pad)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint32_t)ed * pad) return;
-    const int a = t / pad, r = t % pad;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)ed * pad) return;
+    const int a = idx / pad, t = idx % pad;
     uint32_t v = 0;
-    if (r < ed) {
-        const uint32_t xr = params[r], ya = params[DIRECT_CAP + a];
-        uint32_t Aa_xr = 1, Aa_ya = 1, R_ya = 1, Rr = 1;
+    if (t < ed + ep) {
+        const uint32_t z = params[t], ya = params[DIRECT_CAP + a];  // the target: x_r or y_t
+        uint32_t Aa_z = 1, Aa_ya = 1, R_ya = 1, R_z = 1;  // (R_z: without the target's own factor when it is a lost row)
         for (int s = 0; s < ed; ++s) {
             const uint32_t ys = params[DIRECT_CAP + s], xs = params[s];
-            if (s != a) Aa_xr = gf::mul(Aa_xr, gf::sub(xr, ys)), Aa_ya = gf::mul(Aa_ya, gf::sub(ya, ys));
+            if (s != a) Aa_z = gf::mul(Aa_z, gf::sub(z, ys)), Aa_ya = gf::mul(Aa_ya, gf::sub(ya, ys));
             R_ya = gf::mul(R_ya, gf::sub(ya, xs));
-            if (s != r) Rr = gf::mul(Rr, gf::sub(xr, xs));
+            if (s != t) R_z = gf::mul(R_z, gf::sub(z, xs));
         }
-        const uint32_t num = gf::mul(gf::mul(N, Aa_xr), R_ya);
-        const uint32_t den = gf::mul(gf::mul(gf::mul(xr, Rr), gf::sub(dev_pow(ya, N), 1u)), Aa_ya);
+        // lost row: (z^N - 1) / R(z) -> N / (z R_r(z));  further target: (z^N - 1) / R(z) as it stands
+        const uint32_t num = gf::mul(gf::mul(t < ed ? N : gf::sub(dev_pow(z, N), 1u), Aa_z), R_ya);
+        const uint32_t den = gf::mul(gf::mul(gf::mul(t < ed ? z : 1u, R_z), gf::sub(dev_pow(ya, N), 1u)), Aa_ya);
         v = gf::mul(gf::mul(num, dev_pow(den, gf::P - 2u)), gf::MONT_ONE);
     }
-    coef[coef_index(K + (uint32_t)a, (uint32_t)r, K + (uint32_t)ed, (uint32_t)pad)] = v;
+    coef[coef_index(K + (uint32_t)a, (uint32_t)t, K + (uint32_t)ed, (uint32_t)pad)] = v;
 }
 
 int hip_code(const char* what, hipError_t e)
@@ -638,21 +655,36 @@ int direct_build_lagrange(DirectPass* p, uint32_t wd, uint32_t K, const std::vec
 }
 
 int direct_build_interp(DirectPass* p, uint32_t wd, uint64_t N, uint32_t K, const std::vector<uint32_t>& lost_rows, const std::vector<uint32_t>& lost_points,
-                        const std::vector<uint32_t>& node_rows, const std::vector<uint32_t>& node_points, hipStream_t st)
+                        const std::vector<uint32_t>& node_rows, const std::vector<uint32_t>& node_points, hipStream_t st, const std::vector<uint32_t>* more_points,
+                        const std::vector<uint32_t>* more_pos)
 {
-    const int ed = (int)lost_rows.size();
-    if (lost_points.size() != lost_rows.size() || node_rows.size() != lost_rows.size() || node_points.size() != lost_rows.size() || K < 1) return FASTECC_E_INVAL;
-    const int rc = pass_common(p, K + (uint32_t)ed, K, ed);
+    const int ed = (int)lost_rows.size(), ep = more_points ? (int)more_points->size() : 0;
+    if (lost_points.size() != lost_rows.size() || node_rows.size() != lost_rows.size() || node_points.size() != lost_rows.size() || K < 1 || ed < 1) return FASTECC_E_INVAL;
+    if (ep != 0 && (!more_pos || more_pos->size() != more_points->size() || ed + ep > DIRECT_CAP)) return FASTECC_E_INVAL;
+    const int rc = pass_common(p, K + (uint32_t)ed, K, ed + ep);
     if (rc != FASTECC_OK) return rc;
-    std::vector<uint32_t> pos(ed);
-    for (int r = 0; r < ed; r++) pos[r] = 2u * lost_rows[r];
-    DIR_TRY(hipMemcpyAsync(p->params, lost_points.data(), ed * 4, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> pos(ed + ep), targets(ed + ep), cfar(ep);
+    for (int r = 0; r < ed; r++) pos[r] = 2u * lost_rows[r], targets[r] = lost_points[r];
+    auto fsub = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + gf::P - b) % gf::P); };
+    const uint32_t inv_n = gf::h_inv((uint32_t)(N % gf::P));
+    for (int t = 0; t < ep; t++) {
+        const uint32_t y = (*more_points)[t];
+        uint32_t A = 1, R = 1;
+        for (int s = 0; s < ed; s++) A = gf::h_mul(A, fsub(y, node_points[s])), R = gf::h_mul(R, fsub(y, lost_points[s]));
+        if (A == 0 || R == 0) return FASTECC_E_INVAL;  // a target that is a node or a lost data point
+        pos[ed + t] = (*more_pos)[t];
+        targets[ed + t] = y;
+        cfar[t] = gf::h_mul(gf::h_mul(gf::h_mul(fsub(gf::h_pow(y, N), 1u), A), inv_n), gf::h_inv(R));  // (y^N - 1) A(y) / (N R(y))
+    }
+    DIR_TRY(hipMemcpyAsync(p->params, targets.data(), (ed + ep) * 4, hipMemcpyHostToDevice, st));
     DIR_TRY(hipMemcpyAsync(p->params + DIRECT_CAP, node_points.data(), ed * 4, hipMemcpyHostToDevice, st));
+    if (ep) DIR_TRY(hipMemcpyAsync(p->params + 2 * DIRECT_CAP + ed, cfar.data(), ep * 4, hipMemcpyHostToDevice, st));
     DIR_TRY(hipMemcpyAsync(p->lists, node_rows.data(), ed * 4, hipMemcpyHostToDevice, st));
-    DIR_TRY(hipMemcpyAsync(p->lists + DIRECT_CAP, pos.data(), ed * 4, hipMemcpyHostToDevice, st));
+    DIR_TRY(hipMemcpyAsync(p->lists + DIRECT_CAP, pos.data(), (ed + ep) * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(interp_params_kernel, dim3((ed + 255) / 256), dim3(256), 0, st, p->params, ed);
-    hipLaunchKernelGGL(interp_coef_kernel, dim3((K + 255) / 256), dim3(256), 0, st, p->coef, p->params, wd, K, K + (uint32_t)ed, ed, p->pad);
-    hipLaunchKernelGGL(interp_node_kernel, dim3((unsigned)(((uint64_t)ed * p->pad + 255) / 256)), dim3(256), 0, st, p->coef, p->params, K, (uint32_t)(N % gf::P), ed, p->pad);
+    hipLaunchKernelGGL(interp_coef_kernel, dim3((K + 255) / 256), dim3(256), 0, st, p->coef, p->params, wd, K, K + (uint32_t)ed, ed, ep, p->pad);
+    hipLaunchKernelGGL(interp_node_kernel, dim3((unsigned)(((uint64_t)ed * p->pad + 255) / 256)), dim3(256), 0, st, p->coef, p->params, K, (uint32_t)(N % gf::P), ed, ep,
+                       p->pad);
     DIR_TRY(hipGetLastError());
     DIR_TRY(hipStreamSynchronize(st));
     p->built = true;

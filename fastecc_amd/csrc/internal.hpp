@@ -34,8 +34,11 @@ int direct_cap();                  // most outputs (lost or parity blocks) of on
 int direct_build_lagrange(DirectPass* p, uint32_t wd, uint32_t K, const std::vector<uint32_t>& y, const std::vector<uint32_t>& c, const std::vector<uint32_t>& out_pos,
                           hipStream_t st);
 // The lost data rows (points lost_points) from the surviving data rows and as many surviving parity rows (node_rows at node_points).
+// more_points / more_pos: further outputs on the same nodes — f at those points, written to row pos >> 1 of the parity (pos odd) or data stripe: the lost
+// parity blocks, for fastecc_repair in one pass.
 int direct_build_interp(DirectPass* p, uint32_t wd, uint64_t N, uint32_t K, const std::vector<uint32_t>& lost_rows, const std::vector<uint32_t>& lost_points,
-                        const std::vector<uint32_t>& node_rows, const std::vector<uint32_t>& node_points, hipStream_t st);
+                        const std::vector<uint32_t>& node_rows, const std::vector<uint32_t>& node_points, hipStream_t st,
+                        const std::vector<uint32_t>* more_points = nullptr, const std::vector<uint32_t>* more_pos = nullptr);
 // kernel: 0 = choose, 1 = VALU (96-bit lazy accumulation), 2 = MFMA (i8 digits) when the stripes allow it
 int direct_run(DirectPass* p, const uint32_t* data, const uint32_t* parity, uint32_t* data_out, uint32_t* parity_out, uint32_t S, int kernel, hipStream_t st);
 bool direct_mfma_applies(const void* data, const void* parity, uint64_t words);

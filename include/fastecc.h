@@ -304,9 +304,9 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            when more than an eighth of the codeword is lost).
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
  * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
- * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.3-3.5 ms, no transform contexts) and decode
+ * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.2-3.5 ms, no transform contexts) and decode
  * is one read of the data plus a few parity blocks — 0.4 ms for up to 16 lost blocks of a 2 GiB stripe, 0.7 ms for 64, 2.6 ms for 256 (matrix
- * cores; option "direct_kernel") against 3.8-5.7 ms on the transform path (repair: a second read for the lost parity); every GF(0xFFF00001)
+ * cores; option "direct_kernel") against 3.8-5.7 ms on the transform path (repair: the lost parity blocks in the same pass when at most 32 blocks are lost in all, else in a second read); every GF(0xFFF00001)
  * code, and the (2k,k) codes of GF((2^61-1)^2); identical results.  n = 4k / 8k over GF((2^61-1)^2): the data and the first coset are a (2k,k) code,
  * and up to 16 losses among THOSE 2k blocks (lost blocks of the other cosets do not count; repair re-encodes them) take that code's direct path.
  */
