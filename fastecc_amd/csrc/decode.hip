@@ -1536,17 +1536,24 @@ static int decode_impl(fastecc_ctx* c, void* data, const void* parity, int mem_k
         // any layout, few losses: the lost data from the surviving data + a few parity blocks, then (repair) the lost parity from the data
         const uint32_t S = (uint32_t)ci.words;
         uint32_t* dpar_out = mem_kind == FASTECC_MEM_HOST ? d->parity_dev : (uint32_t*)parity_out;
+        // (profile: one "direct_pass" per read of the stripe)
+        auto pass = [&](DirectPass* p, const uint32_t* par_in, uint32_t* data_to, uint32_t* par_to) -> int {
+            void* scope = profile_scope_begin(c, st, "direct_pass", (ci.user_k + (uint64_t)d->sub_lost_data) * block);
+            const int rc = direct_run(p, ddata, par_in, data_to, par_to, S, d->direct_kernel, st);
+            profile_scope_end(scope);
+            return rc;
+        };
         if (d->sub_both && (rebuild || d->sub_only_both)) {
             // data and parity lost: one pass over the survivors writes both (fastecc_decode: the data only)
-            const int rc = direct_run(d->direct_both, ddata, dparity, ddata, rebuild ? dpar_out : nullptr, S, d->direct_kernel, st);
+            const int rc = pass(d->direct_both, dparity, ddata, rebuild ? dpar_out : nullptr);
             if (rc != FASTECC_OK) return rc;
         } else {
             if (d->sub_lost_data > 0) {
-                const int rc = direct_run(d->direct_data, ddata, dparity, ddata, nullptr, S, d->direct_kernel, st);
+                const int rc = pass(d->direct_data, dparity, ddata, nullptr);
                 if (rc != FASTECC_OK) return rc;
             }
             if (rebuild) {
-                const int rc = direct_run(d->direct_parity, ddata, nullptr, nullptr, dpar_out, S, d->direct_kernel, st);
+                const int rc = pass(d->direct_parity, nullptr, nullptr, dpar_out);
                 if (rc != FASTECC_OK) return rc;
             }
         }

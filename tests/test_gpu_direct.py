@@ -164,3 +164,41 @@ def test_headline_size(torch_cuda, fe, lost):
             enc.repair(d, q)
             torch.cuda.synchronize()
             assert torch.equal(d, x) and torch.equal(q, par), (lost, kernel)
+
+
+@pytest.mark.parametrize("N,S", [(64, 16), (4096, 33), (1 << 15, 64)])
+def test_a_repair_of_few_losses_reads_the_stripe_once(torch_cuda, fe, oracle, N, S):
+    """Data AND parity lost, at most 32 blocks in all: fastecc_repair is ONE pass over the survivors (the lost parity blocks are further outputs of the
+    interpolation on the data pass's nodes) — the profile counts the passes; fastecc_decode on the same pattern is that pass too and leaves the parity
+    stripe alone.  Only parity lost, or more than 32 blocks: as before (one pass for the data from the survivors, one for the parity from the data)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(N + S)
+    x = rng.integers(0, P, size=(N, S), dtype=np.uint64).astype(np.uint32)
+    par = oracle.encode(x)
+    with fe.Encoder(2 * N, N, 4 * S) as enc:
+        enc.set_option("decode_direct_max", 256)
+        for nd, npar, passes_repair, passes_decode in ((1, 1, 1, 1), (8, 8, 1, 1), (3, 29, 1, 1), (31, 1, 1, 1), (0, 5, 1, 0), (5, 0, 1, 1), (17, 16, 2, 1), (2, 40, 2, 1)):
+            if nd + npar > N:
+                continue
+            dp, pp = np.ones(N, np.uint8), np.ones(N, np.uint8)
+            dp[rng.permutation(N)[:nd]] = 0
+            pp[rng.permutation(N)[:npar]] = 0
+            bad_x, bad_p = x.copy(), par.copy()
+            bad_x[dp == 0] = 0x12345678
+            bad_p[pp == 0] = 0x0BADF00D
+            for kernel in (1, 2):
+                enc.set_option("direct_kernel", kernel)
+                enc.decode_prepare(dp, pp)
+                for call, passes in (("decode", passes_decode), ("repair", passes_repair)):
+                    d, q = torch.from_numpy(bad_x.view(np.int32)).to("cuda:0"), torch.from_numpy(bad_p.view(np.int32)).to("cuda:0")
+                    enc.profile(True)
+                    enc.profile_reset()
+                    getattr(enc, call)(d, q)
+                    torch.cuda.synchronize()
+                    prof = enc.profile_read()
+                    enc.profile(False)
+                    assert prof.get("direct_pass", (0, 0, 0))[1] == passes, (nd, npar, kernel, call, prof)
+                    assert (d.cpu().numpy().view(np.uint32).reshape(N, S) == x).all(), (nd, npar, kernel, call)
+                    want_p = par if call == "repair" else bad_p
+                    assert (q.cpu().numpy().view(np.uint32).reshape(N, S) == want_p).all(), (nd, npar, kernel, call)
+        enc.set_option("direct_kernel", 0)
