@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_restore(const uint64_t* __restrict__ ag
 }
 
 // ---- few losses: every lost block is a fixed linear combination of the surviving ones (see decode.hip, "Few losses") ----
-constexpr int DIRECT_MAX = 16;
+constexpr int DIRECT_MAX = DECODE_DIRECT_MAX;  // 32 (16 until the nodes became k blocks instead of all survivors); a power of two: the tables' capacity
 constexpr uint32_t DIRECT_ROWS = 512, DIRECT_SEGS = 32;
 
 // ---- lazy accumulation: no reduction per term ----
@@ -509,49 +509,76 @@ __device__ __forceinline__ uint64_t gather3(const Acc3& s)
     return fold(fold(s.t0) + shl(fold(s.t1), 21) + shl(fold(s.t2), 42));                                    // the sum is below 2^63
 }
 
-// coef[u][j] = -w^(u - e_j) * prod_{i != j} (w^u - w^e_i) / prod_{i != j} (w^e_j - w^e_i) on surviving positions, 0 on lost ones
-__global__ __launch_bounds__(256) void k_direct_coef(uint32_t* __restrict__ coef, const uint64_t* __restrict__ wpow, const uint8_t* __restrict__ state,
-                                                     const uint32_t* __restrict__ epos, const uint64_t* __restrict__ inv, uint32_t NC, int e, int pad)
+// The nodes of the interpolation are k blocks: the data rows (a lost one gets zero weights) and as many surviving parity blocks y_a as data
+// blocks are lost — half the read, and half the arithmetic, of a sum over all 2k - e survivors (round 6: 11.8 -> 6 ms for one lost block at
+// k = 2^19 x 64 KB).  The formulas are decode.hip's / direct.hip's (interp_coef_kernel): with x_i = w^2i, A(x) = prod_a (x - y_a), R(x) = prod_r
+// (x - x_r) over the lost data rows, R_r = R / (x - x_r), and y^k = -1 at every parity point:
+//     data row i, lost data row r:     C_r x_i R_r(x_i) / A(x_i),                   C_r = -A(x_r) / (x_r R_r(x_r))
+//     data row i, lost parity block t: c_t x_i R(x_i) / (A(x_i) (y_t - x_i)),       c_t = -2 A(y_t) / (k R(y_t))
+//     parity node a: on the host (decode_prepare), packed by k_direct_pack
+// params (elements): [0, MAX) the targets x_r then y_t, [MAX, 2 MAX) y_a, [2 MAX, 3 MAX) C_r then c_t
+__device__ __forceinline__ Elem subc(Elem x, Elem y) { return Elem{subc(x.re, y.re), subc(x.im, y.im)}; }
+__device__ __forceinline__ void store_weight(uint32_t* __restrict__ o, Elem v)
 {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= NC) return;
-    const gf61::Opaque k = gf61::make_opaque();
-    const bool held = state[u] == ST_HELD;
-    const Elem wu = ld(wpow + 2ull * u);
-    for (int j = 0; j < pad; ++j) {
-        Elem v{0, 0};
-        if (held && j < e) {
-            v = ld(inv + 2ull * j);
-            for (int i = 0; i < e; ++i) {
-                if (i == j) continue;
-                const Elem wi = ld(wpow + 2ull * epos[i]);
-                v = mulc(v, Elem{subc(wu.re, wi.re), subc(wu.im, wi.im)}, k);
-            }
-            const uint32_t ej = epos[j];
-            v = mulc(v, ld(wpow + 2ull * (u >= ej ? u - ej : u + NC - ej)), k);
-        }
-        uint32_t* o = coef + ((uint64_t)u * pad + j) * COEF_WORDS;
-        if ((v.re | v.im) == 0) {
-            for (int i = 0; i < COEF_WORDS; ++i) o[i] = 0;
-            continue;
-        }
-        const uint64_t e = gf61::P - v.im;
-        const uint64_t parts[6] = {v.re, times_2_32(v.re), v.im, times_2_32(v.im), e, times_2_32(e)};
-        for (int i = 0; i < 6; ++i) {
-            const Limbs l = limbs_of(parts[i]);
-            o[3 * i] = l.l0;
-            o[3 * i + 1] = l.l1;
-            o[3 * i + 2] = l.l2;
-        }
+    if ((v.re | v.im) == 0) {
+        for (int i = 0; i < COEF_WORDS; ++i) o[i] = 0;
+        return;
+    }
+    const uint64_t e = gf61::P - v.im;
+    const uint64_t parts[6] = {v.re, times_2_32(v.re), v.im, times_2_32(v.im), e, times_2_32(e)};
+    for (int i = 0; i < 6; ++i) {
+        const Limbs l = limbs_of(parts[i]);
+        o[3 * i] = l.l0;
+        o[3 * i + 1] = l.l1;
+        o[3 * i + 2] = l.l2;
     }
 }
+__global__ __launch_bounds__(256) void k_direct_coef(uint32_t* __restrict__ coef, const uint64_t* __restrict__ wpow, const uint64_t* __restrict__ params, uint32_t N,
+                                                     int ed, int ep, int pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const gf61::Opaque k = gf61::make_opaque();
+    const uint64_t *z = params, *ya = params + 2 * DIRECT_MAX, *c = params + 4 * DIRECT_MAX;
+    const Elem xi = ld(wpow + 4ull * i);  // w^2i
+    Elem A{1, 0}, R{1, 0}, D{1, 0};
+    for (int a = 0; a < ed; ++a) {
+        A = mulc(A, subc(xi, ld(ya + 2 * a)), k);
+        R = mulc(R, subc(xi, ld(z + 2 * a)), k);
+    }
+    for (int t = 0; t < ep; ++t) D = mulc(D, subc(ld(z + 2 * (ed + t)), xi), k);
+    const bool node = (R.re | R.im) != 0;  // (a lost row is no node)
+    const Elem inv = invc(mulc(A, D, k), k);  // one inversion for both denominators: A(x_i) and prod_t (y_t - x_i), neither is zero
+    const Elem base = mulc(xi, mulc(inv, D, k), k), base_far = mulc(mulc(base, R, k), mulc(inv, A, k), k);
+    for (int j = 0; j < pad; ++j) {
+        Elem v{0, 0};
+        if (node && j < ed) {
+            Elem Rr{1, 0};
+            for (int s = 0; s < ed; ++s)
+                if (s != j) Rr = mulc(Rr, subc(xi, ld(z + 2 * s)), k);
+            v = mulc(mulc(ld(c + 2 * j), base, k), Rr, k);
+        } else if (node && j < ed + ep) {
+            Elem Q{1, 0};
+            for (int s = ed; s < ed + ep; ++s)
+                if (s != j) Q = mulc(Q, subc(ld(z + 2 * s), xi), k);
+            v = mulc(mulc(ld(c + 2 * j), base_far, k), Q, k);
+        }
+        store_weight(coef + ((uint64_t)i * pad + j) * COEF_WORDS, v);
+    }
+}
+// the parity nodes' rows (k .. k + ed - 1 of the table) from their weights as elements
+__global__ __launch_bounds__(256) void k_direct_pack(uint32_t* __restrict__ coef_rows, const uint64_t* __restrict__ weights, uint32_t count)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) store_weight(coef_rows + (uint64_t)t * COEF_WORDS, ld(weights + 2ull * t));
+}
 
-// partial[chunk][j][col] = sum over the chunk's positions of block(u)[col] * coef[u][j] (lazy values); a wave owns (chunk, 64 element columns, a sweep
-// of EB outputs: blockIdx.y)
+// partial[chunk][j][col] = sum over the chunk's rows of block(u)[col] * coef[u][j] (lazy values); rows u < n_data are the data blocks, the others the
+// parity blocks nodes[u - n_data]; a wave owns (chunk, 64 element columns, a sweep of EB outputs: blockIdx.y)
 template <int EB>
 __global__ __launch_bounds__(256) void k_direct_accumulate(const uint64_t* __restrict__ data, const uint64_t* __restrict__ parity,
                                                            const uint32_t* __restrict__ coef, uint64_t* __restrict__ partial, uint32_t elems, uint32_t NC,
-                                                           uint32_t col_chunks, uint64_t items, uint32_t pad)
+                                                           uint32_t col_chunks, uint64_t items, uint32_t pad, uint32_t n_data, const uint32_t* __restrict__ nodes)
 {
     constexpr int U = EB >= 8 ? 2 : 4;      // rows per trip of the loop; the next trip's rows are requested before this trip's arithmetic
     constexpr int G = EB >= 4 ? 4 : EB;     // outputs and
@@ -572,7 +599,8 @@ __global__ __launch_bounds__(256) void k_direct_accumulate(const uint64_t* __res
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const uint32_t u = min(ub + i, u1 - 1u);
-            x[i] = ld(((u & 1u) ? parity : data) + ((uint64_t)(u >> 1) * elems + col) * 2);
+            const uint64_t* row = u < n_data ? data + (uint64_t)u * elems * 2 : parity + (uint64_t)nodes[u - n_data] * elems * 2;  // (wave-uniform)
+            x[i] = ld(row + 2ull * col);
         }
     };
     Elem xn[U];
@@ -734,10 +762,12 @@ struct Decoder {
     // few losses: the direct path
     int direct = 0, direct_pad = 0;
     uint64_t direct_nc = 0;              // positions of the code the direct path works in (2k; NC unless e > 1)
+    int direct_ed = 0;                   // ... of its outputs the first direct_ed are the lost data blocks
+    uint64_t direct_rows = 0;            // ... and its rows: the k data blocks, then direct_ed parity blocks
     uint32_t* direct_coef = nullptr;     // [NC][pad][COEF_WORDS]: the limbs of each weight
     uint64_t direct_coef_elems = 0;
-    uint64_t* direct_inv = nullptr;      // [DIRECT_MAX] elements
-    uint32_t* direct_pos = nullptr;      // [DIRECT_MAX]
+    uint64_t* direct_inv = nullptr;      // the table kernels' parameters (3 DIRECT_MAX elements) and the parity nodes' weights
+    uint32_t* direct_pos = nullptr;      // [0, MAX) output positions, [MAX, 2 MAX) the parity nodes' rows
     uint64_t* direct_partial = nullptr;  // [chunks + DIRECT_SEGS][pad][elems] elements
     uint64_t direct_partial_elems = 0;
     uint64_t* direct_wpow = nullptr;     // the w^u table when only this path has been used (else d->wpow)
@@ -817,7 +847,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     // the parity half (largest h <= 5 that leaves enough survivors) and the parity half's transform shrinks to k >> h rows ----
     int split_shift = 0;
     uint64_t unused_held = 0;  // parity blocks the caller holds that the split leaves aside: they count as lost in the locator
-    const bool few = erased_data + erased_parity != 0 && (int)(erased_data + erased_parity) <= std::min(direct_max, 16);
+    const bool few = erased_data + erased_parity != 0 && (int)(erased_data + erased_parity) <= std::min(direct_max, DECODE_DIRECT_MAX);
     if (split && log2k >= 11 && erased_data != 0 && !few && !(*slot && (*slot)->split_unavailable)) {
         // (a pattern that has lost parity blocks too may be REPAIRED: the split then runs a second MID + DIT chain for the odd positions — or, without
         //  the memory for its extra stripe, re-encodes — see decode())
@@ -834,7 +864,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     const uint64_t n_erased = erased_data + erased_parity + unused_held;
     if (n_erased > NC - N) return FASTECC_E_INVAL;  // fewer than k blocks survive
     std::vector<uint32_t> erased;
-    if (n_erased != 0 && (int64_t)n_erased <= std::min(direct_max, DIRECT_MAX))
+    if (n_erased != 0 && (int64_t)n_erased <= std::min(direct_max, DECODE_DIRECT_MAX))
         for (uint64_t u = 0; u < NC; u++)
             if (state[u] == ST_LOST) erased.push_back((uint32_t)u);
     // n = 4k / 8k, few losses: the data and the FIRST coset are a (2k,k) code of their own (generator w_2k, parity blocks 0 .. k-1), and that code's
@@ -842,10 +872,10 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     // cosets are re-encoded (fastecc_repair)
     std::vector<uint8_t> state_sub;
     std::vector<uint32_t> erased_sub;
-    if (e > 1 && erased_data != 0 && (int64_t)erased_data <= std::min(direct_max_user, DIRECT_MAX)) {
+    if (e > 1 && erased_data != 0 && (int64_t)erased_data <= std::min(direct_max_user, DECODE_DIRECT_MAX)) {
         uint64_t lost0 = 0;
         for (uint64_t j = 0; j < N; j++) lost0 += !parity_present[j];
-        if ((int64_t)(erased_data + lost0) <= std::min(direct_max_user, DIRECT_MAX) && erased_data + lost0 <= N) {  // (k of the inner code's 2k blocks survive)
+        if ((int64_t)(erased_data + lost0) <= std::min(direct_max_user, DECODE_DIRECT_MAX) && erased_data + lost0 <= N) {  // (k of the inner code's 2k blocks survive)
             state_sub.resize(2 * N);
             for (uint64_t i = 0; i < N; i++) {
                 state_sub[2 * i] = data_present[i] ? ST_HELD : ST_LOST;
@@ -902,7 +932,7 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
     const std::vector<uint32_t>& erased_all = erased;
     const std::vector<uint8_t>& state_all = state;
     const uint64_t NC_all = NC;
-    if (direct_sub || (!erased.empty() && (int)erased.size() <= std::min(direct_max, DIRECT_MAX))) {
+    if (direct_sub || (!erased.empty() && (int)erased.size() <= std::min(direct_max, DECODE_DIRECT_MAX))) {
         // few losses: a coefficient table, no locator tree and no transform contexts.  Out of memory for its tables is not an
         // error: the transform path below needs none of them.
         const int rc_direct = [&]() -> int {
@@ -917,18 +947,41 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
             int pad = 1;
             while (pad < e) pad <<= 1;
             const gf61::Elem w = gf61::h_root(NC);
-            std::vector<gf61::Elem> we(e);
-            std::vector<uint64_t> inv(2 * e);
-            std::vector<uint32_t> epos(DIRECT_MAX, 0xFFFFFFFFu);
-            for (int j = 0; j < e; j++) we[j] = gf61::h_pow(w, erased[j]), epos[j] = erased[j];
-            for (int j = 0; j < e; j++) {
-                gf61::Elem l0{1, 0};
-                for (int i = 0; i < e; i++)
-                    if (i != j) l0 = gf61::h_mul(l0, gf61::Elem{gf61::h_subp(we[j].re, we[i].re), gf61::h_subp(we[j].im, we[i].im)});
-                const gf61::Elem r = gf61::h_inv(l0);
-                inv[2 * j] = gf61::h_subp(0, r.re);  // -1 / l0(w^e_j)
-                inv[2 * j + 1] = gf61::h_subp(0, r.im);
+            // nodes: the data rows and the first |lost data| surviving parity blocks; targets: the lost data rows, then the lost parity blocks
+            using gf61::Elem;
+            const uint64_t Nd = NC / 2;
+            std::vector<uint32_t> Rr, Pl, An;
+            for (uint32_t u : erased) ((u & 1u) ? Pl : Rr).push_back(u >> 1);
+            for (uint64_t q = 0; q < Nd && An.size() < Rr.size(); q++)
+                if (state[2 * q + 1] == ST_HELD) An.push_back((uint32_t)q);
+            if (An.size() != Rr.size()) return FASTECC_E_INVAL;
+            const int ed = (int)Rr.size(), ep = (int)Pl.size();
+            auto sub = [](Elem a, Elem b) { return Elem{gf61::h_subp(a.re, b.re), gf61::h_subp(a.im, b.im)}; };
+            auto neg = [](Elem a) { return Elem{gf61::h_subp(0, a.re), gf61::h_subp(0, a.im)}; };
+            auto mul = [](Elem a, Elem b) { return gf61::h_mul(a, b); };
+            const Elem one{1, 0}, two{2, 0}, kk{Nd % P, 0};
+            std::vector<Elem> z(e), ya(ed), cst(e), nodew((size_t)ed * pad, Elem{0, 0});
+            for (int r = 0; r < ed; r++) z[r] = gf61::h_pow(w, 2ull * Rr[r]), ya[r] = gf61::h_pow(w, 2ull * An[r] + 1);
+            for (int t = 0; t < ep; t++) z[ed + t] = gf61::h_pow(w, 2ull * Pl[t] + 1);
+            auto A_at = [&](Elem x, int skip) { Elem v = one; for (int a = 0; a < ed; a++) if (a != skip) v = mul(v, sub(x, ya[a])); return v; };
+            auto R_at = [&](Elem x, int skip) { Elem v = one; for (int r = 0; r < ed; r++) if (r != skip) v = mul(v, sub(x, z[r])); return v; };
+            for (int r = 0; r < ed; r++) cst[r] = neg(mul(A_at(z[r], -1), gf61::h_inv(mul(z[r], R_at(z[r], r)))));  // C_r = -A(x_r) / (x_r R_r(x_r))
+            for (int t = ed; t < e; t++) cst[t] = neg(mul(mul(two, A_at(z[t], -1)), gf61::h_inv(mul(kk, R_at(z[t], -1)))));  // c_t = -2 A(y_t) / (k R(y_t))
+            for (int a = 0; a < ed; a++) {
+                // parity node a (y_a^k - 1 = -2): target r: k A_a(x_r) R(y_a) / (-2 x_r R_r(x_r) A_a(y_a)); target t: A_a(y_t) R(y_a) / (R(y_t) A_a(y_a))
+                const Elem Rya = R_at(ya[a], -1), Aaya = A_at(ya[a], a);
+                for (int r = 0; r < ed; r++)
+                    nodew[(size_t)a * pad + r] = mul(mul(mul(kk, A_at(z[r], a)), Rya), gf61::h_inv(neg(mul(mul(mul(two, z[r]), R_at(z[r], r)), Aaya))));
+                for (int t = ed; t < e; t++) nodew[(size_t)a * pad + t] = mul(mul(A_at(z[t], a), Rya), gf61::h_inv(mul(R_at(z[t], -1), Aaya)));
             }
+            std::vector<uint64_t> params(6 * DIRECT_MAX, 0);
+            std::vector<uint32_t> lists(2 * DIRECT_MAX, 0xFFFFFFFFu);  // [0, MAX) output positions (row << 1 | parity), [MAX, 2 MAX) the parity nodes' rows
+            for (int j = 0; j < e; j++) {
+                params[2 * j] = z[j].re, params[2 * j + 1] = z[j].im;
+                params[4 * DIRECT_MAX + 2 * j] = cst[j].re, params[4 * DIRECT_MAX + 2 * j + 1] = cst[j].im;
+                lists[j] = j < ed ? 2u * Rr[j] : 2u * Pl[j - ed] + 1u;
+            }
+            for (int a = 0; a < ed; a++) params[2 * DIRECT_MAX + 2 * a] = ya[a].re, params[2 * DIRECT_MAX + 2 * a + 1] = ya[a].im, lists[DIRECT_MAX + a] = An[a];
             hipStream_t s0 = nullptr;
             uint64_t* wp = direct_sub ? d->direct_wpow : d->built ? d->wpow : d->direct_wpow;  // (the inner code's table is its own: w_2k, not w_n)
             if (!wp) {
@@ -944,9 +997,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                 }
                 d->direct_wpow = wp = fresh;
             }
-            if (!d->direct_state) D61_TRY(hipMalloc((void**)&d->direct_state, NC_all));
-            // [NC][pad] weights: sized for this pattern's pad (1 GiB instead of 8 GiB at NC = 2^25 for one lost block), grown on demand
-            const uint64_t coef_elems = (NC + 4) * (uint64_t)pad;  // (k_direct_accumulate fetches the rows of a trip together)
+            // [k + ed][pad] weights: sized for this pattern's pad (0.5 GiB instead of 16 GiB at k = 2^24 for one lost block), grown on demand
+            const uint64_t rows = Nd + (uint64_t)ed;
+            const uint64_t coef_elems = (rows + 4) * (uint64_t)pad;  // (k_direct_accumulate fetches the rows of a trip together)
             if (d->direct_coef_elems < coef_elems) {
                 if (d->direct_coef) (void)hipFree(d->direct_coef);
                 d->direct_coef = nullptr;
@@ -954,9 +1007,9 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                 D61_TRY(hipMalloc((void**)&d->direct_coef, coef_elems * COEF_WORDS * 4));
                 d->direct_coef_elems = coef_elems;
             }
-            if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, DIRECT_MAX * 16));
-            if (!d->direct_pos) D61_TRY(hipMalloc((void**)&d->direct_pos, DIRECT_MAX * 4));
-            const uint64_t chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+            if (!d->direct_inv) D61_TRY(hipMalloc((void**)&d->direct_inv, (6 * DIRECT_MAX + 2 * DIRECT_MAX * DIRECT_MAX) * 8));  // the parameters, the nodes' weights
+            if (!d->direct_pos) D61_TRY(hipMalloc((void**)&d->direct_pos, 2 * DIRECT_MAX * 4));
+            const uint64_t chunks = (rows + DIRECT_ROWS - 1) / DIRECT_ROWS;
             const uint64_t need = (chunks + DIRECT_SEGS) * pad * elems;
             if (d->direct_partial_elems < need) {
                 if (d->direct_partial) (void)hipFree(d->direct_partial);
@@ -965,13 +1018,19 @@ int decode_prepare(Decoder** slot, int log2k, uint64_t elems, const uint8_t* dat
                 D61_TRY(hipMalloc((void**)&d->direct_partial, need * 16));
                 d->direct_partial_elems = need;
             }
-            D61_TRY(hipMemcpyAsync(d->direct_state, state.data(), NC, hipMemcpyHostToDevice, s0));
-            D61_TRY(hipMemcpyAsync(d->direct_pos, epos.data(), DIRECT_MAX * 4, hipMemcpyHostToDevice, s0));
-            D61_TRY(hipMemcpyAsync(d->direct_inv, inv.data(), e * 16, hipMemcpyHostToDevice, s0));
-            hipLaunchKernelGGL(k_direct_coef, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s0, d->direct_coef, wp, d->direct_state, d->direct_pos,
-                               d->direct_inv, (uint32_t)NC, e, pad);
+            D61_TRY(hipMemcpyAsync(d->direct_pos, lists.data(), 2 * DIRECT_MAX * 4, hipMemcpyHostToDevice, s0));
+            D61_TRY(hipMemcpyAsync(d->direct_inv, params.data(), 6 * DIRECT_MAX * 8, hipMemcpyHostToDevice, s0));
+            D61_TRY(hipMemsetAsync(d->direct_coef + rows * pad * COEF_WORDS, 0, 4ull * pad * COEF_WORDS * 4, s0));  // (the four spare rows)
+            hipLaunchKernelGGL(k_direct_coef, dim3((unsigned)((Nd + 255) / 256)), dim3(256), 0, s0, d->direct_coef, wp, d->direct_inv, (uint32_t)Nd, ed, ep, pad);
+            if (ed > 0) {
+                D61_TRY(hipMemcpyAsync(d->direct_inv + 6 * DIRECT_MAX, nodew.data(), (size_t)ed * pad * 16, hipMemcpyHostToDevice, s0));
+                hipLaunchKernelGGL(k_direct_pack, dim3((unsigned)((ed * pad + 255) / 256)), dim3(256), 0, s0, d->direct_coef + Nd * pad * COEF_WORDS, d->direct_inv + 6 * DIRECT_MAX,
+                                   (uint32_t)(ed * pad));
+            }
             D61_TRY(hipGetLastError());
             D61_TRY(hipStreamSynchronize(s0));
+            d->direct_ed = ed;
+            d->direct_rows = rows;
             d->direct = e;
             d->direct_pad = pad;
             d->direct_nc = NC;
@@ -1238,25 +1297,28 @@ int decode(Decoder* d, uint64_t* data, uint64_t* parity, Path* rebuild_with, hip
     };
     if (d->direct > 0) {
         if (d->erased_data == 0 && !rebuild) return FASTECC_OK;
-        const uint32_t NC = (uint32_t)d->direct_nc, chunks = (NC + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        // rows: the k data blocks and as many parity blocks as data blocks are lost; outputs: the lost data blocks first — fastecc_decode stops after them
+        const uint32_t rows = (uint32_t)d->direct_rows, chunks = (rows + DIRECT_ROWS - 1) / DIRECT_ROWS;
+        const int outputs = rebuild ? d->direct : d->direct_ed;
         const uint64_t items = (uint64_t)chunks * col_chunks;
         const dim3 grid((unsigned)((items + 3) / 4));
-#define FASTECC_DIRECT61(EB)                                                                                                                     \
-    hipLaunchKernelGGL(k_direct_accumulate<EB>, dim3(grid.x, (unsigned)(d->direct_pad / EB)), dim3(256), 0, s0, data, parity, d->direct_coef, d->direct_partial, \
-                       elems, NC, col_chunks, items, (uint32_t)d->direct_pad)
+#define FASTECC_DIRECT61(EB)                                                                                                                                  \
+    hipLaunchKernelGGL(k_direct_accumulate<EB>, dim3(grid.x, (unsigned)((std::min(outputs, d->direct_pad) + EB - 1) / EB)), dim3(256), 0, s0, data, parity,    \
+                       d->direct_coef, d->direct_partial, elems, rows, col_chunks, items, (uint32_t)d->direct_pad, (uint32_t)(d->direct_nc / 2),               \
+                       d->direct_pos + DIRECT_MAX)
         switch (d->direct_pad) {
             case 1: FASTECC_DIRECT61(1); break;
             case 2: FASTECC_DIRECT61(2); break;
             case 4: FASTECC_DIRECT61(4); break;
-            default: FASTECC_DIRECT61(8); break;  // 8, 16, ...: sweeps of 8 outputs
+            default: FASTECC_DIRECT61(8); break;  // 8, 16, 32: sweeps of 8 outputs
         }
 #undef FASTECC_DIRECT61
         D61_TRY(hipGetLastError());
         uint64_t* stage = d->direct_partial + 2ull * (uint64_t)chunks * d->direct_pad * elems;
-        hipLaunchKernelGGL(k_direct_reduce1, dim3((elems + 255) / 256, (unsigned)d->direct, DIRECT_SEGS), dim3(256), 0, s0, d->direct_partial, stage, elems, chunks,
-                           d->direct_pad, d->direct);
-        hipLaunchKernelGGL(k_direct_reduce2, dim3((elems + 255) / 256, (unsigned)d->direct), dim3(256), 0, s0, stage, d->direct_pos, data, parity, elems,
-                           d->direct_pad, d->direct, rebuild);
+        hipLaunchKernelGGL(k_direct_reduce1, dim3((elems + 255) / 256, (unsigned)outputs, DIRECT_SEGS), dim3(256), 0, s0, d->direct_partial, stage, elems, chunks,
+                           d->direct_pad, outputs);
+        hipLaunchKernelGGL(k_direct_reduce2, dim3((elems + 255) / 256, (unsigned)outputs), dim3(256), 0, s0, stage, d->direct_pos, data, parity, elems,
+                           d->direct_pad, outputs, rebuild);
         D61_TRY(hipGetLastError());
         // (n = 4k / 8k: that was the (2k,k) code of the data and the first coset; the other cosets' lost blocks are re-encoded)
         if (d->e > 1 && rebuild && (d->lost_coset_mask & ~1u) != 0) return rebuild_cosets(d->lost_coset_mask & ~1u, true);

@@ -19,6 +19,7 @@ struct LaunchHooks {
 // n = log2 k (1..MAX_LOG2_K); elems = GF(p^2) elements (16 bytes) per block.  Returns a FASTECC_* code; on
 // failure `detail` gets a short message.  The current device must already be the target device.
 constexpr int MAX_LOG2_K = 24;   // 3 tables of 16 * k bytes
+constexpr int DECODE_DIRECT_MAX = 32;  // the decoder's direct path: most lost blocks (option "decode_direct_max"): 1.84 ms each at k = 2^19 x 64 KB, the transform path 71 ms
 constexpr int DEFAULT_LEVELS = 4;
 int create(Path** out, int n, uint64_t elems, char* detail, size_t detail_cap);
 // The same pipeline — DIF over all levels with the inverse roots, the block holding coefficient m times its factor, DIT back

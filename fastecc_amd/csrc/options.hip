@@ -94,7 +94,7 @@ int fastecc_set_option(fastecc_ctx* c, const char* name, int value)
         return FASTECC_OK;
     }
     if (!strcmp(name, "decode_direct_max")) {  // takes effect at the next fastecc_decode_prepare
-        if (value < 0 || value > (c->p61 ? 16 : direct_cap())) return FASTECC_E_INVAL;
+        if (value < 0 || value > (c->p61 ? p61::DECODE_DIRECT_MAX : direct_cap())) return FASTECC_E_INVAL;
         c->decode_direct_max = value;
         return FASTECC_OK;
     }

@@ -303,12 +303,12 @@ int fastecc_check_range(fastecc_ctx *ctx, const void *data, int mem_kind, void *
  *                            stripe and the parity blocks the decoder reads travel up, the rebuilt blocks back (whole stripes
  *                            when more than an eighth of the codeword is lost).
  * fastecc_decode leaves erased parity blocks alone; fastecc_repair rebuilds them too.
- * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 16 for GF((2^61-1)^2)) take a direct path: every
+ * Patterns with at most 256 lost blocks (option "decode_direct_max", 0..256, default 256; 32 for GF((2^61-1)^2)) take a direct path: every
  * lost block is a fixed linear combination of surviving ones, so prepare builds weight tables (0.2-3.5 ms, no transform contexts) and decode
  * is one read of the data plus a few parity blocks — 0.4 ms for up to 16 lost blocks of a 2 GiB stripe, 0.7 ms for 64, 2.6 ms for 256 (matrix
  * cores; option "direct_kernel") against 3.8-5.7 ms on the transform path (repair: the lost parity blocks in the same pass when at most 32 blocks are lost in all, else in a second read); every GF(0xFFF00001)
  * code, and the (2k,k) codes of GF((2^61-1)^2); identical results.  n = 4k / 8k over GF((2^61-1)^2): the data and the first coset are a (2k,k) code,
- * and up to 16 losses among THOSE 2k blocks (lost blocks of the other cosets do not count; repair re-encodes them) take that code's direct path.
+ * and up to 32 losses among THOSE 2k blocks (lost blocks of the other cosets do not count; repair re-encodes them) take that code's direct path.
  */
 int fastecc_decode_prepare(fastecc_ctx *ctx, const uint8_t *data_present, const uint8_t *parity_present);
 int fastecc_decode(fastecc_ctx *ctx, void *data, const void *parity, int mem_kind, void *stream);
@@ -388,7 +388,7 @@ const char *fastecc_plan_string(fastecc_ctx *ctx);
  *                  basis — one read of the data (0.4 ms up to 16 parity blocks ... 1.4 ms for 128 at k = 2^19 x 4 KB) instead of the transform
  *                  pipeline (2.4 ms); same parity bits.  Rows the matrix-core kernel cannot take (odd length, < 64 words, not 8-byte aligned)
  *                  stop at 32;
- *   "decode_direct_max" = 0..256 (default 256; 0..16 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
+ *   "decode_direct_max" = 0..256 (default 256; 0..32 for GF((2^61-1)^2)): lost blocks up to which the decoder's direct path is used (next
  *                  decode_prepare); rows the matrix-core kernel cannot take stop at 96 (not for mixed-radix orders above 2^20, whose transform
  *                  path is much dearer: there the option alone decides);
  *   "decode_split" = 0 / 1 / 2 (default 1; codes over GF(0xFFF00001) with n <= 2k and k >= 2^17 (power-of-two orders), next decode_prepare): the

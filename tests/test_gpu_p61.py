@@ -357,14 +357,15 @@ def test_decode_transform_is_folded(torch_cuda, fe, logn, elems):
 
 @pytest.mark.parametrize("N,elems", [(2, 3), (16, 70), (1024, 9), (1 << 14, 4)])
 def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
-    """Up to 16 lost blocks: recomputed straight from the survivors (no locator tree, no transform); same bits as the transform
+    """Up to 32 lost blocks: recomputed straight from k of the survivors — the data and as many parity blocks as data blocks are lost — (no locator
+    tree, no transform); same bits as the transform
     path (decode_direct_max = 0), the original stripes and — small N — the oracle's Lagrange decoder; decode and repair."""
     torch = torch_cuda
     rng = np.random.default_rng(N * 3 + elems)
     x = rand_stripe(rng, N, elems)
     par = orc61.encode(x)
     with encoder(fe, N, elems) as enc:
-        for e in (1, 2, 3, 7, 16, 17):
+        for e in (1, 2, 3, 7, 16, 17, 32, 33):
             if e > N:
                 continue
             lost = np.unique(np.r_[int(rng.integers(0, N)), rng.permutation(2 * N)[: e - 1]])
@@ -374,7 +375,7 @@ def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
             bad_x, bad_p = x.copy(), par.copy()
             bad_x[dp == 0] = 11
             bad_p[pp == 0] = 13
-            for direct_max in (16, 0):
+            for direct_max in (32, 0):
                 enc.set_option("decode_direct_max", direct_max)
                 enc.decode_prepare(dp, pp)
                 d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
@@ -390,7 +391,7 @@ def test_few_losses_take_the_direct_path(torch_cuda, fe, orc61, N, elems):
                 assert (hx == x).all() and (hp == par).all(), (e, direct_max)
             if N <= 64:
                 assert (orc61.decode(bad_x, bad_p, dp, pp) == x).all()
-        enc.set_option("decode_direct_max", 16)
+        enc.set_option("decode_direct_max", 32)
 
 
 @pytest.mark.parametrize("k,m,elems", [(100, 30, 8), (256, 64, 5), (1000, 1000, 4), (300, 512, 6), (4096, 256, 16), (5, 1, 3), (2048, 2048 // 16, 7)])
@@ -521,7 +522,7 @@ def test_decode_of_the_n_equals_4k_code_is_folded(torch_cuda, fe, orc61, logn, e
             torch.cuda.synchronize()
             prof = enc.profile_read()
             enc.profile(False)
-            if int((dp == 0).sum()) + int((pp == 0).sum()) > 16:  # (fewer: the direct path)
+            if int((dp == 0).sum()) + int((pp == 0).sum()) > 32:  # (fewer: the direct path)
                 assert prof.get("p61_tile_mid7_fold4", (0, 0, 0))[1] == 1, prof
                 if logn in (11, 12):
                     assert any(name.endswith("_gather") for name in prof) and any(name.endswith("_scatter") for name in prof), prof
@@ -574,14 +575,14 @@ def test_decode_of_the_n_equals_8k_code_is_folded(torch_cuda, fe, orc61, logn, e
             enc.repair(d, q)
             torch.cuda.synchronize()
             assert (to_host(d).reshape(x.shape) == x).all() and (to_host(q).reshape(want.shape) == want).all(), nlost
-        enc.set_option("decode_direct_max", 16)
+        enc.set_option("decode_direct_max", 32)
 
 
 @pytest.mark.parametrize("logn,e,elems", [(1, 2, 3), (4, 2, 70), (6, 3, 5), (10, 2, 9), (12, 3, 4), (14, 2, 2)])
 def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch_cuda, fe, orc61, logn, e, elems):
-    """n = 4k / 8k with at most 16 blocks lost among the data and the FIRST coset: those 2k blocks are a (2k,k) code of their own, and its direct
+    """n = 4k / 8k with at most 32 blocks lost among the data and the FIRST coset: those 2k blocks are a (2k,k) code of their own, and its direct
     path rebuilds the data from 2k - few survivors — no transform over n runs (the profile is empty of the paths' kernels).  Lost parity blocks of
-    the other cosets do not count against the 16; fastecc_repair re-encodes them.  Same bits as the transform path (decode_direct_max = 0) and the
+    the other cosets do not count against the 32; fastecc_repair re-encodes them.  Same bits as the transform path (decode_direct_max = 0) and the
     original stripes; one loss more and the transform path runs."""
     torch = torch_cuda
     N = 1 << logn
@@ -591,7 +592,7 @@ def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch
     want = p61_oracle_coset_parity(orc61, x, e)
     with fe.Encoder(N << e, N, 16 * elems, field=fe.FIELD_GF_P61_SQUARED) as enc:
         cases = []  # (lost data, lost blocks of coset 0, lost blocks of the other cosets)
-        for nd, n0, nother in ((1, 0, 0), (2, 3, 5), (9, 7, 40), (16, 0, rows), (10, 7, 0), (1, 16, 3)):
+        for nd, n0, nother in ((1, 0, 0), (2, 3, 5), (9, 7, 40), (16, 0, rows), (10, 7, 0), (1, 16, 3), (20, 12, 9), (17, 16, 0)):
             nd, n0 = min(nd, N), min(n0, N)
             cases.append((nd, n0, max(0, min(nother, rows - N, rows - nd - n0))))  # (at least k blocks survive)
         for nd, n0, nother in cases:
@@ -602,7 +603,7 @@ def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch
             bad_x, bad_p = x.copy(), want.copy()
             bad_x[dp == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
             bad_p[pp == 0] = np.uint64(0xDEADBEEFDEADBEEF)
-            for direct_max in (16, 0):
+            for direct_max in (32, 0):
                 enc.set_option("decode_direct_max", direct_max)
                 enc.decode_prepare(dp, pp)
                 d, q = to_dev(torch, bad_x), to_dev(torch, bad_p)
@@ -612,7 +613,7 @@ def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch
                 torch.cuda.synchronize()
                 prof = enc.profile_read()
                 enc.profile(False)
-                direct = direct_max == 16 and nd + n0 <= min(16, N)  # (k of the inner code's 2k blocks must survive)
+                direct = direct_max == 32 and nd + n0 <= min(32, N)  # (k of the inner code's 2k blocks must survive)
                 assert (len(prof) == 0) == direct, (nd, n0, nother, direct_max, prof)
                 assert (to_host(d).reshape(x.shape) == x).all(), (nd, n0, nother, direct_max)
                 assert (to_host(q).reshape(want.shape) == bad_p).all()  # decode leaves the parity stripe alone
@@ -622,7 +623,7 @@ def test_few_losses_in_n_equals_4k_and_8k_take_the_inner_codes_direct_path(torch
                 hx, hp = bad_x.copy(), bad_p.copy()
                 enc.repair(hx, hp, mem=fe.MEM_HOST)
                 assert (hx == x).all() and (hp == want).all(), (nd, n0, nother, direct_max)
-        enc.set_option("decode_direct_max", 16)
+        enc.set_option("decode_direct_max", 32)
 
 
 @pytest.mark.parametrize("logn", [1, 2, 5, 6, 7, 9, 12, 13, 14])
