@@ -771,7 +771,6 @@ struct Decoder {
     uint64_t* direct_partial = nullptr;  // [chunks + DIRECT_SEGS][pad][elems] elements
     uint64_t direct_partial_elems = 0;
     uint64_t* direct_wpow = nullptr;     // the w^u table when only this path has been used (else d->wpow)
-    uint8_t* direct_state = nullptr;
     bool ready = false;
 };
 
@@ -795,7 +794,7 @@ void destroy_decoder(Decoder* d)
     for (Path* t : d->tree) destroy(t);
     for (void* b : {(void*)d->tree_x, (void*)d->tree_y, (void*)d->tree_f, (void*)d->wpow, (void*)d->roots, (void*)d->lv, (void*)d->fin,
                     (void*)d->gout, (void*)d->gout_all, (void*)d->erased, (void*)d->state, (void*)d->work, (void*)d->rec, (void*)d->again, (void*)d->stage, (void*)d->direct_coef,
-                    (void*)d->direct_inv, (void*)d->direct_pos, (void*)d->direct_partial, (void*)d->direct_wpow, (void*)d->direct_state})
+                    (void*)d->direct_inv, (void*)d->direct_pos, (void*)d->direct_partial, (void*)d->direct_wpow})
         if (b) (void)hipFree(b);
     delete d;
 }
